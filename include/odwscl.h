@@ -1,0 +1,109 @@
+/*
+ * odwscl.h -- C-ABI of libodwscl.so: the MI355X (gfx950) native operators of
+ * OD-WSCL's proposal-feature hot path.
+ *
+ * This is the drop-in boundary.  The reference binds its native operators
+ * through the pybind11 module `wetectron._C` (csrc/vision.cpp:9-25); every
+ * entry point below names the reference interface it replaces.  INTEGRATION.md
+ * shows the ctypes stub a wetectron maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch/ATen types; all pointers are DEVICE
+ *     pointers unless a parameter is documented as host
+ *   - the caller owns every buffer (outputs and workspaces are caller-allocated)
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     nothing synchronises (safe to call from the autograd thread)
+ *   - return 0 on success, a negative ODW_E* code otherwise; odw_last_error()
+ *     returns a thread-local message (the Python layer raises RuntimeError,
+ *     mirroring AT_ASSERTM/AT_ERROR in the reference)
+ *   - no global mutable state besides the thread-local error string
+ *   - tensors are dense row-major fp32 unless stated; rois are (R,5) rows
+ *     [batch_index, x1, y1, x2, y2] exactly as modeling/poolers.py:85-96 builds
+ */
+#ifndef ODWSCL_H_
+#define ODWSCL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODW_OK 0
+#define ODW_EINVAL (-1)   /* bad argument                        */
+#define ODW_ELAUNCH (-2)  /* hipGetLastError() after a launch    */
+#define ODW_EWORKSPACE (-3) /* workspace too small               */
+
+const char* odw_last_error(void);
+int odw_version(void);
+
+/* ---- ROIPool --------------------------------------------------------------
+ * replaces _C.roi_pool_forward / roi_pool_backward
+ * (csrc/ROIPool.h:11-45 -> csrc/cuda/ROIPool_cuda.cu:17-108,110-202).
+ * feat (B,C,H,W); out (R,C,PH,PW) fp32; argmax (R,C,PH,PW) int32 (h*W+w or -1).
+ * workspace: odw_roi_pool_workspace(R,PH,PW) bytes (per-ROI bin tables). */
+int64_t odw_roi_pool_workspace(int R, int PH, int PW);
+int odw_roi_pool_forward(const float* feat, const float* rois, float spatial_scale,
+                         int B, int C, int H, int W, int R, int PH, int PW,
+                         float* out, int32_t* argmax, void* workspace, int64_t workspace_bytes,
+                         void* stream);
+/* grad_in (B,C,H,W) is fully written (zero where nothing pools). */
+int odw_roi_pool_backward(const float* grad_out, const int32_t* argmax, const float* rois,
+                          int B, int C, int H, int W, int R, int PH, int PW,
+                          float* grad_in, void* stream);
+
+/* ---- ROIAlign -------------------------------------------------------------
+ * replaces _C.roi_align_forward / roi_align_backward
+ * (csrc/ROIAlign.h:11-45 -> csrc/cuda/ROIAlign_cuda.cu:65-254,
+ *  csrc/cpu/ROIAlign_cpu.cpp:114-257).  Legacy (un-aligned) sampling;
+ * sampling_ratio <= 0 means adaptive ceil(roi/pooled). */
+int odw_roi_align_forward(const float* feat, const float* rois, float spatial_scale,
+                          int B, int C, int H, int W, int R, int PH, int PW, int sampling_ratio,
+                          float* out, void* stream);
+int odw_roi_align_backward(const float* grad_out, const float* rois, float spatial_scale,
+                           int B, int C, int H, int W, int R, int PH, int PW, int sampling_ratio,
+                           float* grad_in, void* stream);
+
+/* ---- NMS --------------------------------------------------------------------
+ * mode ODW_NMS_TV : torchvision.ops.nms semantics -- the live path
+ *                   (structures/boxlist_ops.py:32,57): IoU without +1, suppress
+ *                   when IoU > thr, keep[] in descending-score order.
+ * mode ODW_NMS_WT_GE / ODW_NMS_WT_GT : wetectron `_C.nms` (csrc/nms.h:10-28):
+ *                   +1 areas, suppress when >= thr (csrc/cpu/nms_cpu.cpp:60) or
+ *                   > thr (csrc/cuda/nms.cu:60), keep[] ascending original index.
+ * boxes (n,4) xyxy, scores (n).  keep: int64[n] device; n_keep: int32[1] device.
+ * Score ties are ordered by ascending index (stable sort).  n <= ODW_NMS_MAX_N.
+ * workspace: odw_nms_workspace(n) bytes. */
+#define ODW_NMS_TV 0
+#define ODW_NMS_WT_GE 1
+#define ODW_NMS_WT_GT 2
+#define ODW_NMS_MAX_N 8192
+int64_t odw_nms_workspace(int n);
+int odw_nms(const float* boxes, const float* scores, int n, float thr, int mode,
+            int64_t* keep, int32_t* n_keep, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- box IoU ----------------------------------------------------------------
+ * replaces structures/boxlist_ops.py:127-160 (boxlist_iou, TO_REMOVE=1).
+ * a (N,4), b (M,4) -> iou (N,M). */
+int odw_box_iou(const float* a, int N, const float* b, int M, float* iou, void* stream);
+
+/* ---- proposal x proposal similarity -----------------------------------------
+ * replaces `torch.mm(sim_feature, sim_feature.T)` of
+ * roi_heads/weak_head/loss.py:319.  E (P,D) fp32, D % 4 == 0 -> S (P,P) fp32. */
+int odw_pairwise_sim(const float* E, int P, int D, float* S, void* stream);
+
+/* ---- SupConLossV2 ------------------------------------------------------------
+ * replaces roi_heads/sim_head/sim_loss.py:49-80 forward + its autograd
+ * backward.  F (N,D) fp32 rows, labels (N) int32, w (N) fp32 (detached),
+ * temperature tau.  loss: fp32[1] = mean_i( -log(A_i/B_i) * w_i ) (not yet
+ * multiplied by lmda).  dF (N,D) = dloss/dF * grad_scale, or NULL to skip.
+ * workspace: odw_supcon_workspace(N) bytes. */
+int64_t odw_supcon_workspace(int N);
+int odw_supcon_v2(const float* F, const int32_t* labels, const float* w, int N, int D, float tau,
+                  float grad_scale, float* loss, float* dF,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODWSCL_H_ */

@@ -1,0 +1,149 @@
+"""`wetectron._C`-shaped module: the five operators the reference binds through
+pybind11 (csrc/vision.cpp:9-25), same names, argument order and return values,
+backed by libodwscl.so.  `wetectron/layers/*.py` works unchanged with
+`from od_wscl_amd import _C`.
+"""
+import torch
+
+from . import _lib as L
+
+_NMS_MODE = {"tv": 0, "wt_ge": 1, "wt_gt": 2}
+
+
+def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
+    """-> (output (R,C,PH,PW) fp32, argmax (R,C,PH,PW) int32).  csrc/ROIPool.h:11-24."""
+    L.need_gpu(input, rois)
+    input = input.contiguous().float()   # ROIPool_cuda.cu:140 takes .contiguous()
+    rois = rois.contiguous().float()
+    B, C, H, W = input.shape
+    R = rois.shape[0]
+    out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device)
+    argmax = torch.zeros((R, C, pooled_height, pooled_width), dtype=torch.int32, device=input.device)
+    if out.numel() == 0:
+        return out, argmax
+    nbytes = L.lib().odw_roi_pool_workspace(R, pooled_height, pooled_width)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
+    L.check(L.lib().odw_roi_pool_forward(L.ptr(input), L.ptr(rois), float(spatial_scale), B, C, H, W, R,
+                                         pooled_height, pooled_width, L.ptr(out), L.ptr(argmax),
+                                         L.ptr(ws), nbytes, L.stream()), "roi_pool_forward")
+    return out, argmax
+
+
+def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, pooled_width,
+                      batch_size, channels, height, width):
+    """-> grad_input (B,C,H,W).  csrc/ROIPool.h:26-45 (input is only used for its sizes)."""
+    L.need_gpu(grad, rois, argmax)
+    grad = grad.contiguous().float()
+    rois = rois.contiguous().float()
+    argmax = argmax.contiguous()
+    gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
+    if gin.numel() == 0:
+        return gin
+    L.check(L.lib().odw_roi_pool_backward(L.ptr(grad), L.ptr(argmax), L.ptr(rois), batch_size, channels,
+                                          height, width, rois.shape[0], pooled_height, pooled_width,
+                                          L.ptr(gin), L.stream()), "roi_pool_backward")
+    return gin
+
+
+def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
+    """-> output (R,C,PH,PW).  csrc/ROIAlign.h:11-25."""
+    L.need_gpu(input, rois)
+    input = input.contiguous().float()
+    rois = rois.contiguous().float()
+    B, C, H, W = input.shape
+    R = rois.shape[0]
+    out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device)
+    if out.numel() == 0:
+        return out
+    L.check(L.lib().odw_roi_align_forward(L.ptr(input), L.ptr(rois), float(spatial_scale), B, C, H, W, R,
+                                          pooled_height, pooled_width, int(sampling_ratio), L.ptr(out),
+                                          L.stream()), "roi_align_forward")
+    return out
+
+
+def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                       height, width, sampling_ratio):
+    """-> grad_input (B,C,H,W).  csrc/ROIAlign.h:27-45."""
+    L.need_gpu(grad, rois)
+    grad = grad.contiguous().float()
+    rois = rois.contiguous().float()
+    gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
+    if gin.numel() == 0:
+        return gin
+    L.check(L.lib().odw_roi_align_backward(L.ptr(grad), L.ptr(rois), float(spatial_scale), batch_size,
+                                           channels, height, width, rois.shape[0], pooled_height,
+                                           pooled_width, int(sampling_ratio), L.ptr(gin), L.stream()),
+            "roi_align_backward")
+    return gin
+
+
+def _nms(dets, scores, threshold, mode):
+    L.need_gpu(dets, scores)
+    n = dets.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dets.device)
+    dets = dets.contiguous().float()
+    scores = scores.contiguous().float()
+    keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
+    nkeep = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    nbytes = L.lib().odw_nms_workspace(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dets.device)
+    L.check(L.lib().odw_nms(L.ptr(dets), L.ptr(scores), n, float(threshold), _NMS_MODE[mode], L.ptr(keep),
+                            L.ptr(nkeep), L.ptr(ws), nbytes, L.stream()), "nms")
+    return keep[: int(nkeep.item())]
+
+
+def nms(dets, scores, threshold):
+    """wetectron `_C.nms` on a GPU tensor: +1 areas, `>` rule, ascending kept indices
+    (csrc/nms.h:10-28 -> csrc/cuda/nms.cu:60,127-130)."""
+    return _nms(dets, scores, threshold, "wt_gt")
+
+
+def nms_cpu_rule(dets, scores, threshold):
+    """Same, with the `>=` rule of csrc/cpu/nms_cpu.cpp:60."""
+    return _nms(dets, scores, threshold, "wt_ge")
+
+
+def nms_torchvision(boxes, scores, iou_threshold):
+    """torchvision.ops.nms semantics (the reference's live path, structures/boxlist_ops.py:57)."""
+    return _nms(boxes, scores, iou_threshold, "tv")
+
+
+def box_iou(a, b):
+    """boxlist_iou on raw (N,4)/(M,4) xyxy tensors (structures/boxlist_ops.py:127-160)."""
+    L.need_gpu(a, b)
+    a = a.contiguous().float()
+    b = b.contiguous().float()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    if out.numel():
+        L.check(L.lib().odw_box_iou(L.ptr(a), a.shape[0], L.ptr(b), b.shape[0], L.ptr(out), L.stream()),
+                "box_iou")
+    return out
+
+
+def pairwise_sim(E):
+    """E E^T (roi_heads/weak_head/loss.py:319)."""
+    L.need_gpu(E)
+    E = E.contiguous().float()
+    P, D = E.shape
+    S = torch.empty((P, P), dtype=torch.float32, device=E.device)
+    if P:
+        L.check(L.lib().odw_pairwise_sim(L.ptr(E), P, D, L.ptr(S), L.stream()), "pairwise_sim")
+    return S
+
+
+def supcon_v2(F, labels, weights, temperature, grad_scale=1.0, need_grad=True):
+    """-> (loss scalar tensor, dF or None).  roi_heads/sim_head/sim_loss.py:49-80."""
+    L.need_gpu(F, labels, weights)
+    F = F.contiguous().float()
+    labels = labels.contiguous().to(torch.int32)
+    weights = weights.contiguous().float()
+    N, D = F.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=F.device)
+    dF = torch.empty_like(F) if need_grad else None
+    nbytes = L.lib().odw_supcon_workspace(N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=F.device)
+    L.check(L.lib().odw_supcon_v2(L.ptr(F), L.ptr(labels), L.ptr(weights), N, D, float(temperature),
+                                  float(grad_scale), L.ptr(loss), L.ptr(dF), L.ptr(ws), nbytes, L.stream()),
+            "supcon_v2")
+    return loss[0], dF

@@ -1,0 +1,74 @@
+"""ctypes binding of libodwscl.so (the C-ABI in include/odwscl.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every
+operator below hands raw device pointers + the current stream to the hand
+written gfx950 kernels.  There is NO fallback: if the shared object is missing
+or a tensor is not on the GPU the call raises (the reference raises
+"Not implemented on the CPU" the same way, csrc/ROIPool.h:23).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libodwscl.so")
+_lib = None
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/odwscl.h declares
+SIGNATURES = {
+    "odw_last_error": (ctypes.c_char_p, []),
+    "odw_version": (c_i, []),
+    "odw_roi_pool_workspace": (c_l, [c_i, c_i, c_i]),
+    "odw_roi_pool_forward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_p]),
+    "odw_roi_pool_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_roi_align_forward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_roi_align_backward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_nms_workspace": (c_l, [c_i]),
+    "odw_nms": (c_i, [c_p, c_p, c_i, c_f, c_i, c_p, c_p, c_p, c_l, c_p]),
+    "odw_box_iou": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
+    "odw_pairwise_sim": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    "odw_supcon_workspace": (c_l, [c_i]),
+    "odw_supcon_v2": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_l, c_p]),
+}
+
+
+def lib():
+    """Load (once) and return the shared object; raises if it was never built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libodwscl.so is missing (%s): build it with `python -m od_wscl_amd._build` -- "
+                "there is no CPU/PyTorch fallback for the hot path" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, code, lib().odw_last_error().decode()))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("od_wscl_amd: tensor is not on the GPU -- the hot path has no CPU implementation")

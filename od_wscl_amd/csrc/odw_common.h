@@ -1,0 +1,45 @@
+// odw_common.h -- shared helpers for libodwscl.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/odwscl.h"
+
+#define ODW_EXPORT extern "C" __attribute__((visibility("default")))
+
+// thread-local last-error message (the only mutable state in the library)
+void odw_set_error(const char* fmt, ...);
+
+#define ODW_REQUIRE(cond, ...)                    \
+    do {                                          \
+        if (!(cond)) {                            \
+            odw_set_error(__VA_ARGS__);           \
+            return ODW_EINVAL;                    \
+        }                                         \
+    } while (0)
+
+#define ODW_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            odw_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return ODW_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+#define ODW_CHECK_HIP(expr, name)                                        \
+    do {                                                                 \
+        hipError_t e_ = (expr);                                          \
+        if (e_ != hipSuccess) {                                          \
+            odw_set_error("%s: %s", name, hipGetErrorString(e_));        \
+            return ODW_ELAUNCH;                                          \
+        }                                                                \
+    } while (0)
+
+__host__ __device__ static inline int64_t odw_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// MI355X constants used for launch geometry
+constexpr int ODW_NUM_CU = 256;
+constexpr int ODW_LDS_BYTES = 160 * 1024;
+constexpr int ODW_WAVE = 64;

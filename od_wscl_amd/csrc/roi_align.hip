@@ -1,0 +1,280 @@
+// roi_align.hip -- ROIAlign forward/backward for gfx950 (legacy, un-aligned
+// sampling: wetectron/csrc/cuda/ROIAlign_cuda.cu:16-254 ==
+// csrc/cpu/ROIAlign_cpu.cpp:18-219).
+//
+// Same plane-resident structure as roi_pool.hip: CG channel planes of one
+// image sit in LDS, every ROI of the image is served from there (bilinear
+// gather in LDS, coalesced HBM reads of the planes only); backward scatters
+// the 4 taps with LDS float atomics and writes each plane back once.
+// Built with -ffp-contract=off: the sample coordinate
+//   start + ph*bin + (iy+.5)*bin/grid          (ROIAlign_cuda.cu:109-112)
+// must be evaluated as separate fp32 mul/add/div, not FMA, to land on the
+// same side of integer boundaries as the reference.
+#include "odw_common.h"
+
+namespace {
+
+constexpr int kPlaneThreads = 1024;
+
+struct RoiGeom {
+    int b;
+    float sw, sh, bin_w, bin_h;
+    int gw, gh;
+    float count;
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ roi, float scale, int PH, int PW,
+                                            int sampling_ratio) {
+    RoiGeom g;
+    g.b = (int)roi[0];
+    g.sw = roi[1] * scale;
+    g.sh = roi[2] * scale;
+    float ew = roi[3] * scale, eh = roi[4] * scale;
+    float rw = fmaxf(ew - g.sw, 1.0f), rh = fmaxf(eh - g.sh, 1.0f);
+    g.bin_h = rh / (float)PH;
+    g.bin_w = rw / (float)PW;
+    g.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+    g.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+    g.count = (float)(g.gh * g.gw);
+    return g;
+}
+
+// 4 taps of one bilinear sample; false = outside [-1,H]x[-1,W]
+__device__ __forceinline__ bool taps(int H, int W, float y, float x, int pos[4], float wg[4]) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return false;
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
+    float ly = y - (float)yl, lx = x - (float)xl;
+    float hy = 1.0f - ly, hx = 1.0f - lx;
+    pos[0] = yl * W + xl; pos[1] = yl * W + xh; pos[2] = yh * W + xl; pos[3] = yh * W + xh;
+    wg[0] = hy * hx; wg[1] = hy * lx; wg[2] = ly * hx; wg[3] = ly * lx;
+    return true;
+}
+
+__device__ __forceinline__ float align_one(const float* p, const RoiGeom& g, int H, int W, int ph, int pw) {
+    float acc = 0.0f;
+    for (int iy = 0; iy < g.gh; ++iy) {
+        float y = g.sh + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)g.gh;
+        for (int ix = 0; ix < g.gw; ++ix) {
+            float x = g.sw + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)g.gw;
+            int pos[4]; float wg[4];
+            if (!taps(H, W, y, x, pos, wg)) continue;
+            acc += wg[0] * p[pos[0]] + wg[1] * p[pos[1]] + wg[2] * p[pos[2]] + wg[3] * p[pos[3]];
+        }
+    }
+    return acc / g.count;
+}
+
+template <typename AddFn>
+__device__ __forceinline__ void align_scatter(const RoiGeom& g, int H, int W, int ph, int pw, float go,
+                                              AddFn add) {
+    for (int iy = 0; iy < g.gh; ++iy) {
+        float y = g.sh + (float)ph * g.bin_h + ((float)iy + 0.5f) * g.bin_h / (float)g.gh;
+        for (int ix = 0; ix < g.gw; ++ix) {
+            float x = g.sw + (float)pw * g.bin_w + ((float)ix + 0.5f) * g.bin_w / (float)g.gw;
+            int pos[4]; float wg[4];
+            if (!taps(H, W, y, x, pos, wg)) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) add(pos[k], go * wg[k] / g.count);  // ROIAlign_cuda.cu:237-240
+        }
+    }
+}
+
+template <int CG>
+__global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(
+    const float* __restrict__ feat, const float* __restrict__ rois, float scale, int C, int H, int W,
+    int R, int PH, int PW, int sr, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float plane[];
+    const int groups = (C + CG - 1) / CG;
+    const int b = blockIdx.x / groups;
+    const int c0 = (blockIdx.x % groups) * CG;
+    const int nc = min(CG, C - c0);
+    const int HW = H * W;
+    {
+        const float* src = feat + ((size_t)b * C + c0) * HW;
+        const int count = nc * HW;
+        if ((((uintptr_t)src) & 15) == 0 && (count & 3) == 0) {
+            for (int i = threadIdx.x; i < count / 4; i += blockDim.x)
+                reinterpret_cast<float4*>(plane)[i] = reinterpret_cast<const float4*>(src)[i];
+        } else {
+            for (int i = threadIdx.x; i < count; i += blockDim.x) plane[i] = src[i];
+        }
+    }
+    __syncthreads();
+    const int nb = PH * PW, per_roi = nc * nb;
+    int n = threadIdx.x / per_roi, r = threadIdx.x % per_roi;
+    const int dn = kPlaneThreads / per_roi, dr = kPlaneThreads % per_roi;
+    for (; n < R; n += dn, r += dr) {
+        if (r >= per_roi) { r -= per_roi; ++n; if (n >= R) break; }
+        const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
+        if (g.b != b) continue;
+        const int cl = r / nb, bin = r - cl * nb;
+        const int ph = bin / PW, pw = bin - ph * PW;
+        out[((size_t)n * C + c0 + cl) * nb + bin] = align_one(plane + cl * HW, g, H, W, ph, pw);
+    }
+}
+
+__global__ void roi_align_fwd_direct(const float* __restrict__ feat, const float* __restrict__ rois,
+                                     float scale, int C, int H, int W, int R, int PH, int PW, int sr,
+                                     float* __restrict__ out) {
+    const int nb = PH * PW;
+    const size_t total = (size_t)R * C * nb;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int bin = (int)(i % nb), c = (int)((i / nb) % C), n = (int)(i / nb / C);
+        const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
+        int ph = bin / PW, pw = bin - ph * PW;
+        out[i] = align_one(feat + ((size_t)g.b * C + c) * H * W, g, H, W, ph, pw);
+    }
+}
+
+template <int CG>
+__global__ __launch_bounds__(kPlaneThreads) void roi_align_bwd_plane(
+    const float* __restrict__ grad_out, const float* __restrict__ rois, float scale, int C, int H, int W,
+    int R, int PH, int PW, int sr, float* __restrict__ grad_in) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int groups = (C + CG - 1) / CG;
+    const int b = blockIdx.x / groups;
+    const int c0 = (blockIdx.x % groups) * CG;
+    const int nc = min(CG, C - c0);
+    const int HW = H * W;
+    for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) acc[i] = 0.0f;
+    __syncthreads();
+    const int nb = PH * PW, per_roi = nc * nb;
+    int n = threadIdx.x / per_roi, r = threadIdx.x % per_roi;
+    const int dn = kPlaneThreads / per_roi, dr = kPlaneThreads % per_roi;
+    for (; n < R; n += dn, r += dr) {
+        if (r >= per_roi) { r -= per_roi; ++n; if (n >= R) break; }
+        const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
+        if (g.b != b) continue;
+        const int cl = r / nb, bin = r - cl * nb;
+        const int ph = bin / PW, pw = bin - ph * PW;
+        float* p = acc + cl * HW;
+        const float go = grad_out[((size_t)n * C + c0 + cl) * nb + bin];
+        align_scatter(g, H, W, ph, pw, go, [p](int pos, float v) { atomicAdd(p + pos, v); });
+    }
+    __syncthreads();
+    float* dst = grad_in + ((size_t)b * C + c0) * HW;
+    for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) dst[i] = acc[i];
+}
+
+__global__ void roi_align_bwd_direct(const float* __restrict__ grad_out, const float* __restrict__ rois,
+                                     float scale, int C, int H, int W, int R, int PH, int PW, int sr,
+                                     float* __restrict__ grad_in) {
+    const int nb = PH * PW;
+    const size_t total = (size_t)R * C * nb;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int bin = (int)(i % nb), c = (int)((i / nb) % C), n = (int)(i / nb / C);
+        const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
+        int ph = bin / PW, pw = bin - ph * PW;
+        float* p = grad_in + ((size_t)g.b * C + c) * H * W;
+        align_scatter(g, H, W, ph, pw, grad_out[i], [p](int pos, float v) { atomicAdd(p + pos, v); });
+    }
+}
+
+int pick_cg(int B, int C, int HW) {
+    const int cands[3] = {4, 2, 1};
+    int fit = 0;
+    for (int k = 0; k < 3; ++k) {
+        int cg = cands[k];
+        if ((int64_t)cg * HW * 4 > ODW_LDS_BYTES) continue;
+        if (!fit) fit = cg;
+        if ((int64_t)B * ((C + cg - 1) / cg) >= ODW_NUM_CU) return cg;
+    }
+    return fit ? 1 : 0;
+}
+
+template <typename K>
+hipError_t allow_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+ODW_EXPORT int odw_roi_align_forward(const float* feat, const float* rois, float scale, int B, int C,
+                                     int H, int W, int R, int PH, int PW, int sr, float* out,
+                                     void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 0,
+                "roi_align_forward: bad dims");
+    if (R == 0 || B == 0) return ODW_OK;
+    ODW_REQUIRE(feat && rois && out, "roi_align_forward: null pointer");
+    ODW_REQUIRE(PH * PW <= kPlaneThreads / 4, "roi_align_forward: pooled size too large");
+    const int HW = H * W;
+    const int cg = pick_cg(B, C, HW);
+    if (cg == 0) {
+        size_t total = (size_t)R * C * PH * PW;
+        int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        roi_align_fwd_direct<<<grid, 256, 0, stream>>>(feat, rois, scale, C, H, W, R, PH, PW, sr, out);
+        ODW_CHECK_LAUNCH("roi_align_fwd_direct");
+        return ODW_OK;
+    }
+    const int grid = B * ((C + cg - 1) / cg);
+    const size_t lds = (size_t)cg * HW * 4;
+    switch (cg) {
+        case 4:
+            ODW_CHECK_HIP(allow_lds(roi_align_fwd_plane<4>, lds), "roi_align_fwd_plane attr");
+            roi_align_fwd_plane<4><<<grid, kPlaneThreads, lds, stream>>>(feat, rois, scale, C, H, W, R, PH, PW, sr, out);
+            break;
+        case 2:
+            ODW_CHECK_HIP(allow_lds(roi_align_fwd_plane<2>, lds), "roi_align_fwd_plane attr");
+            roi_align_fwd_plane<2><<<grid, kPlaneThreads, lds, stream>>>(feat, rois, scale, C, H, W, R, PH, PW, sr, out);
+            break;
+        default:
+            ODW_CHECK_HIP(allow_lds(roi_align_fwd_plane<1>, lds), "roi_align_fwd_plane attr");
+            roi_align_fwd_plane<1><<<grid, kPlaneThreads, lds, stream>>>(feat, rois, scale, C, H, W, R, PH, PW, sr, out);
+            break;
+    }
+    ODW_CHECK_LAUNCH("roi_align_fwd_plane");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_roi_align_backward(const float* grad_out, const float* rois, float scale, int B, int C,
+                                      int H, int W, int R, int PH, int PW, int sr, float* grad_in,
+                                      void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 0,
+                "roi_align_backward: bad dims");
+    if (B == 0) return ODW_OK;
+    ODW_REQUIRE(grad_in, "roi_align_backward: null grad_in");
+    const size_t in_bytes = (size_t)B * C * H * W * 4;
+    if (R == 0) {
+        ODW_CHECK_HIP(hipMemsetAsync(grad_in, 0, in_bytes, stream), "roi_align_backward memset");
+        return ODW_OK;
+    }
+    ODW_REQUIRE(grad_out && rois, "roi_align_backward: null pointer");
+    ODW_REQUIRE(PH * PW <= kPlaneThreads / 4, "roi_align_backward: pooled size too large");
+    const int HW = H * W;
+    const int cg = pick_cg(B, C, HW);
+    if (cg == 0) {
+        ODW_CHECK_HIP(hipMemsetAsync(grad_in, 0, in_bytes, stream), "roi_align_backward memset");
+        size_t total = (size_t)R * C * PH * PW;
+        int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        roi_align_bwd_direct<<<grid, 256, 0, stream>>>(grad_out, rois, scale, C, H, W, R, PH, PW, sr, grad_in);
+        ODW_CHECK_LAUNCH("roi_align_bwd_direct");
+        return ODW_OK;
+    }
+    const int grid = B * ((C + cg - 1) / cg);
+    const size_t lds = (size_t)cg * HW * 4;
+    switch (cg) {
+        case 4:
+            ODW_CHECK_HIP(allow_lds(roi_align_bwd_plane<4>, lds), "roi_align_bwd_plane attr");
+            roi_align_bwd_plane<4><<<grid, kPlaneThreads, lds, stream>>>(grad_out, rois, scale, C, H, W, R, PH, PW, sr, grad_in);
+            break;
+        case 2:
+            ODW_CHECK_HIP(allow_lds(roi_align_bwd_plane<2>, lds), "roi_align_bwd_plane attr");
+            roi_align_bwd_plane<2><<<grid, kPlaneThreads, lds, stream>>>(grad_out, rois, scale, C, H, W, R, PH, PW, sr, grad_in);
+            break;
+        default:
+            ODW_CHECK_HIP(allow_lds(roi_align_bwd_plane<1>, lds), "roi_align_bwd_plane attr");
+            roi_align_bwd_plane<1><<<grid, kPlaneThreads, lds, stream>>>(grad_out, rois, scale, C, H, W, R, PH, PW, sr, grad_in);
+            break;
+    }
+    ODW_CHECK_LAUNCH("roi_align_bwd_plane");
+    return ODW_OK;
+}

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ops_golden():
+    return np.load(os.path.join(GOLDEN, "ops_ref.npz"))
+
+
+@pytest.fixture(scope="session")
+def weights_np():
+    """The one formula-generated weight set every e2e golden was produced with (WEIGHT_SEED=1)."""
+    from od_wscl_amd import synthetic
+    from oracle import hotpath_ref as H
+    return synthetic.init_state_dict(H.param_shapes(21), 1,
+                                     overrides={"predictor": 0.002, "model_sim.mlp.2": 0.05})
+
+
+def load_e2e(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def e2e_inputs(g):
+    """Rebuild the formula-generated inputs of an e2e golden from its recipe."""
+    import torch
+    from od_wscl_amd import synthetic
+    seed = int(g["spec_seed"])
+    specs = g["spec_images"]
+    cnt, flat = g["spec_labels_count"], g["spec_labels_flat"]
+    hm = max(synthetic.pad_to(int(h)) for h, w, p in specs)
+    wm = max(synthetic.pad_to(int(w)) for h, w, p in specs)
+    batch = torch.zeros(len(specs), 3, hm, wm)
+    boxes, labels, o = [], [], 0
+    for k, (h, w, p) in enumerate(specs):
+        h, w, p = int(h), int(w), int(p)
+        batch[k, :, :h, :w] = torch.from_numpy(synthetic.make_image(seed, k, h, w)[:, :h, :w].copy())
+        boxes.append(torch.from_numpy(synthetic.make_proposals(seed, k, p, h, w, min_size=12)))
+        labels.append(torch.tensor(flat[o:o + cnt[k]], dtype=torch.int64))
+        o += cnt[k]
+    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler=str(g["spec_pooler"]), scale=0.125,
+               sampling_ratio=0)
+    return seed, batch, boxes, labels, cfg

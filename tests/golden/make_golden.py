@@ -1,0 +1,281 @@
+"""Generate the committed golden vectors by running the REFERENCE in this container.
+
+Usage (only where /root/reference exists):   python tests/golden/make_golden.py
+
+The reference Python is imported read-only through oracle/refimport.py (stub
+packages for absent third-party modules, no reference code copied).  What is
+stored is DATA: small inputs, or the seed/shape recipe of formula-generated
+inputs, plus the reference's outputs.  The GPU box never sees the reference.
+
+Files written next to this script:
+  ops_ref.npz   per-operator vectors from the reference's own code:
+                  - roi_align_forward  : compiled csrc/cpu/ROIAlign_cpu.cpp (oracle/_ref)
+                  - nms (>= rule)      : compiled csrc/cpu/nms_cpu.cpp      (oracle/_ref)
+                  - boxlist_iou, cal_iou, easy_nms, BoxCoder.encode, smooth_l1_loss,
+                    DropBlock2D (given the uniform draw), od_layer, SupConLossV2 fwd + autograd
+  e2e_*.npz     full train-mode forward+backward of build_detection_model(cfg) on
+                formula-generated inputs: 8 losses, 4 accuracies, selected index sets,
+                per-parameter gradient norms.  Randomness is injected (see _inject_rng).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import refimport  # noqa: E402
+from od_wscl_amd import synthetic  # noqa: E402
+from od_wscl_amd.utils import rng  # noqa: E402
+
+E2E_CASES = {
+    # name: (seed, [(H, W, P)], num_classes, pooler)
+    "e2e_voc_2img": dict(seed=7, images=[(96, 128, 48), (80, 112, 40)], labels=[[3, 9], [9]], pooler="ROIPool"),
+    "e2e_voc_1img": dict(seed=11, images=[(128, 128, 64)], labels=[[5]], pooler="ROIPool"),
+    "e2e_align_1img": dict(seed=13, images=[(96, 96, 32)], labels=[[2, 17]], pooler="ROIAlign"),
+}
+# predictor / Sim_Net scales that give well separated scores (the reference's N(0,0.001)
+# predictor init makes every score nearly tied, which no fp32 re-ordering survives)
+OVERRIDES = {"predictor": 0.002, "model_sim.mlp.2": 0.05}
+WEIGHT_SEED = 1   # one weight set for every e2e case (tests cache it)
+CFG_OPTS = ["nms", 0.1, "lmda", 0.03, "temp", 0.2]
+
+
+def edge_rois():
+    """ROIs exercising rounding (x.5 after scaling), degenerate, out-of-bounds, full-image cases."""
+    return np.array([
+        [0, 0, 0, 95, 79], [0, 4, 4, 12, 12], [0, 12, 20, 52, 60], [1, 3.9, 4.1, 60.2, 70.7],
+        [1, 20, 20, 20, 20], [0, 30, 30, 10, 10], [1, -40, -40, 20, 20], [0, 80, 60, 200, 200],
+        [0, 2, 6, 10, 14], [1, 18, 22, 50, 58], [0, 90, 70, 95, 79], [1, 0, 0, 7, 7],
+        [0, 1000, 1000, 1100, 1100], [1, 44, 36, 84, 76], [0, 6, 2, 90, 10], [1, 5, 5, 9, 75],
+    ], np.float32)
+
+
+def gen_ops(out):
+    w = refimport.load_reference()
+    ref_c = refimport._STATE["ref_c"]
+    g = {}
+    # ---- ROIAlign forward from the reference's compiled CPU kernel
+    feat = rng.normal(3, 1, 2 * 5 * 10 * 12).reshape(2, 5, 10, 12)
+    rois = edge_rois()
+    extra = np.concatenate([np.zeros((24, 1), np.float32), synthetic.make_proposals(3, 0, 24, 80, 96, min_size=4)], 1)
+    extra[::2, 0] = 1
+    rois = np.concatenate([rois, extra], 0)
+    g["ra_feat"], g["ra_rois"] = feat, rois
+    for sr in (0, 2):
+        for scale in (0.125, 0.25):
+            o = ref_c.roi_align_forward(torch.from_numpy(feat), torch.from_numpy(rois), scale, 7, 7, sr)
+            g["ra_out_sr%d_s%g" % (sr, scale)] = o.numpy()
+    o = ref_c.roi_align_forward(torch.from_numpy(feat), torch.from_numpy(rois), 0.125, 3, 5, 0)
+    g["ra_out_3x5"] = o.numpy()
+    # ---- NMS from the reference's compiled CPU kernel (>= rule, +1 areas, ascending output)
+    boxes = synthetic.make_proposals(5, 0, 300, 200, 300, min_size=8)
+    scores = rng.uniform(5, 2, 300)
+    scores[10:20] = scores[10]          # ties
+    g["nms_boxes"], g["nms_scores"] = boxes, scores
+    for thr in (0.1, 0.3, 0.5, 0.7):
+        g["nms_keep_ge_%g" % thr] = ref_c.nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr).numpy()
+    # exact-threshold case: two boxes whose +1 IoU is exactly 0.5
+    eb = np.array([[0, 0, 9, 9], [0, 0, 9, 4], [20, 20, 29, 29]], np.float32)
+    es = np.array([0.9, 0.8, 0.7], np.float32)
+    g["nms_eq_boxes"], g["nms_eq_scores"] = eb, es
+    g["nms_eq_keep_ge"] = ref_c.nms(torch.from_numpy(eb), torch.from_numpy(es), 0.5).numpy()
+
+    # ---- Python-side helpers of the reference
+    from wetectron.structures.bounding_box import BoxList
+    from wetectron.structures.boxlist_ops import boxlist_iou
+    from wetectron.utils.utils import cal_iou, easy_nms
+    from wetectron.modeling.box_coder import BoxCoder
+    from wetectron.layers import smooth_l1_loss
+    a = synthetic.make_proposals(6, 0, 40, 120, 160, min_size=8)
+    b = synthetic.make_proposals(6, 1, 7, 120, 160, min_size=8)
+    bl_a, bl_b = BoxList(torch.from_numpy(a), (160, 120), "xyxy"), BoxList(torch.from_numpy(b), (160, 120), "xyxy")
+    g["iou_a"], g["iou_b"] = a, b
+    g["iou_ab"] = boxlist_iou(bl_a, bl_b).numpy()
+    idx, sc = cal_iou(bl_a, torch.tensor(3), 0.5)
+    g["cal_iou_idx"], g["cal_iou_score"] = idx.numpy(), sc.numpy()
+    cluster = torch.arange(0, 40, 2)
+    csc = torch.from_numpy(rng.uniform(6, 5, 40))
+    g["easy_nms_scores"] = csc.numpy()
+    g["easy_nms_cluster"] = cluster.numpy()
+    g["easy_nms_out"] = easy_nms(bl_a, cluster, csc, nms_iou=0.1).numpy()
+    coder = BoxCoder(weights=(10.0, 10.0, 5.0, 5.0))
+    g["encode_out"] = coder.encode(torch.from_numpy(a[:7]), torch.from_numpy(b)).numpy()
+    x = torch.from_numpy(rng.normal(6, 7, 60).reshape(15, 4) * 2)
+    t = torch.from_numpy(rng.normal(6, 8, 60).reshape(15, 4))
+    g["sl1_x"], g["sl1_t"] = x.numpy(), t.numpy()
+    g["sl1_out"] = smooth_l1_loss(x, t, beta=1, reduction=False).numpy()
+
+    # ---- DropBlock2D given the uniform draw
+    from wetectron.modeling.dropblock.drop_block import DropBlock2D
+    xin = torch.from_numpy(rng.normal(8, 1, 6 * 4 * 7 * 7).reshape(6, 4, 7, 7))
+    for bs in (1, 3):
+        u = torch.from_numpy(rng.uniform(8, 10 + bs, 6 * 7 * 7).reshape(6, 7, 7))
+        real_rand = torch.rand
+        torch.rand = lambda *s, **k: u
+        try:
+            db = DropBlock2D(drop_prob=0.3, block_size=bs)
+            db.train()
+            g["db_out_bs%d" % bs] = db(xin).numpy()
+        finally:
+            torch.rand = real_rand
+        g["db_u_bs%d" % bs] = u.numpy()
+    g["db_x"] = xin.numpy()
+
+    # ---- SupConLossV2 forward + autograd backward
+    from wetectron.modeling.roi_heads.sim_head.sim_loss import SupConLossV2
+    crit = SupConLossV2(0.2)
+    for name, n, ncls in (("a", 7, 2), ("b", 64, 3), ("c", 300, 5), ("d", 97, 20)):
+        Fm = rng.normal(9, ord(name), n * 128).reshape(n, 128)
+        Fm /= np.linalg.norm(Fm, axis=1, keepdims=True)
+        # class-major grouping like pgt_update: sizes differ per class, every class >= 2 rows
+        cuts = np.sort((rng.uniform(9, 100 + ord(name), ncls - 1) * (n - 2 * ncls)).astype(np.int64)) + 2 * np.arange(1, ncls)
+        cuts = np.concatenate([[0], cuts, [n]])
+        ft = torch.from_numpy(Fm.copy()).requires_grad_(True)
+        enc = [ft[cuts[c]:cuts[c + 1]] for c in range(ncls)]
+        wts = torch.from_numpy(rng.uniform(9, 200 + ord(name), n))
+        loss = crit(enc, wts, "cpu")
+        loss.backward()
+        labels = np.concatenate([np.full(cuts[c + 1] - cuts[c], c, np.int32) for c in range(ncls)])
+        g["sc_%s_F" % name], g["sc_%s_labels" % name], g["sc_%s_w" % name] = Fm, labels, wts.numpy()
+        g["sc_%s_loss" % name], g["sc_%s_dF" % name] = loss.item(), ft.grad.numpy()
+
+    # ---- od_layer
+    from wetectron.modeling.roi_heads.weak_head.pseudo_label_generator import od_layer
+    refimport.reference_cfg(opts=CFG_OPTS)
+    layer = od_layer()
+    P, C = 40, 21
+    score = torch.softmax(torch.from_numpy(rng.normal(10, 1, P * C).reshape(P, C) * 3), dim=1)
+    labvec = torch.zeros(C)
+    labvec[[4, 11]] = 1
+    pgt = [torch.zeros(0, dtype=torch.long) for _ in range(C - 1)]
+    pgt[3] = torch.tensor([5, 17, 2])
+    pgt[10] = torch.tensor([int(torch.argmax(score[:, 11]))])
+    pl, lw, rt = layer(bl_a, score, labvec, "cpu", pgt, return_targets=True)
+    g["od_score"], g["od_labvec"] = score.numpy(), labvec.numpy()
+    g["od_pgt3"], g["od_pgt10"] = pgt[3].numpy(), pgt[10].numpy()
+    g["od_pseudo"], g["od_weights"], g["od_targets"] = pl.numpy(), lw.numpy(), rt.numpy()
+    np.savez_compressed(out, **g)
+    print("wrote", out, len(g), "arrays")
+
+
+# --------------------------------------------------------------------------------- e2e
+class _DetDropout(torch.nn.Module):
+    def __init__(self, rand, p=0.5):
+        super().__init__()
+        self.rand, self.p = rand, p
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        return self.rand.dropout(x, self.p)
+
+
+def _inject_rng(model, rand):
+    """Replace the reference's three random sources with the counter-based generator, consumed
+    in the reference's own call order: nn.Dropout (vgg16.py:124,127), torch.rand
+    (drop_block.py:42), torch.normal (vgg16.py:178)."""
+    cl = model.roi_heads.feature_extractor.classifier
+    cl[3] = _DetDropout(rand)
+    cl[6] = _DetDropout(rand)
+    real = (torch.rand, torch.normal)
+    torch.rand = lambda *shape, **k: rand.uniform(tuple(shape))
+    torch.normal = lambda mean, std, size=None, **k: rand.normal(tuple(size)) * std + mean
+    return real
+
+
+def gen_e2e(name, spec, out):
+    from oracle import hotpath_ref as H
+    refimport.load_reference()
+    from wetectron.structures.bounding_box import BoxList
+    from wetectron.structures.image_list import to_image_list
+    cfg = refimport.reference_cfg(opts=CFG_OPTS + ["MODEL.ROI_BOX_HEAD.POOLER_METHOD", spec["pooler"]])
+    model = refimport.build_reference_model(cfg)
+    model.train()
+    seed = spec["seed"]
+    shapes = [(n, tuple(p.shape)) for n, p in model.named_parameters()]
+    assert [s[0] for s in shapes] == [s[0] for s in H.param_shapes(21)], "parameter naming drifted"
+    sd = synthetic.init_state_dict(shapes, WEIGHT_SEED, overrides=OVERRIDES)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(sd[n]))
+    imgs, rois, targets, boxes_np = [], [], [], []
+    for k, (h, w, pcount) in enumerate(spec["images"]):
+        imgs.append(torch.from_numpy(synthetic.make_image(seed, k, h, w)[:, :h, :w].copy()))
+        bx = synthetic.make_proposals(seed, k, pcount, h, w, min_size=12)
+        boxes_np.append(bx)
+        rois.append(BoxList(torch.from_numpy(bx), (w, h), "xyxy"))
+        t = BoxList(torch.zeros((len(spec["labels"][k]), 4)), (w, h), "xyxy")
+        t.add_field("labels", torch.tensor(spec["labels"][k], dtype=torch.int64))
+        targets.append(t)
+    images = to_image_list(imgs, 32)
+    rand = H.Rand(seed)
+    real = _inject_rng(model, rand)
+    rec = {}
+    # record the reference's own intermediate selections
+    import wetectron.modeling.roi_heads.weak_head.loss as L
+    real_od = model.roi_heads.loss_evaluator.od_layer
+    calls = []
+
+    def od_spy(proposals, source_score, labels, device, pgt_instance, return_targets=False):
+        r = real_od(proposals, source_score, labels, device, pgt_instance, return_targets=return_targets)
+        calls.append((r[0].clone(), r[1].clone(), [p.clone() for p in pgt_instance]))
+        return r
+    model.roi_heads.loss_evaluator.od_layer = od_spy
+    real_sim = model.roi_heads.loss_evaluator.sim_loss.forward
+
+    def sim_spy(enc, col, device):
+        rec["supcon_n"] = np.array(sum(e.shape[0] for e in enc))
+        rec["supcon_weights"] = col.detach().numpy().copy()
+        rec["supcon_class_sizes"] = np.array([e.shape[0] for e in enc])
+        return real_sim(enc, col, device)
+    model.roi_heads.loss_evaluator.sim_loss.forward = sim_spy
+    try:
+        losses, accs = model(images, targets, rois, iteration={"iter": 1})
+        total = sum(losses.values())
+        total.backward()
+    finally:
+        torch.rand, torch.normal = real
+    n_ref = 3
+    for idx in range(len(imgs)):
+        for i in range(n_ref):
+            pl, lw, pgt = calls[idx * n_ref + i]
+            rec["pseudo_%d_%d" % (idx, i)] = pl.numpy()
+            rec["weights_%d_%d" % (idx, i)] = lw.numpy()
+            for c, p in enumerate(pgt):
+                if p.numel():
+                    rec["pgt_instance_%d_%d_%d" % (idx, i, c)] = p.numpy()
+    for k, v in losses.items():
+        rec["loss/" + k] = np.float64(v.item())
+    for k, v in accs.items():
+        rec["acc/" + k] = np.float64(float(v))
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            rec["gradnorm/" + n] = np.float64(p.grad.double().norm().item())
+            rec["gradsum/" + n] = np.float64(p.grad.double().sum().item())
+    rec["spec_seed"] = np.array(seed)
+    rec["spec_images"] = np.array(spec["images"])
+    rec["spec_pooler"] = np.array(spec["pooler"])
+    rec["spec_labels_flat"] = np.array([l for ls in spec["labels"] for l in ls])
+    rec["spec_labels_count"] = np.array([len(ls) for ls in spec["labels"]])
+    rec["streams_used"] = np.array(rand.s.next)
+    np.savez_compressed(out, **rec)
+    print("wrote", out)
+    for k in sorted(rec):
+        if k.startswith(("loss/", "acc/")):
+            print("   %-22s %.9g" % (k, rec[k]))
+    print("   supcon N =", rec["supcon_n"], "class sizes", rec["supcon_class_sizes"][rec["supcon_class_sizes"] > 0])
+    return rec
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops"] + list(E2E_CASES)
+    if "ops" in which:
+        gen_ops(os.path.join(HERE, "ops_ref.npz"))
+    for name, spec in E2E_CASES.items():
+        if name in which:
+            gen_e2e(name, spec, os.path.join(HERE, name + ".npz"))

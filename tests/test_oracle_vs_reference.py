@@ -1,0 +1,180 @@
+"""The CPU oracle against vectors produced by the reference itself (tests/golden/).
+
+No GPU.  These tests pin the checker: if they pass, comparing the HIP path with
+the oracle is comparing it with the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import e2e_inputs, load_e2e
+from oracle import hotpath_ref as H
+from oracle import native
+
+
+def test_roi_align_forward_matches_reference_cpu_kernel(ops_golden):
+    g = ops_golden
+    for sr in (0, 2):
+        for scale in (0.125, 0.25):
+            out = native.roi_align_fwd(g["ra_feat"], g["ra_rois"], scale, 7, 7, sr)
+            np.testing.assert_array_equal(out, g["ra_out_sr%d_s%g" % (sr, scale)])
+    np.testing.assert_array_equal(native.roi_align_fwd(g["ra_feat"], g["ra_rois"], 0.125, 3, 5, 0), g["ra_out_3x5"])
+
+
+def test_nms_wetectron_rule_matches_reference_cpu_kernel(ops_golden):
+    g = ops_golden
+    for thr in (0.1, 0.3, 0.5, 0.7):
+        keep = native.nms_wt(g["nms_boxes"], g["nms_scores"], thr, use_ge=True)
+        np.testing.assert_array_equal(keep, g["nms_keep_ge_%g" % thr])
+    np.testing.assert_array_equal(native.nms_wt(g["nms_eq_boxes"], g["nms_eq_scores"], 0.5, True), g["nms_eq_keep_ge"])
+    # the CUDA rule (nms.cu:60, strict >) keeps the box whose IoU equals the threshold
+    assert list(native.nms_wt(g["nms_eq_boxes"], g["nms_eq_scores"], 0.5, False)) == [0, 1, 2]
+    assert list(g["nms_eq_keep_ge"]) == [0, 2]
+
+
+def test_nms_torchvision_semantics_known_answers(ops_golden):
+    # torchvision is absent from the reference tree: known-answer vectors for its documented rule
+    b = np.array([[0, 0, 10, 10], [0, 0, 10, 5], [0, 0, 10, 10], [20, 20, 30, 30]], np.float32)
+    s = np.array([0.5, 0.9, 0.5, 0.1], np.float32)
+    assert list(native.nms_tv(b, s, 0.5)) == [1, 0, 3]        # IoU(1,0)=0.5 is NOT > 0.5; tie 0/2 -> lower index
+    assert list(native.nms_tv(b, s, 0.49)) == [1, 3]
+    assert list(native.nms_tv(b[:0], s[:0], 0.5)) == []
+    g = ops_golden
+    out = g["easy_nms_cluster"][native.nms_tv(g["iou_a"][g["easy_nms_cluster"]], g["easy_nms_scores"][g["easy_nms_cluster"]], 0.1)]
+    np.testing.assert_array_equal(out, g["easy_nms_out"])
+
+
+def test_box_iou_and_cal_iou(ops_golden):
+    g = ops_golden
+    np.testing.assert_array_equal(native.box_iou(g["iou_a"], g["iou_b"]), g["iou_ab"])
+    a = torch.from_numpy(g["iou_a"])
+    np.testing.assert_array_equal(H.boxlist_iou(a, torch.from_numpy(g["iou_b"])).numpy(), g["iou_ab"])
+    iou = H.boxlist_iou(a, a[3].view(1, 4))
+    idx = torch.nonzero(torch.ge(iou, 0.5).max(dim=1)[0]).view(-1)
+    np.testing.assert_array_equal(idx.numpy(), g["cal_iou_idx"])
+
+
+def test_encode_and_smooth_l1(ops_golden):
+    g = ops_golden
+    enc = H.box_encode(torch.from_numpy(g["iou_a"][:7]), torch.from_numpy(g["iou_b"]))
+    np.testing.assert_array_equal(enc.numpy(), g["encode_out"])
+    out = H.smooth_l1(torch.from_numpy(g["sl1_x"]), torch.from_numpy(g["sl1_t"]), 1.0)
+    np.testing.assert_array_equal(out.numpy(), g["sl1_out"])
+
+
+def test_dropblock_given_the_draw(ops_golden):
+    g = ops_golden
+
+    class Fixed(object):
+        def __init__(self, u):
+            self.u = u
+
+        def uniform(self, shape):
+            return torch.from_numpy(self.u)
+    for bs in (1, 3):
+        out = H.dropblock(torch.from_numpy(g["db_x"]), bs, 0.3, Fixed(g["db_u_bs%d" % bs]))
+        np.testing.assert_array_equal(out.numpy(), g["db_out_bs%d" % bs])
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_supcon_v2_forward_and_gradient(ops_golden, name):
+    g = ops_golden
+    F_, y, w = g["sc_%s_F" % name], g["sc_%s_labels" % name], g["sc_%s_w" % name]
+    loss, dF = native.supcon_v2(F_, y, w, 0.2)
+    assert abs(loss - float(g["sc_%s_loss" % name])) <= 2e-6 * abs(float(g["sc_%s_loss" % name]))
+    ref = g["sc_%s_dF" % name]
+    assert np.abs(dF - ref).max() <= 2e-5 * np.abs(ref).max()
+    # torch restatement (class-major features, weights in append order)
+    ft = torch.from_numpy(F_.copy()).requires_grad_(True)
+    enc = [ft[torch.from_numpy(y == c)] for c in range(int(y.max()) + 1)]
+    l2 = H.supcon_v2(enc, torch.from_numpy(w), 0.2)[0]
+    assert abs(l2.item() - float(g["sc_%s_loss" % name])) <= 1e-6 * abs(float(g["sc_%s_loss" % name]))
+
+
+def test_od_layer(ops_golden):
+    g = ops_golden
+    pgt = [torch.zeros(0, dtype=torch.long) for _ in range(20)]
+    pgt[3] = torch.from_numpy(g["od_pgt3"])
+    pgt[10] = torch.from_numpy(g["od_pgt10"])
+    pl, lw, rt = H.od_layer(torch.from_numpy(g["iou_a"]), torch.from_numpy(g["od_score"]),
+                            torch.from_numpy(g["od_labvec"]), pgt)
+    np.testing.assert_array_equal(pl.numpy(), g["od_pseudo"])
+    np.testing.assert_array_equal(lw.numpy(), g["od_weights"])
+    np.testing.assert_array_equal(rt.numpy(), g["od_targets"])
+
+
+def test_roi_pool_known_answers():
+    """ROIPool has no CPU implementation in the reference (csrc/ROIPool.h:23): hand-checked cases of
+    ROIPool_cuda.cu's arithmetic (C round(), +1 extent, floor/ceil bins, first max, empty bin -> 0/-1)."""
+    feat = np.arange(2 * 1 * 4 * 6, dtype=np.float32).reshape(2, 1, 4, 6)
+    feat[1] = -feat[1]
+    rois = np.array([[0, 0, 0, 5, 3],        # scale 1: whole map, 2x3 pooling -> 2x2 bins
+                     [1, 0, 0, 5, 3],        # negative map: first max = top-left of each bin
+                     [0, 2.5, 0.5, 2.5, 0.5],  # round(2.5)=3 (half away from zero), round(.5)=1 -> 1x1 roi
+                     [0, 10, 10, 12, 12]], np.float32)  # outside -> empty bins
+    out, arg = native.roi_pool_fwd(feat, rois, 1.0, 2, 3)
+    np.testing.assert_array_equal(out[0, 0], [[7, 9, 11], [19, 21, 23]])
+    np.testing.assert_array_equal(arg[0, 0], [[7, 9, 11], [19, 21, 23]])
+    np.testing.assert_array_equal(arg[1, 0], [[0, 2, 4], [12, 14, 16]])
+    np.testing.assert_array_equal(out[1, 0], -np.array([[24, 26, 28], [36, 38, 40]], np.float32))
+    assert (out[2, 0] == feat[0, 0, 1, 3]).all() and (arg[2, 0] == 1 * 6 + 3).all()
+    assert (out[3] == 0).all() and (arg[3] == -1).all()
+    gin = native.roi_pool_bwd(np.ones_like(out), arg, rois, feat.shape, 2, 3)
+    assert gin[0, 0, 1, 3] == 6 + 1 and gin[0, 0, 1, 1] == 1 and gin.sum() == 6 + 6 + 6
+
+
+E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img"]
+
+
+@pytest.mark.parametrize("name", E2E)
+def test_end_to_end_matches_imported_reference(name, weights_np):
+    """Full train-mode forward + backward of the restated hot path vs the reference's own run."""
+    g = load_e2e(name)
+    seed, batch, boxes, labels, cfg = e2e_inputs(g)
+    sd = {}
+    for k, v in weights_np.items():
+        t = torch.from_numpy(v.copy())
+        if not k.startswith(H.FROZEN):
+            t.requires_grad_(True)
+        sd[k] = t
+    tr = {}
+    rand = H.Rand(seed)
+    losses, accs = H.forward(batch, boxes, labels, sd, rand, cfg, tr)
+    assert rand.s.next == int(g["streams_used"])           # same number of random draws, same order
+    for k, v in losses.items():
+        ref = float(g["loss/" + k])
+        assert abs(float(v) - ref) <= 1e-5 * max(abs(ref), 1e-6), (k, float(v), ref)
+    for k, v in accs.items():
+        assert abs(float(v) - float(g["acc/" + k])) < 1e-6
+    for k in g.files:                                       # index selection must be bit-exact
+        if k.startswith(("pseudo_", "pgt_instance_")):
+            np.testing.assert_array_equal(tr[k].numpy(), g[k], err_msg=k)
+        if k.startswith("weights_"):
+            np.testing.assert_allclose(tr[k].numpy(), g[k], rtol=1e-5, atol=1e-9)
+    assert int(tr["supcon_n"]) == int(g["supcon_n"])
+    np.testing.assert_allclose(tr["supcon_weights"].numpy(), g["supcon_weights"], rtol=1e-5, atol=1e-12)
+    sum(losses.values()).backward()
+    for n, p in sd.items():
+        key = "gradnorm/" + n
+        if key in g.files:
+            ref = float(g[key])
+            assert abs(p.grad.double().norm().item() - ref) <= 1e-4 * max(ref, 1e-9), n
+        else:
+            assert p.grad is None or n.startswith(H.FROZEN)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/wetectron"), reason="reference tree not present")
+def test_reference_build_exports_expected_functions():
+    """oracle/_ref is the reference's own csrc/cpu compiled in place; it must export the functions
+    the golden vectors were produced with and refuse ROIPool on CPU like the reference does."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import build_ref
+    build_ref.build()
+    m = build_ref.load_ref()
+    assert m is not None
+    for fn in ("nms", "roi_align_forward", "roi_pool_forward", "roi_align_backward"):
+        assert hasattr(m, fn)
+    with pytest.raises(RuntimeError):
+        m.roi_pool_forward(torch.zeros(1, 1, 4, 4), torch.zeros(1, 5), 1.0, 2, 2)
