@@ -103,6 +103,35 @@ int odw_supcon_v2(const float* F, const int32_t* labels, const float* w, int N, 
                   float grad_scale, float* loss, float* dF,
                   void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- counter-based randomness --------------------------------------------------
+ * The reference draws dropout masks and the noise view from torch's device
+ * generator (modeling/backbone/vgg16.py:124,127,177-180) and DropBlock centres
+ * from the CPU generator (modeling/dropblock/drop_block.py:42).  Here every
+ * draw is a pure function of (key, element index); (k0,k1) = the 64-bit key of
+ * a (seed, stream) pair (od_wscl_amd/utils/rng.py:stream_key).
+ *   uniform : out[i] = U[0,1) of element (i + offset)
+ *   normal  : Box-Muller pairs of the stream
+ *   dropout : out = x * [u >= p] / (1 - p); its backward is the same call on the
+ *             gradient with the same key (no mask is stored)
+ *   noise_mul : out = x + N(0,1) * x */
+int odw_rng_uniform(float* out, int64_t n, uint32_t k0, uint32_t k1, uint32_t offset, void* stream);
+int odw_rng_normal(float* out, int64_t n, uint32_t k0, uint32_t k1, void* stream);
+int odw_dropout(const float* x, float* out, int64_t n, uint32_t k0, uint32_t k1, float p, void* stream);
+int odw_noise_mul(const float* x, float* out, int64_t n, uint32_t k0, uint32_t k1, void* stream);
+
+/* ---- object-discovery pseudo-label assignment -------------------------------------
+ * replaces the tail of od_layer.__call__ / oicr_layer.__call__
+ * (roi_heads/weak_head/pseudo_label_generator.py:171-190): IoU(+1) of every
+ * proposal against the G pseudo-GT boxes, row max and FIRST argmax (the reference
+ * does this on the host with numpy, :176-177), labels (0 where max IoU <= fg_thresh),
+ * loss weights = gt_scores[argmax], regression targets = BoxCoder.encode
+ * (modeling/box_coder.py:22-50) with weights (wx,wy,ww,wh).
+ * boxes (P,4), gt_boxes (G,4), gt_classes int64 (G), gt_scores (G) ->
+ * labels int64 (P), weights (P), targets (P,4). */
+int odw_od_assign(const float* boxes, int P, const float* gt_boxes, const int64_t* gt_classes,
+                  const float* gt_scores, int G, float fg_thresh, float wx, float wy, float ww, float wh,
+                  int64_t* labels, float* weights, float* targets, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

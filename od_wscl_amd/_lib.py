@@ -19,6 +19,7 @@ c_f = ctypes.c_float
 c_i = ctypes.c_int
 c_l = ctypes.c_int64
 c_p = ctypes.c_void_p
+c_u = ctypes.c_uint32
 
 # name -> (restype, argtypes); must list every symbol include/odwscl.h declares
 SIGNATURES = {
@@ -35,6 +36,11 @@ SIGNATURES = {
     "odw_pairwise_sim": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "odw_supcon_workspace": (c_l, [c_i]),
     "odw_supcon_v2": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_l, c_p]),
+    "odw_rng_uniform": (c_i, [c_p, c_l, c_u, c_u, c_u, c_p]),
+    "odw_rng_normal": (c_i, [c_p, c_l, c_u, c_u, c_p]),
+    "odw_dropout": (c_i, [c_p, c_p, c_l, c_u, c_u, c_f, c_p]),
+    "odw_noise_mul": (c_i, [c_p, c_p, c_l, c_u, c_u, c_p]),
+    "odw_od_assign": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
 }
 
 

@@ -1,0 +1,65 @@
+"""Defaults of every key the hot path reads, with the reference's names and values
+(wetectron/config/defaults.py; line numbers cited per group)."""
+from .node import CfgNode as CN
+
+
+def make_defaults():
+    c = CN()
+    c.MODEL = CN()
+    c.MODEL.DEVICE = "cuda"                                   # :27
+    c.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"             # :28
+    c.MODEL.WSOD_ON = False
+    c.MODEL.FASTER_RCNN = True
+    c.MODEL.CLS_AGNOSTIC_BBOX_REG = False
+    c.MODEL.WEIGHT = ""
+    c.MODEL.BACKBONE = CN()
+    c.MODEL.BACKBONE.CONV_BODY = "R-50-C4"
+    c.MODEL.BACKBONE.FREEZE_CONV_BODY_AT = 2                  # :128
+    c.MODEL.ROI_HEADS = CN()
+    c.MODEL.ROI_HEADS.FG_IOU_THRESHOLD = 0.5
+    c.MODEL.ROI_HEADS.BBOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)   # :213
+    c.MODEL.ROI_HEADS.SCORE_THRESH = 0.05
+    c.MODEL.ROI_HEADS.NMS = 0.5
+    c.MODEL.ROI_HEADS.DETECTIONS_PER_IMG = 100
+    c.MODEL.ROI_BOX_HEAD = CN()
+    c.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR = "ResNet50Conv5ROIFeatureExtractor"
+    c.MODEL.ROI_BOX_HEAD.POOLER_METHOD = "ROIAlign"
+    c.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 14
+    c.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO = 0
+    c.MODEL.ROI_BOX_HEAD.POOLER_SCALES = (1.0 / 16,)
+    c.MODEL.ROI_BOX_HEAD.NUM_CLASSES = 81                     # :243
+    c.MODEL.ROI_WEAK_HEAD = CN()
+    c.MODEL.ROI_WEAK_HEAD.PREDICTOR = "MISTPredictor"
+    c.MODEL.ROI_WEAK_HEAD.LOSS = "RoIRegLoss"
+    c.MODEL.ROI_WEAK_HEAD.OICR_P = 0.0
+    c.MODEL.ROI_WEAK_HEAD.REGRESS_ON = False
+    c.MODEL.ROI_WEAK_HEAD.REGRESS_HEUR = "AVG"
+    c.MODEL.ROI_WEAK_HEAD.PARTIAL_LABELS = "none"             # :292
+    c.MODEL.ROI_WEAK_HEAD.ROI_LOSS_REFINE = False
+    c.DB = CN()
+    c.DB.METHOD = "none"
+    c.INPUT = CN()
+    c.INPUT.PIXEL_MEAN = [102.9801, 115.9465, 122.7717]       # :66
+    c.DATALOADER = CN()
+    c.DATALOADER.SIZE_DIVISIBILITY = 0
+    c.SOLVER = CN()
+    c.SOLVER.MAX_ITER = 40000
+    c.SOLVER.BASE_LR = 0.001
+    c.SOLVER.BIAS_LR_FACTOR = 2
+    c.SOLVER.MOMENTUM = 0.9
+    c.SOLVER.WEIGHT_DECAY = 0.0005
+    c.SOLVER.WEIGHT_DECAY_BIAS = 0
+    c.SOLVER.IMS_PER_BATCH = 16
+    c.SOLVER.CONTRA = False
+    # OD-WSCL hyper-parameters, lower-case top-level keys (:540-551)
+    c.nms = 0.1
+    c.lmda = 0.1
+    c.pos_update = 0
+    c.thres = 0.5
+    c.iou = 0.5          # unused by the loss (Q9)
+    c.temp = 0.2
+    c.loss = "supconv2"
+    c.OUTPUT_DIR = "."
+    c.DTYPE = "float32"  # :559
+    c.SEED = -1
+    return c

@@ -1,0 +1,73 @@
+// od_assign.hip -- pseudo-label assignment of the object-discovery layer, fused:
+// IoU(P,G) -> row max / FIRST argmax -> labels, loss weights, background test, box-regression
+// targets.  Reference: roi_heads/weak_head/pseudo_label_generator.py:171-190 (the IoU matrix is
+// copied to the host and reduced with numpy there, :176-177) + modeling/box_coder.py:22-50.
+// One thread per proposal; the G pseudo-GT boxes (a handful) sit in LDS.
+#include "odw_common.h"
+
+namespace {
+
+constexpr int kMaxGT = 2048;
+
+__global__ __launch_bounds__(256) void od_assign_kernel(const float* __restrict__ boxes, int P,
+                                                        const float* __restrict__ gt_boxes,
+                                                        const long long* __restrict__ gt_classes,
+                                                        const float* __restrict__ gt_scores, int G,
+                                                        float fg_thresh, float wx, float wy, float ww, float wh,
+                                                        long long* __restrict__ labels,
+                                                        float* __restrict__ weights,
+                                                        float* __restrict__ targets) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // G x 5: box + area
+    for (int j = threadIdx.x; j < G; j += blockDim.x) {
+        float4 q = reinterpret_cast<const float4*>(gt_boxes)[j];
+        sh[5 * j + 0] = q.x; sh[5 * j + 1] = q.y; sh[5 * j + 2] = q.z; sh[5 * j + 3] = q.w;
+        sh[5 * j + 4] = (q.z - q.x + 1) * (q.w - q.y + 1);
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 p = reinterpret_cast<const float4*>(boxes)[i];
+    const float ap = (p.z - p.x + 1) * (p.w - p.y + 1);
+    float best = -1.0f;
+    int bj = 0;
+    for (int j = 0; j < G; ++j) {
+        float w = fminf(p.z, sh[5 * j + 2]) - fmaxf(p.x, sh[5 * j + 0]) + 1;
+        float h = fminf(p.w, sh[5 * j + 3]) - fmaxf(p.y, sh[5 * j + 1]) + 1;
+        w = w < 0 ? 0 : w;
+        h = h < 0 ? 0 : h;
+        const float inter = w * h;
+        const float iou = inter / (ap + sh[5 * j + 4] - inter);   // boxlist_ops.py:154-159
+        if (iou > best) { best = iou; bj = j; }                    // first maximum (numpy argmax)
+    }
+    labels[i] = best <= fg_thresh ? 0 : gt_classes[bj];            // bg test is <= (:183)
+    weights[i] = gt_scores[bj];
+    // BoxCoder.encode(gt[bj], proposal i)
+    const float ew = p.z - p.x + 1, eh = p.w - p.y + 1;
+    const float ex = p.x + 0.5f * ew, ey = p.y + 0.5f * eh;
+    const float gw = sh[5 * bj + 2] - sh[5 * bj + 0] + 1, gh = sh[5 * bj + 3] - sh[5 * bj + 1] + 1;
+    const float gx = sh[5 * bj + 0] + 0.5f * gw, gy = sh[5 * bj + 1] + 0.5f * gh;
+    float4 t;
+    t.x = wx * (gx - ex) / ew;
+    t.y = wy * (gy - ey) / eh;
+    t.z = ww * logf(gw / ew);
+    t.w = wh * logf(gh / eh);
+    reinterpret_cast<float4*>(targets)[i] = t;
+}
+
+}  // namespace
+
+ODW_EXPORT int odw_od_assign(const float* boxes, int P, const float* gt_boxes, const int64_t* gt_classes,
+                             const float* gt_scores, int G, float fg_thresh, float wx, float wy, float ww,
+                             float wh, int64_t* labels, float* weights, float* targets, void* stream_) {
+    ODW_REQUIRE(P >= 0 && G >= 1 && G <= kMaxGT, "od_assign: P=%d G=%d (1..%d pseudo-GT boxes)", P, G, kMaxGT);
+    if (P == 0) return ODW_OK;
+    ODW_REQUIRE(boxes && gt_boxes && gt_classes && gt_scores && labels && weights && targets,
+                "od_assign: null pointer");
+    ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)gt_boxes) & 15) == 0 &&
+                (((uintptr_t)targets) & 15) == 0, "od_assign: boxes/targets must be 16-byte aligned");
+    od_assign_kernel<<<(P + 255) / 256, 256, (size_t)G * 5 * 4, (hipStream_t)stream_>>>(
+        boxes, P, gt_boxes, (const long long*)gt_classes, gt_scores, G, fg_thresh, wx, wy, ww, wh,
+        (long long*)labels, weights, targets);
+    ODW_CHECK_LAUNCH("od_assign_kernel");
+    return ODW_OK;
+}

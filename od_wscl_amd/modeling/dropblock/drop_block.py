@@ -1,0 +1,32 @@
+"""DropBlock2D (wetectron/modeling/dropblock/drop_block.py:7-71).
+
+One Bernoulli(drop_prob / block_size^2) mask per ROI over the 7x7 grid, shared by all
+channels, dilated by a block_size max-pool, applied and rescaled by numel/sum over the
+WHOLE mask tensor.  The reference draws the mask with the CPU generator and copies it to
+the device (:42-44); here the draw is the counter-based device stream, the (N,7,7) mask
+algebra stays in tiny tensors and the big (N,C,7,7) tensor is touched once."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class DropBlock2D(nn.Module):
+    def __init__(self, drop_prob, block_size):
+        super().__init__()
+        self.drop_prob = drop_prob
+        self.block_size = block_size
+
+    def forward(self, x, rand=None):
+        assert x.dim() == 4, "Expected input with 4 dimensions (bsize, channels, height, width)"
+        if not self.training or self.drop_prob == 0.0:
+            return x
+        gamma = self.drop_prob / (self.block_size ** 2)
+        shape = (x.shape[0], x.shape[2], x.shape[3])
+        u = rand.uniform(shape) if rand is not None else torch.rand(shape, device=x.device)
+        centres = (u < gamma).float()
+        block = F.max_pool2d(centres[:, None], kernel_size=self.block_size, stride=1, padding=self.block_size // 2)
+        if self.block_size % 2 == 0:
+            block = block[:, :, :-1, :-1]
+        block = 1 - block.squeeze(1)
+        # (x * block) * numel / sum, evaluated in the reference's order (:49-50)
+        return x * block[:, None, :, :] * block.numel() / block.sum()

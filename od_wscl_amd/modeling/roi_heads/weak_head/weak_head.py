@@ -1,0 +1,52 @@
+"""ROIWeakRegHead (wetectron/modeling/roi_heads/weak_head/weak_head.py:72-157), training path:
+clean pass -> Sim_Net embedding -> DropBlock pass -> predictor -> OD-WSCL loss."""
+import torch
+from torch import nn
+
+from ... import registry
+from ..sim_head.sim_net import Sim_Net
+from .loss import make_roi_weak_loss_evaluator
+from .roi_weak_predictors import make_roi_weak_predictor
+
+
+class ROIWeakRegHead(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        name = cfg.MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR
+        self.feature_extractor = registry.ROI_BOX_FEATURE_EXTRACTORS[name](cfg, in_channels)
+        self.predictor = make_roi_weak_predictor(cfg, self.feature_extractor.out_channels)
+        self.loss_evaluator = make_roi_weak_loss_evaluator(cfg)
+        self.HEUR = cfg.MODEL.ROI_WEAK_HEAD.REGRESS_HEUR
+        self.DB_METHOD = cfg.DB.METHOD
+        self.model_sim = Sim_Net(cfg, self.feature_extractor.out_channels)
+
+    def set_rand(self, rand):
+        """Install the counter-based random source for this step (dropout / DropBlock / noise)."""
+        self.feature_extractor.rand = rand
+
+    def go_through_cdb(self, pooled, proposals):
+        if not self.training or self.DB_METHOD == "none":
+            return pooled
+        if self.DB_METHOD == "dropblock":
+            return self.feature_extractor.forward_dropblock(pooled, proposals)
+        raise ValueError("DB.METHOD %r is outside the OD-WSCL hot path" % self.DB_METHOD)
+
+    def forward(self, features, proposals, targets=None, model_cdb=None, iteration=None):
+        clean_feats, clean_pooled = self.feature_extractor.forward(features, proposals)
+        if not self.training:
+            cls, det, refs, boxes = self.predictor(clean_feats, proposals)
+            final = torch.mean(torch.stack(refs), dim=0)
+            return clean_feats, (final, torch.mean(torch.stack(boxes), dim=0)), {}, {}
+        sim_feature = self.model_sim(clean_feats)
+        aug_pooled = self.go_through_cdb(clean_pooled, proposals)
+        aug_feats = self.feature_extractor.forward_neck(aug_pooled)
+        cls, det, refs, boxes = self.predictor(aug_feats, proposals)
+        loss, acc = self.loss_evaluator([cls], [det], refs, boxes, sim_feature, clean_pooled,
+                                        self.feature_extractor, self.model_sim, proposals, targets)
+        return aug_feats, proposals, loss, acc
+
+
+def build_roi_weak_head(cfg, in_channels):
+    if not cfg.MODEL.ROI_WEAK_HEAD.REGRESS_ON:
+        raise NotImplementedError("only the regression head (ROIWeakRegHead) is on the OD-WSCL hot path")
+    return ROIWeakRegHead(cfg, in_channels)

@@ -291,6 +291,20 @@ def topk_accuracy(labels_vec, scores):
     return labels_vec[pred].mean()
 
 
+def _note_margin(tr, kind, value):
+    """Record how close a data-dependent decision was to flipping (smaller = more fragile).
+    The golden cases are chosen so that every margin is far above fp32 re-ordering noise."""
+    key = "margin/" + kind
+    v = float(value)
+    if key not in tr or v < float(tr[key]):
+        tr[key] = torch.tensor(v)
+
+
+def _top2_gap(col):
+    v = torch.topk(col.detach(), min(2, col.numel()))[0]
+    return ((v[0] - v[1]) / v[0].abs().clamp(min=1e-30)) if v.numel() > 1 else torch.tensor(1.0)
+
+
 # --------------------------------------------------------------------------- the loss
 def roi_reg_loss(cls_logit, det_logit, ref_logits, bbox_preds, sim_feature, clean_pooled, sd, rand,
                  boxes_per_image, labels_per_image, cfg, trace=None):
@@ -332,6 +346,7 @@ def roi_reg_loss(cls_logit, det_logit, ref_logits, bbox_preds, sim_feature, clea
             for c in pos_classes[idx]:
                 c = int(c)
                 top = torch.argmax(pscore[:, c])
+                _note_margin(tr, "argmax_rel", _top2_gap(pscore[:, c]))
                 iou = boxlist_iou(boxes, boxes[top].view(1, 4))
                 near = torch.nonzero(torch.ge(iou, thres).max(dim=1)[0]).view(-1)   # utils/utils.py:22-26
                 pgt_index[idx][c] = torch.cat((pgt_index[idx][c], near)).unique()
@@ -362,14 +377,22 @@ def roi_reg_loss(cls_logit, det_logit, ref_logits, bbox_preds, sim_feature, clea
                 top = torch.argmax(pscore[:, c])
                 sim_mat = torch.mm(E, E.T)
                 thr = torch.mm(E[top].view(1, -1), pgt_collection[c].T).mean()
+                _note_margin(tr, "sim_thresh_abs", (sim_mat[top] - thr).abs().min())
                 if pos_classes[idx].shape[0] > 1:
                     close = torch.ge(sim_mat[top], thr)
                     for nc in pos_classes[idx][pos_classes[idx] != c]:
                         ntop = torch.argmax(pscore[:, int(nc)])
+                        gap = (close.float() - sim_mat[ntop]).abs()
+                        if not bool(close[ntop]):      # 0 >= |e|^2 ~ 1 is robustly false; 1 >= |e|^2 is not
+                            gap = torch.cat((gap[:ntop], gap[ntop + 1:]))
+                        _note_margin(tr, "q3_abs", gap.min())
                         close = torch.ge(close, sim_mat[ntop])                        # Q3 (bool vs float)
                     close = close.nonzero(as_tuple=False).view(-1)
                 else:
                     close = torch.ge(sim_mat[top], thr).nonzero(as_tuple=False).view(-1)
+                if close.numel() > 1:
+                    ss = torch.sort(pscore[:, c][close].detach(), descending=True)[0]
+                    _note_margin(tr, "nms_order_rel", ((ss[:-1] - ss[1:]) / ss[:-1].abs().clamp(min=1e-30)).min())
                 with torch.no_grad():                                                 # utils/utils.py:28-33
                     close = close[nms_tv(boxes[close], pscore[:, c][close].detach(), nms_thr)]
                 if close.numel() == 0:

@@ -1,0 +1,122 @@
+"""End-to-end parity on the GPU: the product model (od_wscl_amd.modeling, gfx950 kernels) against
+the golden vectors the REFERENCE produced on the same formula-generated inputs, and against the
+CPU oracle's intermediate tensors.  `pytest -m gpu`.
+
+Bars (BASELINE.json north_star): ROI / NMS / pseudo-label index selection bit-exact, fp32 losses
+within 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import e2e_inputs, load_e2e
+
+pytestmark = pytest.mark.gpu
+
+E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img"]
+LOSS_RTOL = 1e-3
+
+
+def build_model(pooler, weights_np):
+    from od_wscl_amd.config import make_defaults
+    from od_wscl_amd.modeling.detector import build_detection_model
+    cfg = make_defaults()
+    cfg.merge_from_list(["MODEL.BACKBONE.CONV_BODY", "VGG16-OICR", "MODEL.WSOD_ON", True, "MODEL.FASTER_RCNN", False,
+                         "MODEL.ROI_BOX_HEAD.NUM_CLASSES", 21, "MODEL.ROI_BOX_HEAD.POOLER_METHOD", pooler,
+                         "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7, "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,),
+                         "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR", "VGG16.roi_head",
+                         "MODEL.ROI_WEAK_HEAD.REGRESS_ON", True, "DB.METHOD", "dropblock", "SOLVER.CONTRA", True,
+                         "nms", 0.1, "lmda", 0.03, "temp", 0.2])
+    model = build_detection_model(cfg).cuda()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(weights_np[n]))
+    model.train()
+    return model
+
+
+@pytest.mark.parametrize("name", E2E)
+def test_model_matches_reference_golden(name, weights_np):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.structures import BoxList, to_image_list
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    g = load_e2e(name)
+    seed, batch, boxes, labels, cfg = e2e_inputs(g)
+    model = build_model(cfg["pooler"], weights_np)
+    specs = g["spec_images"]
+    rois, targets = [], []
+    for k, (h, w, p) in enumerate(specs):
+        rois.append(BoxList(boxes[k].cuda(), (int(w), int(h)), "xyxy"))
+        t = BoxList(torch.zeros((len(labels[k]), 4)).cuda(), (int(w), int(h)), "xyxy")
+        t.add_field("labels", labels[k].cuda())
+        targets.append(t)
+    images = to_image_list(batch.cuda())
+    rand = DeviceRand(seed)
+    trace = {}
+    model.roi_heads.loss_evaluator.trace = trace
+    losses, accs = model(images, targets, rois, iteration={"iter": 1}, rand=rand)
+    assert rand.s.next == int(g["streams_used"])
+    for k, v in losses.items():
+        ref = float(g["loss/" + k])
+        assert abs(float(v) - ref) <= LOSS_RTOL * max(abs(ref), 1e-6), (k, float(v), ref)
+    for k, v in accs.items():
+        assert abs(float(v) - float(g["acc/" + k])) < 1e-6, k
+    for k in g.files:
+        if k.startswith(("pseudo_", "pgt_instance_")):
+            np.testing.assert_array_equal(trace[k].cpu().numpy(), g[k], err_msg=k)   # bit-exact selection
+        if k.startswith("weights_"):
+            np.testing.assert_allclose(trace[k].cpu().numpy(), g[k], rtol=1e-3, atol=1e-7)
+    assert trace["supcon_n"] == int(g["supcon_n"])
+    np.testing.assert_allclose(trace["supcon_weights"].cpu().numpy(), g["supcon_weights"], rtol=1e-3, atol=1e-9)
+    sum(losses.values()).backward()
+    for n, p in model.named_parameters():
+        key = "gradnorm/" + n
+        if key in g.files:
+            ref = float(g[key])
+            got = p.grad.double().norm().item()
+            assert abs(got - ref) <= 2e-3 * max(ref, 1e-9), (n, got, ref)
+        else:
+            assert p.grad is None
+
+
+def test_device_rng_matches_host():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.utils import rng
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    r = DeviceRand(99, first_stream=5)
+    u = r.uniform((1000, 7, 7)).cpu().numpy().ravel()
+    np.testing.assert_array_equal(u, rng.uniform(99, 5, 49000))          # bit-identical stream
+    z = r.normal((333, 3)).cpu().numpy().ravel()
+    np.testing.assert_allclose(z, rng.normal(99, 6, 999), rtol=0, atol=5e-6)
+    x = torch.randn(257, 33, device="cuda", requires_grad=True)
+    y = r.dropout(x, 0.5)
+    keep = rng.uniform(99, 7, 257 * 33).reshape(257, 33) >= 0.5
+    np.testing.assert_array_equal(y.detach().cpu().numpy(), x.detach().cpu().numpy() * keep * 2.0)
+    y.sum().backward()
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), keep * 2.0)       # backward re-derives the mask
+    x2 = torch.randn(64, 10, device="cuda", requires_grad=True)
+    n = r.noise_mul(x2)
+    zn = rng.normal(99, 8, 640).reshape(64, 10)
+    np.testing.assert_allclose(n.detach().cpu().numpy(), x2.detach().cpu().numpy() * (1 + zn), rtol=1e-5, atol=1e-6)
+
+
+def test_od_assign_kernel(ops_golden):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd import _C
+    g = ops_golden
+    a = torch.from_numpy(g["iou_a"]).cuda()
+    score = torch.from_numpy(g["od_score"]).cuda()
+    prob = score[:, 1:].clone()
+    gt_b, gt_c, gt_s = [], [], []
+    for c, key in ((3, "od_pgt3"), (10, "od_pgt10")):
+        col = prob[:, c]
+        top = torch.argmax(col)
+        picked = torch.from_numpy(g[key]).cuda()
+        gt_b.append(a[picked]); gt_c.append(torch.full((picked.numel(),), c + 1, device="cuda")); gt_s.append(col[picked].clone())
+        prob[top].fill_(0)
+    pl, lw, rt = _C.od_assign(a, torch.cat(gt_b), torch.cat(gt_c), torch.cat(gt_s))
+    np.testing.assert_array_equal(pl.cpu().numpy(), g["od_pseudo"])
+    np.testing.assert_array_equal(lw.cpu().numpy(), g["od_weights"])
+    np.testing.assert_allclose(rt.cpu().numpy(), g["od_targets"], rtol=1e-6, atol=1e-6)
