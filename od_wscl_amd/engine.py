@@ -46,13 +46,27 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234):
     use_autocast = dtype == "bf16"
     model.roi_heads.loss_evaluator.amp = use_autocast
 
+    import os
+    debug = os.environ.get("ODW_DEBUG_SYNC", "").split(",")
+    kernel_timer.enabled = os.environ.get("ODW_NO_TIMER") != "1"
+
+    def mark(tag):
+        if tag in debug or "all" in debug:
+            torch.cuda.synchronize()
+            print("[odw] ok", tag, flush=True)
+
     def step(images, targets, rois, rand):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_autocast):
             losses, accs = net(images, targets, rois, rand=rand)
+        mark("forward")
         loss = sum(losses.values())
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        mark("backward")
         opt.step()
+        mark("optimizer")
+        if "loss" in debug:
+            print("[odw] losses", {k: round(float(v), 5) for k, v in losses.items()}, flush=True)
         return losses, accs
 
     info = {"gemm_backend": "torch/hipBLASLt (%s)" % dtype, "conv_backend": "torch/MIOpen (%s)" % dtype}

@@ -74,7 +74,9 @@ def test_model_matches_reference_golden(name, weights_np):
         if key in g.files:
             ref = float(g[key])
             got = p.grad.double().norm().item()
-            assert abs(got - ref) <= 2e-3 * max(ref, 1e-9), (n, got, ref)
+            # analytically-zero gradients (e.g. det_score.bias: a column softmax ignores its bias) are pure
+            # rounding noise ~1e-8 in both implementations -> absolute floor
+            assert abs(got - ref) <= 2e-3 * ref + 1e-6, (n, got, ref)
         else:
             assert p.grad is None
 
