@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--size", type=int, default=600)
     ap.add_argument("--classes", type=int, default=21)
     ap.add_argument("--dtype", default=os.environ.get("ODW_DTYPE", "bf16"), choices=["bf16", "f32"])
+    ap.add_argument("--backend", default=os.environ.get("ODW_BACKEND", "hip"), choices=["hip", "torch"],
+                    help="hip = hand-written gfx950 kernels for the ROI head (default); torch = library comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proposals", type=int, default=500)
     return ap.parse_args()
@@ -127,7 +129,8 @@ def main():
 
     cfg = build_cfg(args.classes)
     seed = cfg.SEED
-    step_fn, info = engine.build_training_step(cfg, device, dtype=args.dtype, world=world, seed=seed)
+    step_fn, info = engine.build_training_step(cfg, device, dtype=args.dtype, world=world, seed=seed,
+                                                 backend=args.backend)
     images, targets, rois = synthetic_batch(seed, rank, args.size, args.proposals, args.classes, device)
 
     def barrier():
@@ -153,7 +156,7 @@ def main():
     value = world * args.proposals * args.steps / dt
 
     if rank == 0:
-        roof = engine.kernel_timer.roofline(args.dtype, MFMA_PEAK_TFLOPS, HBM_PEAK_GBPS)
+        roof = engine.kernel_timer.roofline(args.dtype, MFMA_PEAK_TFLOPS, HBM_PEAK_GBPS, dominant="fc6_fwd")
         out = {
             "metric": "proposals/sec fwd+bwd (VGG16, %d proposals, %dpx)" % (args.proposals, args.size),
             "value": round(value, 1), "unit": "proposals/s", "n_gpus": world, "steps": args.steps,
@@ -163,7 +166,7 @@ def main():
                                    "OD-WSCL loss (CONTRA), SGD step, %d classes"
                                    % (args.proposals, args.size, images.tensors.shape[-1], args.classes),
                        "global_batch": world, "parallelism": "dp%d" % world, "lr": BENCH_LR, "gemm_backend": info["gemm_backend"],
-                       "conv_backend": info["conv_backend"]},
+                       "conv_backend": info["conv_backend"], "optimizer": info["optimizer"]},
             "per_gpu": round(value / world, 1),
             "roofline": roof,
         }

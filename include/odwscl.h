@@ -132,6 +132,33 @@ int odw_od_assign(const float* boxes, int P, const float* gt_boxes, const int64_
                   const float* gt_scores, int G, float fg_thresh, float wx, float wy, float ww, float wh,
                   int64_t* labels, float* weights, float* targets, void* stream);
 
+/* ---- ROI-head GEMM on the bf16 matrix cores ---------------------------------------
+ * C[M,N] (+)= epilogue( alpha * sum_k A[M,K] B[N,K] )   both operands bf16, K contiguous.
+ * Serves the forward / dgrad / wgrad products of every Linear layer on the path
+ * (modeling/backbone/vgg16.py:121-127 fc6/fc7, roi_heads/sim_head/sim_net.py:12-16,
+ * roi_heads/weak_head/roi_weak_predictors.py:158-165 fused into one N=5C+12C GEMM) -- the
+ * reference calls cuBLAS through torch.nn.Linear.
+ *   lda, ldb : row strides in elements, multiples of 8; K rounded up to 8 must fit (zero padded)
+ *   C        : bf16 (c_is_bf16) or fp32, row stride ldc; accumulate (fp32 only): C += result
+ *   epilogue : + bias[N] (nullable), ReLU, dropout(drop_p) with counter-based keys:
+ *              nseg row segments (seg_rows[i] = first row, seg_keys[2i..2i+1] = key); element
+ *              (m,n) of segment s uses index (m - seg_rows[s]) * N + n   (HOST arrays, <= 4)
+ * odw_linear_bwd_prep: dZ = dY * [Y != 0] * scale (Y = saved bf16 output, nullable), emitted
+ *   row-major (ld_z) and transposed (N x ld_t), both zero padded; db[n] += column sums.
+ * odw_transpose_to_bf16 / odw_f32_to_bf16: layout + precision helpers for the operands.
+ * odw_sgd_momentum: fused SGD step over flat fp32 buffers (solver/build.py:10-24 semantics),
+ *   optionally refreshing the bf16 shadow the GEMMs read. */
+int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C, int ldc,
+                     int c_is_bf16, const float* bias, int relu, float alpha, float drop_p, int nseg,
+                     const int* seg_rows, const uint32_t* seg_keys, int accumulate, void* stream);
+int odw_linear_bwd_prep(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
+                        float scale, void* dZ, int ld_z, void* dZT, int ld_t, float* db, void* stream);
+int odw_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
+                          void* stream);
+int odw_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+int odw_sgd_momentum(float* p, const float* g, float* buf, void* shadow_bf16, int64_t n, float lr, float wd,
+                     float momentum, float grad_scale, int first_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,392 @@
+// gemm_bf16.hip -- the ROI-head GEMM of the hot path on the gfx950 matrix cores.
+//
+//   C[M,N] (+)= epilogue( sum_k A[M,K] * B[N,K] )        "NT": both operands K-contiguous bf16
+//
+// One kernel serves all three products of a Linear layer (vgg16.py:121-127 fc6/fc7,
+// sim_net.py:12-16, roi_weak_predictors.py:158-165):
+//   forward  Y  = X  W^T      A = X  (M x K),    B = W     (N x K)
+//   dgrad    dX = dY W        A = dY (M x N),    B = W^T   (K x N)   (bf16 transposed shadow)
+//   wgrad    dW = dY^T X      A = dY^T (N x M),  B = X^T   (K x M)   (bf16 transposed copies)
+// so the MFMA operand fetch is always two 16-byte K-contiguous reads per lane.
+//
+// Structure (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per
+// wave = 2x2 v_mfma_f32_32x32x16_bf16 accumulators), BK = 64, LDS double buffer (64 KB ->
+// 2 workgroups/CU, 512 tiles of fc6 = one wave of workgroups on 256 CUs).  Global -> register
+// -> LDS staging with the NEXT tile's loads issued before the current tile's MFMAs (T14).
+// LDS rows are 128 B; 16-byte chunk c of row r lives in slot c ^ ((r >> 1) & 7): ds_write_b128
+// (8-lane groups = one row) and ds_read_b128 (16-lane groups = 16 rows) are both conflict-free.
+// Workgroup -> tile mapping is XCD-aware: the 8 XCDs (block id mod 8) each own a contiguous
+// band of N tiles, so a band of B stays in that XCD's L2 while A streams through the MALL.
+// Epilogue fused: bias, ReLU, counter-based dropout (odw_rng.h), bf16 or fp32 store,
+// optional accumulate (C += ...) for weight gradients shared by several passes.
+#include "odw_common.h"
+#include "odw_rng.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kChunksPerRow = BK / 8;                 // 16-byte chunks per LDS row
+constexpr int kTileChunks = BM * kChunksPerRow;       // 1024 uint4 per operand tile
+constexpr int kLoadsPerThread = kTileChunks / kThreads;  // 4
+
+struct Epilogue {
+    const float* bias;     // (N) or null
+    int relu;
+    float drop_p;          // 0 = no dropout
+    int nseg;              // dropout row segments (each logical draw has its own key)
+    int seg_row[4];
+    uint32_t seg_k0[4], seg_k1[4];
+    int accumulate;        // fp32 output only: C += result
+    float alpha;           // scales the product before bias
+};
+
+__device__ __forceinline__ int lds_slot(int row, int chunk) { return row * kChunksPerRow + (chunk ^ ((row >> 1) & 7)); }
+
+__device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+
+// staging: thread t moves 16-byte chunks t, t+256, t+512, t+768 of each operand tile
+__device__ __forceinline__ void load_tile(const unsigned short* __restrict__ A, int lda,
+                                          const unsigned short* __restrict__ B, int ldb, int M, int N, int K,
+                                          int m0, int n0, int kt, int tid, uint4 (&ra)[kLoadsPerThread],
+                                          uint4 (&rb)[kLoadsPerThread]) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; ++i) {
+        const int id = tid + i * kThreads;
+        const int row = id >> 3, c = id & 7;
+        const int k = k0 + c * 8;
+        const int gm = m0 + row, gn = n0 + row;
+        uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+        if (gm < M && k < K) va = *reinterpret_cast<const uint4*>(A + (size_t)gm * lda + k);
+        if (gn < N && k < K) vb = *reinterpret_cast<const uint4*>(B + (size_t)gn * ldb + k);
+        ra[i] = va;
+        rb[i] = vb;
+    }
+}
+
+__device__ __forceinline__ void store_tile(uint4* __restrict__ sa, uint4* __restrict__ sb, int tid,
+                                           const uint4 (&ra)[kLoadsPerThread], const uint4 (&rb)[kLoadsPerThread]) {
+#pragma unroll
+    for (int i = 0; i < kLoadsPerThread; ++i) {
+        const int id = tid + i * kThreads;
+        const int row = id >> 3, c = id & 7;
+        sa[lds_slot(row, c)] = ra[i];
+        sb[lds_slot(row, c)] = rb[i];
+    }
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_kernel(
+    const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
+    int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [stage][A|B][kTileChunks]
+    // ---- XCD-aware tile mapping (block b runs on XCD b % 8; correctness never depends on it)
+    const int nblk = tiles_m * tiles_n;
+    int b = blockIdx.x;
+    int tile;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective
+    }
+    const int tn = tile / tiles_m, tm = tile % tiles_m;       // consecutive tiles share the B band
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    uint4 ra[kLoadsPerThread], rb[kLoadsPerThread];
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int nk = (K + BK - 1) / BK;
+    load_tile(A, lda, B, ldb, M, N, K, m0, n0, 0, tid, ra, rb);
+    store_tile(lds, lds + kTileChunks, tid, ra, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) load_tile(A, lda, B, ldb, M, N, K, m0, n0, kt + 1, tid, ra, rb);   // in flight under the MFMAs
+        const uint4* sa = lds + (size_t)stage * 2 * kTileChunks;
+        const uint4* sb = sa + kTileChunks;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int c = kk * 2 + half;
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + l31;
+                fa[i] = __builtin_bit_cast(bf16x8, sa[lds_slot(row, c)]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + l31;
+                fb[j] = __builtin_bit_cast(bf16x8, sb[lds_slot(row, c)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            uint4* na = lds + (size_t)(stage ^ 1) * 2 * kTileChunks;
+            store_tile(na, na + kTileChunks, tid, ra, rb);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= N) continue;
+        const float bias = ep.bias ? ep.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                float v = acc[i][j][r] * ep.alpha + bias;
+                if (ep.relu) v = fmaxf(v, 0.0f);
+                if (ep.drop_p > 0.0f) {
+                    int srow = ep.seg_row[0];
+                    uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
+                    if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
+                    if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
+                    if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+                    const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)n;
+                    v = odw_uniform(idx, k0, k1) >= ep.drop_p ? v * (1.0f / (1.0f - ep.drop_p)) : 0.0f;
+                }
+                if (OUT_BF16) {
+                    reinterpret_cast<unsigned short*>(Cv)[(size_t)m * ldc + n] = f2bf(v);
+                } else {
+                    float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
+                    *c = ep.accumulate ? *c + v : v;
+                }
+            }
+        }
+    }
+}
+
+// ---- layout helpers ---------------------------------------------------------------------
+// out[c][r] = bf16(in[r][c]); in is fp32 or bf16 (IN_F32).  32x32 tiles through LDS.
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __restrict__ in, int ld_in, int R,
+                                                                int Cc, unsigned short* __restrict__ out,
+                                                                int ld_out) {
+    __shared__ unsigned short t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        unsigned short v = 0;
+        if (r < R && c < Cc)
+            v = IN_F32 ? f2bf(reinterpret_cast<const float*>(in)[(size_t)r * ld_in + c])
+                       : reinterpret_cast<const unsigned short*>(in)[(size_t)r * ld_in + c];
+        t[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < Cc && r < ld_out) out[(size_t)c * ld_out + r] = r < R ? t[tx][ty + 8 * k] : (unsigned short)0;
+    }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        ushort4 o;
+        o.x = f2bf(v.x); o.y = f2bf(v.y); o.z = f2bf(v.z); o.w = f2bf(v.w);
+        reinterpret_cast<ushort4*>(out)[i] = o;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = f2bf(in[i]);
+}
+
+// Backward prologue of a fused Linear: dZ = dY * [Y != 0] * scale (ReLU + dropout mask re-derived
+// from the saved bf16 output; Y == nullptr -> dZ = dY), written row-major (ld_z, zero padded) AND
+// transposed (N x ld_t, zero padded) for the dgrad / wgrad GEMMs, plus the bias gradient
+// db[n] += sum_m dZ[m][n].  32x32 tiles through LDS; dY is fp32 or bf16.
+template <bool DY_F32>
+__global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __restrict__ dY, int ld_dy,
+                                                              const unsigned short* __restrict__ Y, int ld_y,
+                                                              int M, int N, float scale,
+                                                              unsigned short* __restrict__ dZ, int ld_z,
+                                                              unsigned short* __restrict__ dZT, int ld_t,
+                                                              float* __restrict__ db) {
+    __shared__ float t[32][33];
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = m0 + ty + 8 * k, n = n0 + tx;
+        float v = 0.0f;
+        if (m < M && n < N) {
+            v = DY_F32 ? reinterpret_cast<const float*>(dY)[(size_t)m * ld_dy + n]
+                       : __uint_as_float((unsigned int)reinterpret_cast<const unsigned short*>(dY)[(size_t)m * ld_dy + n] << 16);
+            if (Y) v = (Y[(size_t)m * ld_y + n] & 0x7fff) != 0 ? v * scale : 0.0f;
+        }
+        t[ty + 8 * k][tx] = v;
+        if (m < M && n < ld_z) dZ[(size_t)m * ld_z + n] = f2bf(v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = n0 + ty + 8 * k, m = m0 + tx;
+        if (n < N && m < ld_t) dZT[(size_t)n * ld_t + m] = f2bf(t[tx][ty + 8 * k]);
+    }
+    if (db && ty == 0) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) sum += t[r][tx];
+        if (n0 + tx < N) atomicAdd(db + n0 + tx, sum);
+    }
+}
+
+// Fused SGD with momentum over flat fp32 buffers (torch.optim.SGD semantics, solver/build.py:10-24:
+// d = g + wd*p ; buf = mu*buf + d ; p -= lr*buf), optionally refreshing the bf16 shadow of p.
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                           unsigned short* __restrict__ shadow, size_t n, float lr, float wd, float mu,
+                           float gscale, int first) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 bv = first ? make_float4(0, 0, 0, 0) : reinterpret_cast<float4*>(buf)[i];
+        float d;
+        d = gv.x * gscale + wd * pv.x; bv.x = first ? d : mu * bv.x + d; pv.x -= lr * bv.x;
+        d = gv.y * gscale + wd * pv.y; bv.y = first ? d : mu * bv.y + d; pv.y -= lr * bv.y;
+        d = gv.z * gscale + wd * pv.z; bv.z = first ? d : mu * bv.z + d; pv.z -= lr * bv.z;
+        d = gv.w * gscale + wd * pv.w; bv.w = first ? d : mu * bv.w + d; pv.w -= lr * bv.w;
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(buf)[i] = bv;
+        if (shadow) {
+            ushort4 o;
+            o.x = f2bf(pv.x); o.y = f2bf(pv.y); o.z = f2bf(pv.z); o.w = f2bf(pv.w);
+            reinterpret_cast<ushort4*>(shadow)[i] = o;
+        }
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float pv = p[i];
+        float d = g[i] * gscale + wd * pv;
+        float bv = first ? d : mu * buf[i] + d;
+        pv -= lr * bv;
+        p[i] = pv; buf[i] = bv;
+        if (shadow) shadow[i] = f2bf(pv);
+    }
+}
+
+}  // namespace
+
+ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
+                                int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
+                                int nseg, const int* seg_rows, const uint32_t* seg_keys, int accumulate,
+                                void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_nt_bf16: bad dims M=%d N=%d K=%d", M, N, K);
+    if (M == 0 || N == 0) return ODW_OK;
+    ODW_REQUIRE(A && B && C, "gemm_nt_bf16: null pointer");
+    ODW_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0,
+                "gemm_nt_bf16: A/B rows must be 16-byte aligned (lda=%d ldb=%d)", lda, ldb);
+    ODW_REQUIRE(((K + 7) / 8) * 8 <= lda && ((K + 7) / 8) * 8 <= ldb,
+                "gemm_nt_bf16: K=%d rounded up to 8 must fit in lda=%d / ldb=%d (zero padded)", K, lda, ldb);
+    ODW_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && nseg >= 0 && nseg <= 4, "gemm_nt_bf16: bad dropout args");
+    ODW_REQUIRE(!(accumulate && c_is_bf16), "gemm_nt_bf16: accumulate needs an fp32 C");
+    Epilogue ep;
+    ep.bias = bias; ep.relu = relu; ep.drop_p = drop_p; ep.nseg = nseg; ep.accumulate = accumulate; ep.alpha = alpha;
+    for (int i = 0; i < 4; ++i) {
+        ep.seg_row[i] = (i < nseg && seg_rows) ? seg_rows[i] : 0;
+        ep.seg_k0[i] = (i < nseg && seg_keys) ? seg_keys[2 * i] : 0;
+        ep.seg_k1[i] = (i < nseg && seg_keys) ? seg_keys[2 * i + 1] : 0;
+    }
+    if (drop_p > 0.0f) ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_bf16: dropout needs row segments starting at 0");
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);   // 64 KB
+    if (c_is_bf16) {
+        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "gemm attr");
+        gemm_nt_bf16_kernel<true><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(
+            (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, tiles_m, tiles_n);
+    } else {
+        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "gemm attr");
+        gemm_nt_bf16_kernel<false><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(
+            (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, tiles_m, tiles_n);
+    }
+    ODW_CHECK_LAUNCH("gemm_nt_bf16_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
+                                     void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(R >= 0 && Cc >= 0 && ld_in >= Cc && ld_out >= R, "transpose_to_bf16: bad dims");
+    if (R == 0 || Cc == 0) return ODW_OK;
+    ODW_REQUIRE(in && out, "transpose_to_bf16: null pointer");
+    dim3 grid((Cc + 31) / 32, (ld_out + 31) / 32);   // covers the zero padding up to ld_out
+    if (in_is_f32)
+        transpose_to_bf16_kernel<true><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out);
+    else
+        transpose_to_bf16_kernel<false><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out);
+    ODW_CHECK_LAUNCH("transpose_to_bf16_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_f32_to_bf16(const float* in, void* out, int64_t n, void* stream_) {
+    ODW_REQUIRE(n >= 0, "f32_to_bf16: bad n");
+    if (n == 0) return ODW_OK;
+    ODW_REQUIRE(in && out && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "f32_to_bf16: pointers");
+    size_t g = ((size_t)n / 4 + 255) / 256;
+    f32_to_bf16_kernel<<<(int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)), 256, 0, (hipStream_t)stream_>>>(in, (unsigned short*)out, (size_t)n);
+    ODW_CHECK_LAUNCH("f32_to_bf16_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_linear_bwd_prep(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
+                                   float scale, void* dZ, int ld_z, void* dZT, int ld_t, float* db, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(M >= 0 && N >= 0 && ld_z >= N && ld_t >= M && ld_dy >= N, "linear_bwd_prep: bad dims");
+    if (M == 0 || N == 0) return ODW_OK;
+    ODW_REQUIRE(dY && dZ && dZT, "linear_bwd_prep: null pointer");
+    dim3 grid((ld_z + 31) / 32, (ld_t + 31) / 32);     // covers the zero padding of both outputs
+    if (dy_is_f32)
+        linear_bwd_prep_kernel<true><<<grid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
+                                                               (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, db);
+    else
+        linear_bwd_prep_kernel<false><<<grid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
+                                                                (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, db);
+    ODW_CHECK_LAUNCH("linear_bwd_prep_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_sgd_momentum(float* p, const float* g, float* buf, void* shadow_bf16, int64_t n, float lr, float wd,
+                                float momentum, float grad_scale, int first_step, void* stream_) {
+    ODW_REQUIRE(n >= 0, "sgd_momentum: bad n");
+    if (n == 0) return ODW_OK;
+    ODW_REQUIRE(p && g && buf, "sgd_momentum: null pointer");
+    ODW_REQUIRE((((uintptr_t)p) & 15) == 0 && (((uintptr_t)g) & 15) == 0 && (((uintptr_t)buf) & 15) == 0 &&
+                    (((uintptr_t)shadow_bf16) & 7) == 0, "sgd_momentum: buffers must be 16-byte aligned");
+    size_t blocks = ((size_t)n / 4 + 255) / 256;
+    sgd_kernel<<<(int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks)), 256, 0, (hipStream_t)stream_>>>(
+        p, g, buf, (unsigned short*)shadow_bf16, (size_t)n, lr, wd, momentum, grad_scale, first_step);
+    ODW_CHECK_LAUNCH("sgd_kernel");
+    return ODW_OK;
+}

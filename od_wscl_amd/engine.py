@@ -1,9 +1,26 @@
 """One training step of the hot path (the caller of GeneralizedRCNN.forward in the reference:
-engine/trainer.py:79-120 -- forward, sum of losses, backward, DDP all-reduce, SGD step)."""
+engine/trainer.py:79-120 -- forward, sum of losses, backward, gradient all-reduce, SGD step;
+optimiser semantics of solver/build.py:10-24).
+
+MI355X-first structure:
+  * every trainable parameter lives in ONE flat fp32 buffer, its gradient in a second and its
+    momentum in a third (611 MB each for VGG16/VOC out of 288 GB of HBM): the optimiser is
+    three launches of one fused kernel (GEMM weights / other weights / biases) instead of 50
+    parameter groups, and the data-parallel exchange is an RCCL all-reduce of contiguous
+    slices of the gradient buffer -- no bucketing copies.
+  * the big Linear weights get their gradient written by the wgrad GEMM straight into the
+    flat buffer ("fresh" flag = overwrite on first touch, accumulate afterwards), so the
+    411 MB fc6 gradient is never zero-filled nor copied.
+  * the fused SGD kernel also refreshes the bf16 shadow weights the matrix cores read.
+"""
+import os
+
 import torch
 import torch.distributed as dist
 
+from . import _lib as L
 from . import synthetic
+from .layers import linear as linear_layer
 from .modeling.detector import build_detection_model
 from .utils.kernel_timer import kernel_timer  # noqa: F401  (re-exported for bench.py)
 
@@ -17,8 +34,8 @@ def load_formula_weights(model, seed, overrides=None):
 
 
 def make_optimizer(cfg, model):
-    """solver/build.py:10-24: one group per parameter; biases get lr x BIAS_LR_FACTOR and
-    WEIGHT_DECAY_BIAS."""
+    """torch.optim.SGD with the reference's parameter groups (solver/build.py:10-24) -- the
+    comparison path; the production path is FlatSGD below."""
     groups = []
     for key, value in model.named_parameters():
         if not value.requires_grad:
@@ -30,30 +47,158 @@ def make_optimizer(cfg, model):
     return torch.optim.SGD(groups, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
 
 
-def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234):
+class FlatSGD(object):
+    """Parameters, gradients and momenta as three flat fp32 buffers + the fused SGD kernel."""
+
+    def __init__(self, cfg, model, world=1):
+        self.cfg, self.world = cfg, world
+        self.momentum = cfg.SOLVER.MOMENTUM
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        gemm_w = [(n, p) for n, p in named if self._is_gemm_weight(model, n, p)]
+        gemm_ids = set(id(p) for _, p in gemm_w)
+        other_w = [(n, p) for n, p in named if id(p) not in gemm_ids and "bias" not in n]
+        biases = [(n, p) for n, p in named if "bias" in n]
+        order = gemm_w + other_w + biases
+        sizes = [(p.numel() + 3) // 4 * 4 for _, p in order]     # keep every slice 16-byte aligned
+        total = sum(sizes)
+        dev = order[0][1].device
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self.slices = {}
+        for (n, p), sz in zip(order, sizes):
+            view = self.flat_p[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
+            self.slices[n] = (off, p.numel())
+            off += sz
+        n_gemm = sum(s for s, _ in zip(sizes, gemm_w))
+        n_other = sum(sizes[len(gemm_w):len(gemm_w) + len(other_w)])
+        self.regions = [  # (start, length, lr, wd)
+            (0, n_gemm, cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY),
+            (n_gemm, n_other, cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY),
+            (n_gemm + n_other, total - n_gemm - n_other, cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR,
+             cfg.SOLVER.WEIGHT_DECAY_BIAS)]
+        self.gemm_params = [p for _, p in gemm_w]
+        self.n_gemm = n_gemm
+        self.first = True
+        self.total = total
+        # bf16 shadows of the GEMM weights: one flat buffer the SGD kernel refreshes in the same pass
+        self.flat_w16 = None
+        self.shadows = []
+        if gemm_w:
+            from . import gemm
+            self.flat_w16 = torch.empty(n_gemm, dtype=torch.bfloat16, device=dev)
+            for n, p in gemm_w:
+                mod = model.get_submodule(n.rsplit(".", 1)[0])
+                o, cnt = self.slices[n]
+                sh = gemm.Shadow(p)
+                sh.w = self.flat_w16[o:o + cnt].view(p.shape)
+                sh.managed = True
+                mod._shadow = sh
+                self.shadows.append(sh)
+            self._refresh_shadows(initial=True)
+
+    def _refresh_shadows(self, initial=False):
+        from . import gemm
+        if initial:
+            L.check(L.lib().odw_f32_to_bf16(L.ptr(self.flat_p), L.ptr(self.flat_w16), self.n_gemm, L.stream()),
+                    "f32_to_bf16")
+        for sh in self.shadows:
+            n, k = sh.weight.shape
+            sh.wt = gemm.transpose_bf16(sh.w, n, k)
+
+    @staticmethod
+    def _is_gemm_weight(model, name, p):
+        if linear_layer.get_backend() != "hip_bf16" or p.dim() != 2:
+            return False
+        mod = model.get_submodule(name.rsplit(".", 1)[0])
+        return isinstance(mod, linear_layer.Linear)
+
+    def begin_step(self):
+        """Gradient buffer state for a new step: GEMM weights are overwritten by their first wgrad
+        launch; everything autograd accumulates into (convs, predictor heads, biases) is zeroed."""
+        for p in self.gemm_params:
+            p._odw_fresh = True
+        self.flat_g[self.n_gemm:].zero_()
+
+    def all_reduce(self):
+        if self.world > 1:
+            # contiguous slices of the flat buffer, large first (fc6 region); RCCL over xGMI
+            works = []
+            chunk = 64 * 1024 * 1024       # 256 MB of fp32 per collective
+            for s in range(0, self.total, chunk):
+                works.append(dist.all_reduce(self.flat_g[s:min(self.total, s + chunk)], async_op=True))
+            for w in works:
+                w.wait()
+
+    def step(self):
+        lib = L.lib()
+        scale = 1.0 / self.world
+        for i, (start, n, lr, wd) in enumerate(self.regions):
+            if n == 0:
+                continue
+            shadow = self.flat_w16 if (i == 0 and self.flat_w16 is not None) else None
+            L.check(lib.odw_sgd_momentum(L.ptr(self.flat_p[start:]), L.ptr(self.flat_g[start:]),
+                                         L.ptr(self.flat_m[start:]), L.ptr(shadow), n, lr, wd, self.momentum, scale,
+                                         1 if self.first else 0, L.stream()), "sgd_momentum")
+        self.first = False
+        self._refresh_shadows()
+
+
+def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="hip"):
+    """backend "hip": Linear layers on the hand-written MFMA GEMM (bf16), fused SGD, flat buffers.
+    backend "torch": F.linear / torch.optim.SGD (fp32 or bf16 autocast) -- comparison only."""
+    hip = backend == "hip"
+    linear_layer.set_backend("hip_bf16" if hip else "torch")
     model = build_detection_model(cfg).to(device)
     load_formula_weights(model, 1)
     model.train()
     fe = model.roi_heads.feature_extractor
     fe.classifier[1].tag = "fc6"
     fe.classifier[4].tag = "fc7"
-    kernel_timer.enabled = True
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], broadcast_buffers=False,
-                                                        bucket_cap_mb=128, gradient_as_bucket_view=True)
-    opt = make_optimizer(cfg, model)
-    use_autocast = dtype == "bf16"
-    model.roi_heads.loss_evaluator.amp = use_autocast
-
-    import os
-    debug = os.environ.get("ODW_DEBUG_SYNC", "").split(",")
+    model.roi_heads.model_sim.mlp[0].tag = "sim0"
     kernel_timer.enabled = os.environ.get("ODW_NO_TIMER") != "1"
+    debug = os.environ.get("ODW_DEBUG_SYNC", "").split(",")
 
     def mark(tag):
         if tag in debug or "all" in debug:
             torch.cuda.synchronize()
             print("[odw] ok", tag, flush=True)
+
+    use_autocast = dtype == "bf16"
+    if hip:
+        model.backbone_autocast = torch.bfloat16 if use_autocast else None
+        model.roi_heads.loss_evaluator.amp = False
+        opt = FlatSGD(cfg, model, world)
+
+        def step(images, targets, rois, rand):
+            opt.begin_step()
+            losses, accs = model(images, targets, rois, rand=rand)
+            mark("forward")
+            loss = sum(losses.values())
+            loss.backward()
+            mark("backward")
+            opt.all_reduce()
+            opt.step()
+            mark("optimizer")
+            if "loss" in debug:
+                print("[odw] losses", {k: round(float(v), 5) for k, v in losses.items()}, flush=True)
+            return losses, accs
+
+        info = {"gemm_backend": "od_wscl_amd HIP MFMA gemm_nt_bf16 (bf16 in, fp32 acc)",
+                "conv_backend": "torch/MIOpen (%s)" % ("bf16 autocast" if use_autocast else "f32"),
+                "optimizer": "od_wscl_amd fused flat SGD"}
+        return step, info
+
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], broadcast_buffers=False,
+                                                        bucket_cap_mb=128, gradient_as_bucket_view=True)
+    opt = make_optimizer(cfg, model)
+    model.roi_heads.loss_evaluator.amp = use_autocast
 
     def step(images, targets, rois, rand):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_autocast):
@@ -69,5 +214,6 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234):
             print("[odw] losses", {k: round(float(v), 5) for k, v in losses.items()}, flush=True)
         return losses, accs
 
-    info = {"gemm_backend": "torch/hipBLASLt (%s)" % dtype, "conv_backend": "torch/MIOpen (%s)" % dtype}
+    info = {"gemm_backend": "torch/hipBLASLt (%s)" % dtype, "conv_backend": "torch/MIOpen (%s)" % dtype,
+            "optimizer": "torch.optim.SGD"}
     return step, info

@@ -1,0 +1,147 @@
+"""Python front-end of the bf16 MFMA GEMM (csrc/gemm_bf16.hip) and the fused Linear autograd op.
+
+A Linear layer keeps its fp32 master weight (the parameter the optimiser and checkpoints see,
+reference names unchanged) plus two bf16 shadows the matrix cores read: W (N x K) for the
+forward product and W^T (K x N8) for the input gradient.  Shadows are refreshed when the
+parameter's version counter moves (after every optimiser step).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _r8(n):
+    return (n + 7) // 8 * 8
+
+
+def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, segs=None, accumulate=False):
+    """out[M,N] (+)= epilogue(alpha * a[M,K] @ b[N,K]^T); a, b bf16 2-D tensors (row stride % 8 == 0)."""
+    L.need_gpu(a, b, out)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    nseg = len(segs) if segs else 0
+    rows = (ctypes.c_int * 4)(*([s[0] for s in segs] + [0] * (4 - nseg))) if nseg else None
+    keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
+    L.check(L.lib().odw_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out), out.stride(0),
+                                     1 if out.dtype == torch.bfloat16 else 0, L.ptr(bias), 1 if relu else 0,
+                                     float(alpha), float(drop_p), nseg,
+                                     ctypes.cast(rows, ctypes.c_void_p) if nseg else None,
+                                     ctypes.cast(keys, ctypes.c_void_p) if nseg else None,
+                                     1 if accumulate else 0, L.stream()), "gemm_nt_bf16")
+    return out
+
+
+def to_bf16(x):
+    """fp32 -> bf16 copy (round to nearest even) on the device."""
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().odw_f32_to_bf16(L.ptr(x), L.ptr(out), x.numel(), L.stream()), "f32_to_bf16")
+    return out
+
+
+def transpose_bf16(x, rows, cols):
+    """(rows x cols) fp32|bf16 -> (cols x r8(rows)) bf16, zero padded."""
+    ld = _r8(rows)
+    out = torch.empty((cols, ld), dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().odw_transpose_to_bf16(L.ptr(x), 1 if x.dtype == torch.float32 else 0, x.stride(0), rows, cols,
+                                          L.ptr(out), ld, L.stream()), "transpose_to_bf16")
+    return out
+
+
+class Shadow(object):
+    """bf16 copies of one fp32 weight: w (N x K) and wt (K x r8(N))."""
+
+    def __init__(self, weight):
+        self.weight = weight
+        self.version = -1
+        self.w = None
+        self.wt = None
+        self.managed = False      # True: the optimiser refreshes w / wt itself (engine.FlatSGD)
+
+    def refresh(self):
+        w = self.weight
+        if self.managed or (self.version == w._version and self.w is not None):
+            return self
+        n, k = w.shape
+        assert k % 8 == 0, "in_features must be a multiple of 8"
+        with torch.no_grad():
+            self.w = to_bf16(w.detach())
+            self.wt = transpose_bf16(w.detach(), n, k)
+        self.version = w._version
+        return self
+
+
+class _FusedLinear(torch.autograd.Function):
+    """y = dropout(relu(x W^T + b)) on the matrix cores, bf16 in / bf16 or fp32 out.
+
+    backward: one prologue kernel rebuilds the ReLU+dropout mask from the saved output and emits
+    dZ / dZ^T / db; dX and dW are two more launches of the same NT GEMM; dW is accumulated
+    straight into weight.grad (fp32) -- nothing the size of fc6's 411 MB gradient is ever
+    materialised twice."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, shadow, relu, drop_p, segs, out_f32, timer_tag):
+        from .utils.kernel_timer import kernel_timer
+        sh = shadow.refresh()
+        M, K = x.shape
+        N = weight.shape[0]
+        xb = x if x.dtype == torch.bfloat16 else to_bf16(x)
+        xb = xb if xb.stride(1) == 1 and xb.stride(0) % 8 == 0 else xb.contiguous()
+        y = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        with kernel_timer.region(timer_tag and timer_tag + "_fwd", flops=2.0 * M * N * K):
+            gemm_nt(xb, sh.w, M, N, K, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs)
+        ctx.save_for_backward(xb, y if (relu or drop_p > 0) else None, weight, bias)
+        ctx.cfg = (sh, relu, drop_p, x.dtype, timer_tag)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .utils.kernel_timer import kernel_timer
+        xb, y, weight, bias = ctx.saved_tensors
+        sh, relu, drop_p, x_dtype, tag = ctx.cfg
+        M, K = xb.shape
+        N = weight.shape[0]
+        dy = dy.contiguous()
+        n8, m8 = _r8(N), _r8(M)
+        dz = torch.empty((M, n8), dtype=torch.bfloat16, device=dy.device)
+        dzt = torch.empty((N, m8), dtype=torch.bfloat16, device=dy.device)
+        if bias is not None:
+            if bias.grad is None:
+                bias.grad = torch.zeros_like(bias)
+            db = bias.grad
+        else:
+            db = None
+        scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+        if y is not None and y.dtype != torch.bfloat16:
+            y = y.to(torch.bfloat16)
+        L.check(L.lib().odw_linear_bwd_prep(L.ptr(dy), 1 if dy.dtype == torch.float32 else 0, dy.stride(0),
+                                            L.ptr(y), y.stride(0) if y is not None else 0, M, N, scale,
+                                            L.ptr(dz), n8, L.ptr(dzt), m8, L.ptr(db), L.stream()), "linear_bwd_prep")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=x_dtype, device=dy.device)
+            with kernel_timer.region(tag and tag + "_dgrad", flops=2.0 * M * N * K):
+                gemm_nt(dz, sh.wt, M, K, N, dx)
+        dw = None
+        if weight.requires_grad:
+            xt = transpose_bf16(xb, M, K)
+            if weight.is_leaf:          # accumulate straight into the parameter's gradient buffer
+                fresh = weight.grad is None or getattr(weight, "_odw_fresh", False)
+                if weight.grad is None:
+                    weight.grad = torch.empty_like(weight)
+                weight._odw_fresh = False
+                target = weight.grad
+            else:                       # a derived weight (e.g. the concatenated predictor heads)
+                fresh = True
+                target = dw = torch.empty_like(weight)
+            with kernel_timer.region(tag and tag + "_wgrad", flops=2.0 * M * N * K):
+                gemm_nt(dzt, xt, N, K, M, target, accumulate=not fresh)
+        if bias is not None and not bias.is_leaf:
+            raise RuntimeError("fused_linear: bias must be a leaf parameter or None")
+        return dx, dw, None, None, None, None, None, None, None
+
+
+def fused_linear(x, weight, bias, shadow, relu=False, drop_p=0.0, segs=None, out_f32=False, tag=None):
+    return _FusedLinear.apply(x, weight, bias, shadow, relu, drop_p, segs, out_f32, tag)

@@ -7,6 +7,7 @@ from collections import OrderedDict
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import registry
 from ..dropblock import DropBlock2D
@@ -101,19 +102,33 @@ class VGG16FC67ROIFeatureExtractor(nn.Module):
                     nn.init.normal_(m.weight, 0, 0.01)
                     nn.init.constant_(m.bias, 0)
 
-    def _fc(self, x):
+    def _fc(self, x, segs6=None, segs7=None):
+        """fc6, ReLU, Dropout, fc7, ReLU, Dropout (vgg16.py:121-127).  With a counter-based `rand`
+        the two dropouts are fused into the GEMM epilogues; `segs*` carry per-pass keys when
+        several passes are stacked along the row dimension."""
         fc6, fc7 = self.classifier[1], self.classifier[4]
-        x = torch.relu(fc6(x))
-        x = self._dropout(x)
-        x = torch.relu(fc7(x))
-        return self._dropout(x)
-
-    def _dropout(self, x):
         if not self.training:
-            return x
-        if self.rand is not None:
-            return self.rand.dropout(x, 0.5)
-        return torch.nn.functional.dropout(x, 0.5, True)
+            return torch.relu(fc7(torch.relu(fc6(x))))
+        if self.rand is None:
+            x = F.dropout(torch.relu(fc6(x)), 0.5, True)
+            return F.dropout(torch.relu(fc7(x)), 0.5, True)
+        if segs6 is None:
+            k6, k7 = self.rand.key(), self.rand.key()
+            segs6, segs7 = [(0, k6[0], k6[1])], [(0, k7[0], k7[1])]
+        x = fc6.fused(x, relu=True, drop_p=0.5, segs=segs6)
+        return fc7.fused(x, relu=True, drop_p=0.5, segs=segs7)
+
+    def forward_clean_and_aug(self, pooled):
+        """The clean pass and the DropBlock pass of ROIWeakRegHead.forward (weak_head.py:107-112) as
+        ONE stacked fc6/fc7 evaluation (M = 2P): random draws are numbered in the reference's
+        order (clean fc6, clean fc7, DropBlock centres, aug fc6, aug fc7)."""
+        P = pooled.shape[0]
+        k1, k2 = self.rand.key(), self.rand.key()
+        aug = self.forward_dropblock(pooled) if hasattr(self, "dropblock") else pooled
+        k4, k5 = self.rand.key(), self.rand.key()
+        x = torch.cat([pooled.reshape(P, -1), aug.reshape(P, -1)], dim=0)
+        h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5])
+        return h[:P], h[P:]
 
     def forward(self, x, proposals):
         pooled = self.pooler(x, proposals)

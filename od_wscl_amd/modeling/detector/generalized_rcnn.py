@@ -1,5 +1,6 @@
 """GeneralizedRCNN with precomputed proposals (wetectron/modeling/detector/generalized_rcnn.py:23-97):
 backbone -> ROI weak head -> (loss dict, accuracy dict)."""
+import torch
 from torch import nn
 
 from ..backbone import build_backbone
@@ -21,7 +22,12 @@ class GeneralizedRCNN(nn.Module):
             raise ValueError("precomputed proposals (rois) are required")
         if rand is not None:
             self.roi_heads.set_rand(rand)
-        features = self.backbone(images.tensors)
+        amp = getattr(self, "backbone_autocast", None)
+        if amp is not None:
+            with torch.autocast("cuda", dtype=amp):
+                features = [f.float() for f in self.backbone(images.tensors)]
+        else:
+            features = self.backbone(images.tensors)
         x, result, losses, accuracy = self.roi_heads(features, rois, targets, model_cdb, iteration)
         if self.training:
             return dict(losses), accuracy

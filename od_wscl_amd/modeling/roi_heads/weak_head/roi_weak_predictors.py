@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import registry
+from ....layers.linear import get_backend
 
 _HEADS = ("cls_score", "det_score", "ref1", "bbox_pred1", "ref2", "bbox_pred2", "ref3", "bbox_pred3")
 
@@ -31,7 +32,12 @@ class MISTPredictor(nn.Module):
         heads = [getattr(self, n) for n in _HEADS]
         w = torch.cat([h.weight for h in heads], dim=0)
         b = torch.cat([h.bias for h in heads], dim=0)
-        out = F.linear(x, w, b).split([h.out_features for h in heads], dim=1)
+        if get_backend() == "hip_bf16" and x.is_cuda:
+            from .... import gemm
+            out = gemm.fused_linear(x, w, None, gemm.Shadow(w), out_f32=True, tag="predictor") + b
+        else:
+            out = F.linear(x, w, b)
+        out = out.split([h.out_features for h in heads], dim=1)
         cls, det, r1, b1, r2, b2, r3, b3 = out
         if not self.training:       # roi_weak_predictors.py:167-181
             cls = F.softmax(cls, dim=1)

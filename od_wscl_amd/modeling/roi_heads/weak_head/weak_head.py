@@ -32,14 +32,21 @@ class ROIWeakRegHead(nn.Module):
         raise ValueError("DB.METHOD %r is outside the OD-WSCL hot path" % self.DB_METHOD)
 
     def forward(self, features, proposals, targets=None, model_cdb=None, iteration=None):
-        clean_feats, clean_pooled = self.feature_extractor.forward(features, proposals)
+        fe = self.feature_extractor
         if not self.training:
+            clean_feats, clean_pooled = fe.forward(features, proposals)
             cls, det, refs, boxes = self.predictor(clean_feats, proposals)
             final = torch.mean(torch.stack(refs), dim=0)
             return clean_feats, (final, torch.mean(torch.stack(boxes), dim=0)), {}, {}
-        sim_feature = self.model_sim(clean_feats)
-        aug_pooled = self.go_through_cdb(clean_pooled, proposals)
-        aug_feats = self.feature_extractor.forward_neck(aug_pooled)
+        if fe.rand is not None and self.DB_METHOD in ("dropblock", "none"):
+            # clean pass + DropBlock pass as one stacked fc6/fc7 evaluation (same draws, same order)
+            clean_pooled = fe.forward_pooler(features, proposals)
+            clean_feats, aug_feats = fe.forward_clean_and_aug(clean_pooled)
+            sim_feature = self.model_sim(clean_feats)
+        else:
+            clean_feats, clean_pooled = fe.forward(features, proposals)
+            sim_feature = self.model_sim(clean_feats)
+            aug_feats = fe.forward_neck(self.go_through_cdb(clean_pooled, proposals))
         cls, det, refs, boxes = self.predictor(aug_feats, proposals)
         loss, acc = self.loss_evaluator([cls], [det], refs, boxes, sim_feature, clean_pooled,
                                         self.feature_extractor, self.model_sim, proposals, targets)

@@ -46,6 +46,18 @@ class _NoiseMul(torch.autograd.Function):
         return out, None, None
 
 
+def dropout_with_segments(x, p, segs):
+    """Dropout of a row-stacked activation: rows [segs[i][0], segs[i+1][0]) use key segs[i][1:]
+    with element index relative to the segment's first row."""
+    if len(segs) == 1:
+        return _Dropout.apply(x.float(), segs[0][1], segs[0][2], float(p))
+    parts = []
+    bounds = [s[0] for s in segs] + [x.shape[0]]
+    for i, s in enumerate(segs):
+        parts.append(_Dropout.apply(x[bounds[i]:bounds[i + 1]].float(), s[1], s[2], float(p)))
+    return torch.cat(parts, dim=0)
+
+
 class DeviceRand(object):
     def __init__(self, seed, first_stream=1 << 20, device="cuda"):
         self.s = _rng.Streams(seed, first_stream)
@@ -53,6 +65,10 @@ class DeviceRand(object):
 
     def _key(self):
         return _rng.stream_key(self.s.seed, self.s.take())
+
+    def key(self):
+        """(k0, k1) of the next logical draw (for epilogue-fused dropout)."""
+        return self._key()
 
     def uniform(self, shape):
         k0, k1 = self._key()

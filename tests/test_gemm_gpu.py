@@ -1,0 +1,123 @@
+"""The bf16 MFMA GEMM and the fused Linear op against PyTorch fp32 references of the same
+product on bf16-rounded operands (so the only difference is accumulation order).  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from od_wscl_amd.utils import rng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd import gemm
+    return gemm
+
+
+def rnd(seed, shape, scale=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy((rng.normal(seed, 1, n) * scale).reshape(shape)).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1, 1, 8), (257, 357, 4096), (300, 128, 72), (2000, 512, 2000),
+                                   (64, 4096, 1024), (130, 70, 25088)])
+def test_gemm_nt_matches_fp32_reference(G, M, N, K):
+    k8 = (K + 7) // 8 * 8
+    a = torch.zeros(M, k8, device="cuda").bfloat16()
+    b = torch.zeros(N, k8, device="cuda").bfloat16()
+    a[:, :K] = rnd(1, (M, K)).bfloat16()
+    b[:, :K] = rnd(2, (N, K)).bfloat16()
+    out = torch.empty(M, N, device="cuda")
+    G.gemm_nt(a, b, M, N, K, out)
+    ref = a.float() @ b.float().T
+    # exact products, fp32 accumulation in a different order: error ~ sqrt(K) * eps * |a||b|
+    tol = 1e-5 * np.sqrt(K) * 4
+    assert (out - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (out - ref).abs().max().item()
+    ob = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    G.gemm_nt(a, b, M, N, K, ob)
+    assert (ob.float() - ref).abs().max().item() <= 8e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_asymmetric_identity(G):
+    # A = I, asymmetric B: catches transposed / permuted C writes
+    n = 128
+    a = torch.eye(n, device="cuda").bfloat16()
+    b = (torch.arange(n * n, device="cuda").reshape(n, n) % 251).float().bfloat16()
+    out = torch.empty(n, n, device="cuda")
+    G.gemm_nt(a, b, n, n, n, out)
+    assert torch.equal(out, b.float().T)
+
+
+def test_gemm_epilogue_bias_relu_dropout_accumulate(G):
+    M, N, K = 300, 200, 256
+    a, b = rnd(3, (M, K)).bfloat16(), rnd(4, (N, K)).bfloat16()
+    bias = rnd(5, (N,))
+    ref = torch.relu(a.float() @ b.float().T * 0.5 + bias)
+    k1, k2 = rng.stream_key(7, 11), rng.stream_key(7, 12)
+    out = torch.empty(M, N, device="cuda")
+    G.gemm_nt(a, b, M, N, K, out, bias=bias, relu=True, alpha=0.5, drop_p=0.5, segs=[(0,) + k1, (100,) + k2])
+    keep = np.concatenate([rng.uniform(7, 11, 100 * N).reshape(100, N), rng.uniform(7, 12, 200 * N).reshape(200, N)]) >= 0.5
+    exp = ref * torch.from_numpy(keep).cuda() * 2.0
+    assert (out - exp).abs().max().item() <= 1e-3
+    acc = torch.ones(M, N, device="cuda")
+    G.gemm_nt(a, b, M, N, K, acc, accumulate=True)
+    assert (acc - (1 + a.float() @ b.float().T)).abs().max().item() <= 1e-3
+
+
+def test_transpose_and_convert(G):
+    x = rnd(6, (70, 45))
+    t = G.transpose_bf16(x, 70, 45)
+    assert t.shape == (45, 72)
+    assert torch.equal(t[:, :70], x.bfloat16().T) and (t[:, 70:] == 0).all()
+    tb = G.transpose_bf16(x.bfloat16().contiguous(), 70, 45)
+    assert torch.equal(tb, t)
+    assert torch.equal(G.to_bf16(x), x.bfloat16())
+
+
+@pytest.mark.parametrize("M,K,N,relu,drop,out_f32", [(300, 512, 256, True, 0.5, False), (190, 4096, 357, False, 0.0, True),
+                                                      (64, 1024, 128, True, 0.0, False)])
+def test_fused_linear_forward_backward(G, M, K, N, relu, drop, out_f32):
+    x = rnd(8, (M, K), 0.5).requires_grad_(True)
+    w = torch.nn.Parameter(rnd(9, (N, K), 0.05))
+    b = torch.nn.Parameter(rnd(10, (N,), 0.1))
+    key = rng.stream_key(3, 4)
+    y = G.fused_linear(x, w, b, G.Shadow(w), relu=relu, drop_p=drop, segs=[(0,) + key] if drop else None, out_f32=out_f32)
+    g = rnd(11, (M, N))
+    y.backward(g.to(y.dtype))
+    # fp32 reference on bf16-rounded operands
+    xr = x.detach().bfloat16().float().requires_grad_(True)
+    wr = w.detach().bfloat16().float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    z = xr @ wr.T + br
+    if relu:
+        z = torch.relu(z)
+    if drop:
+        keep = torch.from_numpy(rng.uniform(3, 4, M * N).reshape(M, N) >= drop).cuda()
+        z = z * keep * (1.0 / (1 - drop))
+    z.backward(g.to(y.dtype).float())
+    s = lambda t: max(t.abs().max().item(), 1e-6)
+    assert (y.float() - z).abs().max().item() <= 1e-2 * s(z)
+    assert (x.grad - xr.grad).abs().max().item() <= 2e-2 * s(xr.grad)
+    assert (w.grad - wr.grad).abs().max().item() <= 2e-2 * s(wr.grad)
+    assert (b.grad - br.grad).abs().max().item() <= 2e-2 * s(br.grad)
+
+
+def test_sgd_kernel(G):
+    from od_wscl_amd import _lib as L
+    n = 100003
+    p, g = rnd(12, (n,)), rnd(13, (n,))
+    p0 = p.clone()
+    buf = torch.empty(n, device="cuda")
+    sh = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref_p], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for it in range(3):
+        ref_p.grad = g.clone()
+        opt.step()
+        L.check(L.lib().odw_sgd_momentum(L.ptr(p), L.ptr(g), L.ptr(buf), L.ptr(sh), n, 0.01, 1e-4, 0.9, 1.0,
+                                         1 if it == 0 else 0, L.stream()), "sgd")
+    assert (p - ref_p.detach()).abs().max().item() <= 1e-6
+    assert torch.equal(sh, p.bfloat16())
