@@ -94,7 +94,7 @@ def cpu_baseline(args, seed):
     from od_wscl_amd import synthetic
     from oracle import hotpath_ref as H
     p = args.cpu_proposals
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)     # beyond ~32 threads torch-CPU GEMMs of this size stop scaling
     torch.set_num_threads(cores)
     sd = H.make_state(1, args.classes)
     img = torch.from_numpy(synthetic.make_image(seed, 0, args.size, args.size))[None]
@@ -106,7 +106,7 @@ def cpu_baseline(args, seed):
     sum(losses.values()).backward()
     dt = time.time() - t0
     return {"value": round(p / dt, 2), "unit": "proposals/s", "cores": cores, "kind": "port",
-            "sample": "1 step fwd+bwd (no optimizer), VGG16 %dpx, %d of the %d proposals, torch-CPU fp32 oracle, %d threads"
+            "sample": "1 step fwd+bwd (no optimizer), VGG16 %dpx, %d of the %d proposals, torch-CPU fp32 oracle (C ROIPool single-threaded), %d threads"
                       % (args.size, p, args.proposals, cores), "seconds": round(dt, 2)}
 
 
@@ -156,7 +156,7 @@ def main():
     value = world * args.proposals * args.steps / dt
 
     if rank == 0:
-        roof = engine.kernel_timer.roofline(args.dtype, MFMA_PEAK_TFLOPS, HBM_PEAK_GBPS, dominant="fc6_fwd")
+        roof = engine.kernel_timer.roofline(args.dtype, MFMA_PEAK_TFLOPS, HBM_PEAK_GBPS)
         out = {
             "metric": "proposals/sec fwd+bwd (VGG16, %d proposals, %dpx)" % (args.proposals, args.size),
             "value": round(value, 1), "unit": "proposals/s", "n_gpus": world, "steps": args.steps,

@@ -21,6 +21,7 @@
 // optional accumulate (C += ...) for weight gradients shared by several passes.
 #include "odw_common.h"
 #include "odw_rng.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -82,6 +83,45 @@ __device__ __forceinline__ void store_tile(uint4* __restrict__ sa, uint4* __rest
         const int row = id >> 3, c = id & 7;
         sa[lds_slot(row, c)] = ra[i];
         sb[lds_slot(row, c)] = rb[i];
+    }
+}
+
+
+template <bool OUT_BF16>
+__device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], void* __restrict__ Cv, int ldc, int M, int N,
+                                               int m0, int n0, int wm, int wn, int half, int l31,
+                                               const Epilogue& ep) {
+    // ---- epilogue.  C layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= N) continue;
+        const float bias = ep.bias ? ep.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                float v = acc[i][j][r] * ep.alpha + bias;
+                if (ep.relu) v = fmaxf(v, 0.0f);
+                if (ep.drop_p > 0.0f) {
+                    int srow = ep.seg_row[0];
+                    uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
+                    if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
+                    if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
+                    if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+                    const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)n;
+                    v = odw_uniform(idx, k0, k1) >= ep.drop_p ? v * (1.0f / (1.0f - ep.drop_p)) : 0.0f;
+                }
+                if (OUT_BF16) {
+                    reinterpret_cast<unsigned short*>(Cv)[(size_t)m * ldc + n] = f2bf(v);
+                } else {
+                    float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
+                    *c = ep.accumulate ? *c + v : v;
+                }
+            }
+        }
     }
 }
 
@@ -149,38 +189,92 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_kernel(
         __syncthreads();
     }
 
-    // ---- epilogue.  C layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
+}
+
+
+// ---- LDS-DMA variant ---------------------------------------------------------------------
+// Same tile / swizzle / MFMA schedule, but the operand tiles go HBM -> LDS directly with
+// global_load_lds_dwordx4 (16 B per lane, no VGPR round trip, no ds_write pass).  The DMA writes
+// 64 consecutive 16-byte slots per wave instruction (LDS image is lane-linear), so the XOR swizzle
+// is applied to the per-lane SOURCE address: lane l fills physical slot (l & 7) of row (l >> 3)
+// with logical chunk (l & 7) ^ f(row) -- still one full 128-byte line per row.
+// Needs lda/ldb >= K rounded up to 64 with zero padding (the caller's scratch operands are
+// allocated that way); out-of-range rows are clamped (their products are never stored).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ __forceinline__ void dma_tile(const unsigned short* __restrict__ G, int ld, int nrows, int row0, int k0,
+                                         uint4* __restrict__ tile, int wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
-        if (n >= N) continue;
-        const float bias = ep.bias ? ep.bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= M) continue;
-                float v = acc[i][j][r] * ep.alpha + bias;
-                if (ep.relu) v = fmaxf(v, 0.0f);
-                if (ep.drop_p > 0.0f) {
-                    int srow = ep.seg_row[0];
-                    uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
-                    if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
-                    if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
-                    if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
-                    const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)n;
-                    v = odw_uniform(idx, k0, k1) >= ep.drop_p ? v * (1.0f / (1.0f - ep.drop_p)) : 0.0f;
-                }
-                if (OUT_BF16) {
-                    reinterpret_cast<unsigned short*>(Cv)[(size_t)m * ldc + n] = f2bf(v);
-                } else {
-                    float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
-                    *c = ep.accumulate ? *c + v : v;
-                }
-            }
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int rbase = wave * 32 + i * 8;              // 8 rows x 8 slots per instruction
+        const int row = rbase + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int g = row0 + row;
+        g = g < nrows ? g : nrows - 1;
+        const unsigned short* src = G + (size_t)g * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(tile + rbase * kChunksPerRow), 16, 0, 0);
     }
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_glds_kernel(
+    const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
+    int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    const int nblk = tiles_m * tiles_n;
+    int tile;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tn = tile / tiles_m, tm = tile % tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int nk = (K + BK - 1) / BK;
+    dma_tile(A, lda, M, m0, 0, lds, wave, lane);
+    dma_tile(B, ldb, N, n0, 0, lds + kTileChunks, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        uint4* sa = lds + (size_t)stage * 2 * kTileChunks;
+        uint4* sb = sa + kTileChunks;
+        if (kt + 1 < nk) {
+            uint4* na = lds + (size_t)(stage ^ 1) * 2 * kTileChunks;
+            dma_tile(A, lda, M, m0, (kt + 1) * BK, na, wave, lane);
+            dma_tile(B, ldb, N, n0, (kt + 1) * BK, na + kTileChunks, wave, lane);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int c = kk * 2 + half;
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[lds_slot(wm * 64 + i * 32 + l31, c)]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed ...
+        __syncthreads();                                     // ... and so has everyone else's
+    }
+    store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
 }
 
 // ---- layout helpers ---------------------------------------------------------------------
@@ -320,17 +414,25 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     if (drop_p > 0.0f) ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_bf16: dropout needs row segments starting at 0");
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);   // 64 KB
-    if (c_is_bf16) {
-        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "gemm attr");
-        gemm_nt_bf16_kernel<true><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(
-            (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, tiles_m, tiles_n);
+    const int k64 = (K + 63) / 64 * 64;
+    const char* force = getenv("ODW_GEMM_VARIANT");     // "reg" / "glds": A/B switch for tools/gemm_bench.py
+    bool use_glds = lda >= k64 && ldb >= k64 && K > 0;
+    if (force && force[0] == 'r') use_glds = false;
+#define ODW_LAUNCH_GEMM(KERNEL, OUTBF)                                                                          \
+    do {                                                                                                        \
+        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<OUTBF>),                         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "gemm attr"); \
+        KERNEL<OUTBF><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(                                      \
+            (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, tiles_m, tiles_n); \
+    } while (0)
+    if (use_glds) {
+        if (c_is_bf16) ODW_LAUNCH_GEMM(gemm_nt_bf16_glds_kernel, true);
+        else ODW_LAUNCH_GEMM(gemm_nt_bf16_glds_kernel, false);
     } else {
-        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "gemm attr");
-        gemm_nt_bf16_kernel<false><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(
-            (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, tiles_m, tiles_n);
+        if (c_is_bf16) ODW_LAUNCH_GEMM(gemm_nt_bf16_kernel, true);
+        else ODW_LAUNCH_GEMM(gemm_nt_bf16_kernel, false);
     }
+#undef ODW_LAUNCH_GEMM
     ODW_CHECK_LAUNCH("gemm_nt_bf16_kernel");
     return ODW_OK;
 }

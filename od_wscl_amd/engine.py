@@ -47,6 +47,21 @@ def make_optimizer(cfg, model):
     return torch.optim.SGD(groups, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
 
 
+def all_reduce_flat(flat, world, chunk_elems=64 * 1024 * 1024, group=None):
+    """Sum-all-reduce a flat gradient buffer in place over `world` ranks as a few large contiguous
+    collectives (256 MB of fp32 each by default: large messages for RCCL's rings over xGMI, and
+    no bucketing copies because the buffer is already contiguous).  The 1/world of the mean is
+    folded into the fused SGD kernel (grad_scale).  No-op for world == 1."""
+    if world <= 1:
+        return
+    works = []
+    n = flat.numel()
+    for s in range(0, n, chunk_elems):
+        works.append(dist.all_reduce(flat[s:min(n, s + chunk_elems)], async_op=True, group=group))
+    for w in works:
+        w.wait()
+
+
 class FlatSGD(object):
     """Parameters, gradients and momenta as three flat fp32 buffers + the fused SGD kernel."""
 
@@ -125,14 +140,7 @@ class FlatSGD(object):
         self.flat_g[self.n_gemm:].zero_()
 
     def all_reduce(self):
-        if self.world > 1:
-            # contiguous slices of the flat buffer, large first (fc6 region); RCCL over xGMI
-            works = []
-            chunk = 64 * 1024 * 1024       # 256 MB of fp32 per collective
-            for s in range(0, self.total, chunk):
-                works.append(dist.all_reduce(self.flat_g[s:min(self.total, s + chunk)], async_op=True))
-            for w in works:
-                w.wait()
+        all_reduce_flat(self.flat_g, self.world)
 
     def step(self):
         lib = L.lib()

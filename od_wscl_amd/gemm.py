@@ -10,10 +10,17 @@ import ctypes
 import torch
 
 from . import _lib as L
+from .utils.kernel_timer import kernel_timer
 
 
 def _r8(n):
     return (n + 7) // 8 * 8
+
+
+def _r64(n):
+    """Leading dimension of scratch operands: the LDS-DMA GEMM reads whole 64-element K tiles, so the
+    reduction dimension is zero padded to a multiple of 64."""
+    return (n + 63) // 64 * 64
 
 
 def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, segs=None, accumulate=False):
@@ -24,12 +31,16 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     nseg = len(segs) if segs else 0
     rows = (ctypes.c_int * 4)(*([s[0] for s in segs] + [0] * (4 - nseg))) if nseg else None
     keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
-    L.check(L.lib().odw_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out), out.stride(0),
-                                     1 if out.dtype == torch.bfloat16 else 0, L.ptr(bias), 1 if relu else 0,
-                                     float(alpha), float(drop_p), nseg,
-                                     ctypes.cast(rows, ctypes.c_void_p) if nseg else None,
-                                     ctypes.cast(keys, ctypes.c_void_p) if nseg else None,
-                                     1 if accumulate else 0, L.stream()), "gemm_nt_bf16")
+    out_bf16 = out.dtype == torch.bfloat16
+    # per-symbol timing for bench.py's roofline object (same names as rocprofv3's kernel trace)
+    sym = "gemm_nt_bf16_glds_kernel<%s>" % ("true" if out_bf16 else "false")
+    with kernel_timer.region(sym, flops=2.0 * M * N * K):
+        L.check(L.lib().odw_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out),
+                                         out.stride(0), 1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0,
+                                         float(alpha), float(drop_p), nseg,
+                                         ctypes.cast(rows, ctypes.c_void_p) if nseg else None,
+                                         ctypes.cast(keys, ctypes.c_void_p) if nseg else None,
+                                         1 if accumulate else 0, L.stream()), "gemm_nt_bf16")
     return out
 
 
@@ -42,8 +53,8 @@ def to_bf16(x):
 
 
 def transpose_bf16(x, rows, cols):
-    """(rows x cols) fp32|bf16 -> (cols x r8(rows)) bf16, zero padded."""
-    ld = _r8(rows)
+    """(rows x cols) fp32|bf16 -> (cols x r64(rows)) bf16, zero padded."""
+    ld = _r64(rows)
     out = torch.empty((cols, ld), dtype=torch.bfloat16, device=x.device)
     L.check(L.lib().odw_transpose_to_bf16(L.ptr(x), 1 if x.dtype == torch.float32 else 0, x.stride(0), rows, cols,
                                           L.ptr(out), ld, L.stream()), "transpose_to_bf16")
@@ -51,7 +62,7 @@ def transpose_bf16(x, rows, cols):
 
 
 class Shadow(object):
-    """bf16 copies of one fp32 weight: w (N x K) and wt (K x r8(N))."""
+    """bf16 copies of one fp32 weight: w (N x K) and wt (K x r64(N))."""
 
     def __init__(self, weight):
         self.weight = weight
@@ -83,14 +94,13 @@ class _FusedLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, shadow, relu, drop_p, segs, out_f32, timer_tag):
-        from .utils.kernel_timer import kernel_timer
         sh = shadow.refresh()
         M, K = x.shape
         N = weight.shape[0]
         xb = x if x.dtype == torch.bfloat16 else to_bf16(x)
         xb = xb if xb.stride(1) == 1 and xb.stride(0) % 8 == 0 else xb.contiguous()
         y = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
-        with kernel_timer.region(timer_tag and timer_tag + "_fwd", flops=2.0 * M * N * K):
+        with kernel_timer.region(timer_tag and "layer/" + timer_tag + "_fwd", flops=2.0 * M * N * K):
             gemm_nt(xb, sh.w, M, N, K, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs)
         ctx.save_for_backward(xb, y if (relu or drop_p > 0) else None, weight, bias)
         ctx.cfg = (sh, relu, drop_p, x.dtype, timer_tag)
@@ -98,13 +108,12 @@ class _FusedLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from .utils.kernel_timer import kernel_timer
         xb, y, weight, bias = ctx.saved_tensors
         sh, relu, drop_p, x_dtype, tag = ctx.cfg
         M, K = xb.shape
         N = weight.shape[0]
         dy = dy.contiguous()
-        n8, m8 = _r8(N), _r8(M)
+        n8, m8 = _r64(N), _r64(M)
         dz = torch.empty((M, n8), dtype=torch.bfloat16, device=dy.device)
         dzt = torch.empty((N, m8), dtype=torch.bfloat16, device=dy.device)
         if bias is not None:
@@ -122,7 +131,7 @@ class _FusedLinear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=x_dtype, device=dy.device)
-            with kernel_timer.region(tag and tag + "_dgrad", flops=2.0 * M * N * K):
+            with kernel_timer.region(tag and "layer/" + tag + "_dgrad", flops=2.0 * M * N * K):
                 gemm_nt(dz, sh.wt, M, K, N, dx)
         dw = None
         if weight.requires_grad:
@@ -136,7 +145,7 @@ class _FusedLinear(torch.autograd.Function):
             else:                       # a derived weight (e.g. the concatenated predictor heads)
                 fresh = True
                 target = dw = torch.empty_like(weight)
-            with kernel_timer.region(tag and tag + "_wgrad", flops=2.0 * M * N * K):
+            with kernel_timer.region(tag and "layer/" + tag + "_wgrad", flops=2.0 * M * N * K):
                 gemm_nt(dzt, xt, N, K, M, target, accumulate=not fresh)
         if bias is not None and not bias.is_leaf:
             raise RuntimeError("fused_linear: bias must be a leaf parameter or None")

@@ -53,5 +53,5 @@ class Linear(nn.Linear):
         if self.tag is None or not kernel_timer.enabled:
             return F.linear(x, self.weight, self.bias)
         flops = 2.0 * x.shape[0] * self.in_features * self.out_features
-        with kernel_timer.region(self.tag + "_fwd", flops=flops):
+        with kernel_timer.region("layer/" + self.tag + "_fwd", flops=flops):
             return F.linear(x, self.weight, self.bias)

@@ -39,23 +39,23 @@ class KernelTimer(object):
         return out
 
     def roofline(self, dtype, mfma_peaks, hbm_peak_gbps, dominant=None):
+        """The `roofline` object of bench.py for the dominant KERNEL SYMBOL (keys not starting with
+        "layer/"): achieved = algorithmic FLOPs of its launches / their measured duration."""
         summ = self.summary()
-        if not summ:
+        kern = {k: v for k, v in summ.items() if not k.startswith("layer/")}
+        if not kern:
             return None
-        name = dominant or max(summ, key=lambda k: summ[k]["total_ms"])
-        r = summ[name]
-        if r["flops"] > 0:
-            achieved = r["flops"] / (r["avg_ms"] * 1e-3) / 1e12
-            peak = mfma_peaks[dtype]
-            return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                    "avg_launch_ms": round(r["avg_ms"], 4), "launches": r["launches"],
-                    "flops_per_launch": r["flops"],
-                    "others": {k: round(v["total_ms"], 3) for k, v in summ.items() if k != name}}
-        achieved = r["bytes"] / (r["avg_ms"] * 1e-3) / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": hbm_peak_gbps,
-                "unit": "GB/s", "frac": round(achieved / hbm_peak_gbps, 4), "traffic": None,
-                "avg_launch_ms": round(r["avg_ms"], 4), "launches": r["launches"], "bytes_per_launch": r["bytes"]}
+        name = dominant if dominant in kern else max(kern, key=lambda k: kern[k]["total_ms"])
+        r = kern[name]
+        layers = {k[6:]: {"ms_per_launch": round(v["avg_ms"], 4), "TFLOP/s": round(v["flops"] / (v["avg_ms"] * 1e-3) / 1e12, 1),
+                          "launches": v["launches"]} for k, v in summ.items() if k.startswith("layer/")}
+        achieved = r["flops"] / (r["avg_ms"] * 1e-3) / 1e12
+        peak = mfma_peaks[dtype]
+        return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(r["avg_ms"], 4),
+                "launches": r["launches"], "flops_per_launch": r["flops"],
+                "other_kernels_ms": {k: round(v["total_ms"], 3) for k, v in kern.items() if k != name},
+                "layers": layers}
 
 
 kernel_timer = KernelTimer()

@@ -41,6 +41,29 @@ def test_gemm_nt_matches_fp32_reference(G, M, N, K):
     assert (ob.float() - ref).abs().max().item() <= 8e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 357, 4096), (2000, 512, 1984), (130, 70, 25088), (5, 3, 64)])
+def test_gemm_lds_dma_variant(G, M, N, K):
+    """Operands padded to a multiple of 64 in K take the global_load_lds path; it must agree with the
+    register-staged kernel (selected by ODW_GEMM_VARIANT=reg) to fp32 re-association."""
+    import os
+    k64 = (K + 63) // 64 * 64
+    a = torch.zeros(M, k64, device="cuda").bfloat16()
+    b = torch.zeros(N, k64, device="cuda").bfloat16()
+    a[:, :K] = rnd(21, (M, K)).bfloat16()
+    b[:, :K] = rnd(22, (N, K)).bfloat16()
+    o1 = torch.empty(M, N, device="cuda")
+    o2 = torch.empty(M, N, device="cuda")
+    G.gemm_nt(a, b, M, N, K, o1)
+    os.environ["ODW_GEMM_VARIANT"] = "reg"
+    try:
+        G.gemm_nt(a, b, M, N, K, o2)
+    finally:
+        del os.environ["ODW_GEMM_VARIANT"]
+    ref = a.float() @ b.float().T
+    tol = 1e-5 * np.sqrt(K) * 4 * max(1.0, ref.abs().max().item())
+    assert (o1 - ref).abs().max().item() <= tol and (o2 - ref).abs().max().item() <= tol
+
+
 def test_gemm_asymmetric_identity(G):
     # A = I, asymmetric B: catches transposed / permuted C writes
     n = 128
@@ -70,7 +93,7 @@ def test_gemm_epilogue_bias_relu_dropout_accumulate(G):
 def test_transpose_and_convert(G):
     x = rnd(6, (70, 45))
     t = G.transpose_bf16(x, 70, 45)
-    assert t.shape == (45, 72)
+    assert t.shape == (45, 128)
     assert torch.equal(t[:, :70], x.bfloat16().T) and (t[:, 70:] == 0).all()
     tb = G.transpose_bf16(x.bfloat16().contiguous(), 70, 45)
     assert torch.equal(tb, t)
