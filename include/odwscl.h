@@ -142,7 +142,7 @@ int odw_od_assign(const float* boxes, int P, const float* gt_boxes, const int64_
  *   C        : bf16 (c_is_bf16) or fp32, row stride ldc; accumulate (fp32 only): C += result
  *   epilogue : + bias[N] (nullable), ReLU, dropout(drop_p) with counter-based keys:
  *              nseg row segments (seg_rows[i] = first row, seg_keys[2i..2i+1] = key); element
- *              (m,n) of segment s uses index (m - seg_rows[s]) * N + n   (HOST arrays, <= 4)
+ *              (m,n) of segment s uses index (m - seg_rows[s]) * N + n   (HOST arrays, <= 16)
  * odw_linear_bwd_prep: dZ = dY * [Y != 0] * scale (Y = saved bf16 output, nullable), emitted
  *   row-major (ld_z) and transposed (N x ld_t), both zero padded; db[n] += column sums.
  * odw_transpose_to_bf16 / odw_f32_to_bf16: layout + precision helpers for the operands.
@@ -158,6 +158,28 @@ int odw_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, int R, int C
 int odw_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int odw_sgd_momentum(float* p, const float* g, float* buf, void* shadow_bf16, int64_t n, float lr, float wd,
                      float momentum, float grad_scale, int first_step, void* stream);
+
+/* ---- OD-WSCL selection logic on the device ------------------------------------------
+ * replaces the Python loops of roi_heads/weak_head/loss.py:281-345 (IoU sampling, object
+ * discovery) and the pseudo-GT bookkeeping of od_layer (pseudo_label_generator.py:143-166);
+ * one workgroup per image, sets as P-bit masks in LDS, no host synchronisation inside.
+ *   s0,s1,s2  : the three branch score matrices (sumP x C): final_score, softmax(ref1), softmax(ref2)
+ *   img_off   : int32[n_img+1] first proposal of each image; pos_cls int32[n_img][maxpos] positive
+ *               class indices c (0-based over foreground, ascending); n_pos int32[n_img]
+ * discover_iou -> tops[n_img][3][maxpos] (first argmax of column c+1), masks uint32[n_img][maxpos][ceil(max_p/32)]
+ *               (pgt_index bit sets), rows int32[n_img][maxpos][pstride] (ascending), counts[n_img][maxpos]
+ * discover_sim : E (sumP x 128) embeddings; bank (rows x 128) class-major banks with bank_off/bank_cnt[C-1];
+ *               updates masks; emits per (img,branch,class) NMS survivors in descending class score
+ *               (inst_*), the not-yet-known survivors ascending (fresh_*), and per (img,branch) the od_layer
+ *               pseudo-GT lists gt_idx/gt_cls/gt_score [n_img][3][maxpos*pstride] + gt_cnt[n_img][3]. */
+int odw_discover_iou(const float* s0, const float* s1, const float* s2, int C, const float* boxes,
+                     const int* img_off, int n_img, int max_p, const int* pos_cls, const int* n_pos, int maxpos,
+                     float thres, int* tops, uint32_t* masks, int* rows, int pstride, int* counts, void* stream);
+int odw_discover_sim(const float* E, const float* s0, const float* s1, const float* s2, int C, const float* boxes,
+                     const int* img_off, int n_img, int max_p, const int* pos_cls, const int* n_pos, int maxpos,
+                     const int* tops, uint32_t* masks, const float* bank, const int* bank_off, const int* bank_cnt,
+                     float nms_thr, int pstride, int* inst_idx, int* inst_cnt, int* fresh_idx, int* fresh_cnt,
+                     int* gt_idx, int* gt_cls, float* gt_score, int* gt_cnt, void* stream);
 
 #ifdef __cplusplus
 }

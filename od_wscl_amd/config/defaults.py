@@ -61,5 +61,8 @@ def make_defaults():
     c.loss = "supconv2"
     c.OUTPUT_DIR = "."
     c.DTYPE = "float32"  # :559
+    # build-specific switches (not in the reference)
+    c.ODW = CN()
+    c.ODW.LOSS_IMPL = "fused"     # "fused": selection logic on the device; "loops": straight-line restatement
     c.SEED = -1
     return c

@@ -30,6 +30,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kThreads = 256;
+constexpr int kMaxSeg = 16;     // stacked logical passes per launch (each has its own dropout key)
 constexpr int kChunksPerRow = BK / 8;                 // 16-byte chunks per LDS row
 constexpr int kTileChunks = BM * kChunksPerRow;       // 1024 uint4 per operand tile
 constexpr int kLoadsPerThread = kTileChunks / kThreads;  // 4
@@ -39,8 +40,8 @@ struct Epilogue {
     int relu;
     float drop_p;          // 0 = no dropout
     int nseg;              // dropout row segments (each logical draw has its own key)
-    int seg_row[4];
-    uint32_t seg_k0[4], seg_k1[4];
+    int seg_row[kMaxSeg];
+    uint32_t seg_k0[kMaxSeg], seg_k1[kMaxSeg];
     int accumulate;        // fp32 output only: C += result
     float alpha;           // scales the product before bias
 };
@@ -108,9 +109,9 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], void* 
                 if (ep.drop_p > 0.0f) {
                     int srow = ep.seg_row[0];
                     uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
-                    if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
-                    if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
-                    if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+#pragma unroll
+                    for (int t = 1; t < kMaxSeg; ++t)      // static indices: stays in SGPRs
+                        if (t < ep.nseg && m >= ep.seg_row[t]) { srow = ep.seg_row[t]; k0 = ep.seg_k0[t]; k1 = ep.seg_k1[t]; }
                     const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)n;
                     v = odw_uniform(idx, k0, k1) >= ep.drop_p ? v * (1.0f / (1.0f - ep.drop_p)) : 0.0f;
                 }
@@ -402,11 +403,11 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
                 "gemm_nt_bf16: A/B rows must be 16-byte aligned (lda=%d ldb=%d)", lda, ldb);
     ODW_REQUIRE(((K + 7) / 8) * 8 <= lda && ((K + 7) / 8) * 8 <= ldb,
                 "gemm_nt_bf16: K=%d rounded up to 8 must fit in lda=%d / ldb=%d (zero padded)", K, lda, ldb);
-    ODW_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && nseg >= 0 && nseg <= 4, "gemm_nt_bf16: bad dropout args");
+    ODW_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && nseg >= 0 && nseg <= kMaxSeg, "gemm_nt_bf16: bad dropout args");
     ODW_REQUIRE(!(accumulate && c_is_bf16), "gemm_nt_bf16: accumulate needs an fp32 C");
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = drop_p; ep.nseg = nseg; ep.accumulate = accumulate; ep.alpha = alpha;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kMaxSeg; ++i) {
         ep.seg_row[i] = (i < nseg && seg_rows) ? seg_rows[i] : 0;
         ep.seg_k0[i] = (i < nseg && seg_keys) ? seg_keys[2 * i] : 0;
         ep.seg_k1[i] = (i < nseg && seg_keys) ? seg_keys[2 * i + 1] : 0;

@@ -234,4 +234,12 @@ class RoIRegLossComputation(object):
 
 
 def make_roi_weak_loss_evaluator(cfg):
-    return registry.ROI_WEAK_LOSS[cfg.MODEL.ROI_WEAK_HEAD.LOSS](cfg)
+    """`RoIRegLoss` (the reference's registry key) resolves to the device-side implementation
+    (loss_fused.RoIRegLossFused) unless cfg.ODW.LOSS_IMPL == "loops" asks for the straight-line
+    restatement above; both reproduce the reference and are tested against the same golden vectors."""
+    from . import loss_fused  # noqa: F401  (registers RoIRegLossFused)
+    name = cfg.MODEL.ROI_WEAK_HEAD.LOSS
+    impl = cfg.ODW.LOSS_IMPL if "ODW" in cfg else "fused"
+    if name == "RoIRegLoss" and impl == "fused":
+        name = "RoIRegLossFused"
+    return registry.ROI_WEAK_LOSS[name](cfg)

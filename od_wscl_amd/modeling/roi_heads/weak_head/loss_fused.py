@@ -1,0 +1,240 @@
+"""RoIRegLossFused -- the OD-WSCL loss with its selection logic on the device.
+
+Same inputs, same outputs, same reference semantics (wetectron/modeling/roi_heads/weak_head/loss.py:233-411,
+quirks Q1-Q12 kept) as `loss.RoIRegLossComputation`, restructured for the GPU:
+
+  * loop 1 / loop 2 / od_layer bookkeeping = two kernel launches (csrc/discover.hip); the host
+    reads two small count vectors per step instead of synchronising at every argmax / nonzero /
+    unique / NMS;
+  * the drop-view and noise-view passes of EVERY (image, class) are stacked into one fc6/fc7/Sim_Net
+    evaluation (per-segment counter-based dropout keys, drawn in the reference's order);
+  * SupCon features / weights are assembled with one gather each from the concatenated embedding
+    matrix; the refinement losses use masked, fixed-shape expressions (no nonzero()).
+"""
+import torch
+from torch.nn import functional as F
+
+from .... import _C
+from .... import _lib as L
+from ....layers import smooth_l1_loss
+from ... import registry
+from ..sim_head.sim_loss import SupConLossV2
+from .loss import RoIRegLossComputation
+
+
+def _i32(values, device):
+    return torch.tensor(values, dtype=torch.int32, device=device)
+
+
+@registry.ROI_WEAK_LOSS.register("RoIRegLossFused")
+class RoIRegLossFused(RoIRegLossComputation):
+    def _call(self, class_score, det_score, ref_scores, ref_bbox_preds, sim_feature, clean_pooled_feats,
+              feature_extractor, model_sim, proposals, targets, epsilon=1e-8):
+        if not self.contra or feature_extractor.rand is None:
+            return super()._call(class_score, det_score, ref_scores, ref_bbox_preds, sim_feature,
+                                 clean_pooled_feats, feature_extractor, model_sim, proposals, targets, epsilon)
+        lib = L.lib()
+        sizes = [len(p) for p in proposals]
+        n_img, sum_p, max_p = len(sizes), sum(sizes), max(sizes)
+        device = class_score[0].device
+        rand = feature_extractor.rand
+        tr = self.trace
+
+        class_score = F.softmax(torch.cat(class_score, dim=0), dim=1)
+        det = torch.cat(det_score, dim=0)
+        final_det = torch.cat([F.softmax(d, dim=0) for d in det.split(sizes)], dim=0) if n_img > 1 else F.softmax(det, dim=0)
+        final_score = class_score * final_det
+        C = final_score.shape[1]
+        n_ref = len(ref_scores)
+        assert n_ref == 3, "the OD-WSCL head has three refinement branches"
+        srcs = [final_score.detach().contiguous(), F.softmax(ref_scores[0].detach(), dim=1),
+                F.softmax(ref_scores[1].detach(), dim=1)]
+        boxes_all = torch.cat([p.bbox for p in proposals], dim=0).float().contiguous()
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+
+        # ---- image-level labels (host side: they are inputs of the step)
+        pos_host = []
+        for t in targets:
+            lab = t.get_field("labels_host") if t.has_field("labels_host") else t.get_field("labels").tolist()
+            pos_host.append(sorted(set(int(v) - 1 for v in lab if int(v) > 0)))
+        maxpos = max(1, max(len(p) for p in pos_host))
+        lab_vecs = torch.zeros((n_img, C), device=device)
+        for idx, pc in enumerate(pos_host):
+            if pc:
+                lab_vecs[idx, torch.tensor([c + 1 for c in pc], device=device)] = 1
+        pos_cls = _i32([pc + [0] * (maxpos - len(pc)) for pc in pos_host], device)
+        n_pos = _i32([len(pc) for pc in pos_host], device)
+        img_off = _i32(offs, device)
+
+        # ---- kernel A: tops + IoU-sampled row sets
+        w32 = (max_p + 31) // 32
+        tops = torch.zeros((n_img, 3, maxpos), dtype=torch.int32, device=device)
+        masks = torch.zeros((n_img, maxpos, w32), dtype=torch.int32, device=device)
+        rows = torch.empty((n_img, maxpos, max_p), dtype=torch.int32, device=device)
+        counts = torch.zeros((n_img, maxpos), dtype=torch.int32, device=device)
+        L.check(lib.odw_discover_iou(L.ptr(srcs[0]), L.ptr(srcs[1]), L.ptr(srcs[2]), C, L.ptr(boxes_all),
+                                     L.ptr(img_off), n_img, max_p, L.ptr(pos_cls), L.ptr(n_pos), maxpos,
+                                     float(self.p_thres), L.ptr(tops), L.ptr(masks), L.ptr(rows), max_p,
+                                     L.ptr(counts), L.stream()), "discover_iou")
+        counts_h = counts.tolist()                                            # host sync 1
+
+        # ---- stacked drop / noise passes of every (image, class)  (loss.py:292-305)
+        parts, segs6, segs7, meta = [], [], [], []
+        row0 = 0
+        for idx in range(n_img):
+            for ci, c in enumerate(pos_host[idx]):
+                k = counts_h[idx][ci]
+                r_img = rows[idx, ci, :k].long()
+                picked = clean_pooled_feats[offs[idx]:offs[idx + 1]][r_img]
+                drop = feature_extractor.drop_pool(picked)
+                k6d, k7d = rand.key(), rand.key()
+                noisy = feature_extractor.noise_pool(picked)
+                k6n, k7n = rand.key(), rand.key()
+                parts += [drop.reshape(k, -1), noisy.reshape(k, -1)]
+                segs6 += [(row0,) + k6d, (row0 + k,) + k6n]
+                segs7 += [(row0,) + k7d, (row0 + k,) + k7n]
+                meta.append((idx, ci, c, k, row0, r_img))
+                row0 += 2 * k
+                if tr is not None:
+                    tr["iou_samples_%d_%d" % (idx, c)] = r_img.clone()
+        n_seg = len(segs6)
+        if n_seg > 16:      # more stacked passes than one launch carries keys for: split
+            emb = self._embed_in_chunks(feature_extractor, model_sim, parts, segs6, segs7)
+        else:
+            x = torch.cat(parts, dim=0)
+            emb = model_sim(feature_extractor._fc(x, segs6=segs6, segs7=segs7)).float()
+        all_emb = torch.cat([sim_feature, emb], dim=0)            # rows: proposals, then the stacked views
+
+        # ---- class banks (pgt_collection, Q2: class-major over the images processed so far)
+        classes = sorted(set(c for pc in pos_host for c in pc))
+        bank_parts = {c: [] for c in classes}
+        for (idx, ci, c, k, r0, r_img) in meta:
+            bank_parts[c] += [r_img + offs[idx], torch.arange(sum_p + r0, sum_p + r0 + 2 * k, device=device)]
+        bank_index, bank_off_h, bank_cnt_h = [], [0] * (C - 1), [0] * (C - 1)
+        pos = 0
+        for c in classes:
+            ix = torch.cat(bank_parts[c])
+            bank_index.append(ix)
+            bank_off_h[c], bank_cnt_h[c] = pos, int(ix.numel())
+            pos += int(ix.numel())
+        bank_index_all = torch.cat(bank_index)
+        bank = all_emb.detach()[bank_index_all].contiguous()
+        bank_off, bank_cnt = _i32(bank_off_h, device), _i32(bank_cnt_h, device)
+
+        # ---- kernel B: object discovery + pseudo-GT lists
+        shp = (n_img, 3, maxpos)
+        inst_idx = torch.empty(shp + (max_p,), dtype=torch.int32, device=device)
+        fresh_idx = torch.empty(shp + (max_p,), dtype=torch.int32, device=device)
+        inst_cnt = torch.zeros(shp, dtype=torch.int32, device=device)
+        fresh_cnt = torch.zeros(shp, dtype=torch.int32, device=device)
+        gt_idx = torch.empty((n_img, 3, maxpos * max_p), dtype=torch.int32, device=device)
+        gt_cls = torch.empty((n_img, 3, maxpos * max_p), dtype=torch.int32, device=device)
+        gt_score = torch.empty((n_img, 3, maxpos * max_p), dtype=torch.float32, device=device)
+        gt_cnt = torch.zeros((n_img, 3), dtype=torch.int32, device=device)
+        E = sim_feature.detach().contiguous()
+        L.check(lib.odw_discover_sim(L.ptr(E), L.ptr(srcs[0]), L.ptr(srcs[1]), L.ptr(srcs[2]), C, L.ptr(boxes_all),
+                                     L.ptr(img_off), n_img, max_p, L.ptr(pos_cls), L.ptr(n_pos), maxpos, L.ptr(tops),
+                                     L.ptr(masks), L.ptr(bank), L.ptr(bank_off), L.ptr(bank_cnt), float(self.nms),
+                                     max_p, L.ptr(inst_idx), L.ptr(inst_cnt), L.ptr(fresh_idx), L.ptr(fresh_cnt),
+                                     L.ptr(gt_idx), L.ptr(gt_cls), L.ptr(gt_score), L.ptr(gt_cnt), L.stream()),
+                "discover_sim")
+        cnts_h = torch.cat([fresh_cnt.reshape(-1), gt_cnt.reshape(-1), inst_cnt.reshape(-1)]).tolist()   # host sync 2
+        nf = n_img * 3 * maxpos
+        fresh_h = [[cnts_h[(idx * 3 + i) * maxpos:(idx * 3 + i + 1) * maxpos] for i in range(3)] for idx in range(n_img)]
+        gt_h = [cnts_h[nf + idx * 3: nf + idx * 3 + 3] for idx in range(n_img)]
+
+        # ---- SupCon inputs.  features: class-major (bank of the class, then its discoveries in loop
+        # order); weights: append order (Q1)
+        colsum = [final_score[offs[idx]:offs[idx + 1]].sum(dim=0) for idx in range(n_img)]
+        feat_index, feat_label = [], []
+        for c, bix in zip(classes, bank_index):
+            ix = [bix]
+            for idx in range(n_img):
+                if c in pos_host[idx]:
+                    ci = pos_host[idx].index(c)
+                    for i in range(3):
+                        ix.append(fresh_idx[idx, i, ci, :fresh_h[idx][i][ci]].long() + offs[idx])
+            ix = torch.cat(ix)
+            feat_index.append(ix)
+            feat_label.append(torch.full((ix.numel(),), c, dtype=torch.int32, device=device))
+        features = all_emb[torch.cat(feat_index)]
+        labels = torch.cat(feat_label)
+        wparts = []
+        for (idx, ci, c, k, r0, r_img) in meta:                                      # loop 1 order
+            h = final_score[offs[idx]:offs[idx + 1]][r_img, c + 1] / colsum[idx][c + 1]   # Q12
+            wparts += [h, h, h]
+        for idx in range(n_img):                                                      # loop 2 order
+            for i in range(3):
+                for ci, c in enumerate(pos_host[idx]):
+                    f = fresh_idx[idx, i, ci, :fresh_h[idx][i][ci]].long()
+                    wparts.append(final_score[offs[idx]:offs[idx + 1]][f, c + 1] / colsum[idx][c + 1])
+        weights = torch.cat(wparts).detach()
+        if tr is not None:
+            inst_h = cnts_h[nf + n_img * 3:]
+            for idx in range(n_img):
+                for i in range(3):
+                    for ci, c in enumerate(pos_host[idx]):
+                        n_i = inst_h[(idx * 3 + i) * maxpos + ci]
+                        tr["pgt_instance_%d_%d_%d" % (idx, i, c)] = inst_idx[idx, i, ci, :n_i].long().clone()
+                        tr["sim_new_%d_%d_%d" % (idx, i, c)] = fresh_idx[idx, i, ci, :fresh_h[idx][i][ci]].long().clone()
+            tr["supcon_weights"] = weights.clone()
+            tr["supcon_n"] = int(weights.numel())
+        from ..sim_head.sim_loss import _SupConV2Fn
+        losses = {"loss_img": 0, "loss_sim": self.sim_lmda * _SupConV2Fn.apply(features, labels, weights, self.temp)}
+        accs = {"acc_img": 0}
+        for i in range(n_ref):
+            losses["loss_ref_cls%d" % i] = 0
+            losses["loss_ref_reg%d" % i] = 0
+            accs["acc_ref%d" % i] = 0
+
+        # ---- MIL image loss + refinement branches (loss.py:349-400), fixed shapes, no host sync
+        ar4 = torch.arange(4, device=device)
+        for idx in range(n_img):
+            sl = slice(offs[idx], offs[idx + 1])
+            lab = lab_vecs[idx]
+            bx = boxes_all[sl]
+            img_score = torch.clamp(final_score[sl].sum(dim=0), min=epsilon, max=1 - epsilon)
+            losses["loss_img"] = losses["loss_img"] + F.binary_cross_entropy(img_score, lab)
+            for i in range(n_ref):
+                g = gt_h[idx][i]
+                gi = gt_idx[idx, i, :g].long()
+                pseudo, weights_i, targets_reg = _C.od_assign(bx, bx[gi], gt_cls[idx, i, :g].long(), gt_score[idx, i, :g],
+                                                              self.od_layer.fg_thresh, self.od_layer.weights)
+                if tr is not None:
+                    tr["pseudo_%d_%d" % (idx, i)] = pseudo.clone()
+                    tr["weights_%d_%d" % (idx, i)] = weights_i.clone()
+                lam = 3 if i == 0 else 1
+                ce = F.cross_entropy(ref_scores[i][sl], pseudo, reduction="none")
+                losses["loss_ref_cls%d" % i] = losses["loss_ref_cls%d" % i] + lam * torch.mean(ce * weights_i)
+                fg = (pseudo > 0).to(weights_i.dtype)
+                cols = (4 * pseudo[:, None] + ar4) if not self.cls_agnostic_bbox_reg else (4 + ar4).expand(len(pseudo), 4)
+                picked_reg = torch.gather(ref_bbox_preds[i][sl], 1, cols)
+                sl1 = smooth_l1_loss(picked_reg, targets_reg, beta=1, reduction=False)
+                reg = lam * torch.sum(sl1 * (weights_i * fg)[:, None])
+                losses["loss_ref_reg%d" % i] = losses["loss_ref_reg%d" % i] + reg / pseudo.numel()
+            with torch.no_grad():
+                k_img = max(len(pos_host[idx]), 1)
+                accs["acc_img"] = accs["acc_img"] + lab[img_score.topk(k_img)[1]].mean()
+                for i in range(n_ref):
+                    rs = torch.sum(ref_scores[i][sl], dim=0)
+                    accs["acc_ref%d" % i] = accs["acc_ref%d" % i] + lab[1:][rs[1:].topk(k_img)[1]].mean()
+
+        for k in losses:
+            if "sim" not in k:
+                losses[k] = losses[k] / n_img
+        for k in accs:
+            accs[k] = accs[k] / n_img
+        return losses, accs
+
+    @staticmethod
+    def _embed_in_chunks(fe, model_sim, parts, segs6, segs7, max_segs=16):
+        out = []
+        for s in range(0, len(parts), max_segs):
+            chunk = parts[s:s + max_segs]
+            r0 = segs6[s][0]
+            s6 = [(a - r0, b, c) for (a, b, c) in segs6[s:s + max_segs]]
+            s7 = [(a - r0, b, c) for (a, b, c) in segs7[s:s + max_segs]]
+            out.append(model_sim(fe._fc(torch.cat(chunk, dim=0), segs6=s6, segs7=s7)).float())
+        return torch.cat(out, dim=0)

@@ -16,7 +16,7 @@ E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img"]
 LOSS_RTOL = 1e-3
 
 
-def build_model(pooler, weights_np):
+def build_model(pooler, weights_np, loss_impl="fused"):
     from od_wscl_amd.config import make_defaults
     from od_wscl_amd.modeling.detector import build_detection_model
     cfg = make_defaults()
@@ -25,7 +25,7 @@ def build_model(pooler, weights_np):
                          "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7, "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,),
                          "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR", "VGG16.roi_head",
                          "MODEL.ROI_WEAK_HEAD.REGRESS_ON", True, "DB.METHOD", "dropblock", "SOLVER.CONTRA", True,
-                         "nms", 0.1, "lmda", 0.03, "temp", 0.2])
+                         "nms", 0.1, "lmda", 0.03, "temp", 0.2, "ODW.LOSS_IMPL", loss_impl])
     model = build_detection_model(cfg).cuda()
     with torch.no_grad():
         for n, p in model.named_parameters():
@@ -34,15 +34,16 @@ def build_model(pooler, weights_np):
     return model
 
 
+@pytest.mark.parametrize("loss_impl", ["fused", "loops"])
 @pytest.mark.parametrize("name", E2E)
-def test_model_matches_reference_golden(name, weights_np):
+def test_model_matches_reference_golden(name, loss_impl, weights_np):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from od_wscl_amd.structures import BoxList, to_image_list
     from od_wscl_amd.utils.device_rand import DeviceRand
     g = load_e2e(name)
     seed, batch, boxes, labels, cfg = e2e_inputs(g)
-    model = build_model(cfg["pooler"], weights_np)
+    model = build_model(cfg["pooler"], weights_np, loss_impl)
     specs = g["spec_images"]
     rois, targets = [], []
     for k, (h, w, p) in enumerate(specs):
