@@ -142,7 +142,7 @@ int odw_od_assign(const float* boxes, int P, const float* gt_boxes, const int64_
  *   C        : bf16 (c_is_bf16) or fp32, row stride ldc; accumulate (fp32 only): C += result
  *   epilogue : + bias[N] (nullable), ReLU, dropout(drop_p) with counter-based keys:
  *              nseg row segments (seg_rows[i] = first row, seg_keys[2i..2i+1] = key); element
- *              (m,n) of segment s uses index (m - seg_rows[s]) * N + n   (HOST arrays, <= 16)
+ *              (m,n) of segment s uses index (m - seg_rows[s]) * N + n   (HOST arrays, <= 4)
  * odw_linear_bwd_prep: dZ = dY * [Y != 0] * scale (Y = saved bf16 output, nullable), emitted
  *   row-major (ld_z) and transposed (N x ld_t), both zero padded; db[n] += column sums.
  * odw_transpose_to_bf16 / odw_f32_to_bf16: layout + precision helpers for the operands.
@@ -180,6 +180,30 @@ int odw_discover_sim(const float* E, const float* s0, const float* s1, const flo
                      const int* tops, uint32_t* masks, const float* bank, const int* bank_off, const int* bank_cnt,
                      float nms_thr, int pstride, int* inst_idx, int* inst_cnt, int* fresh_idx, int* fresh_cnt,
                      int* gt_idx, int* gt_cls, float* gt_score, int* gt_cnt, void* stream);
+
+/* ---- backbone convolutions (NHWC bf16, implicit GEMM on the MFMA tile) ----------------------
+ * replaces the cuDNN convolutions behind torch.nn.Conv2d in VGG_Base
+ * (modeling/backbone/vgg16.py:34-36,58-83: 3x3, stride 1, padding = dilation).
+ * odw_conv3x3_nhwc_bf16: Y[m][n] = act( sum_{tap,c} X[m+shift(tap)][c] * Wk[n][tap*C+c] + bias[n] ),
+ *   X (n_pix x C) NHWC bf16 with C a power of two >= 8, n_pix = B*H*W; Wk rows zero padded to a
+ *   multiple of 64 (ldw); mirror=1 flips the taps (input gradient with the [ci][tap*Cout+co] copy);
+ *   mask (bf16, n_pix x ldmask, nullable) zeroes the result where mask == 0 (ReLU backward);
+ *   zero_page = >= 16 bytes of zeros in device memory (source of padding taps).
+ * odw_conv_weight_prep / odw_conv_wgrad_unpack: torch (Cout,Cin,3,3) fp32 <-> the packed layouts.
+ * odw_im2col_t_bf16: (9*C x ldm) pixel-contiguous patches for the weight-gradient GEMM.
+ * odw_maxpool2x2_nhwc_bf16(_bwd): 2x2/2 max pool; backward routes to the first maximum and folds
+ *   the ReLU mask of the pooled activation.
+ * odw_nchw_f32_to_nhwc_bf16 / odw_nhwc_bf16_to_nchw_f32: the two ends of the backbone. */
+int odw_conv3x3_nhwc_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, int mirror, const void* Wk,
+                          int ldw, int N, void* Y, int ldy, int y_is_bf16, const float* bias, int relu,
+                          const void* mask, int ldmask, const void* zero_page, void* stream);
+int odw_conv_weight_prep(const float* w, int Co, int Ci, int Cp, void* wk, int ldk, void* wd, int ldd, void* stream);
+int odw_conv_wgrad_unpack(const float* dwk, int ld, int Co, int Ci, int Cp, float* dw, void* stream);
+int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm, void* stream);
+int odw_maxpool2x2_nhwc_bf16(const void* X, int B, int H, int W, int C, void* Y, void* stream);
+int odw_maxpool2x2_nhwc_bf16_bwd(const void* X, const void* dY, int B, int H, int W, int C, void* dX, void* stream);
+int odw_nhwc_bf16_to_nchw_f32(const void* in, int B, int HW, int C, float* out, void* stream);
+int odw_nchw_f32_to_nhwc_bf16(const float* in, int B, int HW, int C, int Cp, void* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,14 @@ SIGNATURES = {
     "odw_discover_iou": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p]),
     "odw_discover_sim": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_i,
                                c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "odw_conv3x3_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_p]),
+    "odw_conv_weight_prep": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p]),
+    "odw_conv_wgrad_unpack": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_im2col_t_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "odw_maxpool2x2_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_maxpool2x2_nhwc_bf16_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_nhwc_bf16_to_nchw_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "odw_nchw_f32_to_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_od_assign": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
 }
 

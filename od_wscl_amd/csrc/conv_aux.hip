@@ -1,0 +1,252 @@
+// conv_aux.hip -- layout / pooling helpers around the implicit-GEMM convolution (gemm_bf16.hip):
+// the VGG16-OICR backbone (modeling/backbone/vgg16.py:58-104) runs in NHWC bf16 on the device.
+//   * weight repacking: torch (Cout,Cin,3,3) fp32 -> [Cout][tap*Cp+ci] (forward) and
+//     [Cin][tap*Cout+co] (input gradient) bf16, rows zero padded to a multiple of 64
+//   * transposed im2col for the weight gradient (reduction over pixels needs pixel-contiguous operands)
+//   * 2x2 max pooling forward / backward (first maximum wins, like torch) with the ReLU mask folded in
+//   * NCHW fp32 <-> NHWC bf16 at the two ends of the backbone
+#include "odw_common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// wk[co][t*Cp + ci] (ld = ldk) and wd[ci][t*Co + co] (ld = ldd); either may be null.
+__global__ void weight_prep_kernel(const float* __restrict__ w, int Co, int Ci, int Cp,
+                                   unsigned short* __restrict__ wk, int ldk, unsigned short* __restrict__ wd, int ldd) {
+    const int total_k = Co * ldk;
+    const int total_d = wd ? Ci * ldd : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_k + total_d; i += gridDim.x * blockDim.x) {
+        if (i < total_k) {
+            if (!wk) continue;
+            const int co = i / ldk, k = i - co * ldk;
+            const int t = k / Cp, ci = k - t * Cp;
+            wk[i] = (t < 9 && ci < Ci) ? f2bf(w[((size_t)co * Ci + ci) * 9 + t]) : (unsigned short)0;
+        } else {
+            const int j = i - total_k;
+            const int ci = j / ldd, k = j - ci * ldd;
+            const int t = k / Co, co = k - t * Co;
+            wd[j] = (t < 9) ? f2bf(w[((size_t)co * Ci + ci) * 9 + t]) : (unsigned short)0;
+        }
+    }
+}
+
+// dw[co][ci][t] = dwk[co][t*Cp + ci]
+__global__ void wgrad_unpack_kernel(const float* __restrict__ dwk, int ld, int Co, int Ci, int Cp,
+                                    float* __restrict__ dw) {
+    const int total = Co * Ci * 9;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int t = i % 9, ci = (i / 9) % Ci, co = i / (9 * Ci);
+        dw[i] = dwk[(size_t)co * ld + t * Cp + ci];
+    }
+}
+
+// out[(t*C + ci)][m] = X[m + shift(t)][ci] (0 in the padding), m < ldm zero padded.  32(m) x 32(ci) tiles.
+__global__ __launch_bounds__(256) void im2col_t_kernel(const unsigned short* __restrict__ X, int M, int H, int W,
+                                                       int C, int dil, unsigned short* __restrict__ out, int ldm) {
+    __shared__ unsigned short tile[32][33];
+    const int t = blockIdx.z;
+    const int ty9 = t / 3, tx9 = t - 3 * ty9;
+    const int dh = (ty9 - 1) * dil, dw = (tx9 - 1) * dil;
+    const int c0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int hw = H * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = m0 + ty + 8 * k, c = c0 + tx;
+        unsigned short v = 0;
+        if (m < M && c < C) {
+            const int p = m % hw;
+            const int y = p / W + dh, x = p % W + dw;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = X[(size_t)(m + dh * W + dw) * C + c];
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, m = m0 + tx;
+        if (c < C && m < ldm) out[((size_t)t * C + c) * ldm + m] = tile[tx][ty + 8 * k];
+    }
+}
+
+// NHWC bf16 2x2/2 max pool, 8 channels per thread
+__global__ void maxpool_fwd_kernel(const uint4* __restrict__ X, int B, int H, int W, int C8, uint4* __restrict__ Y) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        size_t q = i / C8;
+        const int xo = (int)(q % Wo); q /= Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C8 + c;
+        const uint4 v[4] = {X[base], X[base + C8], X[base + (size_t)W * C8], X[base + (size_t)W * C8 + C8]};
+        uint4 o;
+        unsigned int* op = reinterpret_cast<unsigned int*>(&o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int r = 0;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                float best = -__builtin_inff();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned int word = reinterpret_cast<const unsigned int*>(&v[k])[j];
+                    const float f = bf2f((unsigned short)(hlf ? word >> 16 : word & 0xffff));
+                    best = f > best ? f : best;
+                }
+                r |= (unsigned int)f2bf(best) << (16 * hlf);
+            }
+            op[j] = r;
+        }
+        Y[i] = o;
+    }
+}
+
+// dX (pre-pool, NHWC bf16) = unpool(dY) routed to the FIRST maximum of each window, times [X > 0]
+// (X = the post-ReLU activation that was pooled: modeling/backbone/vgg16.py:61-80 conv,ReLU,...,MaxPool)
+__global__ void maxpool_bwd_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY, int B,
+                                   int H, int W, int C, unsigned short* __restrict__ dX) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t q = i / C;
+        const int xo = (int)(q % Wo); q /= Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c;
+        const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+        float best = -__builtin_inff();
+        int bi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float f = bf2f(X[base + off[k]]);
+            if (f > best) { best = f; bi = k; }
+        }
+        const unsigned short g = best > 0.0f ? dY[i] : (unsigned short)0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dX[base + off[k]] = k == bi ? g : (unsigned short)0;
+    }
+}
+
+// out[b][c][p] fp32 = in[b][p][c] bf16   (p = h*W+w), 32x32 tiles
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const unsigned short* __restrict__ in, int HW, int C,
+                                                           float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const unsigned short* src = in + (size_t)b * HW * C;
+    float* dst = out + (size_t)b * HW * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (p < HW && c < C) ? bf2f(src[(size_t)p * C + c]) : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, p = p0 + tx;
+        if (c < C && p < HW) dst[(size_t)c * HW + p] = tile[tx][ty + 8 * k];
+    }
+}
+
+// out[b][p][c] bf16 (c < Cp, zero padded) = in[b][c][p] fp32
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, int HW, int C, int Cp,
+                                                           unsigned short* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + (size_t)b * HW * C;
+    unsigned short* dst = out + (size_t)b * HW * Cp;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, p = p0 + tx;
+        tile[ty + 8 * k][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + ty + 8 * k, c = c0 + tx;
+        if (p < HW && c < Cp) dst[(size_t)p * Cp + c] = f2bf(tile[tx][ty + 8 * k]);
+    }
+}
+
+int blocks_for(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+}  // namespace
+
+ODW_EXPORT int odw_conv_weight_prep(const float* w, int Co, int Ci, int Cp, void* wk, int ldk, void* wd, int ldd,
+                                    void* stream_) {
+    ODW_REQUIRE(Co > 0 && Ci > 0 && Cp >= Ci, "conv_weight_prep: bad dims");
+    ODW_REQUIRE(w && (wk || wd), "conv_weight_prep: null pointer");
+    ODW_REQUIRE((!wk || ldk >= 9 * Cp) && (!wd || ldd >= 9 * Co), "conv_weight_prep: leading dimensions too small");
+    size_t n = (size_t)Co * ldk + (wd ? (size_t)Ci * ldd : 0);
+    weight_prep_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream_>>>(w, Co, Ci, Cp, (unsigned short*)wk, ldk,
+                                                                        (unsigned short*)wd, ldd);
+    ODW_CHECK_LAUNCH("weight_prep_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_conv_wgrad_unpack(const float* dwk, int ld, int Co, int Ci, int Cp, float* dw, void* stream_) {
+    ODW_REQUIRE(Co > 0 && Ci > 0 && Cp >= Ci && ld >= 9 * Cp && dwk && dw, "conv_wgrad_unpack: bad arguments");
+    wgrad_unpack_kernel<<<blocks_for((size_t)Co * Ci * 9), 256, 0, (hipStream_t)stream_>>>(dwk, ld, Co, Ci, Cp, dw);
+    ODW_CHECK_LAUNCH("wgrad_unpack_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm,
+                                 void* stream_) {
+    ODW_REQUIRE(n_pix > 0 && H > 0 && W > 0 && C > 0 && ldm >= n_pix && n_pix % (H * W) == 0 && X && out,
+                "im2col_t: bad arguments");
+    dim3 grid((C + 31) / 32, (ldm + 31) / 32, 9);
+    im2col_t_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X, n_pix, H, W, C, dilation,
+                                                            (unsigned short*)out, ldm);
+    ODW_CHECK_LAUNCH("im2col_t_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_maxpool2x2_nhwc_bf16(const void* X, int B, int H, int W, int C, void* Y, void* stream_) {
+    ODW_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && X && Y, "maxpool2x2: bad arguments");
+    ODW_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 15) == 0, "maxpool2x2: 16-byte alignment");
+    size_t n = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    maxpool_fwd_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream_>>>((const uint4*)X, B, H, W, C / 8, (uint4*)Y);
+    ODW_CHECK_LAUNCH("maxpool_fwd_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_maxpool2x2_nhwc_bf16_bwd(const void* X, const void* dY, int B, int H, int W, int C, void* dX,
+                                            void* stream_) {
+    ODW_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && X && dY && dX, "maxpool2x2_bwd: bad arguments");
+    size_t n = (size_t)B * (H / 2) * (W / 2) * C;
+    maxpool_bwd_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X,
+                                                                        (const unsigned short*)dY, B, H, W, C,
+                                                                        (unsigned short*)dX);
+    ODW_CHECK_LAUNCH("maxpool_bwd_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_nhwc_bf16_to_nchw_f32(const void* in, int B, int HW, int C, float* out, void* stream_) {
+    ODW_REQUIRE(B > 0 && HW > 0 && C > 0 && in && out, "nhwc_to_nchw: bad arguments");
+    dim3 grid((C + 31) / 32, (HW + 31) / 32, B);
+    nhwc_to_nchw_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>((const unsigned short*)in, HW, C, out);
+    ODW_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_nchw_f32_to_nhwc_bf16(const float* in, int B, int HW, int C, int Cp, void* out, void* stream_) {
+    ODW_REQUIRE(B > 0 && HW > 0 && C > 0 && Cp >= C && in && out, "nchw_to_nhwc: bad arguments");
+    dim3 grid((HW + 31) / 32, (Cp + 31) / 32, B);
+    nchw_to_nhwc_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(in, HW, C, Cp, (unsigned short*)out);
+    ODW_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return ODW_OK;
+}

@@ -30,7 +30,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kThreads = 256;
-constexpr int kMaxSeg = 16;     // stacked logical passes per launch (each has its own dropout key)
+constexpr int kMaxSeg = 4;      // stacked logical passes per launch (each has its own dropout key); more = more launches
 constexpr int kChunksPerRow = BK / 8;                 // 16-byte chunks per LDS row
 constexpr int kTileChunks = BM * kChunksPerRow;       // 1024 uint4 per operand tile
 constexpr int kLoadsPerThread = kTileChunks / kThreads;  // 4
@@ -44,6 +44,8 @@ struct Epilogue {
     uint32_t seg_k0[kMaxSeg], seg_k1[kMaxSeg];
     int accumulate;        // fp32 output only: C += result
     float alpha;           // scales the product before bias
+    const unsigned short* mask;   // optional bf16 (M x ldmask): result forced to 0 where mask == 0 (ReLU backward)
+    int ldmask;
 };
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * kChunksPerRow + (chunk ^ ((row >> 1) & 7)); }
@@ -106,12 +108,13 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], void* 
                 if (m >= M) continue;
                 float v = acc[i][j][r] * ep.alpha + bias;
                 if (ep.relu) v = fmaxf(v, 0.0f);
+                if (ep.mask && (ep.mask[(size_t)m * ep.ldmask + n] & 0x7fff) == 0) v = 0.0f;
                 if (ep.drop_p > 0.0f) {
                     int srow = ep.seg_row[0];
                     uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
-#pragma unroll
-                    for (int t = 1; t < kMaxSeg; ++t)      // static indices: stays in SGPRs
-                        if (t < ep.nseg && m >= ep.seg_row[t]) { srow = ep.seg_row[t]; k0 = ep.seg_k0[t]; k1 = ep.seg_k1[t]; }
+                    if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
+                    if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
+                    if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
                     const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)n;
                     v = odw_uniform(idx, k0, k1) >= ep.drop_p ? v * (1.0f / (1.0f - ep.drop_p)) : 0.0f;
                 }
@@ -278,6 +281,110 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_glds_kernel(
     store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
 }
 
+// ---- implicit-GEMM 3x3 convolution on the same tile ------------------------------------------
+// Backbone convolutions (modeling/backbone/vgg16.py:58-83: 3x3, stride 1, padding = dilation in
+// {1,2}) as C[m][co] = sum_{tap,ci} X[m + shift(tap)][ci] * Wk[co][tap*C + ci] with NHWC bf16
+// activations: row m = (b,h,w) of the output, K = 9*C walks (tap, ci).  Nothing is materialised: the
+// LDS-DMA source address of each 16-byte chunk (8 channels of one tap) is computed per lane, taps
+// that fall into the zero padding (or past K) read a zero page.  sign = -1 mirrors the taps (input
+// gradient: the same kernel on dZ with the [ci][tap][co] weight copy).  C must be a power of two >= 8.
+struct ConvGeom {
+    int H, W, C, logC, dil, sign;
+    const unsigned short* zero;     // >= 16 bytes of zeros in global memory
+};
+
+__device__ __forceinline__ void dma_tile_conv(const unsigned short* __restrict__ X, const ConvGeom& g, int k0,
+                                              uint4* __restrict__ tile, int wave, int lane, const int (&rm)[4],
+                                              const int (&rh)[4], const int (&rw)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rbase = wave * 32 + i * 8;
+        const int row = rbase + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int k = k0 + c * 8;
+        const int tap = k >> g.logC, ci = k & (g.C - 1);
+        const int ty = (tap * 11) >> 5;             // tap / 3 for tap in [0, 15]
+        const int tx = tap - 3 * ty;
+        const int dh = (ty - 1) * g.dil * g.sign, dw = (tx - 1) * g.dil * g.sign;
+        const int y = rh[i] + dh, x = rw[i] + dw;
+        const bool ok = rm[i] >= 0 && tap < 9 && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+        const unsigned short* src = ok ? X + ((size_t)(rm[i] + dh * g.W + dw) << g.logC) + ci : g.zero;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(tile + rbase * kChunksPerRow), 16, 0, 0);
+    }
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
+    const unsigned short* __restrict__ X, ConvGeom g, const unsigned short* __restrict__ B, int ldb, int M, int N,
+    void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    const int nblk = tiles_m * tiles_n;
+    int tile;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    // consecutive tiles walk N first: the (few) weight bands of one output row-block share its activations
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int K = 9 * g.C;
+
+    int rm[4], rh[4], rw[4];          // this lane's 4 staging rows: pixel index, y, x
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wave * 32 + i * 8 + (lane >> 3);
+        const int hw = g.H * g.W;
+        const int p = m % hw;
+        rm[i] = m < M ? m : -1;
+        rh[i] = p / g.W;
+        rw[i] = p - rh[i] * g.W;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int nk = (K + BK - 1) / BK;
+    dma_tile_conv(X, g, 0, lds, wave, lane, rm, rh, rw);
+    dma_tile(B, ldb, N, n0, 0, lds + kTileChunks, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        uint4* sa = lds + (size_t)stage * 2 * kTileChunks;
+        uint4* sb = sa + kTileChunks;
+        if (kt + 1 < nk) {
+            uint4* na = lds + (size_t)(stage ^ 1) * 2 * kTileChunks;
+            dma_tile_conv(X, g, (kt + 1) * BK, na, wave, lane, rm, rh, rw);
+            dma_tile(B, ldb, N, n0, (kt + 1) * BK, na + kTileChunks, wave, lane);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int c = kk * 2 + half;
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[lds_slot(wm * 64 + i * 32 + l31, c)]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
+}
+
 // ---- layout helpers ---------------------------------------------------------------------
 // out[c][r] = bf16(in[r][c]); in is fp32 or bf16 (IN_F32).  32x32 tiles through LDS.
 template <bool IN_F32>
@@ -407,6 +514,7 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     ODW_REQUIRE(!(accumulate && c_is_bf16), "gemm_nt_bf16: accumulate needs an fp32 C");
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = drop_p; ep.nseg = nseg; ep.accumulate = accumulate; ep.alpha = alpha;
+    ep.mask = nullptr; ep.ldmask = 0;
     for (int i = 0; i < kMaxSeg; ++i) {
         ep.seg_row[i] = (i < nseg && seg_rows) ? seg_rows[i] : 0;
         ep.seg_k0[i] = (i < nseg && seg_keys) ? seg_keys[2 * i] : 0;
@@ -491,5 +599,44 @@ ODW_EXPORT int odw_sgd_momentum(float* p, const float* g, float* buf, void* shad
     sgd_kernel<<<(int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks)), 256, 0, (hipStream_t)stream_>>>(
         p, g, buf, (unsigned short*)shadow_bf16, (size_t)n, lr, wd, momentum, grad_scale, first_step);
     ODW_CHECK_LAUNCH("sgd_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_conv3x3_nhwc_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, int mirror,
+                                     const void* Wk, int ldw, int N, void* Y, int ldy, int y_is_bf16,
+                                     const float* bias, int relu, const void* mask, int ldmask, const void* zero_page,
+                                     void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(n_pix >= 0 && H > 0 && W > 0 && N > 0 && n_pix % (H * W) == 0, "conv3x3: bad dims");
+    ODW_REQUIRE(C >= 8 && (C & (C - 1)) == 0, "conv3x3: channel count %d must be a power of two >= 8", C);
+    ODW_REQUIRE(dilation >= 1 && dilation <= 4, "conv3x3: dilation %d", dilation);
+    if (n_pix == 0) return ODW_OK;
+    ODW_REQUIRE(X && Wk && Y && zero_page, "conv3x3: null pointer");
+    const int K = 9 * C, k64 = (K + 63) / 64 * 64;
+    ODW_REQUIRE(ldw >= k64 && ldw % 8 == 0, "conv3x3: weight rows must be zero padded to %d (ldw=%d)", k64, ldw);
+    ODW_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Wk) & 15) == 0 && (((uintptr_t)zero_page) & 15) == 0,
+                "conv3x3: 16-byte alignment");
+    ConvGeom g;
+    g.H = H; g.W = W; g.C = C; g.dil = dilation; g.sign = mirror ? -1 : 1; g.zero = (const unsigned short*)zero_page;
+    g.logC = 0;
+    while ((1 << g.logC) < C) ++g.logC;
+    Epilogue ep;
+    ep.bias = bias; ep.relu = relu; ep.drop_p = 0.0f; ep.nseg = 0; ep.accumulate = 0; ep.alpha = 1.0f;
+    ep.mask = (const unsigned short*)mask; ep.ldmask = ldmask;
+    for (int i = 0; i < kMaxSeg; ++i) { ep.seg_row[i] = 0; ep.seg_k0[i] = 0; ep.seg_k1[i] = 0; }
+    const int tiles_m = (n_pix + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);
+    if (y_is_bf16) {
+        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_glds_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "conv attr");
+        conv3x3_glds_kernel<true><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(
+            (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_pix, N, Y, ldy, ep, tiles_m, tiles_n);
+    } else {
+        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_glds_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "conv attr");
+        conv3x3_glds_kernel<false><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(
+            (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_pix, N, Y, ldy, ep, tiles_m, tiles_n);
+    }
+    ODW_CHECK_LAUNCH("conv3x3_glds_kernel");
     return ODW_OK;
 }

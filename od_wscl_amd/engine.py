@@ -178,7 +178,14 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
 
     use_autocast = dtype == "bf16"
     if hip:
-        model.backbone_autocast = torch.bfloat16 if use_autocast else None
+        conv = os.environ.get("ODW_CONV", "hip")
+        if conv == "hip" and use_autocast and cfg.MODEL.BACKBONE.CONV_BODY.startswith("VGG16"):
+            from .modeling.backbone.vgg16_hip import VGGBackboneHip
+            model.backbone_hip = VGGBackboneHip(model.backbone.body)
+            conv_desc = "od_wscl_amd HIP implicit-GEMM conv3x3 (NHWC bf16, MFMA)"
+        else:
+            model.backbone_autocast = torch.bfloat16 if use_autocast else None
+            conv_desc = "torch/MIOpen (%s)" % ("bf16 autocast" if use_autocast else "f32")
         model.roi_heads.loss_evaluator.amp = False
         opt = FlatSGD(cfg, model, world)
 
@@ -197,8 +204,7 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             return losses, accs
 
         info = {"gemm_backend": "od_wscl_amd HIP MFMA gemm_nt_bf16 (bf16 in, fp32 acc)",
-                "conv_backend": "torch/MIOpen (%s)" % ("bf16 autocast" if use_autocast else "f32"),
-                "optimizer": "od_wscl_amd fused flat SGD"}
+                "conv_backend": conv_desc, "optimizer": "od_wscl_amd fused flat SGD"}
         return step, info
 
     net = model

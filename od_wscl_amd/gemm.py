@@ -13,6 +13,9 @@ from . import _lib as L
 from .utils.kernel_timer import kernel_timer
 
 
+MAX_SEGS = 4      # dropout row segments one GEMM launch carries keys for (kMaxSeg in csrc/gemm_bf16.hip)
+
+
 def _r8(n):
     return (n + 7) // 8 * 8
 
@@ -29,9 +32,9 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
     nseg = len(segs) if segs else 0
-    assert nseg <= 16, "at most 16 stacked passes per GEMM launch"
-    rows = (ctypes.c_int * 16)(*([s[0] for s in segs] + [0] * (16 - nseg))) if nseg else None
-    keys = (ctypes.c_uint32 * 32)(*([k for s in segs for k in (s[1], s[2])] + [0] * (32 - 2 * nseg))) if nseg else None
+    assert nseg <= MAX_SEGS, "at most %d stacked passes per GEMM launch" % MAX_SEGS
+    rows = (ctypes.c_int * 4)(*([s[0] for s in segs] + [0] * (4 - nseg))) if nseg else None
+    keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
     out_bf16 = out.dtype == torch.bfloat16
     # per-symbol timing for bench.py's roofline object (same names as rocprofv3's kernel trace)
     sym = "gemm_nt_bf16_glds_kernel<%s>" % ("true" if out_bf16 else "false")

@@ -1,0 +1,166 @@
+"""VGG16-OICR backbone on the gfx950 kernels: NHWC bf16 activations, every 3x3 convolution an
+implicit GEMM on the MFMA tile (csrc/gemm_bf16.hip:conv3x3_glds_kernel) with bias+ReLU fused,
+forward AND backward as one autograd node (the reference: 13 cuDNN convs + 12 ReLUs + 3 pools as
+separate autograd nodes, modeling/backbone/vgg16.py:34-36,58-83).
+
+The parameters stay the nn.Conv2d weights of `VGG_Base.features` (same names, same layout for
+checkpoints and the optimiser); packed bf16 copies are refreshed from them at the start of each
+forward.  Frozen layers (FREEZE_CONV_BODY_AT=2 -> conv1_x, conv2_x) run forward only, and no input
+gradient is computed below the first trainable convolution."""
+import torch
+from torch import nn
+
+from ... import _lib as L
+from ... import gemm
+from ...utils.kernel_timer import kernel_timer
+
+
+def _r64(n):
+    return (n + 63) // 64 * 64
+
+
+class _Layer(object):
+    __slots__ = ("conv", "cin", "cp", "cout", "dil", "relu", "pool", "trainable", "wk", "wd")
+
+
+def _layers_of(features):
+    mods = list(features)
+    out = []
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            l = _Layer()
+            l.conv, l.cin, l.cout, l.dil = m, m.in_channels, m.out_channels, m.dilation[0]
+            assert m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding[0] == m.dilation[0]
+            l.cp = max(8, 1 << (l.cin - 1).bit_length())
+            l.relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            j = i + (2 if l.relu else 1)
+            l.pool = j < len(mods) and isinstance(mods[j], nn.MaxPool2d)
+            l.trainable = m.weight.requires_grad
+            l.wk = l.wd = None
+            out.append(l)
+        i += 1
+    return out
+
+
+class _VGGFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, net, *params):
+        lib = L.lib()
+        B, C, H, W = images.shape
+        dev = images.device
+        st = L.stream()
+        x = torch.empty((B * H * W, 8), dtype=torch.bfloat16, device=dev)
+        L.check(lib.odw_nchw_f32_to_nhwc_bf16(L.ptr(images.contiguous()), B, H * W, C, 8, L.ptr(x), st), "nchw_to_nhwc")
+        saved = []          # per layer: (input activation, pre-pool activation or None, H, W)
+        h, w = H, W
+        for l in net.layers:
+            m = B * h * w
+            y = torch.empty((m, l.cout), dtype=torch.bfloat16, device=dev)
+            with kernel_timer.region("conv3x3_glds_kernel<true>", flops=2.0 * m * l.cout * 9 * l.cin):
+                L.check(lib.odw_conv3x3_nhwc_bf16(L.ptr(x), m, h, w, l.cp, l.dil, 0, L.ptr(l.wk), l.wk.stride(0), l.cout,
+                                                  L.ptr(y), l.cout, 1, L.ptr(l.conv.bias), 1 if l.relu else 0, None, 0,
+                                                  L.ptr(net.zero_page), st), "conv3x3")
+            pre = None
+            if l.pool:
+                pre = y
+                p = torch.empty((B * (h // 2) * (w // 2), l.cout), dtype=torch.bfloat16, device=dev)
+                L.check(lib.odw_maxpool2x2_nhwc_bf16(L.ptr(y), B, h, w, l.cout, L.ptr(p), st), "maxpool")
+                y = p
+            saved.append((x if l.trainable else None, pre if l.trainable else None, h, w))
+            if l.pool:
+                h, w = h // 2, w // 2
+            x = y
+        feat = torch.empty((B, net.layers[-1].cout, h, w), dtype=torch.float32, device=dev)
+        L.check(lib.odw_nhwc_bf16_to_nchw_f32(L.ptr(x), B, h * w, net.layers[-1].cout, L.ptr(feat), st), "nhwc_to_nchw")
+        ctx.net, ctx.saved_acts, ctx.batch = net, saved, B
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        lib = L.lib()
+        net, saved, B = ctx.net, ctx.saved_acts, ctx.batch
+        st = L.stream()
+        dev = dfeat.device
+        _, C, h, w = dfeat.shape
+        dz = torch.empty((B * h * w, C), dtype=torch.bfloat16, device=dev)
+        L.check(lib.odw_nchw_f32_to_nhwc_bf16(L.ptr(dfeat.contiguous()), B, h * w, C, C, L.ptr(dz), st), "nchw_to_nhwc")
+        first = min(i for i, l in enumerate(net.layers) if l.trainable)
+        for li in range(len(net.layers) - 1, first - 1, -1):
+            l = net.layers[li]
+            x_in, pre, h, w = saved[li]
+            if l.pool:       # dz arrives at the pooled resolution: route through the pool (+ ReLU mask of `pre`)
+                d_pre = torch.empty((B * h * w, l.cout), dtype=torch.bfloat16, device=dev)
+                L.check(lib.odw_maxpool2x2_nhwc_bf16_bwd(L.ptr(pre), L.ptr(dz), B, h, w, l.cout, L.ptr(d_pre), st),
+                        "maxpool_bwd")
+                dz = d_pre
+            m = B * h * w
+            m64 = _r64(m)
+            if getattr(net, "debug", None) is not None:      # tests: gradient w.r.t. this layer's pre-activation
+                net.debug[li] = dz.float().reshape(B, h, w, l.cout).permute(0, 3, 1, 2).clone()
+            # ---- bias + weight gradient
+            conv = l.conv
+            if conv.bias.grad is None:
+                conv.bias.grad = torch.zeros_like(conv.bias)
+            if conv.weight.grad is None:
+                conv.weight.grad = torch.empty_like(conv.weight)
+            dzc = torch.empty((m, _r64(l.cout)), dtype=torch.bfloat16, device=dev)
+            dzt = torch.empty((l.cout, m64), dtype=torch.bfloat16, device=dev)
+            L.check(lib.odw_linear_bwd_prep(L.ptr(dz), 0, l.cout, None, 0, m, l.cout, 1.0, L.ptr(dzc), dzc.stride(0),
+                                            L.ptr(dzt), m64, L.ptr(conv.bias.grad), st), "conv bias grad")
+            colt = torch.empty((9 * l.cp, m64), dtype=torch.bfloat16, device=dev)
+            L.check(lib.odw_im2col_t_bf16(L.ptr(x_in), m, h, w, l.cp, l.dil, L.ptr(colt), m64, st), "im2col_t")
+            dwk = torch.empty((l.cout, 9 * l.cp), dtype=torch.float32, device=dev)
+            gemm.gemm_nt(dzt, colt, l.cout, 9 * l.cp, m, dwk)
+            L.check(lib.odw_conv_wgrad_unpack(L.ptr(dwk), 9 * l.cp, l.cout, l.cin, l.cp, L.ptr(conv.weight.grad), st),
+                    "wgrad_unpack")
+            # ---- input gradient (masked by the ReLU of the producing layer unless that layer was pooled:
+            #      then the pool backward of the previous iteration applies the mask)
+            if li > first:
+                prev = net.layers[li - 1]
+                dx = torch.empty((m, l.cin), dtype=torch.bfloat16, device=dev)
+                mask = x_in if (prev.relu and not prev.pool) else None
+                with kernel_timer.region("conv3x3_glds_kernel<true>", flops=2.0 * m * l.cout * 9 * l.cin):
+                    L.check(lib.odw_conv3x3_nhwc_bf16(L.ptr(dz), m, h, w, l.cout, l.dil, 1, L.ptr(l.wd), l.wd.stride(0),
+                                                      l.cin, L.ptr(dx), l.cin, 1, None, 0, L.ptr(mask),
+                                                      l.cin if mask is not None else 0, L.ptr(net.zero_page), st),
+                            "conv3x3 dgrad")
+                dz = dx
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class VGGBackboneHip(nn.Module):
+    """Drop-in for VGG_Base.forward: same parameters, gfx950 kernels."""
+
+    def __init__(self, vgg_base):
+        super().__init__()
+        self.base = [vgg_base]            # not registered: the parameters stay owned by VGG_Base
+        self.layers = _layers_of(vgg_base.features)
+        self.zero_page = None
+        self._frozen_ready = False
+
+    def _prep(self):
+        lib = L.lib()
+        dev = self.layers[0].conv.weight.device
+        if self.zero_page is None:
+            self.zero_page = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+        first = min(i for i, l in enumerate(self.layers) if l.trainable) if any(l.trainable for l in self.layers) else 99
+        for i, l in enumerate(self.layers):
+            if not l.trainable and self._frozen_ready:
+                continue
+            if l.wk is None:
+                l.wk = torch.empty((l.cout, _r64(9 * l.cp)), dtype=torch.bfloat16, device=dev)
+                if l.trainable and i > first:
+                    l.wd = torch.empty((l.cin, _r64(9 * l.cout)), dtype=torch.bfloat16, device=dev)
+            L.check(lib.odw_conv_weight_prep(L.ptr(l.conv.weight.detach()), l.cout, l.cin, l.cp, L.ptr(l.wk), l.wk.stride(0),
+                                             L.ptr(l.wd), l.wd.stride(0) if l.wd is not None else 0, L.stream()),
+                    "conv_weight_prep")
+        self._frozen_ready = True
+
+    def forward(self, images):
+        L.need_gpu(images)
+        with torch.no_grad():
+            self._prep()
+        params = [p for l in self.layers for p in (l.conv.weight, l.conv.bias)]
+        return [_VGGFn.apply(images.float(), self, *params)]

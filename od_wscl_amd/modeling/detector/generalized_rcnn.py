@@ -22,8 +22,11 @@ class GeneralizedRCNN(nn.Module):
             raise ValueError("precomputed proposals (rois) are required")
         if rand is not None:
             self.roi_heads.set_rand(rand)
+        hip = getattr(self, "backbone_hip", None)
         amp = getattr(self, "backbone_autocast", None)
-        if amp is not None:
+        if hip is not None:                  # NHWC bf16 implicit-GEMM convolutions (modeling/backbone/vgg16_hip.py)
+            features = hip(images.tensors)
+        elif amp is not None:
             with torch.autocast("cuda", dtype=amp):
                 features = [f.float() for f in self.backbone(images.tensors)]
         else:

@@ -100,7 +100,7 @@ class RoIRegLossFused(RoIRegLossComputation):
                 if tr is not None:
                     tr["iou_samples_%d_%d" % (idx, c)] = r_img.clone()
         n_seg = len(segs6)
-        if n_seg > 16:      # more stacked passes than one launch carries keys for: split
+        if n_seg > 4:       # more stacked passes than one launch carries dropout keys for: split
             emb = self._embed_in_chunks(feature_extractor, model_sim, parts, segs6, segs7)
         else:
             x = torch.cat(parts, dim=0)
@@ -229,7 +229,7 @@ class RoIRegLossFused(RoIRegLossComputation):
         return losses, accs
 
     @staticmethod
-    def _embed_in_chunks(fe, model_sim, parts, segs6, segs7, max_segs=16):
+    def _embed_in_chunks(fe, model_sim, parts, segs6, segs7, max_segs=4):
         out = []
         for s in range(0, len(parts), max_segs):
             chunk = parts[s:s + max_segs]

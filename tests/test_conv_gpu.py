@@ -1,0 +1,181 @@
+"""Implicit-GEMM convolutions and the NHWC bf16 VGG16 backbone vs PyTorch references.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from od_wscl_amd.utils import rng
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, shape, scale=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy((rng.normal(seed, 1, n) * scale).reshape(shape)).cuda()
+
+
+def r64(n):
+    return (n + 63) // 64 * 64
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd import _lib
+    return _lib
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,dil,relu", [(1, 3, 64, 20, 28, 1, True), (2, 64, 64, 16, 24, 1, True),
+                                                    (1, 128, 256, 19, 13, 2, False), (1, 512, 512, 12, 10, 2, True)])
+def test_conv3x3_forward_and_input_gradient(lib, B, Cin, Cout, H, W, dil, relu):
+    L = lib
+    cp = max(8, 1 << (Cin - 1).bit_length())
+    x = rnd(1, (B, Cin, H, W)).bfloat16().float()
+    w = rnd(2, (Cout, Cin, 3, 3), 0.05).bfloat16().float()
+    b = rnd(3, (Cout,), 0.1)
+    zero = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
+    xn = torch.empty((B * H * W, cp), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(x), B, H * W, Cin, cp, L.ptr(xn), L.stream()), "to nhwc")
+    wk = torch.empty((Cout, r64(9 * cp)), dtype=torch.bfloat16, device="cuda")
+    wd = torch.empty((Cin, r64(9 * Cout)), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_conv_weight_prep(L.ptr(w), Cout, Cin, cp, L.ptr(wk), wk.stride(0), L.ptr(wd), wd.stride(0), L.stream()), "prep")
+    y = torch.empty((B * H * W, Cout), dtype=torch.float32, device="cuda")
+    L.check(L.lib().odw_conv3x3_nhwc_bf16(L.ptr(xn), B * H * W, H, W, cp, dil, 0, L.ptr(wk), wk.stride(0), Cout, L.ptr(y), Cout, 0,
+                                          L.ptr(b), 1 if relu else 0, None, 0, L.ptr(zero), L.stream()), "conv")
+    ref = F.conv2d(x, w, b, padding=dil, dilation=dil)
+    if relu:
+        ref = torch.relu(ref)
+    got = y.reshape(B, H, W, Cout).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    # input gradient = the mirrored kernel on dY with the [ci][tap][co] weights
+    if Cout & (Cout - 1) == 0 and Cout >= 8:
+        dy = rnd(4, (B, Cout, H, W)).bfloat16().float()
+        dyn = torch.empty((B * H * W, Cout), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(dy), B, H * W, Cout, Cout, L.ptr(dyn), L.stream()), "to nhwc")
+        dx = torch.empty((B * H * W, Cin), dtype=torch.float32, device="cuda")
+        L.check(L.lib().odw_conv3x3_nhwc_bf16(L.ptr(dyn), B * H * W, H, W, Cout, dil, 1, L.ptr(wd), wd.stride(0), Cin, L.ptr(dx), Cin, 0,
+                                              None, 0, None, 0, L.ptr(zero), L.stream()), "dgrad")
+        xr = x.clone().requires_grad_(True)
+        F.conv2d(xr, w, None, padding=dil, dilation=dil).backward(dy)
+        gotdx = dx.reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+        assert (gotdx - xr.grad).abs().max().item() <= 2e-3 * max(1.0, xr.grad.abs().max().item())
+
+
+def test_maxpool_and_layout_kernels(lib):
+    L = lib
+    B, C, H, W = 2, 16, 8, 12
+    x = torch.relu(rnd(5, (B, C, H, W))).bfloat16().float()
+    x[:, :, 0:2, 0:2] = 0                                   # an all-zero window: first element wins, ReLU mask kills it
+    xn = torch.empty((B * H * W, C), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(x), B, H * W, C, C, L.ptr(xn), L.stream()), "to nhwc")
+    back = torch.empty((B, C, H, W), device="cuda")
+    L.check(L.lib().odw_nhwc_bf16_to_nchw_f32(L.ptr(xn), B, H * W, C, L.ptr(back), L.stream()), "to nchw")
+    assert torch.equal(back, x)
+    p = torch.empty((B * (H // 2) * (W // 2), C), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_maxpool2x2_nhwc_bf16(L.ptr(xn), B, H, W, C, L.ptr(p), L.stream()), "pool")
+    ref = F.max_pool2d(x, 2, 2)
+    assert torch.equal(p.float().reshape(B, H // 2, W // 2, C).permute(0, 3, 1, 2), ref)
+    dy = rnd(6, ref.shape).bfloat16().float()
+    dyn = torch.empty((B * (H // 2) * (W // 2), C), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(dy), B, (H // 2) * (W // 2), C, C, L.ptr(dyn), L.stream()), "to nhwc")
+    dx = torch.empty((B * H * W, C), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_maxpool2x2_nhwc_bf16_bwd(L.ptr(xn), L.ptr(dyn), B, H, W, C, L.ptr(dx), L.stream()), "pool bwd")
+    xr = x.clone().requires_grad_(True)
+    pre = torch.relu(xr)                                    # pooled activation is post-ReLU: mask folded into the kernel
+    F.max_pool2d(pre, 2, 2).backward(dy)
+    assert torch.equal(dx.float().reshape(B, H, W, C).permute(0, 3, 1, 2), xr.grad)
+
+
+def test_vgg16_backbone_forward_backward(lib):
+    """Whole backbone, forward + backward, vs the torch fp32 model holding the same (bf16-rounded) weights."""
+    from od_wscl_amd.config import make_defaults
+    from od_wscl_amd.modeling.backbone import build_backbone
+    from od_wscl_amd.modeling.backbone.vgg16_hip import VGGBackboneHip
+    cfg = make_defaults()
+    cfg.merge_from_list(["MODEL.BACKBONE.CONV_BODY", "VGG16-OICR"])
+    torch.manual_seed(0)
+    bb = build_backbone(cfg).cuda()
+    with torch.no_grad():
+        for p in bb.parameters():
+            p.copy_(p.bfloat16().float())
+            if p.dim() == 1:
+                p.normal_(0, 0.05)
+    hip = VGGBackboneHip(bb.body)
+    x = rnd(7, (1, 3, 64, 96), 50.0)
+    feat = hip(x)[0]
+    g = rnd(8, tuple(feat.shape))
+    feat.backward(g)
+    got = {n: p.grad.clone() for n, p in bb.named_parameters() if p.grad is not None}
+    for p in bb.parameters():
+        p.grad = None
+    # reference: the same torch modules in fp32, activations rounded to bf16 where the kernels store bf16
+    # (otherwise ~0.3 % of the ReLU masks differ from pure-fp32 activations, which alone moves the weight
+    # gradients by ~5 % in L2 -- that is bf16 storage, not the kernels)
+    class RoundBF16(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.bfloat16().float()
+
+        @staticmethod
+        def backward(ctx, gr):
+            return gr.bfloat16().float()
+    # ... and on the CPU: MIOpen's fp32 convolutions (Winograd) are only ~1e-3 accurate, which flips ~0.1 % of
+    # the ReLU masks by itself
+    got = {n: t.cpu() for n, t in got.items()}
+    feat, g = feat.detach().cpu(), g.cpu()
+    bb = bb.cpu()
+    h = x.bfloat16().float().cpu()
+    for m in bb.body.features:
+        h = m(h)
+        if isinstance(m, (torch.nn.ReLU, torch.nn.MaxPool2d)) or m is bb.body.features[-1]:
+            h = RoundBF16.apply(h)
+    ref = h
+    ref.backward(g)
+    cos = lambda a, b: (a.flatten() @ b.flatten() / (a.norm() * b.norm() + 1e-30)).item()
+    assert feat.shape == ref.shape
+    assert cos(feat, ref) > 0.999 and abs(feat.norm().item() / ref.norm().item() - 1) < 2e-2
+    names = [n for n, p in bb.named_parameters() if p.requires_grad]
+    assert set(got) == set(names)                            # frozen conv1_x / conv2_x get no gradient
+    report = {n: (round(cos(got[n], p.grad), 5), round(got[n].norm().item() / p.grad.norm().item(), 4))
+              for n, p in bb.named_parameters() if p.requires_grad}
+    print("GRADREPORT", " ".join("%s:%s/%s" % (n.replace("body.features.", "f"), c, r) for n, (c, r) in report.items()))
+    # Two bf16-storage pipelines with different fp32 summation orders diverge chaotically (a 1-ulp bf16 flip in
+    # layer k perturbs layer k+1, ~0.15 % of the conv5 ReLU masks differ after 12 layers), so the end-to-end bar is
+    # loose; the tight bars are the per-operator tests above and test_conv_weight_gradient below.
+    for n, (c, r) in report.items():
+        assert c > 0.98 and abs(r - 1) < 5e-2, (n, c, r)
+    assert report["body.features.28.weight"][0] > 0.9999
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,dil", [(1, 64, 128, 16, 24, 1), (2, 256, 256, 9, 11, 2), (1, 128, 64, 38, 50, 1)])
+def test_conv_weight_gradient(lib, B, Cin, Cout, H, W, dil):
+    """bias + weight gradient of one layer: transposed im2col + NT GEMM + unpack vs autograd."""
+    from od_wscl_amd import gemm
+    L = lib
+    m = B * H * W
+    m64 = r64(m)
+    x = rnd(11, (B, Cin, H, W)).bfloat16().float()
+    dy = rnd(12, (B, Cout, H, W)).bfloat16().float()
+    xn = torch.empty((m, Cin), dtype=torch.bfloat16, device="cuda")
+    dyn = torch.empty((m, Cout), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(x), B, H * W, Cin, Cin, L.ptr(xn), L.stream()), "to nhwc")
+    L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(dy), B, H * W, Cout, Cout, L.ptr(dyn), L.stream()), "to nhwc")
+    dzc = torch.empty((m, r64(Cout)), dtype=torch.bfloat16, device="cuda")
+    dzt = torch.empty((Cout, m64), dtype=torch.bfloat16, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    L.check(L.lib().odw_linear_bwd_prep(L.ptr(dyn), 0, Cout, None, 0, m, Cout, 1.0, L.ptr(dzc), dzc.stride(0), L.ptr(dzt), m64,
+                                        L.ptr(db), L.stream()), "prep")
+    colt = torch.empty((9 * Cin, m64), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_im2col_t_bf16(L.ptr(xn), m, H, W, Cin, dil, L.ptr(colt), m64, L.stream()), "im2col_t")
+    dwk = torch.empty((Cout, 9 * Cin), device="cuda")
+    gemm.gemm_nt(dzt, colt, Cout, 9 * Cin, m, dwk)
+    dw = torch.empty((Cout, Cin, 3, 3), device="cuda")
+    L.check(L.lib().odw_conv_wgrad_unpack(L.ptr(dwk), 9 * Cin, Cout, Cin, Cin, L.ptr(dw), L.stream()), "unpack")
+    w = torch.zeros((Cout, Cin, 3, 3), device="cuda", requires_grad=True)
+    b = torch.zeros(Cout, device="cuda", requires_grad=True)
+    F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=dil, dilation=dil).backward(dy.cpu())   # CPU: exact fp32 reference
+    wg = torch.autograd.grad(F.conv2d(x, w, b, padding=dil, dilation=dil), [w, b], dy)
+    ref_w, ref_b = wg[0], wg[1]
+    assert (dw - ref_w).abs().max().item() <= 3e-3 * max(1.0, ref_w.abs().max().item())
+    assert (db - ref_b).abs().max().item() <= 3e-3 * max(1.0, ref_b.abs().max().item())
