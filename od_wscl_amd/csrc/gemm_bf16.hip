@@ -90,21 +90,21 @@ __device__ __forceinline__ void store_tile(uint4* __restrict__ sa, uint4* __rest
 }
 
 
-template <bool OUT_BF16>
-__device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], void* __restrict__ Cv, int ldc, int M, int N,
+template <bool OUT_BF16, int MI = 2, int NJ = 2>
+__device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[MI][NJ], void* __restrict__ Cv, int ldc, int M, int N,
                                                int m0, int n0, int wm, int wn, int half, int l31,
                                                const Epilogue& ep) {
     // ---- epilogue.  C layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * (32 * NJ) + j * 32 + l31;
         if (n >= N) continue;
         const float bias = ep.bias ? ep.bias[n] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int m = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= M) continue;
                 float v = acc[i][j][r] * ep.alpha + bias;
                 if (ep.relu) v = fmaxf(v, 0.0f);
@@ -277,6 +277,98 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_glds_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed ...
         __syncthreads();                                     // ... and so has everyone else's
+    }
+    store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
+}
+
+// ---- 256x128 tile, 3-stage LDS ring, counted vmcnt -------------------------------------------------
+// The 128x128 kernel above is LATENCY bound: a tile's DMA is issued one K-step (~0.35 us of MFMA)
+// before it is needed, HBM/L2 latency under load is 1-2 us, so every K-step ends in a vmcnt(0) stall.
+// Here 8 waves (4 x 2, still 64x64 = 2x2 MFMA 32x32x16 per wave) own a 256x128 tile, the operand
+// tiles cycle through THREE 48 KB LDS slots (144 of the CU's 160 KB, one workgroup per CU) and each
+// wave keeps two tiles of DMA in flight: the wait before the barrier is s_waitcnt vmcnt(6) -- "all but
+// my 6 newest loads have landed" -- never vmcnt(0) in the main loop, and the barrier is the raw
+// s_barrier (a __syncthreads() would drain the DMA queue).  25 % less L2->LDS traffic per FLOP too.
+constexpr int RM = 256, RN = 128;
+constexpr int kRingThreads = 512;
+constexpr int kRingStageChunks = (RM + RN) * kChunksPerRow;      // 3072 uint4 = 48 KB
+constexpr int kRingStages = 3;
+
+template <int ROWS_PER_WAVE>
+__device__ __forceinline__ void dma_rows(const unsigned short* __restrict__ G, int ld, int nrows, int row0, int k0,
+                                         uint4* __restrict__ tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_WAVE / 8; ++i) {
+        const int rbase = wave * ROWS_PER_WAVE + i * 8;
+        const int row = rbase + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int g = row0 + row;
+        g = g < nrows ? g : nrows - 1;
+        const unsigned short* src = G + (size_t)g * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(tile + rbase * kChunksPerRow), 16, 0, 0);
+    }
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
+    const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
+    int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [stage][A 256 rows | B 128 rows]
+    const int nblk = tiles_m * tiles_n;
+    int tile;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tn = tile / tiles_m, tm = tile % tiles_m;
+    const int m0 = tm * RM, n0 = tn * RN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;            // 4 x 2 waves, 64 x 64 each
+    const int half = lane >> 5, l31 = lane & 31;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int nk = (K + BK - 1) / BK;
+    // prologue: tiles 0 and 1 in flight (6 DMA instructions per wave per tile: 4 for A, 2 for B)
+    dma_rows<32>(A, lda, M, m0, 0, lds, wave, lane);
+    dma_rows<16>(B, ldb, N, n0, 0, lds + RM * kChunksPerRow, wave, lane);
+    if (nk > 1) {
+        uint4* s1 = lds + kRingStageChunks;
+        dma_rows<32>(A, lda, M, m0, BK, s1, wave, lane);
+        dma_rows<16>(B, ldb, N, n0, BK, s1 + RM * kChunksPerRow, wave, lane);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once at most the 6 loads of tile kt+1 are still outstanding
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // everyone's share of tile kt is in LDS; slot (kt+2)%3 is free
+        if (kt + 2 < nk) {
+            uint4* sn = lds + (size_t)((kt + 2) % kRingStages) * kRingStageChunks;
+            dma_rows<32>(A, lda, M, m0, (kt + 2) * BK, sn, wave, lane);
+            dma_rows<16>(B, ldb, N, n0, (kt + 2) * BK, sn + RM * kChunksPerRow, wave, lane);
+        }
+        const uint4* sa = lds + (size_t)(kt % kRingStages) * kRingStageChunks;
+        const uint4* sb = sa + RM * kChunksPerRow;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int c = kk * 2 + half;
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[lds_slot(wm * 64 + i * 32 + l31, c)]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
     }
     store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
 }
@@ -524,9 +616,14 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);   // 64 KB
     const int k64 = (K + 63) / 64 * 64;
-    const char* force = getenv("ODW_GEMM_VARIANT");     // "reg" / "glds": A/B switch for tools/gemm_bench.py
+    const char* force = getenv("ODW_GEMM_VARIANT");     // "reg" / "glds" / "ring": A/B switch for tools/gemm_bench.py
     bool use_glds = lda >= k64 && ldb >= k64 && K > 0;
-    if (force && force[0] == 'r') use_glds = false;
+    const int rtiles_m = (M + RM - 1) / RM, rtiles_n = (N + RN - 1) / RN;
+    // the 256x128 ring kernel runs one workgroup per CU: use it when its grid fills the chip
+    bool use_ring = use_glds && rtiles_m * rtiles_n >= 192;
+    if (force && force[0] == 'r' && force[1] == 'e') { use_glds = false; use_ring = false; }
+    if (force && force[0] == 'g') use_ring = false;
+    if (force && force[0] == 'r' && force[1] == 'i') use_ring = use_glds;
 #define ODW_LAUNCH_GEMM(KERNEL, OUTBF)                                                                          \
     do {                                                                                                        \
         ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<OUTBF>),                         \
@@ -534,7 +631,20 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
         KERNEL<OUTBF><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(                                      \
             (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, tiles_m, tiles_n); \
     } while (0)
-    if (use_glds) {
+    if (use_ring) {
+        const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);   // 144 KB
+        if (c_is_bf16) {
+            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "ring attr");
+            gemm_nt_bf16_ring_kernel<true><<<rtiles_m * rtiles_n, kRingThreads, ring_lds, stream>>>(
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, rtiles_m, rtiles_n);
+        } else {
+            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "ring attr");
+            gemm_nt_bf16_ring_kernel<false><<<rtiles_m * rtiles_n, kRingThreads, ring_lds, stream>>>(
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, rtiles_m, rtiles_n);
+        }
+    } else if (use_glds) {
         if (c_is_bf16) ODW_LAUNCH_GEMM(gemm_nt_bf16_glds_kernel, true);
         else ODW_LAUNCH_GEMM(gemm_nt_bf16_glds_kernel, false);
     } else {

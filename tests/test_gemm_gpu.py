@@ -41,7 +41,8 @@ def test_gemm_nt_matches_fp32_reference(G, M, N, K):
     assert (ob.float() - ref).abs().max().item() <= 8e-3 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 357, 4096), (2000, 512, 1984), (130, 70, 25088), (5, 3, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 357, 4096), (2000, 512, 1984), (130, 70, 25088), (5, 3, 64),
+                                   (1000, 700, 128), (513, 257, 192)])
 def test_gemm_lds_dma_variant(G, M, N, K):
     """Operands padded to a multiple of 64 in K take the global_load_lds path; it must agree with the
     register-staged kernel (selected by ODW_GEMM_VARIANT=reg) to fp32 re-association."""
@@ -54,14 +55,20 @@ def test_gemm_lds_dma_variant(G, M, N, K):
     o1 = torch.empty(M, N, device="cuda")
     o2 = torch.empty(M, N, device="cuda")
     G.gemm_nt(a, b, M, N, K, o1)
+    o3 = torch.empty(M, N, device="cuda")
     os.environ["ODW_GEMM_VARIANT"] = "reg"
     try:
         G.gemm_nt(a, b, M, N, K, o2)
+        os.environ["ODW_GEMM_VARIANT"] = "ring"          # 256x128 tile, 3-stage ring, counted vmcnt
+        G.gemm_nt(a, b, M, N, K, o3)
+
     finally:
         del os.environ["ODW_GEMM_VARIANT"]
     ref = a.float() @ b.float().T
     tol = 1e-5 * np.sqrt(K) * 4 * max(1.0, ref.abs().max().item())
     assert (o1 - ref).abs().max().item() <= tol and (o2 - ref).abs().max().item() <= tol
+    assert (o3 - ref).abs().max().item() <= tol
+
 
 
 def test_gemm_asymmetric_identity(G):
