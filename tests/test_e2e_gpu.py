@@ -123,3 +123,43 @@ def test_od_assign_kernel(ops_golden):
     np.testing.assert_array_equal(pl.cpu().numpy(), g["od_pseudo"])
     np.testing.assert_array_equal(lw.cpu().numpy(), g["od_weights"])
     np.testing.assert_allclose(rt.cpu().numpy(), g["od_targets"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["e2e_voc_2img", "e2e_voc_1img"])
+def test_bf16_mfma_backend_tracks_the_reference(name, weights_np):
+    """Production back end (bf16 MFMA GEMMs + implicit-GEMM bf16 convs) on a golden case.  bf16 operands
+    cannot meet the 1e-3 bar of the fp32 parity mode above (and may legitimately flip a near-threshold
+    selection); the image-level and first-branch losses must stay within a few per cent of the reference."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.layers import linear as ll
+    from od_wscl_amd.modeling.backbone.vgg16_hip import VGGBackboneHip
+    from od_wscl_amd.structures import BoxList, to_image_list
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    g = load_e2e(name)
+    seed, batch, boxes, labels, cfg = e2e_inputs(g)
+    ll.set_backend("hip_bf16")
+    try:
+        model = build_model(cfg["pooler"], weights_np, "fused")
+        model.backbone_hip = VGGBackboneHip(model.backbone.body)
+        rois, targets = [], []
+        for k, (h, w, p) in enumerate(g["spec_images"]):
+            rois.append(BoxList(boxes[k].cuda(), (int(w), int(h)), "xyxy"))
+            t = BoxList(torch.zeros((len(labels[k]), 4)).cuda(), (int(w), int(h)), "xyxy")
+            t.add_field("labels", labels[k].cuda())
+            targets.append(t)
+        losses, accs = model(to_image_list(batch.cuda()), targets, rois, rand=DeviceRand(seed))
+        total = sum(losses.values())
+        total.backward()
+        report = {k: (round(float(v), 5), round(float(g["loss/" + k]), 5)) for k, v in losses.items()}
+        print("BF16REPORT", name, report)
+        ref_img = float(g["loss/loss_img"])
+        assert abs(float(losses["loss_img"]) - ref_img) <= 2e-2 * abs(ref_img), report
+        close = sum(abs(a - b) <= 5e-2 * max(abs(b), 1e-4) for a, b in report.values())
+        assert close >= len(report) - 2, report        # a bf16-induced selection flip may move one branch's pair
+        assert all(np.isfinite(float(v)) for v in losses.values())
+        gn = model.roi_heads.feature_extractor.classifier[1].weight.grad.double().norm().item()
+        ref = float(g["gradnorm/roi_heads.feature_extractor.classifier.1.weight"])
+        assert abs(gn - ref) <= 0.15 * ref, (gn, ref)
+    finally:
+        ll.set_backend("torch")
