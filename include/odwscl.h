@@ -205,6 +205,23 @@ int odw_maxpool2x2_nhwc_bf16_bwd(const void* X, const void* dY, int B, int H, in
 int odw_nhwc_bf16_to_nchw_f32(const void* in, int B, int HW, int C, float* out, void* stream);
 int odw_nchw_f32_to_nhwc_bf16(const float* in, int B, int HW, int C, int Cp, void* out, void* stream);
 
+/* ---- dense part of the OD-WSCL loss, forward + backward in two launches ----------------------
+ * Y (sumP x ldy) fp32 = the fused predictor output; head_offsets int[8] (HOST) = first column of
+ * cls, det, ref1, bbox1, ref2, bbox2, ref3, bbox3 (roi_weak_predictors.py:158-165), C classes.
+ * odw_wsddn_scores : final_s = softmax_row(cls) * softmax_col-per-image(det) (loss.py:234-247), src1/src2 =
+ *   softmax(ref1/ref2) (loss.py:357); colstat float[n_img][3][128] = det column max, det column sum-exp,
+ *   column sums of final_s.
+ * odw_refine_losses: given pseudo labels int64[3][sumP], loss weights [3][sumP], regression targets
+ *   [3][sumP][4] (od_layer) and image label vectors lab [n_img][C]: out float[n_img][16] = per image
+ *   {loss_img, cls0, reg0, cls1, reg1, cls2, reg2, acc_img, acc_ref0..2}/n_img (loss.py:349-409) and
+ *   dY (sumP x ldy) = d(sum of the 7 losses)/dY. */
+int odw_wsddn_scores(const float* Y, int ldy, const int* head_offsets, int C, const int* img_off, int n_img,
+                     float* final_s, float* src1, float* src2, float* colstat, void* stream);
+int odw_refine_losses(const float* Y, int ldy, const int* head_offsets, int C, const int* img_off, int n_img, int sum_p,
+                      const float* final_s, const float* colstat, const float* lab, const int64_t* pseudo,
+                      const float* weights, const float* targets, const int* n_pos, float eps, float* out, float* dY,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

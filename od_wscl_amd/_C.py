@@ -149,7 +149,7 @@ def supcon_v2(F, labels, weights, temperature, grad_scale=1.0, need_grad=True):
     return loss[0], dF
 
 
-def od_assign(boxes, gt_boxes, gt_classes, gt_scores, fg_thresh=0.5, weights=(10.0, 10.0, 5.0, 5.0)):
+def od_assign(boxes, gt_boxes, gt_classes, gt_scores, fg_thresh=0.5, weights=(10.0, 10.0, 5.0, 5.0), out=None):
     """-> (pseudo_labels int64 (P), loss_weights (P), regression_targets (P,4)).
     roi_heads/weak_head/pseudo_label_generator.py:171-190."""
     L.need_gpu(boxes, gt_boxes, gt_classes, gt_scores)
@@ -158,9 +158,12 @@ def od_assign(boxes, gt_boxes, gt_classes, gt_scores, fg_thresh=0.5, weights=(10
     gt_classes = gt_classes.contiguous().to(torch.int64)
     gt_scores = gt_scores.contiguous().float()
     P, G = boxes.shape[0], gt_boxes.shape[0]
-    labels = torch.empty((P,), dtype=torch.int64, device=boxes.device)
-    lw = torch.empty((P,), dtype=torch.float32, device=boxes.device)
-    tg = torch.empty((P, 4), dtype=torch.float32, device=boxes.device)
+    if out is not None:          # caller-provided contiguous slices (labels int64 (P), weights (P), targets (P,4))
+        labels, lw, tg = out
+    else:
+        labels = torch.empty((P,), dtype=torch.int64, device=boxes.device)
+        lw = torch.empty((P,), dtype=torch.float32, device=boxes.device)
+        tg = torch.empty((P, 4), dtype=torch.float32, device=boxes.device)
     L.check(L.lib().odw_od_assign(L.ptr(boxes), P, L.ptr(gt_boxes), L.ptr(gt_classes), L.ptr(gt_scores), G,
                                   float(fg_thresh), *[float(w) for w in weights], L.ptr(labels), L.ptr(lw),
                                   L.ptr(tg), L.stream()), "od_assign")

@@ -26,6 +26,37 @@ def _i32(values, device):
     return torch.tensor(values, dtype=torch.int32, device=device)
 
 
+def _fused_base(tensors):
+    """If the 8 predictor outputs are column slices of ONE (P, N) fp32 tensor (the fused predictor GEMM,
+    roi_weak_predictors.py), return (base, column offsets); else None."""
+    base = tensors[0]._base
+    if base is None or base.dim() != 2 or base.dtype != torch.float32 or not base.is_contiguous():
+        return None
+    offs = []
+    for t in tensors:
+        if t._base is not base or t.dim() != 2 or t.stride(0) != base.shape[1] or t.stride(1) != 1:
+            return None
+        offs.append(t.storage_offset() - base.storage_offset())
+    if any(o < 0 or o >= base.shape[1] for o in offs):
+        return None
+    return base, offs
+
+
+class _DenseLossFn(torch.autograd.Function):
+    """7 dense losses as one autograd node: the kernel already produced d(sum of losses)/dY; backward scales
+    each head's columns by the incoming gradient of its loss."""
+
+    @staticmethod
+    def forward(ctx, y, losses7, dy, col2loss):
+        ctx.save_for_backward(dy, col2loss)
+        return losses7.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, col2loss = ctx.saved_tensors
+        return dy * g[col2loss][None, :], None, None, None
+
+
 @registry.ROI_WEAK_LOSS.register("RoIRegLossFused")
 class RoIRegLossFused(RoIRegLossComputation):
     def _call(self, class_score, det_score, ref_scores, ref_bbox_preds, sim_feature, clean_pooled_feats,
@@ -40,19 +71,40 @@ class RoIRegLossFused(RoIRegLossComputation):
         rand = feature_extractor.rand
         tr = self.trace
 
-        class_score = F.softmax(torch.cat(class_score, dim=0), dim=1)
-        det = torch.cat(det_score, dim=0)
-        final_det = torch.cat([F.softmax(d, dim=0) for d in det.split(sizes)], dim=0) if n_img > 1 else F.softmax(det, dim=0)
-        final_score = class_score * final_det
-        C = final_score.shape[1]
         n_ref = len(ref_scores)
         assert n_ref == 3, "the OD-WSCL head has three refinement branches"
-        srcs = [final_score.detach().contiguous(), F.softmax(ref_scores[0].detach(), dim=1),
-                F.softmax(ref_scores[1].detach(), dim=1)]
-        boxes_all = torch.cat([p.bbox for p in proposals], dim=0).float().contiguous()
         offs = [0]
-        for s in sizes:
-            offs.append(offs[-1] + s)
+        for sz in sizes:
+            offs.append(offs[-1] + sz)
+        img_off = _i32(offs, device)
+        fused = None
+        if len(class_score) == 1 and len(det_score) == 1:
+            fused = _fused_base([class_score[0], det_score[0], ref_scores[0], ref_bbox_preds[0], ref_scores[1],
+                                 ref_bbox_preds[1], ref_scores[2], ref_bbox_preds[2]])
+        C = class_score[0].shape[1]
+        if fused is not None and C <= 128:
+            ybase, head_offs = fused
+            import ctypes
+            self._heads = (ctypes.c_int * 8)(*head_offs)
+            final_score = torch.empty((sum_p, C), dtype=torch.float32, device=device)
+            src1 = torch.empty_like(final_score)
+            src2 = torch.empty_like(final_score)
+            colstat = torch.empty((n_img, 3, 128), dtype=torch.float32, device=device)
+            L.check(lib.odw_wsddn_scores(L.ptr(ybase), ybase.shape[1], ctypes.cast(self._heads, ctypes.c_void_p), C,
+                                         L.ptr(img_off), n_img, L.ptr(final_score), L.ptr(src1), L.ptr(src2),
+                                         L.ptr(colstat), L.stream()), "wsddn_scores")
+            srcs = [final_score, src1, src2]
+            colsum = [colstat[idx, 2, :C] for idx in range(n_img)]
+        else:
+            ybase = None
+            class_score = F.softmax(torch.cat(class_score, dim=0), dim=1)
+            det = torch.cat(det_score, dim=0)
+            final_det = torch.cat([F.softmax(d, dim=0) for d in det.split(sizes)], dim=0) if n_img > 1 else F.softmax(det, dim=0)
+            final_score = class_score * final_det
+            srcs = [final_score.detach().contiguous(), F.softmax(ref_scores[0].detach(), dim=1),
+                    F.softmax(ref_scores[1].detach(), dim=1)]
+            colsum = [final_score[offs[idx]:offs[idx + 1]].sum(dim=0) for idx in range(n_img)]
+        boxes_all = torch.cat([p.bbox for p in proposals], dim=0).float().contiguous()
 
         # ---- image-level labels (host side: they are inputs of the step)
         pos_host = []
@@ -66,7 +118,6 @@ class RoIRegLossFused(RoIRegLossComputation):
                 lab_vecs[idx, torch.tensor([c + 1 for c in pc], device=device)] = 1
         pos_cls = _i32([pc + [0] * (maxpos - len(pc)) for pc in pos_host], device)
         n_pos = _i32([len(pc) for pc in pos_host], device)
-        img_off = _i32(offs, device)
 
         # ---- kernel A: tops + IoU-sampled row sets
         w32 = (max_p + 31) // 32
@@ -147,7 +198,6 @@ class RoIRegLossFused(RoIRegLossComputation):
 
         # ---- SupCon inputs.  features: class-major (bank of the class, then its discoveries in loop
         # order); weights: append order (Q1)
-        colsum = [final_score[offs[idx]:offs[idx + 1]].sum(dim=0) for idx in range(n_img)]
         feat_index, feat_label = [], []
         for c, bix in zip(classes, bank_index):
             ix = [bix]
@@ -182,29 +232,62 @@ class RoIRegLossFused(RoIRegLossComputation):
             tr["supcon_weights"] = weights.clone()
             tr["supcon_n"] = int(weights.numel())
         from ..sim_head.sim_loss import _SupConV2Fn
-        losses = {"loss_img": 0, "loss_sim": self.sim_lmda * _SupConV2Fn.apply(features, labels, weights, self.temp)}
+        loss_sim = self.sim_lmda * _SupConV2Fn.apply(features, labels, weights, self.temp)
+
+        # ---- pseudo labels of the three branches (od_layer tail, fused kernel)
+        pseudo_all = torch.empty((3, sum_p), dtype=torch.int64, device=device)
+        weight_all = torch.empty((3, sum_p), dtype=torch.float32, device=device)
+        target_all = torch.empty((3, sum_p, 4), dtype=torch.float32, device=device)
+        for idx in range(n_img):
+            sl = slice(offs[idx], offs[idx + 1])
+            bx = boxes_all[sl]
+            for i in range(n_ref):
+                g = gt_h[idx][i]
+                gi = gt_idx[idx, i, :g].long()
+                _C.od_assign(bx, bx[gi], gt_cls[idx, i, :g].long(), gt_score[idx, i, :g], self.od_layer.fg_thresh,
+                             self.od_layer.weights, out=(pseudo_all[i, sl], weight_all[i, sl], target_all[i, sl]))
+                if tr is not None:
+                    tr["pseudo_%d_%d" % (idx, i)] = pseudo_all[i, sl].clone()
+                    tr["weights_%d_%d" % (idx, i)] = weight_all[i, sl].clone()
+
+        names = ["loss_img", "loss_ref_cls0", "loss_ref_reg0", "loss_ref_cls1", "loss_ref_reg1", "loss_ref_cls2",
+                 "loss_ref_reg2"]
+        if ybase is not None and not self.cls_agnostic_bbox_reg:
+            # ---- MIL + refinement losses and their gradient in ONE launch (csrc/refine_loss.hip)
+            import ctypes
+            out = torch.empty((n_img, 16), dtype=torch.float32, device=device)
+            dy = torch.empty_like(ybase)
+            L.check(lib.odw_refine_losses(L.ptr(ybase), ybase.shape[1], ctypes.cast(self._heads, ctypes.c_void_p), C,
+                                          L.ptr(img_off), n_img, sum_p, L.ptr(final_score), L.ptr(colstat),
+                                          L.ptr(lab_vecs), L.ptr(pseudo_all), L.ptr(weight_all), L.ptr(target_all),
+                                          L.ptr(n_pos), float(epsilon), L.ptr(out), L.ptr(dy), L.stream()),
+                    "refine_losses")
+            if tr is not None:
+                tr["dense_loss_kernel"] = True
+            tot = out.sum(dim=0)
+            col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
+            dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
+            losses = {"loss_img": dense[0], "loss_sim": loss_sim}
+            for k in range(1, 7):
+                losses[names[k]] = dense[k]
+            accs = {"acc_img": tot[7], "acc_ref0": tot[8], "acc_ref1": tot[9], "acc_ref2": tot[10]}
+            return losses, accs
+
+        # ---- fallback: the same losses with torch ops (predictor outputs are not one fused tensor)
+        losses = {"loss_img": 0, "loss_sim": loss_sim}
         accs = {"acc_img": 0}
         for i in range(n_ref):
             losses["loss_ref_cls%d" % i] = 0
             losses["loss_ref_reg%d" % i] = 0
             accs["acc_ref%d" % i] = 0
-
-        # ---- MIL image loss + refinement branches (loss.py:349-400), fixed shapes, no host sync
         ar4 = torch.arange(4, device=device)
         for idx in range(n_img):
             sl = slice(offs[idx], offs[idx + 1])
             lab = lab_vecs[idx]
-            bx = boxes_all[sl]
             img_score = torch.clamp(final_score[sl].sum(dim=0), min=epsilon, max=1 - epsilon)
             losses["loss_img"] = losses["loss_img"] + F.binary_cross_entropy(img_score, lab)
             for i in range(n_ref):
-                g = gt_h[idx][i]
-                gi = gt_idx[idx, i, :g].long()
-                pseudo, weights_i, targets_reg = _C.od_assign(bx, bx[gi], gt_cls[idx, i, :g].long(), gt_score[idx, i, :g],
-                                                              self.od_layer.fg_thresh, self.od_layer.weights)
-                if tr is not None:
-                    tr["pseudo_%d_%d" % (idx, i)] = pseudo.clone()
-                    tr["weights_%d_%d" % (idx, i)] = weights_i.clone()
+                pseudo, weights_i, targets_reg = pseudo_all[i, sl], weight_all[i, sl], target_all[i, sl]
                 lam = 3 if i == 0 else 1
                 ce = F.cross_entropy(ref_scores[i][sl], pseudo, reduction="none")
                 losses["loss_ref_cls%d" % i] = losses["loss_ref_cls%d" % i] + lam * torch.mean(ce * weights_i)
@@ -220,13 +303,27 @@ class RoIRegLossFused(RoIRegLossComputation):
                 for i in range(n_ref):
                     rs = torch.sum(ref_scores[i][sl], dim=0)
                     accs["acc_ref%d" % i] = accs["acc_ref%d" % i] + lab[1:][rs[1:].topk(k_img)[1]].mean()
-
         for k in losses:
             if "sim" not in k:
                 losses[k] = losses[k] / n_img
         for k in accs:
             accs[k] = accs[k] / n_img
         return losses, accs
+
+    _col2loss_cache = {}
+
+    @classmethod
+    def _col2loss(cls, heads, C, ncols, device):
+        """column of Y -> index of the loss that owns it (cls, det -> loss_img; ref_i -> cls_i; bbox_i -> reg_i)."""
+        key = (tuple(heads), C, ncols, str(device))
+        if key not in cls._col2loss_cache:
+            m = torch.zeros(ncols, dtype=torch.long)
+            owner = [0, 0, 1, 2, 3, 4, 5, 6]
+            width = [C, C, C, 4 * C, C, 4 * C, C, 4 * C]
+            for o, w, k in zip(heads, width, owner):
+                m[o:o + w] = k
+            cls._col2loss_cache[key] = m.to(device)
+        return cls._col2loss_cache[key]
 
     @staticmethod
     def _embed_in_chunks(fe, model_sim, parts, segs6, segs7, max_segs=4):

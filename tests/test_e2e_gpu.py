@@ -68,6 +68,8 @@ def test_model_matches_reference_golden(name, loss_impl, weights_np):
         if k.startswith("weights_"):
             np.testing.assert_allclose(trace[k].cpu().numpy(), g[k], rtol=1e-3, atol=1e-7)
     assert trace["supcon_n"] == int(g["supcon_n"])
+    if loss_impl == "fused":
+        assert trace.get("dense_loss_kernel"), "the fused dense-loss kernel was not taken"
     np.testing.assert_allclose(trace["supcon_weights"].cpu().numpy(), g["supcon_weights"], rtol=1e-3, atol=1e-9)
     sum(losses.values()).backward()
     for n, p in model.named_parameters():
