@@ -215,12 +215,14 @@ int odw_nchw_f32_to_nhwc_bf16(const float* in, int B, int HW, int C, int Cp, voi
  *   [3][sumP][4] (od_layer) and image label vectors lab [n_img][C]: out float[n_img][16] = per image
  *   {loss_img, cls0, reg0, cls1, reg1, cls2, reg2, acc_img, acc_ref0..2}/n_img (loss.py:349-409) and
  *   dY (sumP x ldy) = d(sum of the 7 losses)/dY. */
-int odw_wsddn_scores(const float* Y, int ldy, const int* head_offsets, int C, const int* img_off, int n_img,
-                     float* final_s, float* src1, float* src2, float* colstat, void* stream);
+int64_t odw_refine_workspace(int n_img);
+int odw_wsddn_scores(const float* Y, int ldy, const int* head_offsets, int C, const int* img_off, int n_img, int max_p,
+                     float* final_s, float* src1, float* src2, float* colstat, void* workspace, int64_t workspace_bytes,
+                     void* stream);
 int odw_refine_losses(const float* Y, int ldy, const int* head_offsets, int C, const int* img_off, int n_img, int sum_p,
-                      const float* final_s, const float* colstat, const float* lab, const int64_t* pseudo,
+                      int max_p, const float* final_s, const float* colstat, const float* lab, const int64_t* pseudo,
                       const float* weights, const float* targets, const int* n_pos, float eps, float* out, float* dY,
-                      void* stream);
+                      void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -56,8 +56,10 @@ SIGNATURES = {
     "odw_maxpool2x2_nhwc_bf16_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_nhwc_bf16_to_nchw_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "odw_nchw_f32_to_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
-    "odw_wsddn_scores": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
-    "odw_refine_losses": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
+    "odw_refine_workspace": (c_l, [c_i]),
+    "odw_wsddn_scores": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p]),
+    "odw_refine_losses": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
+                                c_p, c_l, c_p]),
     "odw_od_assign": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
 }
 

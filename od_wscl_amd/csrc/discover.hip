@@ -72,6 +72,17 @@ __device__ __forceinline__ bool tv_overlap(const float4 a, const float4 b, float
     return inter / (aa + ab - inter) > thr;
 }
 
+
+// <X[r], v> for one row handled by a whole wave: lanes read the 512-byte row coalesced (2 floats each),
+// butterfly-reduce.  v is in LDS.  All 64 lanes return the sum.
+__device__ __forceinline__ float wave_row_dot(const float* __restrict__ row, const float* __restrict__ v, int lane) {
+    const float2 x = reinterpret_cast<const float2*>(row)[lane];
+    float d = x.x * v[2 * lane] + x.y * v[2 * lane + 1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
+    return d;
+}
+
 // sorted list of the set bits of mask[0..W) (32-bit words) -> out, returns count.  scan: LDS int[W+1]
 __device__ int mask_to_list(const unsigned int* mask, int W, int* out, int* scan) {
     for (int w = threadIdx.x; w < W; w += kThreads) scan[w + 1] = __popc(mask[w]);
@@ -193,11 +204,11 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
             {
                 const int nb = a.bank_cnt[c];
                 const float* bk = a.bank + (size_t)a.bank_off[c] * kD;
+                const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
                 float acc = 0.0f;
-                for (int j = threadIdx.x; j < nb; j += kThreads) {
-                    float d = 0.0f;
-                    for (int k = 0; k < kD; ++k) d += etop[k] * bk[(size_t)j * kD + k];
-                    acc += d;
+                for (int j = wave; j < nb; j += kThreads / 64) {
+                    const float d = wave_row_dot(bk + (size_t)j * kD, etop, lane);
+                    if (lane == 0) acc += d;
                 }
                 fred[threadIdx.x] = acc;
                 __syncthreads();
@@ -210,10 +221,12 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
             }
             const float thr = s_thr;
             // ---- close = sim_mat[top] >= thr
-            for (int r = threadIdx.x; r < P; r += kThreads) {
-                float d = 0.0f;
-                for (int k = 0; k < kD; ++k) d += E[(size_t)r * kD + k] * etop[k];
-                close[r] = d >= thr ? 1 : 0;
+            {
+                const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                for (int r = wave; r < P; r += kThreads / 64) {
+                    const float d = wave_row_dot(E + (size_t)r * kD, etop, lane);
+                    if (lane == 0) close[r] = d >= thr ? 1 : 0;
+                }
             }
             __syncthreads();
             // ---- Q3: for every other positive class, close = (float(close) >= sim_mat[neg_top])
@@ -223,10 +236,12 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
                     const int ntop = a.tops[(img * 3 + i) * a.maxpos + cj];
                     if (threadIdx.x < kD) etop[threadIdx.x] = E[(size_t)ntop * kD + threadIdx.x];
                     __syncthreads();
-                    for (int r = threadIdx.x; r < P; r += kThreads) {
-                        float d = 0.0f;
-                        for (int k = 0; k < kD; ++k) d += E[(size_t)r * kD + k] * etop[k];
-                        close[r] = ((close[r] ? 1.0f : 0.0f) >= d) ? 1 : 0;
+                    {
+                        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                        for (int r = wave; r < P; r += kThreads / 64) {
+                            const float d = wave_row_dot(E + (size_t)r * kD, etop, lane);
+                            if (lane == 0) close[r] = ((close[r] ? 1.0f : 0.0f) >= d) ? 1 : 0;
+                        }
                     }
                     __syncthreads();
                 }

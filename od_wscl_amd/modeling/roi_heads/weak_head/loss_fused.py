@@ -90,9 +90,11 @@ class RoIRegLossFused(RoIRegLossComputation):
             src1 = torch.empty_like(final_score)
             src2 = torch.empty_like(final_score)
             colstat = torch.empty((n_img, 3, 128), dtype=torch.float32, device=device)
+            ws_bytes = lib.odw_refine_workspace(n_img)
+            dense_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
             L.check(lib.odw_wsddn_scores(L.ptr(ybase), ybase.shape[1], ctypes.cast(self._heads, ctypes.c_void_p), C,
-                                         L.ptr(img_off), n_img, L.ptr(final_score), L.ptr(src1), L.ptr(src2),
-                                         L.ptr(colstat), L.stream()), "wsddn_scores")
+                                         L.ptr(img_off), n_img, max_p, L.ptr(final_score), L.ptr(src1), L.ptr(src2),
+                                         L.ptr(colstat), L.ptr(dense_ws), ws_bytes, L.stream()), "wsddn_scores")
             srcs = [final_score, src1, src2]
             colsum = [colstat[idx, 2, :C] for idx in range(n_img)]
         else:
@@ -258,10 +260,10 @@ class RoIRegLossFused(RoIRegLossComputation):
             out = torch.empty((n_img, 16), dtype=torch.float32, device=device)
             dy = torch.empty_like(ybase)
             L.check(lib.odw_refine_losses(L.ptr(ybase), ybase.shape[1], ctypes.cast(self._heads, ctypes.c_void_p), C,
-                                          L.ptr(img_off), n_img, sum_p, L.ptr(final_score), L.ptr(colstat),
+                                          L.ptr(img_off), n_img, sum_p, max_p, L.ptr(final_score), L.ptr(colstat),
                                           L.ptr(lab_vecs), L.ptr(pseudo_all), L.ptr(weight_all), L.ptr(target_all),
-                                          L.ptr(n_pos), float(epsilon), L.ptr(out), L.ptr(dy), L.stream()),
-                    "refine_losses")
+                                          L.ptr(n_pos), float(epsilon), L.ptr(out), L.ptr(dy), L.ptr(dense_ws), ws_bytes,
+                                          L.stream()), "refine_losses")
             if tr is not None:
                 tr["dense_loss_kernel"] = True
             tot = out.sum(dim=0)
