@@ -85,6 +85,7 @@ def synthetic_batch(seed, rank, size, proposals, classes, device):
     rois = [BoxList(boxes.to(device), (size, size), "xyxy")]
     t = BoxList(torch.zeros((len(labels), 4), device=device), (size, size), "xyxy")
     t.add_field("labels", labels.to(device))
+    t.add_field("labels_host", labels.tolist())     # the data loader has the image labels on the host anyway
     return images, [t], rois
 
 

@@ -172,7 +172,7 @@ __device__ __forceinline__ bool before(float sa, int ia, float sb, int ib) {
     return (sa > sb) || (sa == sb && ia < ib);
 }
 
-__global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int ppow2) {
+__global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int ppow2, int sbox_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve
     ArgMax* red = reinterpret_cast<ArgMax*>(smem);                       // kThreads * 8
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
     unsigned char* close = reinterpret_cast<unsigned char*>(ki + ppow2);  // ppow2 flags (close / alive)
     unsigned int* zeroed = reinterpret_cast<unsigned int*>(close + ppow2);  // W32 (od_layer zeroed rows)
     int* scan = reinterpret_cast<int*>(zeroed + a.W32);                   // W32 + 1
+    float4* sbox = reinterpret_cast<float4*>(smem + sbox_off);           // ppow2 candidate boxes, sorted order
     __shared__ int s_n, s_k;
     __shared__ float s_thr;
 
@@ -283,7 +284,10 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
             }
             const int n = s_n;
             // ---- greedy NMS in sorted order (torchvision: IoU without +1, suppress when > thr)
-            for (int t = threadIdx.x; t < n; t += kThreads) close[t] = 1;      // alive flags by sorted position
+            for (int t = threadIdx.x; t < n; t += kThreads) {
+                close[t] = 1;                                                   // alive flags by sorted position
+                sbox[t] = bx[ki[t]];                                            // boxes in LDS: the greedy chain below
+            }                                                                   // must not pay a global load per step
             if (threadIdx.x == 0) s_k = 0;
             __syncthreads();
             int* inst = a.inst_idx + slot * a.pstride;
@@ -292,9 +296,9 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
                 int k = s_k;
                 if (k >= n) break;
                 // position k is alive by construction
-                const float4 bk = bx[ki[k]];
+                const float4 bk = sbox[k];
                 for (int t = k + 1 + threadIdx.x; t < n; t += kThreads)
-                    if (close[t] && tv_overlap(bk, bx[ki[t]], a.nms_thr)) close[t] = 0;
+                    if (close[t] && tv_overlap(bk, sbox[t], a.nms_thr)) close[t] = 0;
                 if (threadIdx.x == 0) inst[n_inst] = ki[k];
                 ++n_inst;
                 __syncthreads();
@@ -406,9 +410,11 @@ ODW_EXPORT int odw_discover_sim(const float* E, const float* s0, const float* s1
     const int ppow2 = pow2_at_least(max_p);
     size_t lds = kThreads * sizeof(ArgMax) + kD * 4 + kThreads * 4 + (size_t)ppow2 * 4 + (size_t)ppow2 * 4 +
                  (size_t)ppow2 + (size_t)a.W32 * 4 + (size_t)(a.W32 + 1) * 4 + 64;
+    const int sbox_off = (int)((lds + 15) / 16 * 16);
+    lds = (size_t)sbox_off + (size_t)ppow2 * 16;
     ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(discover_sim_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "discover_sim attr");
-    discover_sim_kernel<<<n_img, kThreads, lds, (hipStream_t)stream_>>>(a, ppow2);
+    discover_sim_kernel<<<n_img, kThreads, lds, (hipStream_t)stream_>>>(a, ppow2, sbox_off);
     ODW_CHECK_LAUNCH("discover_sim_kernel");
     return ODW_OK;
 }

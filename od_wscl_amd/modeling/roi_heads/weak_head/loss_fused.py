@@ -22,8 +22,42 @@ from ..sim_head.sim_loss import SupConLossV2
 from .loss import RoIRegLossComputation
 
 
+_CONST_CACHE = {}
+
+
 def _i32(values, device):
-    return torch.tensor(values, dtype=torch.int32, device=device)
+    """Small int32 device array whose content is the same step after step (image offsets, positive
+    classes): uploaded once and cached -- a fresh torch.tensor(..., device=cuda) is a blocking
+    pageable-memory copy, i.e. a hidden host synchronisation."""
+    flat = tuple(v for row in values for v in row) if values and isinstance(values[0], (list, tuple)) else tuple(values)
+    shape = (len(values), len(values[0])) if values and isinstance(values[0], (list, tuple)) else (len(values),)
+    key = (flat, shape, str(device))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 4096:
+            _CONST_CACHE.clear()
+        t = torch.tensor(values, dtype=torch.int32, device=device).reshape(shape)
+        _CONST_CACHE[key] = t
+    return t
+
+
+class _Staging(object):
+    """Pinned host ring + device buffer for the few int32 values that DO change every step (bank offsets):
+    filled on the host, copied with a non-blocking in-stream memcpy."""
+
+    def __init__(self, device, slots=8, width=512):
+        self.host = torch.zeros((slots, width), dtype=torch.int32).pin_memory()
+        self.dev = torch.zeros((slots, width), dtype=torch.int32, device=device)
+        self.slot, self.slots, self.width = 0, slots, width
+
+    def upload(self, values):
+        n = len(values)
+        assert n <= self.width
+        k = self.slot
+        self.slot = (self.slot + 1) % self.slots
+        self.host[k, :n] = torch.tensor(values, dtype=torch.int32)
+        self.dev[k, :n].copy_(self.host[k, :n], non_blocking=True)
+        return self.dev[k, :n]
 
 
 def _fused_base(tensors):
@@ -114,10 +148,14 @@ class RoIRegLossFused(RoIRegLossComputation):
             lab = t.get_field("labels_host") if t.has_field("labels_host") else t.get_field("labels").tolist()
             pos_host.append(sorted(set(int(v) - 1 for v in lab if int(v) > 0)))
         maxpos = max(1, max(len(p) for p in pos_host))
-        lab_vecs = torch.zeros((n_img, C), device=device)
-        for idx, pc in enumerate(pos_host):
-            if pc:
-                lab_vecs[idx, torch.tensor([c + 1 for c in pc], device=device)] = 1
+        lab_key = ("lab", tuple(tuple(pc) for pc in pos_host), C, str(device))
+        lab_vecs = _CONST_CACHE.get(lab_key)
+        if lab_vecs is None:
+            host = torch.zeros((n_img, C))
+            for idx, pc in enumerate(pos_host):
+                for c in pc:
+                    host[idx, c + 1] = 1
+            lab_vecs = _CONST_CACHE[lab_key] = host.to(device)
         pos_cls = _i32([pc + [0] * (maxpos - len(pc)) for pc in pos_host], device)
         n_pos = _i32([len(pc) for pc in pos_host], device)
 
@@ -174,7 +212,10 @@ class RoIRegLossFused(RoIRegLossComputation):
             pos += int(ix.numel())
         bank_index_all = torch.cat(bank_index)
         bank = all_emb.detach()[bank_index_all].contiguous()
-        bank_off, bank_cnt = _i32(bank_off_h, device), _i32(bank_cnt_h, device)
+        if getattr(self, "_staging", None) is None or self._staging.dev.device != device:
+            self._staging = _Staging(device)
+        both = self._staging.upload(bank_off_h + bank_cnt_h)
+        bank_off, bank_cnt = both[:C - 1], both[C - 1:]
 
         # ---- kernel B: object discovery + pseudo-GT lists
         shp = (n_img, 3, maxpos)
