@@ -289,6 +289,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_glds_kernel(
 // wave keeps two tiles of DMA in flight: the wait before the barrier is s_waitcnt vmcnt(6) -- "all but
 // my 6 newest loads have landed" -- never vmcnt(0) in the main loop, and the barrier is the raw
 // s_barrier (a __syncthreads() would drain the DMA queue).  25 % less L2->LDS traffic per FLOP too.
+// Tried and rejected on this tile (same inputs, tools/gemm_bench.py): splitting the 8 waves into two role
+// groups half a K-step apart (one group issues DMA + reads all 16 fragments while the other runs 16
+// back-to-back MFMAs, two barriers per K-step) -- 555 TF vs 912 TF: the memory half-step takes ~1500 cycles
+// by itself, i.e. the kernel is bound by operand delivery (9.9 GB of L2->LDS traffic per fc6 GEMM, ~11 TB/s),
+// not by MFMA issue; and a 256x256 tile with 128x64 per wave needs > 256 VGPRs at 2 waves/SIMD (spills).
 constexpr int RM = 256, RN = 128;
 constexpr int kRingThreads = 512;
 constexpr int kRingStageChunks = (RM + RN) * kChunksPerRow;      // 3072 uint4 = 48 KB

@@ -62,12 +62,14 @@ def test_gemm_lds_dma_variant(G, M, N, K):
         os.environ["ODW_GEMM_VARIANT"] = "ring"          # 256x128 tile, 3-stage ring, counted vmcnt
         G.gemm_nt(a, b, M, N, K, o3)
 
+
     finally:
         del os.environ["ODW_GEMM_VARIANT"]
     ref = a.float() @ b.float().T
     tol = 1e-5 * np.sqrt(K) * 4 * max(1.0, ref.abs().max().item())
     assert (o1 - ref).abs().max().item() <= tol and (o2 - ref).abs().max().item() <= tol
     assert (o3 - ref).abs().max().item() <= tol
+
 
 
 
