@@ -15,6 +15,19 @@ def make_defaults():
     c.MODEL.BACKBONE = CN()
     c.MODEL.BACKBONE.CONV_BODY = "R-50-C4"
     c.MODEL.BACKBONE.FREEZE_CONV_BODY_AT = 2                  # :128
+    c.MODEL.RESNETS = CN()                                    # :304-330
+    c.MODEL.RESNETS.NUM_GROUPS = 1
+    c.MODEL.RESNETS.WIDTH_PER_GROUP = 64
+    c.MODEL.RESNETS.STRIDE_IN_1X1 = True
+    c.MODEL.RESNETS.TRANS_FUNC = "BottleneckWithFixedBatchNorm"
+    c.MODEL.RESNETS.STEM_FUNC = "StemWithFixedBatchNorm"
+    c.MODEL.RESNETS.RES5_DILATION = 1
+    c.MODEL.RESNETS.BACKBONE_OUT_CHANNELS = 256 * 4
+    c.MODEL.RESNETS.RES2_OUT_CHANNELS = 256
+    c.MODEL.RESNETS.STEM_OUT_CHANNELS = 64
+    c.MODEL.RESNETS.STAGE_WITH_DCN = (False, False, False, False)
+    c.MODEL.RESNETS.WITH_MODULATED_DCN = False
+    c.MODEL.RESNETS.DEFORMABLE_GROUPS = 1
     c.MODEL.ROI_HEADS = CN()
     c.MODEL.ROI_HEADS.FG_IOU_THRESHOLD = 0.5
     c.MODEL.ROI_HEADS.BBOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)   # :213

@@ -31,6 +31,11 @@ def load_formula_weights(model, seed, overrides=None):
     with torch.no_grad():
         for n, p in model.named_parameters():
             p.copy_(torch.from_numpy(sd[n]))
+        bufs = [(n, tuple(b.shape)) for n, b in model.named_buffers()]
+        if bufs:                               # frozen batch-norm statistics of the ResNet bodies
+            bd = synthetic.init_buffers(bufs, seed)
+            for n, b in model.named_buffers():
+                b.copy_(torch.from_numpy(bd[n]))
 
 
 def make_optimizer(cfg, model):
@@ -165,8 +170,8 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
     load_formula_weights(model, 1)
     model.train()
     fe = model.roi_heads.feature_extractor
-    fe.classifier[1].tag = "fc6"
-    fe.classifier[4].tag = "fc7"
+    fe.fc6.tag = "fc6"
+    fe.fc7.tag = "fc7"
     model.roi_heads.model_sim.mlp[0].tag = "sim0"
     kernel_timer.enabled = os.environ.get("ODW_NO_TIMER") != "1"
     debug = os.environ.get("ODW_DEBUG_SYNC", "").split(",")

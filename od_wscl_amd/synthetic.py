@@ -117,6 +117,27 @@ def fill_weights(seed, stream, shape, std):
     return out.reshape(shape)
 
 
+_S_BUFFER = 1 << 16
+
+
+def init_buffers(named_shapes, seed):
+    """Formula values for the frozen batch-norm buffers of the ResNet bodies (layers/batch_norm.py:12-17):
+    weight in [0.5, 1) (x0.5 on the last BN of a block so the residual trunk stays O(1) over 16 blocks),
+    bias and running_mean in [-0.1, 0.1), running_var in [0.5, 1.5) -- the spread a trained network has,
+    so the affine is exercised, not the identity the constructor leaves."""
+    sd = {}
+    for pos, (name, shape) in enumerate(named_shapes):
+        u = rng.uniform(seed, _S_BUFFER + pos, int(np.prod(shape)), 0).reshape(shape)
+        if name.endswith("running_var"):
+            v = np.float32(0.5) + u
+        elif name.endswith(".weight"):
+            v = (np.float32(0.5) + np.float32(0.5) * u) * np.float32(0.5 if ".bn3." in name else 1.0)
+        else:
+            v = (u - np.float32(0.5)) * np.float32(0.2)
+        sd[name] = v.astype(np.float32)
+    return sd
+
+
 def init_state_dict(named_shapes, seed, scheme="reference", overrides=None):
     """Formula weights for every parameter of the detector.
 
@@ -142,6 +163,8 @@ def init_state_dict(named_shapes, seed, scheme="reference", overrides=None):
             if "features" in name or "model_sim" in name:
                 fan_out = shape[0] * int(np.prod(shape[2:])) if len(shape) > 2 else shape[0]
                 std = math.sqrt(2.0 / fan_out)
+            elif "body.stem" in name or "body.layer" in name:
+                std = 1.0 / math.sqrt(int(np.prod(shape[1:])))     # kaiming_uniform_(a=1) (resnet.py:289,333,342,396)
             elif "classifier" in name:
                 std = 0.01
             else:

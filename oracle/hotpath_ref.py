@@ -39,17 +39,52 @@ def vgg_conv_indices():
     return out
 
 
-def param_shapes(num_classes=21):
+RESNET_BLOCKS = {"r50": (3, 4, 6, 3), "r101": (3, 4, 23, 3)}
+
+
+def resnet_convs(arch):
+    """Ordered (prefix, cin, cout, k) of every conv of a *-C5 body in module-registration order
+    (backbone/resnet.py:84-126, :258-343: downsample is registered before conv1)."""
+    out = [("backbone.body.stem.conv1", 3, 64, 7)]
+    cin = 64
+    for li, count in enumerate(RESNET_BLOCKS[arch]):
+        mid, cout = 64 << li, 256 << li
+        for b in range(count):
+            pre = "backbone.body.layer%d.%d." % (li + 1, b)
+            if b == 0:
+                out.append((pre + "downsample.0", cin, cout, 1))
+            out += [(pre + "conv1", cin, mid, 1), (pre + "conv2", mid, mid, 3), (pre + "conv3", mid, cout, 1)]
+            cin = cout
+    return out
+
+
+def resnet_buffer_shapes(arch):
+    """Ordered (name, shape) of the frozen batch-norm buffers (layers/batch_norm.py:12-17)."""
+    out = []
+    for pre, _cin, cout, _k in resnet_convs(arch):
+        bn = pre[:-len("conv1")] + "bn" + pre[-1] if not pre.endswith("downsample.0") else pre[:-1] + "1"
+        for f in ("weight", "bias", "running_mean", "running_var"):
+            out.append((bn + "." + f, (cout,)))
+    return out
+
+
+def param_shapes(num_classes=21, arch="vgg16"):
     """Ordered (name, shape) of every parameter, reference names."""
     shapes = []
-    cin = 3
-    for i, v in zip(vgg_conv_indices(), [v for v in VGG16_OICR if isinstance(v, tuple)]):
-        shapes.append(("backbone.body.features.%d.weight" % i, (v[0], cin, 3, 3)))
-        shapes.append(("backbone.body.features.%d.bias" % i, (v[0],)))
-        cin = v[0]
     fe = "roi_heads.feature_extractor.classifier."
-    shapes += [(fe + "1.weight", (4096, 512 * 7 * 7)), (fe + "1.bias", (4096,)),
-               (fe + "4.weight", (4096, 4096)), (fe + "4.bias", (4096,))]
+    if arch == "vgg16":
+        cin = 3
+        for i, v in zip(vgg_conv_indices(), [v for v in VGG16_OICR if isinstance(v, tuple)]):
+            shapes.append(("backbone.body.features.%d.weight" % i, (v[0], cin, 3, 3)))
+            shapes.append(("backbone.body.features.%d.bias" % i, (v[0],)))
+            cin = v[0]
+        shapes += [(fe + "1.weight", (4096, 512 * 7 * 7)), (fe + "1.bias", (4096,)),
+                   (fe + "4.weight", (4096, 4096)), (fe + "4.bias", (4096,))]
+    else:
+        shapes += [(pre + ".weight", (cout, cin, k, k)) for pre, cin, cout, k in resnet_convs(arch)]
+        # roi_box_feature_extractors.py:58-65: Linear(7*7*2048, 2048), Linear(2048, 4096) at positions 0 and 3
+        shapes += [(fe + "0.weight", (2048, 7 * 7 * 2048)), (fe + "0.bias", (2048,)),
+                   (fe + "3.weight", (4096, 2048)), (fe + "3.bias", (4096,))]
     pr = "roi_heads.predictor."
     for name, n in (("cls_score", num_classes), ("det_score", num_classes), ("ref1", num_classes),
                     ("bbox_pred1", 4 * num_classes), ("ref2", num_classes), ("bbox_pred2", 4 * num_classes),
@@ -63,6 +98,8 @@ def param_shapes(num_classes=21):
 
 # features.{0,2,5,7} are frozen: FREEZE_CONV_BODY_AT=2 (vgg16.py:48-55, config/defaults.py:128)
 FROZEN = tuple("backbone.body.features.%d." % i for i in (0, 2, 5, 7))
+# stem + layer1 are frozen for the ResNets (resnet.py:128-137 with the same FREEZE_CONV_BODY_AT=2)
+FROZEN_RESNET = ("backbone.body.stem.", "backbone.body.layer1.")
 
 
 class Rand(object):
@@ -178,12 +215,41 @@ def backbone_forward(x, sd):
     return x
 
 
+def _frozen_bn(x, sd, name):
+    """FrozenBatchNorm2d.forward (layers/batch_norm.py:19-31), same operation order."""
+    scale = sd[name + ".weight"] * sd[name + ".running_var"].rsqrt()
+    bias = sd[name + ".bias"] - sd[name + ".running_mean"] * scale
+    return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+
+
+def resnet_forward(x, sd, arch="r50"):
+    """ResNet.forward of a *-C5 body (backbone/resnet.py:139-146, stem :398-403, Bottleneck :350-375) with
+    STRIDE_IN_1X1 and the layer4 stride patch of GeneralizedRCNN.__init__ (detector/generalized_rcnn.py:37-45):
+    strides 1,2,2,1 on the first block of layer1..4, carried by conv1 and the downsample conv."""
+    p = "backbone.body."
+    x = F.relu(_frozen_bn(F.conv2d(x, sd[p + "stem.conv1.weight"], stride=2, padding=3), sd, p + "stem.bn1"))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for li, count in enumerate(RESNET_BLOCKS[arch]):
+        for b in range(count):
+            q = p + "layer%d.%d." % (li + 1, b)
+            stride = 2 if (b == 0 and li in (1, 2)) else 1
+            y = F.relu(_frozen_bn(F.conv2d(x, sd[q + "conv1.weight"], stride=stride), sd, q + "bn1"))
+            y = F.relu(_frozen_bn(F.conv2d(y, sd[q + "conv2.weight"], padding=1), sd, q + "bn2"))
+            y = _frozen_bn(F.conv2d(y, sd[q + "conv3.weight"]), sd, q + "bn3")
+            if b == 0:
+                x = _frozen_bn(F.conv2d(x, sd[q + "downsample.0.weight"], stride=stride), sd, q + "downsample.1")
+            x = F.relu(y + x)
+    return x
+
+
 def neck(pooled, sd, rand):
-    """VGG16FC67ROIFeatureExtractor.forward_neck (vgg16.py:159-162): fc6,ReLU,Dropout,fc7,ReLU,Dropout."""
+    """forward_neck of either extractor (vgg16.py:159-162 -- classifier.{1,4};
+    roi_box_feature_extractors.py:90-97 -- classifier.{0,3}): Linear,ReLU,Dropout,Linear,ReLU,Dropout."""
     fe = "roi_heads.feature_extractor.classifier."
+    a, b = ("1", "4") if (fe + "1.weight") in sd else ("0", "3")
     x = pooled.reshape(pooled.shape[0], -1)
-    x = rand.dropout(F.relu(F.linear(x, sd[fe + "1.weight"], sd[fe + "1.bias"])))
-    x = rand.dropout(F.relu(F.linear(x, sd[fe + "4.weight"], sd[fe + "4.bias"])))
+    x = rand.dropout(F.relu(F.linear(x, sd[fe + a + ".weight"], sd[fe + a + ".bias"])))
+    x = rand.dropout(F.relu(F.linear(x, sd[fe + b + ".weight"], sd[fe + b + ".bias"])))
     return x
 
 
@@ -458,7 +524,8 @@ def roi_reg_loss(cls_logit, det_logit, ref_logits, bbox_preds, sim_feature, clea
 def forward(images, boxes_per_image, labels_per_image, sd, rand, cfg, trace=None):
     """GeneralizedRCNN.forward (train) -> ROIWeakRegHead.forward
     (modeling/detector/generalized_rcnn.py:57-97, roi_heads/weak_head/weak_head.py:101-122)."""
-    feat = backbone_forward(images, sd)
+    arch = cfg.get("arch", "vgg16")
+    feat = backbone_forward(images, sd) if arch == "vgg16" else resnet_forward(images, sd, arch)
     rois = rois_with_batch_index(boxes_per_image)
     if cfg.get("pooler", "ROIPool") == "ROIPool":
         pooled = _RoiPoolFn.apply(feat, rois, 7, 7, cfg.get("scale", 0.125))
@@ -477,14 +544,19 @@ def forward(images, boxes_per_image, labels_per_image, sd, rand, cfg, trace=None
                         boxes_per_image, labels_per_image, cfg, trace)
 
 
-def make_state(seed, num_classes=21, overrides=None, requires_grad=True):
-    """Formula-initialised parameters as torch tensors (frozen convs never require grad)."""
+def make_state(seed, num_classes=21, overrides=None, requires_grad=True, arch="vgg16"):
+    """Formula-initialised parameters (and, for the ResNets, frozen batch-norm buffers) as torch tensors;
+    frozen convs never require grad."""
     from od_wscl_amd import synthetic
-    raw = synthetic.init_state_dict(param_shapes(num_classes), seed, overrides=overrides)
+    raw = synthetic.init_state_dict(param_shapes(num_classes, arch), seed, overrides=overrides)
+    frozen = FROZEN if arch == "vgg16" else FROZEN_RESNET
     sd = {}
     for k, v in raw.items():
         t = torch.from_numpy(v)
-        if requires_grad and not k.startswith(FROZEN):
+        if requires_grad and not k.startswith(frozen):
             t.requires_grad_(True)
         sd[k] = t
+    if arch != "vgg16":
+        for k, v in synthetic.init_buffers(resnet_buffer_shapes(arch), seed).items():
+            sd[k] = torch.from_numpy(v)
     return sd

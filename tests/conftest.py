@@ -20,13 +20,31 @@ def ops_golden():
     return np.load(os.path.join(GOLDEN, "ops_ref.npz"))
 
 
+_WEIGHTS = {}
+
+
+def weights_for(arch):
+    """The one formula-generated weight set every e2e golden of `arch` was produced with (WEIGHT_SEED=1);
+    for the ResNets the frozen batch-norm buffers come with it."""
+    if arch not in _WEIGHTS:
+        from od_wscl_amd import synthetic
+        from oracle import hotpath_ref as H
+        sd = synthetic.init_state_dict(H.param_shapes(21, arch), 1,
+                                       overrides={"predictor": 0.002, "model_sim.mlp.2": 0.05})
+        if arch != "vgg16":
+            sd.update(synthetic.init_buffers(H.resnet_buffer_shapes(arch), 1))
+        _WEIGHTS.clear()                       # one set resident at a time (0.6-1 GB each)
+        _WEIGHTS[arch] = sd
+    return _WEIGHTS[arch]
+
+
 @pytest.fixture(scope="session")
 def weights_np():
-    """The one formula-generated weight set every e2e golden was produced with (WEIGHT_SEED=1)."""
-    from od_wscl_amd import synthetic
-    from oracle import hotpath_ref as H
-    return synthetic.init_state_dict(H.param_shapes(21), 1,
-                                     overrides={"predictor": 0.002, "model_sim.mlp.2": 0.05})
+    return weights_for("vgg16")
+
+
+def e2e_arch(g):
+    return str(g["spec_arch"]) if "spec_arch" in g.files else "vgg16"
 
 
 def load_e2e(name):
@@ -44,12 +62,14 @@ def e2e_inputs(g):
     wm = max(synthetic.pad_to(int(w)) for h, w, p in specs)
     batch = torch.zeros(len(specs), 3, hm, wm)
     boxes, labels, o = [], [], 0
+    min_size = int(g["spec_min_size"]) if "spec_min_size" in g.files else 12
+    arch = e2e_arch(g)
     for k, (h, w, p) in enumerate(specs):
         h, w, p = int(h), int(w), int(p)
         batch[k, :, :h, :w] = torch.from_numpy(synthetic.make_image(seed, k, h, w)[:, :h, :w].copy())
-        boxes.append(torch.from_numpy(synthetic.make_proposals(seed, k, p, h, w, min_size=12)))
+        boxes.append(torch.from_numpy(synthetic.make_proposals(seed, k, p, h, w, min_size=min_size)))
         labels.append(torch.tensor(flat[o:o + cnt[k]], dtype=torch.int64))
         o += cnt[k]
-    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler=str(g["spec_pooler"]), scale=0.125,
-               sampling_ratio=0)
+    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler=str(g["spec_pooler"]), sampling_ratio=0,
+               arch=arch, scale=0.125 if arch == "vgg16" else 0.0625)
     return seed, batch, boxes, labels, cfg

@@ -37,6 +37,9 @@ E2E_CASES = {
     "e2e_voc_2img": dict(seed=58, images=[(96, 128, 48), (80, 112, 40)], labels=[[3, 9], [9]], pooler="ROIPool"),
     "e2e_voc_1img": dict(seed=15, images=[(128, 128, 64)], labels=[[5]], pooler="ROIPool"),
     "e2e_align_1img": dict(seed=16, images=[(96, 96, 32)], labels=[[2, 17]], pooler="ROIAlign"),
+    # config 5 of SURVEY.md s8: R-50-C5 body (stride 16) + ResNet50Conv5ROIFeatureExtractor
+    "e2e_r50_2img": dict(seed=27, images=[(256, 320, 48), (224, 288, 40)], labels=[[7], [12]], pooler="ROIPool",
+                         arch="r50", min_size=32, yaml="configs/voc/voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml"),
 }
 # predictor / Sim_Net scales that give well separated scores (the reference's N(0,0.001)
 # predictor init makes every score nearly tied, which no fp32 re-ordering survives)
@@ -180,8 +183,9 @@ def _inject_rng(model, rand):
     in the reference's own call order: nn.Dropout (vgg16.py:124,127), torch.rand
     (drop_block.py:42), torch.normal (vgg16.py:178)."""
     cl = model.roi_heads.feature_extractor.classifier
-    cl[3] = _DetDropout(rand)
-    cl[6] = _DetDropout(rand)
+    for i, m in enumerate(cl):             # classifier.{3,6} for VGG16, .{2,5} for the ResNet extractor
+        if isinstance(m, torch.nn.Dropout):
+            cl[i] = _DetDropout(rand)
     real = (torch.rand, torch.normal)
     torch.rand = lambda *shape, **k: rand.uniform(tuple(shape))
     torch.normal = lambda mean, std, size=None, **k: rand.normal(tuple(size)) * std + mean
@@ -193,20 +197,30 @@ def gen_e2e(name, spec, out):
     refimport.load_reference()
     from wetectron.structures.bounding_box import BoxList
     from wetectron.structures.image_list import to_image_list
-    cfg = refimport.reference_cfg(opts=CFG_OPTS + ["MODEL.ROI_BOX_HEAD.POOLER_METHOD", spec["pooler"]])
+    arch = spec.get("arch", "vgg16")
+    opts = CFG_OPTS + ["MODEL.ROI_BOX_HEAD.POOLER_METHOD", spec["pooler"]]
+    cfg = refimport.reference_cfg(spec["yaml"], opts=opts) if "yaml" in spec else refimport.reference_cfg(opts=opts)
     model = refimport.build_reference_model(cfg)
     model.train()
     seed = spec["seed"]
     shapes = [(n, tuple(p.shape)) for n, p in model.named_parameters()]
-    assert [s[0] for s in shapes] == [s[0] for s in H.param_shapes(21)], "parameter naming drifted"
+    assert shapes == H.param_shapes(21, arch), "parameter naming drifted"
     sd = synthetic.init_state_dict(shapes, WEIGHT_SEED, overrides=OVERRIDES)
     with torch.no_grad():
         for n, p in model.named_parameters():
             p.copy_(torch.from_numpy(sd[n]))
+    bufs = [(n, tuple(b.shape)) for n, b in model.named_buffers()]
+    if arch != "vgg16":
+        assert bufs == H.resnet_buffer_shapes(arch), "buffer naming drifted"
+        bd = synthetic.init_buffers(bufs, WEIGHT_SEED)
+        sd.update(bd)
+        with torch.no_grad():
+            for n, b in model.named_buffers():
+                b.copy_(torch.from_numpy(bd[n]))
     imgs, rois, targets, boxes_np = [], [], [], []
     for k, (h, w, pcount) in enumerate(spec["images"]):
         imgs.append(torch.from_numpy(synthetic.make_image(seed, k, h, w)[:, :h, :w].copy()))
-        bx = synthetic.make_proposals(seed, k, pcount, h, w, min_size=12)
+        bx = synthetic.make_proposals(seed, k, pcount, h, w, min_size=spec.get("min_size", 12))
         boxes_np.append(bx)
         rois.append(BoxList(torch.from_numpy(bx), (w, h), "xyxy"))
         t = BoxList(torch.zeros((len(spec["labels"][k]), 4)), (w, h), "xyxy")
@@ -260,6 +274,8 @@ def gen_e2e(name, spec, out):
     rec["spec_seed"] = np.array(seed)
     rec["spec_images"] = np.array(spec["images"])
     rec["spec_pooler"] = np.array(spec["pooler"])
+    rec["spec_arch"] = np.array(arch)
+    rec["spec_min_size"] = np.array(spec.get("min_size", 12))
     rec["spec_labels_flat"] = np.array([l for ls in spec["labels"] for l in ls])
     rec["spec_labels_count"] = np.array([len(ls) for ls in spec["labels"]])
     rec["streams_used"] = np.array(rand.s.next)
@@ -270,7 +286,8 @@ def gen_e2e(name, spec, out):
     sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
     hm, wm = images.tensors.shape[-2:]
     tr = {}
-    cfg_o = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler=spec["pooler"], scale=0.125, sampling_ratio=0)
+    cfg_o = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler=spec["pooler"], sampling_ratio=0, arch=arch,
+                 scale=0.125 if arch == "vgg16" else 0.0625)
     with torch.no_grad():
         lo, _ = H.forward(images.tensors, [torch.from_numpy(b) for b in boxes_np],
                           [torch.tensor(l) for l in spec["labels"]], sdt, H.Rand(seed), cfg_o, tr)

@@ -8,27 +8,35 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import e2e_inputs, load_e2e
+from conftest import e2e_arch, e2e_inputs, load_e2e, weights_for
 
 pytestmark = pytest.mark.gpu
 
-E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img"]
+E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img", "e2e_r50_2img"]
 LOSS_RTOL = 1e-3
 
 
-def build_model(pooler, weights_np, loss_impl="fused"):
+ARCH_OPTS = {
+    "vgg16": ["MODEL.BACKBONE.CONV_BODY", "VGG16-OICR", "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,),
+              "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR", "VGG16.roi_head"],
+    # configs/voc/voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml
+    "r50": ["MODEL.BACKBONE.CONV_BODY", "R-50-C5", "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.0625,),
+            "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR", "ResNet50Conv5ROIFeatureExtractor"],
+}
+
+
+def build_model(pooler, weights_np, loss_impl="fused", arch="vgg16"):
     from od_wscl_amd.config import make_defaults
     from od_wscl_amd.modeling.detector import build_detection_model
     cfg = make_defaults()
-    cfg.merge_from_list(["MODEL.BACKBONE.CONV_BODY", "VGG16-OICR", "MODEL.WSOD_ON", True, "MODEL.FASTER_RCNN", False,
+    cfg.merge_from_list(["MODEL.WSOD_ON", True, "MODEL.FASTER_RCNN", False,
                          "MODEL.ROI_BOX_HEAD.NUM_CLASSES", 21, "MODEL.ROI_BOX_HEAD.POOLER_METHOD", pooler,
-                         "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7, "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,),
-                         "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR", "VGG16.roi_head",
+                         "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
                          "MODEL.ROI_WEAK_HEAD.REGRESS_ON", True, "DB.METHOD", "dropblock", "SOLVER.CONTRA", True,
-                         "nms", 0.1, "lmda", 0.03, "temp", 0.2, "ODW.LOSS_IMPL", loss_impl])
+                         "nms", 0.1, "lmda", 0.03, "temp", 0.2, "ODW.LOSS_IMPL", loss_impl] + ARCH_OPTS[arch])
     model = build_detection_model(cfg).cuda()
     with torch.no_grad():
-        for n, p in model.named_parameters():
+        for n, p in list(model.named_parameters()) + list(model.named_buffers()):
             p.copy_(torch.from_numpy(weights_np[n]))
     model.train()
     return model
@@ -36,14 +44,14 @@ def build_model(pooler, weights_np, loss_impl="fused"):
 
 @pytest.mark.parametrize("loss_impl", ["fused", "loops"])
 @pytest.mark.parametrize("name", E2E)
-def test_model_matches_reference_golden(name, loss_impl, weights_np):
+def test_model_matches_reference_golden(name, loss_impl):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from od_wscl_amd.structures import BoxList, to_image_list
     from od_wscl_amd.utils.device_rand import DeviceRand
     g = load_e2e(name)
     seed, batch, boxes, labels, cfg = e2e_inputs(g)
-    model = build_model(cfg["pooler"], weights_np, loss_impl)
+    model = build_model(cfg["pooler"], weights_for(e2e_arch(g)), loss_impl, e2e_arch(g))
     specs = g["spec_images"]
     rois, targets = [], []
     for k, (h, w, p) in enumerate(specs):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import e2e_inputs, load_e2e
+from conftest import e2e_arch, e2e_inputs, load_e2e, weights_for
 from oracle import hotpath_ref as H
 from oracle import native
 
@@ -124,18 +124,21 @@ def test_roi_pool_known_answers():
     assert gin[0, 0, 1, 3] == 6 + 1 and gin[0, 0, 1, 1] == 1 and gin.sum() == 6 + 6 + 6
 
 
-E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img"]
+E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img", "e2e_r50_2img"]
 
 
 @pytest.mark.parametrize("name", E2E)
-def test_end_to_end_matches_imported_reference(name, weights_np):
+def test_end_to_end_matches_imported_reference(name):
     """Full train-mode forward + backward of the restated hot path vs the reference's own run."""
     g = load_e2e(name)
     seed, batch, boxes, labels, cfg = e2e_inputs(g)
+    arch = e2e_arch(g)
+    frozen = H.FROZEN if arch == "vgg16" else H.FROZEN_RESNET
+    param_names = set(n for n, _ in H.param_shapes(21, arch))
     sd = {}
-    for k, v in weights_np.items():
+    for k, v in weights_for(arch).items():
         t = torch.from_numpy(v.copy())
-        if not k.startswith(H.FROZEN):
+        if k in param_names and not k.startswith(frozen):
             t.requires_grad_(True)
         sd[k] = t
     tr = {}
@@ -161,7 +164,7 @@ def test_end_to_end_matches_imported_reference(name, weights_np):
             ref = float(g[key])
             assert abs(p.grad.double().norm().item() - ref) <= 1e-4 * max(ref, 1e-9), n
         else:
-            assert p.grad is None or n.startswith(H.FROZEN)
+            assert p.grad is None or n.startswith(frozen)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/wetectron"), reason="reference tree not present")
