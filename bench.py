@@ -30,6 +30,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 # checkpoints here: with random-init weights lr 0.01 diverges to NaN within 4 steps, so the bench
 # keeps the identical work (same SGD update, momentum, weight decay) at a learning rate that stays finite.
 BENCH_LR = 1e-5
+ARCH_NAME = {"vgg16": "VGG16", "r50": "R-50-C5"}
 
 
 def parse():
@@ -43,19 +44,25 @@ def parse():
     ap.add_argument("--dtype", default=os.environ.get("ODW_DTYPE", "bf16"), choices=["bf16", "f32"])
     ap.add_argument("--backend", default=os.environ.get("ODW_BACKEND", "hip"), choices=["hip", "torch"],
                     help="hip = hand-written gfx950 kernels for the ROI head (default); torch = library comparison")
+    ap.add_argument("--arch", default="vgg16", choices=["vgg16", "r50"],
+                    help="vgg16 = the headline workload (BASELINE.json configs[1]); r50 = the R-50-C5 config "
+                         "(configs/voc/voc07_r50_c5_*.yaml), a secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proposals", type=int, default=500)
     return ap.parse_args()
 
 
-def build_cfg(classes):
+def build_cfg(classes, arch="vgg16"):
     from od_wscl_amd.config import make_defaults
     cfg = make_defaults()
-    # == configs/voc/voc07_contra_db_b8_lr0.01_mcg.yaml of the reference
-    cfg.merge_from_list(["MODEL.BACKBONE.CONV_BODY", "VGG16-OICR", "MODEL.WSOD_ON", True, "MODEL.FASTER_RCNN", False,
+    # == configs/voc/voc07_contra_db_b8_lr0.01_mcg.yaml of the reference (voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml for r50)
+    body = (["MODEL.BACKBONE.CONV_BODY", "VGG16-OICR", "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,),
+             "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR", "VGG16.roi_head"] if arch == "vgg16" else
+            ["MODEL.BACKBONE.CONV_BODY", "R-50-C5", "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.0625,),
+             "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR", "ResNet50Conv5ROIFeatureExtractor"])
+    cfg.merge_from_list(body + ["MODEL.WSOD_ON", True, "MODEL.FASTER_RCNN", False,
                          "MODEL.ROI_BOX_HEAD.NUM_CLASSES", classes, "MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool",
-                         "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7, "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,),
-                         "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR", "VGG16.roi_head",
+                         "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
                          "MODEL.ROI_WEAK_HEAD.REGRESS_ON", True, "DB.METHOD", "dropblock", "SOLVER.CONTRA", True,
                          "SOLVER.BASE_LR", BENCH_LR, "SOLVER.WEIGHT_DECAY", 0.0001, "SOLVER.IMS_PER_BATCH", 8,
                          "nms", 0.1, "lmda", 0.03, "temp", 0.2, "SEED", 1234])
@@ -97,18 +104,19 @@ def cpu_baseline(args, seed):
     p = args.cpu_proposals
     cores = min(os.cpu_count() or 1, 32)     # beyond ~32 threads torch-CPU GEMMs of this size stop scaling
     torch.set_num_threads(cores)
-    sd = H.make_state(1, args.classes)
+    sd = H.make_state(1, args.classes, arch=args.arch)
     img = torch.from_numpy(synthetic.make_image(seed, 0, args.size, args.size))[None]
     boxes = [torch.from_numpy(synthetic.make_proposals(seed, 0, p, args.size, args.size))]
     labels = [torch.from_numpy(synthetic.make_labels(seed, 0, args.classes))]
-    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", scale=0.125)
+    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", arch=args.arch,
+               scale=0.125 if args.arch == "vgg16" else 0.0625)
     t0 = time.time()
     losses, _ = H.forward(img, boxes, labels, sd, H.Rand(seed), cfg)
     sum(losses.values()).backward()
     dt = time.time() - t0
     return {"value": round(p / dt, 2), "unit": "proposals/s", "cores": cores, "kind": "port",
-            "sample": "1 step fwd+bwd (no optimizer), VGG16 %dpx, %d of the %d proposals, torch-CPU fp32 oracle (C ROIPool single-threaded), %d threads"
-                      % (args.size, p, args.proposals, cores), "seconds": round(dt, 2)}
+            "sample": "1 step fwd+bwd (no optimizer), %s %dpx, %d of the %d proposals, torch-CPU fp32 oracle (C ROIPool single-threaded), %d threads"
+                      % (ARCH_NAME[args.arch], args.size, p, args.proposals, cores), "seconds": round(dt, 2)}
 
 
 def main():
@@ -128,7 +136,7 @@ def main():
     from od_wscl_amd import engine
     from od_wscl_amd.utils.device_rand import DeviceRand
 
-    cfg = build_cfg(args.classes)
+    cfg = build_cfg(args.classes, args.arch)
     seed = cfg.SEED
     step_fn, info = engine.build_training_step(cfg, device, dtype=args.dtype, world=world, seed=seed,
                                                  backend=args.backend)
@@ -159,13 +167,13 @@ def main():
     if rank == 0:
         roof = engine.kernel_timer.roofline(args.dtype, MFMA_PEAK_TFLOPS, HBM_PEAK_GBPS)
         out = {
-            "metric": "proposals/sec fwd+bwd (VGG16, %d proposals, %dpx)" % (args.proposals, args.size),
+            "metric": "proposals/sec fwd+bwd (%s, %d proposals, %dpx)" % (ARCH_NAME[args.arch], args.proposals, args.size),
             "value": round(value, 1), "unit": "proposals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "VGG16-OICR + %d MCG-like proposals, batch 1/GPU, %dpx (padded %d), ROIPool 7x7, "
+            "config": {"workload": "%s + %d MCG-like proposals, batch 1/GPU, %dpx (padded %d), ROIPool 7x7, "
                                    "OD-WSCL loss (CONTRA), SGD step, %d classes"
-                                   % (args.proposals, args.size, images.tensors.shape[-1], args.classes),
+                                   % ("VGG16-OICR" if args.arch == "vgg16" else "R-50-C5", args.proposals, args.size, images.tensors.shape[-1], args.classes),
                        "global_batch": world, "parallelism": "dp%d" % world, "lr": BENCH_LR, "gemm_backend": info["gemm_backend"],
                        "conv_backend": info["conv_backend"], "optimizer": info["optimizer"]},
             "per_gpu": round(value / world, 1),
