@@ -46,6 +46,7 @@ struct Epilogue {
     float alpha;           // scales the product before bias
     const unsigned short* mask;   // optional bf16 (M x ldmask): result forced to 0 where mask == 0 (ReLU backward)
     int ldmask;
+    int pm;                // tile-order group height (tile_coords); 0 = the kernel's default
 };
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * kChunksPerRow + (chunk ^ ((row >> 1) & 7)); }
@@ -129,20 +130,34 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[MI][NJ], void
     }
 }
 
+// ---- XCD-aware, L2-patch tile mapping (correctness never depends on it) ------------------------
+// Workgroup b is dispatched to XCD b % 8, so XCD x is handed one CONTIGUOUS chunk of the tile order and
+// its 32 CUs run the chunk's first tiles together.  The order itself is grouped: PM row-tiles at a time,
+// walking N inside the group, so the tiles that are co-resident on one XCD form a PM x (resident/PM) patch
+// (~1024 x 1024 of C) instead of one tall column: per K-step they fetch 2 x 1024 rows of operands
+// instead of 4096 + 256, which halves the XCD's L2 miss traffic (fc6: 65 % -> ~83 % L2 hits).
+template <int PM_DEFAULT>
+__device__ __forceinline__ void tile_coords(int b, int tiles_m, int tiles_n, int& tm, int& tn, int pm = 0) {
+    const int PM = pm > 0 ? pm : PM_DEFAULT;
+    const int nblk = tiles_m * tiles_n;
+    const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective
+    const int per_group = PM * tiles_n;
+    const int group = t / per_group, in_group = t - group * per_group;
+    const int first = group * PM;
+    const int gsize = tiles_m - first < PM ? tiles_m - first : PM;
+    tm = first + in_group % gsize;
+    tn = in_group / gsize;
+}
+
 template <bool OUT_BF16>
 __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [stage][A|B][kTileChunks]
     // ---- XCD-aware tile mapping (block b runs on XCD b % 8; correctness never depends on it)
-    const int nblk = tiles_m * tiles_n;
-    int b = blockIdx.x;
-    int tile;
-    {
-        const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective
-    }
-    const int tn = tile / tiles_m, tm = tile % tiles_m;       // consecutive tiles share the B band
+    int tm, tn;
+    tile_coords<8>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -227,14 +242,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_glds_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-    const int nblk = tiles_m * tiles_n;
-    int tile;
-    {
-        const int b = blockIdx.x;
-        const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int tn = tile / tiles_m, tm = tile % tiles_m;
+    int tm, tn;
+    tile_coords<8>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -319,14 +328,8 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [stage][A 256 rows | B 128 rows]
-    const int nblk = tiles_m * tiles_n;
-    int tile;
-    {
-        const int b = blockIdx.x;
-        const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int tn = tile / tiles_m, tm = tile % tiles_m;
+    int tm, tn;
+    tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * RM, n0 = tn * RN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -376,6 +379,208 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
         }
     }
     store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
+}
+
+// ---- 256x256 tile, 8 waves of 128x64 ---------------------------------------------------------
+// The ring kernel is bound by operand delivery, not by MFMA issue (PMC: matrix cores busy 48 %, waves
+// parked on vmcnt/barrier 38 %): a 64x64 wave tile reads 4 KB of LDS per 4 MFMAs and a 256x128 block
+// pulls 48 KB from L2 per K-step of 1024 MFMA cycles.  Here each wave owns 128x64 (4x2 accumulators =
+// 128 registers, still two waves per SIMD inside the 512-entry file) and the block 256x256: LDS
+// reads per MFMA drop 25 %, L2 -> LDS bytes per FLOP drop 33 %, and one K-step is 2048 MFMA cycles per
+// SIMD -- long enough that a plain double buffer (2 x 64 KB) hides the DMA of the next tile completely.
+constexpr int GM = 256, GN = 256;
+constexpr int kBigThreads = 512;
+constexpr int kBigStageChunks = (GM + GN) * kChunksPerRow;        // 4096 uint4 = 64 KB
+
+// One K-slice (16 of K) of a wave's 128x64 block as ONE asm statement, so that the order inside is ours and not
+// the machine scheduler's (left alone, hipcc emits ds_read -> s_waitcnt -> 2 MFMAs and chains MFMAs on one
+// accumulator): wait for the current fragments, then 8 MFMAs on 8 different accumulators with the 6 ds_read_b128
+// of the NEXT slice's fragments issued in their shadow.  SYNC = the slice that closes a K-step: once its own
+// fragments are in registers the wave is done with the current LDS slot, so it also waits for its share of the
+// next tile's DMA and joins the block barrier -- after which the prefetch below reads the OTHER slot and the
+// slot just left can be refilled.  The MFMA pipe never drains around the barrier.
+template <bool SYNC, int X = 0>
+__device__ __forceinline__ void big_slice(f32x16 (&acc)[4][2], const bf16x8 (&ca)[4], const bf16x8 (&cb)[2],
+                                          bf16x8 (&na)[4], bf16x8 (&nb)[2], unsigned addr_a, unsigned addr_b) {
+#define ODW_BIG_BODY                                                                                   \
+        "ds_read_b128 %8, %20\n\t"                                                                     \
+        "v_mfma_f32_32x32x16_bf16 %0, %18, %14, %0\n\t"                                                \
+        "ds_read_b128 %12, %21\n\t"                                                                    \
+        "v_mfma_f32_32x32x16_bf16 %1, %19, %14, %1\n\t"                                                \
+        "ds_read_b128 %9, %20 offset:4096\n\t"                                                         \
+        "v_mfma_f32_32x32x16_bf16 %2, %18, %15, %2\n\t"                                                \
+        "ds_read_b128 %13, %21 offset:4096\n\t"                                                        \
+        "v_mfma_f32_32x32x16_bf16 %3, %19, %15, %3\n\t"                                                \
+        "ds_read_b128 %10, %20 offset:8192\n\t"                                                        \
+        "v_mfma_f32_32x32x16_bf16 %4, %18, %16, %4\n\t"                                                \
+        "ds_read_b128 %11, %20 offset:12288\n\t"                                                       \
+        "v_mfma_f32_32x32x16_bf16 %5, %19, %16, %5\n\t"                                                \
+        "v_mfma_f32_32x32x16_bf16 %6, %18, %17, %6\n\t"                                                \
+        "v_mfma_f32_32x32x16_bf16 %7, %19, %17, %7\n\t"
+#define ODW_BIG_OPERANDS                                                                               \
+        : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),  \
+          "+v"(acc[3][0]), "+v"(acc[3][1]), "=&v"(na[0]), "=&v"(na[1]), "=&v"(na[2]), "=&v"(na[3]), "=&v"(nb[0]),  \
+          "=&v"(nb[1])                                                                                 \
+        : "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(addr_a), "v"(addr_b)       \
+        : "memory"
+    if (SYNC && X == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     "s_barrier\n\t" ODW_BIG_BODY ODW_BIG_OPERANDS);
+    } else if (SYNC && X == 3) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     "s_waitcnt vmcnt(0)\n\t" ODW_BIG_BODY ODW_BIG_OPERANDS);
+    } else if (SYNC) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "s_barrier\n\t" ODW_BIG_BODY ODW_BIG_OPERANDS);
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t" ODW_BIG_BODY ODW_BIG_OPERANDS);
+    }
+#undef ODW_BIG_BODY
+#undef ODW_BIG_OPERANDS
+}
+
+// Epilogue of the 256x256 kernel.  The slices run the MFMAs with the operands swapped, so an accumulator holds a
+// TRANSPOSED 32x32 tile: lane & 31 = row of C, and each group of 4 registers = 4 consecutive columns
+// (col = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Per 32-row band the wave applies the fused epilogue, parks the
+// band in its private LDS region as 8-byte (bf16) / 16-byte (fp32) pieces, and streams it out again with one
+// 16-byte store per lane: full 128-byte (bf16) / 256-byte (fp32) row segments instead of 2-byte scatters.
+template <bool OUT_BF16>
+__device__ __forceinline__ void big_store(const f32x16 (&acc)[4][2], void* __restrict__ Cv, int ldc, int M, int N,
+                                          int mw, int nw, int wave, int lane, const Epilogue& ep, char* lds) {
+    constexpr int kEl = OUT_BF16 ? 2 : 4;
+    constexpr int kRowBytes = 64 * kEl + (OUT_BF16 ? 8 : 16);       // padded: conflict-free b64 / b128 writes
+    char* region = lds + wave * (32 * kRowBytes);
+    const int half = lane >> 5, l31 = lane & 31;
+    const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mw + i * 32 + l31;
+        int srow = ep.seg_row[0];
+        uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
+        if (ep.drop_p > 0.0f) {
+            if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
+            if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
+            if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cw = j * 32 + 8 * g + 4 * half;            // column inside the wave's 64
+                const int n = nw + cw;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = acc[i][j][4 * g + q] * ep.alpha;
+                    if (ep.bias && n + q < N) x += ep.bias[n + q];
+                    if (ep.relu) x = fmaxf(x, 0.0f);
+                    if (ep.mask && m < M && n + q < N && (ep.mask[(size_t)m * ep.ldmask + n + q] & 0x7fff) == 0) x = 0.0f;
+                    if (ep.drop_p > 0.0f) {
+                        const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)(n + q);
+                        x = odw_uniform(idx, k0, k1) >= ep.drop_p ? x * keep_scale : 0.0f;
+                    }
+                    v[q] = x;
+                }
+                if (OUT_BF16) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(region + l31 * kRowBytes + cw * 2) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(region + l31 * kRowBytes + cw * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        // the wave's own LDS traffic is ordered: read the band back row-major, 16 bytes per lane
+        constexpr int kLanesPerRow = 64 * kEl / 16;                  // 8 (bf16) or 16 (fp32)
+        constexpr int kRowsPerPass = 64 / kLanesPerRow;
+#pragma unroll
+        for (int t = 0; t < 32 / kRowsPerPass; ++t) {
+            const int r = t * kRowsPerPass + lane / kLanesPerRow, cchunk = lane % kLanesPerRow;
+            const uint4 d = *reinterpret_cast<const uint4*>(region + r * kRowBytes + cchunk * 16);
+            const int gm = mw + i * 32 + r, gn = nw + cchunk * (16 / kEl);
+            if (gm < M && gn < N) {
+                char* dst = reinterpret_cast<char*>(Cv) + ((size_t)gm * ldc + gn) * kEl;
+                if (!OUT_BF16 && ep.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(dst);
+                    const float4 a = __builtin_bit_cast(float4, d);
+                    *reinterpret_cast<float4*>(dst) = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+                } else {
+                    *reinterpret_cast<uint4*>(dst) = d;
+                }
+            }
+        }
+    }
+}
+
+template <bool OUT_BF16, int X = 0>
+__global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
+    const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
+    int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [slot][A 256 rows | B 256 rows]
+    int tm, tn;
+    tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
+    const int m0 = tm * GM, n0 = tn * GN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;            // 2 x 4 waves, 128 x 64 each
+    const int half = lane >> 5, l31 = lane & 31;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    // LDS byte address of this lane's fragment chunk for K-slice kk: fragment i of A sits 4096*i further on
+    // (32 rows x 128 B), the B tile 32 KB after the A tile, slot 1 64 KB after slot 0
+    const int row_a = wm * 128 + l31, row_b = wn * 64 + l31;
+    unsigned off_a[4], off_b[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        off_a[kk] = (unsigned)lds_slot(row_a, 2 * kk + half) * 16u;
+        off_b[kk] = (unsigned)lds_slot(row_b, 2 * kk + half) * 16u + (unsigned)(GM * kChunksPerRow * 16);
+    }
+    constexpr unsigned kSlotBytes = kBigStageChunks * 16;
+    uint4* const slot0 = lds;
+    uint4* const slot1 = lds + kBigStageChunks;
+
+    const int nk = (K + BK - 1) / BK;
+    // prologue: tile 0 -> slot 0, landed and visible; A half of tile 1 in flight
+    dma_rows<32>(A, lda, M, m0, 0, slot0, wave, lane);
+    dma_rows<32>(B, ldb, N, n0, 0, slot0 + GM * kChunksPerRow, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) dma_rows<32>(A, lda, M, m0, BK, slot1, wave, lane);
+    if (X == 1 && nk > 1) dma_rows<32>(B, ldb, N, n0, BK, slot1 + GM * kChunksPerRow, wave, lane);
+    bf16x8 f0a[4], f0b[2], f1a[4], f1b[2];
+    asm volatile("ds_read_b128 %0, %6\n\t"
+                 "ds_read_b128 %4, %7\n\t"
+                 "ds_read_b128 %1, %6 offset:4096\n\t"
+                 "ds_read_b128 %5, %7 offset:4096\n\t"
+                 "ds_read_b128 %2, %6 offset:8192\n\t"
+                 "ds_read_b128 %3, %6 offset:12288\n\t"
+                 : "=&v"(f0a[0]), "=&v"(f0a[1]), "=&v"(f0a[2]), "=&v"(f0a[3]), "=&v"(f0b[0]), "=&v"(f0b[1])
+                 : "v"(off_a[0]), "v"(off_b[0])
+                 : "memory");
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned cur = (kt & 1) ? kSlotBytes : 0u, nxt = kSlotBytes - cur;
+        uint4* const fill = (kt & 1) ? slot0 : slot1;          // slot of tile kt+1
+        big_slice<false>(acc, f0a, f0b, f1a, f1b, off_a[1] + cur, off_b[1] + cur);
+        if (X == 5) { if (kt + 1 < nk) dma_rows<32>(B, ldb, N, n0, 0, fill + GM * kChunksPerRow, wave, lane); }
+        else if (X != 1 && X != 4 && kt + 1 < nk) dma_rows<32>(B, ldb, N, n0, (kt + 1) * BK, fill + GM * kChunksPerRow, wave, lane);
+        big_slice<false>(acc, f1a, f1b, f0a, f0b, off_a[2] + cur, off_b[2] + cur);
+        big_slice<false>(acc, f0a, f0b, f1a, f1b, off_a[3] + cur, off_b[3] + cur);
+        // closes the step: tile kt+1 complete and visible, slot of tile kt free; prefetch slice 0 of tile kt+1
+        big_slice<true, X>(acc, f1a, f1b, f0a, f0b, off_a[0] + nxt, off_b[0] + nxt);
+        if (X == 5) { if (kt + 2 < nk) dma_rows<32>(A, lda, M, m0, 0, (kt & 1) ? slot1 : slot0, wave, lane); }
+        else if (X != 4 && kt + 2 < nk) dma_rows<32>(A, lda, M, m0, (kt + 2) * BK, (kt & 1) ? slot1 : slot0, wave, lane);
+        if (X == 1 && kt + 2 < nk) dma_rows<32>(B, ldb, N, n0, (kt + 2) * BK, ((kt & 1) ? slot1 : slot0) + GM * kChunksPerRow, wave, lane);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last (unused) prefetch must not outlive its registers
+    __builtin_amdgcn_s_barrier();                           // every wave is done with the operand tiles
+    big_store<OUT_BF16>(acc, Cv, ldc, M, N, m0 + wm * 128, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds));
 }
 
 // ---- implicit-GEMM 3x3 convolution on the same tile ------------------------------------------
@@ -593,7 +798,44 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// Which kernel serves a product.  0 = register-staged 128x128 (any alignment), 1 = LDS-DMA 128x128 (two workgroups
+// per CU), 2 = LDS-DMA 256x128 three-slot ring, 3 = 256x256 asm-scheduled.  The DMA kernels need operand rows
+// padded to a multiple of 64; the 256x256 kernel also 16-byte-aligned rows of C.  Among the eligible ones the
+// cheapest by (rounds of workgroups over 256 CUs) x (tile area) / (measured per-CU rate) wins: the big tiles are
+// ~25 % faster per FLOP but lose when their grid leaves CUs idle (e.g. M = 2000: 128 tiles of 256x256).
+// ODW_GEMM_VARIANT = reg | glds | ring | big forces one (tools/gemm_var.py).
+__host__ int pick_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16) {
+    const int k64 = (K + 63) / 64 * 64;
+    const bool dma_ok = lda >= k64 && ldb >= k64 && K > 0;
+    const int c_el = c_is_bf16 ? 2 : 4;
+    const bool big_ok = dma_ok && N % 8 == 0 && ((size_t)ldc * c_el) % 16 == 0 && (((uintptr_t)C) & 15) == 0;
+    const char* force = getenv("ODW_GEMM_VARIANT");
+    if (force) {
+        if (force[0] == 'r' && force[1] == 'e') return 0;
+        if (force[0] == 'g') return dma_ok ? 1 : 0;
+        if (force[0] == 'r' && force[1] == 'i') return dma_ok ? 2 : 0;
+        if (force[0] == 'b') return big_ok ? 3 : (dma_ok ? 1 : 0);
+    }
+    if (!dma_ok) return 0;
+    auto cost = [&](int tm, int tn, int per_cu, double rate) {
+        const long tiles = (long)((M + tm - 1) / tm) * ((N + tn - 1) / tn);
+        const long rounds = (tiles + 256L * per_cu - 1) / (256L * per_cu);
+        return (double)rounds * per_cu * tm * tn / rate;
+    };
+    int best = 1;
+    double c = cost(BM, BN, 2, 0.97);
+    const double cr = cost(RM, RN, 1, 1.0);
+    if (cr < c) { c = cr; best = 2; }
+    if (big_ok && cost(GM, GN, 1, 1.25) < c) best = 3;
+    return best;
+}
+
 }  // namespace
+
+ODW_EXPORT int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc,
+                                        int c_is_bf16) {
+    return pick_variant(M, N, K, lda, ldb, C, ldc, c_is_bf16);
+}
 
 ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
                                 int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
@@ -612,6 +854,7 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = drop_p; ep.nseg = nseg; ep.accumulate = accumulate; ep.alpha = alpha;
     ep.mask = nullptr; ep.ldmask = 0;
+    { const char* e = getenv("ODW_GEMM_PM"); ep.pm = e ? atoi(e) : 0; }
     for (int i = 0; i < kMaxSeg; ++i) {
         ep.seg_row[i] = (i < nseg && seg_rows) ? seg_rows[i] : 0;
         ep.seg_k0[i] = (i < nseg && seg_keys) ? seg_keys[2 * i] : 0;
@@ -621,14 +864,34 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);   // 64 KB
     const int k64 = (K + 63) / 64 * 64;
-    const char* force = getenv("ODW_GEMM_VARIANT");     // "reg" / "glds" / "ring": A/B switch for tools/gemm_bench.py
-    bool use_glds = lda >= k64 && ldb >= k64 && K > 0;
+    const int variant = pick_variant(M, N, K, lda, ldb, C, ldc, c_is_bf16);
+    const bool use_big = variant == 3, use_ring = variant == 2, use_glds = variant >= 1;
     const int rtiles_m = (M + RM - 1) / RM, rtiles_n = (N + RN - 1) / RN;
-    // the 256x128 ring kernel runs one workgroup per CU: use it when its grid fills the chip
-    bool use_ring = use_glds && rtiles_m * rtiles_n >= 192;
-    if (force && force[0] == 'r' && force[1] == 'e') { use_glds = false; use_ring = false; }
-    if (force && force[0] == 'g') use_ring = false;
-    if (force && force[0] == 'r' && force[1] == 'i') use_ring = use_glds;
+    const int btiles_m = (M + GM - 1) / GM, btiles_n = (N + GN - 1) / GN;
+    if (use_big) {
+        const size_t big_lds = (size_t)2 * kBigStageChunks * sizeof(uint4);   // 128 KB
+        if (c_is_bf16) {
+            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr");
+            gemm_nt_bf16_big_kernel<true><<<btiles_m * btiles_n, kBigThreads, big_lds, stream>>>(
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n);
+        } else {
+            const char* xe = getenv("ODW_GEMM_EXP");
+            const int x = xe ? atoi(xe) : 0;
+#define ODW_BIG_X(XV)                                                                                            \
+            do {                                                                                                 \
+                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, XV>), \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr"); \
+                gemm_nt_bf16_big_kernel<false, XV><<<btiles_m * btiles_n, kBigThreads, big_lds, stream>>>(       \
+                    (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n); \
+            } while (0)
+            if (x == 1) ODW_BIG_X(1); else if (x == 2) ODW_BIG_X(2); else if (x == 3) ODW_BIG_X(3);
+            else if (x == 4) ODW_BIG_X(4); else if (x == 5) ODW_BIG_X(5); else ODW_BIG_X(0);
+#undef ODW_BIG_X
+        }
+        ODW_CHECK_HIP(hipGetLastError(), "gemm_nt_bf16 big launch");
+        return 0;
+    }
 #define ODW_LAUNCH_GEMM(KERNEL, OUTBF)                                                                          \
     do {                                                                                                        \
         ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<OUTBF>),                         \
@@ -737,7 +1000,7 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16(const void* X, int n_pix, int H, int W, int
     while ((1 << g.logC) < C) ++g.logC;
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = 0.0f; ep.nseg = 0; ep.accumulate = 0; ep.alpha = 1.0f;
-    ep.mask = (const unsigned short*)mask; ep.ldmask = ldmask;
+    ep.mask = (const unsigned short*)mask; ep.ldmask = ldmask; ep.pm = 0;
     for (int i = 0; i < kMaxSeg; ++i) { ep.seg_row[i] = 0; ep.seg_k0[i] = 0; ep.seg_k1[i] = 0; }
     const int tiles_m = (n_pix + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);

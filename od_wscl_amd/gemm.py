@@ -26,6 +26,9 @@ def _r64(n):
     return (n + 63) // 64 * 64
 
 
+_VARIANT_SYMBOL = {0: "", 1: "glds_", 2: "ring_", 3: "big_"}      # names as rocprofv3's kernel trace prints them
+
+
 def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, segs=None, accumulate=False):
     """out[M,N] (+)= epilogue(alpha * a[M,K] @ b[N,K]^T); a, b bf16 2-D tensors (row stride % 8 == 0)."""
     L.need_gpu(a, b, out)
@@ -37,10 +40,9 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
     out_bf16 = out.dtype == torch.bfloat16
     # per-symbol timing for bench.py's roofline object (same names as rocprofv3's kernel trace)
-    k64 = _r64(K)
-    fast = a.stride(0) >= k64 and b.stride(0) >= k64
-    ring = fast and ((M + 255) // 256) * ((N + 127) // 128) >= 192          # same rule as odw_gemm_nt_bf16
-    sym = "gemm_nt_bf16_%s_kernel<%s>" % ("ring" if ring else ("glds" if fast else "reg"), "true" if out_bf16 else "false")
+    var = L.lib().odw_gemm_nt_bf16_variant(M, N, K, a.stride(0), b.stride(0), L.ptr(out), out.stride(0),
+                                           1 if out_bf16 else 0)
+    sym = "gemm_nt_bf16_%skernel<%s>" % (_VARIANT_SYMBOL[var], ("true" if out_bf16 else "false") + (", 0" if var == 3 else ""))
     with kernel_timer.region(sym, flops=2.0 * M * N * K):
         L.check(L.lib().odw_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out),
                                          out.stride(0), 1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0,

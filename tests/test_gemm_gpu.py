@@ -99,6 +99,41 @@ def test_gemm_epilogue_bias_relu_dropout_accumulate(G):
     assert (acc - (1 + a.float() @ b.float().T)).abs().max().item() <= 1e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (700, 520, 320), (4000, 1032, 512), (130, 72, 25088), (257, 8, 64)])
+def test_gemm_256x256_variant(G, M, N, K, monkeypatch):
+    """The 256x256-tile kernel (asm-scheduled slices, skewed barrier, LDS-staged coalesced epilogue) forced on
+    ragged shapes: plain product in both output types, then every fused epilogue feature at once."""
+    monkeypatch.setenv("ODW_GEMM_VARIANT", "big")
+    k64 = (K + 63) // 64 * 64
+    a = torch.zeros(M, k64, device="cuda").bfloat16()
+    b = torch.zeros(N, k64, device="cuda").bfloat16()
+    a[:, :K] = rnd(31, (M, K)).bfloat16()
+    b[:, :K] = rnd(32, (N, K)).bfloat16()
+    ref = a.float() @ b.float().T
+    tol = 1e-5 * np.sqrt(K) * 4 * max(1.0, ref.abs().max().item())
+    out = torch.full((M + 1, N + 8), 7.0, device="cuda")
+    G.gemm_nt(a, b, M, N, K, out[:M, :N])
+    assert (out[:M, :N] - ref).abs().max().item() <= tol
+    assert (out[M] == 7).all() and (out[:, N:] == 7).all()                  # nothing written outside C
+    ob = torch.full((M + 1, N + 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    G.gemm_nt(a, b, M, N, K, ob[:M, :N])
+    assert (ob[:M, :N].float() - ref).abs().max().item() <= 8e-3 * max(1.0, ref.abs().max().item())
+    assert (ob[M] == 7).all() and (ob[:, N:] == 7).all()
+    bias = rnd(33, (N,))
+    s1 = min(M - 1, 100)
+    k1, k2 = rng.stream_key(9, 21), rng.stream_key(9, 22)
+    for dt, atol in ((torch.float32, 2e-3), (torch.bfloat16, 8e-3)):
+        o = torch.empty(M, N, device="cuda", dtype=dt)
+        G.gemm_nt(a, b, M, N, K, o, bias=bias, relu=True, alpha=0.5, drop_p=0.5, segs=[(0,) + k1, (s1,) + k2])
+        keep = np.concatenate([rng.uniform(9, 21, s1 * N).reshape(s1, N),
+                               rng.uniform(9, 22, (M - s1) * N).reshape(M - s1, N)]) >= 0.5
+        exp = torch.relu(ref * 0.5 + bias) * torch.from_numpy(keep).cuda() * 2.0
+        assert (o.float() - exp).abs().max().item() <= atol * max(1.0, exp.abs().max().item())
+    acc = torch.ones(M, N, device="cuda")
+    G.gemm_nt(a, b, M, N, K, acc, accumulate=True)
+    assert (acc - (1 + ref)).abs().max().item() <= tol
+
+
 def test_transpose_and_convert(G):
     x = rnd(6, (70, 45))
     t = G.transpose_bf16(x, 70, 45)

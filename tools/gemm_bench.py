@@ -13,7 +13,10 @@ def timeit(fn, iters=10, warmup=3):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 
-shapes = [("fc6_fwd  M=4000", 4000, 4096, 25088), ("fc6_fwd  M=2000", 2000, 4096, 25088),
+if __name__ != "__main__":
+    shapes = []
+else:
+  shapes = [("fc6_fwd  M=4000", 4000, 4096, 25088), ("fc6_fwd  M=2000", 2000, 4096, 25088),
           ("fc6_dgrad", 4000, 25088, 4096), ("fc6_wgrad", 4096, 25088, 4032),
           ("fc7_fwd", 4000, 4096, 4096), ("fc6_fwd M=400 (K rows)", 400, 4096, 25088), ("predictor", 2000, 357, 4096),
           ("square 4096", 4096, 4096, 4096), ("square 8192", 8192, 8192, 8192)]
