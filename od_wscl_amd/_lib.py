@@ -87,7 +87,15 @@ def check(code, what):
         raise RuntimeError("%s failed (%d): %s" % (what, code, lib().odw_last_error().decode()))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """torch's CURRENT stream on the current device as a raw hipStream_t (every launch goes there).
+    torch.cuda.current_stream() builds a Stream object per call (~9 us, 100 calls per step): the raw getter
+    is the same query without the object."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -440,6 +440,54 @@ __device__ __forceinline__ void big_slice(f32x16 (&acc)[4][2], const bf16x8 (&ca
 #undef ODW_BIG_OPERANDS
 }
 
+// The same slice with four LDS-DMA pieces of one operand tile (4 KB of this wave's share) issued one per MFMA in
+// its second half, instead of four back-to-back between slices: m0 = LDS destination of the piece, the source is
+// sbase + voff[lane] (SGPR base advancing 128 B per K-step, constant per-lane row/chunk offsets).
+template <bool SYNC>
+__device__ __forceinline__ void big_slice_dma(f32x16 (&acc)[4][2], const bf16x8 (&ca)[4], const bf16x8 (&cb)[2],
+                                              bf16x8 (&na)[4], bf16x8 (&nb)[2], unsigned addr_a, unsigned addr_b,
+                                              unsigned lds_dst, const unsigned (&voff)[4], unsigned long long sbase) {
+#define ODW_BIG_BODY_DMA                                                                               \
+        "ds_read_b128 %8, %20\n\t"                                                                     \
+        "v_mfma_f32_32x32x16_bf16 %0, %18, %14, %0\n\t"                                                \
+        "ds_read_b128 %12, %21\n\t"                                                                    \
+        "v_mfma_f32_32x32x16_bf16 %1, %19, %14, %1\n\t"                                                \
+        "ds_read_b128 %9, %20 offset:4096\n\t"                                                         \
+        "v_mfma_f32_32x32x16_bf16 %2, %18, %15, %2\n\t"                                                \
+        "ds_read_b128 %13, %21 offset:4096\n\t"                                                        \
+        "s_mov_b32 m0, %22\n\t"                                                                        \
+        "v_mfma_f32_32x32x16_bf16 %3, %19, %15, %3\n\t"                                                \
+        "ds_read_b128 %10, %20 offset:8192\n\t"                                                        \
+        "global_load_lds_dwordx4 %23, %27\n\t"                                                         \
+        "v_mfma_f32_32x32x16_bf16 %4, %18, %16, %4\n\t"                                                \
+        "ds_read_b128 %11, %20 offset:12288\n\t"                                                       \
+        "s_add_u32 m0, %22, 0x400\n\t"                                                                 \
+        "v_mfma_f32_32x32x16_bf16 %5, %19, %16, %5\n\t"                                                \
+        "global_load_lds_dwordx4 %24, %27\n\t"                                                         \
+        "s_add_u32 m0, %22, 0x800\n\t"                                                                 \
+        "v_mfma_f32_32x32x16_bf16 %6, %18, %17, %6\n\t"                                                \
+        "global_load_lds_dwordx4 %25, %27\n\t"                                                         \
+        "s_add_u32 m0, %22, 0xc00\n\t"                                                                 \
+        "v_mfma_f32_32x32x16_bf16 %7, %19, %17, %7\n\t"                                                \
+        "global_load_lds_dwordx4 %26, %27\n\t"
+#define ODW_BIG_OPERANDS_DMA                                                                           \
+        : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),  \
+          "+v"(acc[3][0]), "+v"(acc[3][1]), "=&v"(na[0]), "=&v"(na[1]), "=&v"(na[2]), "=&v"(na[3]), "=&v"(nb[0]),  \
+          "=&v"(nb[1])                                                                                 \
+        : "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(addr_a), "v"(addr_b),      \
+          "s"(lds_dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase)                      \
+        : "memory", "m0", "scc"
+    if (SYNC) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "s_barrier\n\t" ODW_BIG_BODY_DMA ODW_BIG_OPERANDS_DMA);
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t" ODW_BIG_BODY_DMA ODW_BIG_OPERANDS_DMA);
+    }
+#undef ODW_BIG_BODY_DMA
+#undef ODW_BIG_OPERANDS_DMA
+}
+
 // Epilogue of the 256x256 kernel.  The slices run the MFMAs with the operands swapped, so an accumulator holds a
 // TRANSPOSED 32x32 tile: lane & 31 = row of C, and each group of 4 registers = 4 consecutive columns
 // (col = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Per 32-row band the wave applies the fused epilogue, parks the
@@ -564,6 +612,36 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
                  : "=&v"(f0a[0]), "=&v"(f0a[1]), "=&v"(f0a[2]), "=&v"(f0a[3]), "=&v"(f0b[0]), "=&v"(f0b[1])
                  : "v"(off_a[0]), "v"(off_b[0])
                  : "memory");
+    if (X == 0 || X == 6) {
+        // per-lane source offsets of this wave's four pieces of an A / B tile (rows clamped at the matrix edge)
+        unsigned voa[4], vob[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int ga = m0 + row, gb = n0 + row;
+            ga = ga < M ? ga : M - 1;
+            gb = gb < N ? gb : N - 1;
+            voa[i] = (unsigned)ga * (unsigned)lda * 2u + (unsigned)c * 16u;
+            vob[i] = (unsigned)gb * (unsigned)ldb * 2u + (unsigned)c * 16u;
+        }
+        const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)lds + (unsigned)wave * 4096u;
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned cur = (kt & 1) ? kSlotBytes : 0u, nxt = kSlotBytes - cur;
+            // (past the end the pieces re-fetch the last tile into a slot nobody reads: no branches in the loop)
+            const int kb = kt + 1 < nk ? kt + 1 : nk - 1, ka = kt + 2 < nk ? kt + 2 : nk - 1;
+            // B half of tile kt+1 -> the other slot, inside slice 0
+            big_slice_dma<false>(acc, f0a, f0b, f1a, f1b, off_a[1] + cur, off_b[1] + cur,
+                                 lds0 + nxt + (unsigned)(GM * kChunksPerRow * 16), vob,
+                                 (unsigned long long)(uintptr_t)B + (unsigned long long)kb * (BK * 2));
+            big_slice<false>(acc, f1a, f1b, f0a, f0b, off_a[2] + cur, off_b[2] + cur);
+            big_slice<false>(acc, f0a, f0b, f1a, f1b, off_a[3] + cur, off_b[3] + cur);
+            // closes the step; A half of tile kt+2 -> the slot just left, inside the same slice (after its barrier)
+            big_slice_dma<true>(acc, f1a, f1b, f0a, f0b, off_a[0] + nxt, off_b[0] + nxt, lds0 + cur, voa,
+                                (unsigned long long)(uintptr_t)A + (unsigned long long)ka * (BK * 2));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned cur = (kt & 1) ? kSlotBytes : 0u, nxt = kSlotBytes - cur;
         uint4* const fill = (kt & 1) ? slot0 : slot1;          // slot of tile kt+1
@@ -886,7 +964,7 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
                     (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n); \
             } while (0)
             if (x == 1) ODW_BIG_X(1); else if (x == 2) ODW_BIG_X(2); else if (x == 3) ODW_BIG_X(3);
-            else if (x == 4) ODW_BIG_X(4); else if (x == 5) ODW_BIG_X(5); else ODW_BIG_X(0);
+            else if (x == 4) ODW_BIG_X(4); else if (x == 5) ODW_BIG_X(5); else if (x == 6) ODW_BIG_X(6); else ODW_BIG_X(0);
 #undef ODW_BIG_X
         }
         ODW_CHECK_HIP(hipGetLastError(), "gemm_nt_bf16 big launch");

@@ -178,7 +178,9 @@ class RoIRegLossFused(RoIRegLossComputation):
             for ci, c in enumerate(pos_host[idx]):
                 k = counts_h[idx][ci]
                 r_img = rows[idx, ci, :k].long()
-                picked = clean_pooled_feats[offs[idx]:offs[idx + 1]][r_img]
+                # index_select, not x[rows]: the backward of advanced indexing (index_put_ with accumulate) sorts the
+                # indices and blocks the host on a device-to-host copy; index_select's backward is an atomic index_add_
+                picked = clean_pooled_feats[offs[idx]:offs[idx + 1]].index_select(0, r_img)
                 drop = feature_extractor.drop_pool(picked)
                 k6d, k7d = rand.key(), rand.key()
                 noisy = feature_extractor.noise_pool(picked)
@@ -252,7 +254,7 @@ class RoIRegLossFused(RoIRegLossComputation):
             ix = torch.cat(ix)
             feat_index.append(ix)
             feat_label.append(torch.full((ix.numel(),), c, dtype=torch.int32, device=device))
-        features = all_emb[torch.cat(feat_index)]
+        features = all_emb.index_select(0, torch.cat(feat_index))
         labels = torch.cat(feat_label)
         wparts = []
         for (idx, ci, c, k, r0, r_img) in meta:                                      # loop 1 order

@@ -2,9 +2,38 @@
 
 bench.py uses it for the `roofline` object: achieved = algorithmic FLOPs (or bytes) of one
 launch / its average duration, measured live inside the timed region."""
-import contextlib
-
 import torch
+
+
+class _Region(object):
+    """Context manager of one timed launch (a plain class: contextlib's generator wrapper costs more than the
+    two event records it brackets)."""
+    __slots__ = ("timer", "name", "flops", "nbytes", "start")
+
+    def __init__(self, timer, name, flops, nbytes):
+        self.timer, self.name, self.flops, self.nbytes = timer, name, flops, nbytes
+
+    def __enter__(self):
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.timer.records.setdefault(self.name, []).append((self.start, end, self.flops, self.nbytes))
+        return False
+
+
+class _NoRegion(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_REGION = _NoRegion()
 
 
 class KernelTimer(object):
@@ -15,19 +44,11 @@ class KernelTimer(object):
     def reset(self):
         self.records = {}       # name -> list of (start_event, end_event, flops, bytes)
 
-    @contextlib.contextmanager
     def region(self, name, flops=0.0, nbytes=0.0):
+        """with kernel_timer.region(symbol, flops=...): <one launch on torch's current stream>"""
         if not self.enabled or name is None:
-            yield
-            return
-        s = torch.cuda.Event(enable_timing=True)
-        e = torch.cuda.Event(enable_timing=True)
-        s.record(torch.cuda.current_stream())
-        try:
-            yield
-        finally:
-            e.record(torch.cuda.current_stream())
-            self.records.setdefault(name, []).append((s, e, flops, nbytes))
+            return _NO_REGION
+        return _Region(self, name, flops, nbytes)
 
     def summary(self):
         torch.cuda.synchronize()

@@ -10,6 +10,9 @@ for name, M, N, K in [("fc6_fwd", 4000, 4096, 25088), ("fc6_dgrad", 4000, 25088,
     res = {"shape": name}
     for x in sys.argv[1].split(","):
         os.environ["ODW_GEMM_EXP"] = x
+        out.zero_()
         ms = timeit(lambda: gemm.gemm_nt(a, b, M, N, K, out), iters=20)
         res["x" + x] = round(2.0 * M * N * K / ms / 1e9, 1)
+        if x == "0": ref = out.clone()
+        elif x in ("1", "6", "7", "8"): res["err" + x] = (out - ref).abs().max().item()
     print(json.dumps(res), flush=True)
