@@ -151,6 +151,16 @@ int odw_od_assign(const float* boxes, int P, const float* gt_boxes, const int64_
 int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C, int ldc,
                      int c_is_bf16, const float* bias, int relu, float alpha, float drop_p, int nseg,
                      const int* seg_rows, const uint32_t* seg_keys, int accumulate, void* stream);
+/* Stacked clean + DropBlock operand of the first head GEMM, and its gradient (ROIWeakRegHead.forward,
+ * roi_heads/weak_head/weak_head.py:107-112 runs forward() and forward_dropblock()+forward_neck() on the same pooled
+ * features; DropBlock2D.forward, modeling/dropblock/drop_block.py:45-50: out = x * block * numel / sum):
+ *   pooled (P, C, S) fp32, block (P, S) keep mask, block_sum = sum(block) on the device, numel = P*S
+ *   out  (2P x ld) bf16: row p = x, row P+p = ((x * block) * numel) / sum        (ld >= C*S, padding zeroed)
+ *   bwd : dpooled (P, C, S) fp32 = dX[p] + ((dX[P+p] * block) * numel) / sum,   dX (2P x ld) bf16 or fp32 */
+int odw_stack_clean_aug(const float* pooled, const float* block, const float* block_sum, int P, int C, int S,
+                        void* out_bf16, int ld, void* stream);
+int odw_unstack_clean_aug_bwd(const void* dX, int dx_is_f32, int ld, const float* block, const float* block_sum,
+                              int P, int C, int S, float* dpooled, void* stream);
 /* Which kernel odw_gemm_nt_bf16 will launch for this product: 0 register-staged 128x128, 1 LDS-DMA 128x128,
  * 2 LDS-DMA 256x128 ring, 3 256x256 (per-kernel timing in bench.py names its roofline entry from this). */
 int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16);

@@ -40,6 +40,8 @@ SIGNATURES = {
     "odw_rng_normal": (c_i, [c_p, c_l, c_u, c_u, c_p]),
     "odw_dropout": (c_i, [c_p, c_p, c_l, c_u, c_u, c_f, c_p]),
     "odw_noise_mul": (c_i, [c_p, c_p, c_l, c_u, c_u, c_p]),
+    "odw_stack_clean_aug": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "odw_unstack_clean_aug_bwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "odw_gemm_nt_bf16_variant": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i]),
     "odw_gemm_nt_bf16": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_p, c_p, c_i, c_p]),
     "odw_linear_bwd_prep": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_p, c_i, c_p, c_p]),

@@ -476,7 +476,7 @@ __device__ __forceinline__ void big_slice_dma(f32x16 (&acc)[4][2], const bf16x8 
           "=&v"(nb[1])                                                                                 \
         : "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(addr_a), "v"(addr_b),      \
           "s"(lds_dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase)                      \
-        : "memory", "m0", "scc"
+        : "memory", "scc"       /* m0 is rewritten too: hipcc reserves it and reloads it before each use of its own */
     if (SYNC) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                      "s_waitcnt vmcnt(0)\n\t"
@@ -941,7 +941,6 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     if (drop_p > 0.0f) ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_bf16: dropout needs row segments starting at 0");
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);   // 64 KB
-    const int k64 = (K + 63) / 64 * 64;
     const int variant = pick_variant(M, N, K, lda, ldb, C, ldc, c_is_bf16);
     const bool use_big = variant == 3, use_ring = variant == 2, use_glds = variant >= 1;
     const int rtiles_m = (M + RM - 1) / RM, rtiles_n = (N + RN - 1) / RN;

@@ -12,6 +12,10 @@ MI355X-first structure:
     flat buffer ("fresh" flag = overwrite on first touch, accumulate afterwards), so the
     411 MB fc6 gradient is never zero-filled nor copied.
   * the fused SGD kernel also refreshes the bf16 shadow weights the matrix cores read.
+  * the head's parameters (fc6/fc7, Sim_Net, predictor: 99 % of the bytes) are stepped on a SECOND HIP stream as
+    soon as their gradients are final -- when d(loss)/d(pooled) arrives at the ROIPool node -- so their
+    all-reduce (N>1), SGD pass and shadow refresh overlap the backbone's backward, whose small
+    convolutions leave most CUs idle; only the backbone's 15 M parameters are stepped after backward.
 """
 import os
 
@@ -103,6 +107,8 @@ class FlatSGD(object):
              cfg.SOLVER.WEIGHT_DECAY_BIAS)]
         self.gemm_params = [p for _, p in gemm_w]
         self.n_gemm = n_gemm
+        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.early_done = False
         self.first = True
         self.total = total
         # bf16 shadows of the GEMM weights: one flat buffer the SGD kernel refreshes in the same pass
@@ -116,6 +122,7 @@ class FlatSGD(object):
                 o, cnt = self.slices[n]
                 sh = gemm.Shadow(p)
                 sh.w = self.flat_w16[o:o + cnt].view(p.shape)
+                sh.wt = torch.empty((p.shape[1], (p.shape[0] + 63) // 64 * 64), dtype=torch.bfloat16, device=dev)
                 sh.managed = True
                 mod._shadow = sh
                 self.shadows.append(sh)
@@ -128,7 +135,7 @@ class FlatSGD(object):
                     "f32_to_bf16")
         for sh in self.shadows:
             n, k = sh.weight.shape
-            sh.wt = gemm.transpose_bf16(sh.w, n, k)
+            gemm.transpose_bf16(sh.w, n, k, out=sh.wt)        # in place: same buffer every step, no allocator traffic
 
     @staticmethod
     def _is_gemm_weight(model, name, p):
@@ -143,22 +150,42 @@ class FlatSGD(object):
         for p in self.gemm_params:
             p._odw_fresh = True
         self.flat_g[self.n_gemm:].zero_()
+        self.early_done = False
+
+    def _sgd_region(self, i):
+        start, n, lr, wd = self.regions[i]
+        if n == 0:
+            return
+        shadow = self.flat_w16 if (i == 0 and self.flat_w16 is not None) else None
+        L.check(L.lib().odw_sgd_momentum(L.ptr(self.flat_p[start:]), L.ptr(self.flat_g[start:]),
+                                         L.ptr(self.flat_m[start:]), L.ptr(shadow), n, lr, wd, self.momentum,
+                                         1.0 / self.world, 1 if self.first else 0, L.stream()), "sgd_momentum")
+
+    def head_grads_ready(self):
+        """Called from backward (tensor hook on the pooled features) once every gradient of region 0 is final:
+        all-reduce + SGD + shadow refresh of the head on the side stream, overlapping the backbone's backward."""
+        if self.side is None or self.n_gemm == 0 or self.early_done or os.environ.get("ODW_NO_OVERLAP") == "1":
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            all_reduce_flat(self.flat_g[:self.n_gemm], self.world)
+            self._sgd_region(0)
+            self._refresh_shadows()
+        self.early_done = True
 
     def all_reduce(self):
-        all_reduce_flat(self.flat_g, self.world)
+        """Whatever has not been exchanged by head_grads_ready (the backbone and the biases, or everything)."""
+        all_reduce_flat(self.flat_g[self.n_gemm:] if self.early_done else self.flat_g, self.world)
 
     def step(self):
-        lib = L.lib()
-        scale = 1.0 / self.world
-        for i, (start, n, lr, wd) in enumerate(self.regions):
-            if n == 0:
-                continue
-            shadow = self.flat_w16 if (i == 0 and self.flat_w16 is not None) else None
-            L.check(lib.odw_sgd_momentum(L.ptr(self.flat_p[start:]), L.ptr(self.flat_g[start:]),
-                                         L.ptr(self.flat_m[start:]), L.ptr(shadow), n, lr, wd, self.momentum, scale,
-                                         1 if self.first else 0, L.stream()), "sgd_momentum")
+        if not self.early_done:
+            self._sgd_region(0)
+            self._refresh_shadows()
+        self._sgd_region(1)
+        self._sgd_region(2)
+        if self.early_done:
+            torch.cuda.current_stream().wait_stream(self.side)     # the next forward reads the refreshed weights
         self.first = False
-        self._refresh_shadows()
 
 
 def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="hip"):
@@ -193,6 +220,7 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             conv_desc = "torch/MIOpen (%s)" % ("bf16 autocast" if use_autocast else "f32")
         model.roi_heads.loss_evaluator.amp = False
         opt = FlatSGD(cfg, model, world)
+        model.roi_heads.head_grads_ready = opt.head_grads_ready
 
         def step(images, targets, rois, rand):
             opt.begin_step()

@@ -61,10 +61,12 @@ def to_bf16(x):
     return out
 
 
-def transpose_bf16(x, rows, cols):
-    """(rows x cols) fp32|bf16 -> (cols x r64(rows)) bf16, zero padded."""
+def transpose_bf16(x, rows, cols, out=None):
+    """(rows x cols) fp32|bf16 -> (cols x r64(rows)) bf16, zero padded (into `out` when given)."""
     ld = _r64(rows)
-    out = torch.empty((cols, ld), dtype=torch.bfloat16, device=x.device)
+    if out is None:
+        out = torch.empty((cols, ld), dtype=torch.bfloat16, device=x.device)
+    assert out.shape == (cols, ld) and out.dtype == torch.bfloat16
     L.check(L.lib().odw_transpose_to_bf16(L.ptr(x), 1 if x.dtype == torch.float32 else 0, x.stride(0), rows, cols,
                                           L.ptr(out), ld, L.stream()), "transpose_to_bf16")
     return out

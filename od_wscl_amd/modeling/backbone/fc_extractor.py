@@ -10,7 +10,37 @@ import torch.nn.functional as F
 
 from ..dropblock import DropBlock2D
 from ..poolers import Pooler
+from ... import _lib as L
+from ...layers import linear as linear_layer
 from ...layers.linear import Linear
+
+
+class _StackCleanAug(torch.autograd.Function):
+    """pooled (P,C,h,w) fp32 + DropBlock keep mask -> the bf16 (2P x C*h*w) operand of the first GEMM (rows 0..P-1 the
+    clean features, rows P..2P-1 the DropBlock view), one pass each way (csrc/head_aux.hip)."""
+
+    @staticmethod
+    def forward(ctx, pooled, block, block_sum):
+        P, C, h, w = pooled.shape
+        S = h * w
+        pooled = pooled.contiguous()
+        out = torch.empty((2 * P, C * S), dtype=torch.bfloat16, device=pooled.device)
+        L.check(L.lib().odw_stack_clean_aug(L.ptr(pooled), L.ptr(block), L.ptr(block_sum), P, C, S, L.ptr(out),
+                                            out.stride(0), L.stream()), "stack_clean_aug")
+        ctx.save_for_backward(block, block_sum)
+        ctx.shape = (P, C, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        block, block_sum = ctx.saved_tensors
+        P, C, h, w = ctx.shape
+        dx = dx if dx.stride(1) == 1 else dx.contiguous()
+        dp = torch.empty((P, C, h, w), dtype=torch.float32, device=dx.device)
+        L.check(L.lib().odw_unstack_clean_aug_bwd(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
+                                                  L.ptr(block), L.ptr(block_sum), P, C, h * w, L.ptr(dp), L.stream()),
+                "unstack_clean_aug_bwd")
+        return dp, None, None
 
 
 class TwoFCROIFeatureExtractor(nn.Module):
@@ -64,6 +94,16 @@ class TwoFCROIFeatureExtractor(nn.Module):
         order (clean fc6, clean fc7, DropBlock centres, aug fc6, aug fc7)."""
         P = pooled.shape[0]
         k1, k2 = self.rand.key(), self.rand.key()
+        fused = (linear_layer.get_backend() == "hip_bf16" and hasattr(self, "dropblock") and pooled.is_cuda
+                 and pooled.dtype == torch.float32 and (pooled.shape[1] * pooled.shape[2] * pooled.shape[3]) % 64 == 0)
+        if fused:
+            # production path: the DropBlock view is never materialised in fp32 -- one kernel writes the stacked
+            # bf16 GEMM operand, one kernel folds both halves of its gradient back (same draws, same arithmetic)
+            block = self.dropblock.keep_mask(P, pooled.shape[2], pooled.shape[3], pooled.device, self.rand)
+            k4, k5 = self.rand.key(), self.rand.key()
+            x = _StackCleanAug.apply(pooled, block.contiguous(), block.sum())
+            h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5])
+            return h[:P], h[P:]
         aug = self.forward_dropblock(pooled) if hasattr(self, "dropblock") else pooled
         k4, k5 = self.rand.key(), self.rand.key()
         x = torch.cat([pooled.reshape(P, -1), aug.reshape(P, -1)], dim=0)

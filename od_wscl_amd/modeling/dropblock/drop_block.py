@@ -16,17 +16,21 @@ class DropBlock2D(nn.Module):
         self.drop_prob = drop_prob
         self.block_size = block_size
 
-    def forward(self, x, rand=None):
-        assert x.dim() == 4, "Expected input with 4 dimensions (bsize, channels, height, width)"
-        if not self.training or self.drop_prob == 0.0:
-            return x
+    def keep_mask(self, n, h, w, device, rand=None):
+        """The (n, h, w) keep mask after dilation (drop_block.py:38-47, :55-71) -- one draw of n*h*w uniforms."""
         gamma = self.drop_prob / (self.block_size ** 2)
-        shape = (x.shape[0], x.shape[2], x.shape[3])
-        u = rand.uniform(shape) if rand is not None else torch.rand(shape, device=x.device)
+        shape = (n, h, w)
+        u = rand.uniform(shape) if rand is not None else torch.rand(shape, device=device)
         centres = (u < gamma).float()
         block = F.max_pool2d(centres[:, None], kernel_size=self.block_size, stride=1, padding=self.block_size // 2)
         if self.block_size % 2 == 0:
             block = block[:, :, :-1, :-1]
-        block = 1 - block.squeeze(1)
+        return 1 - block.squeeze(1)
+
+    def forward(self, x, rand=None):
+        assert x.dim() == 4, "Expected input with 4 dimensions (bsize, channels, height, width)"
+        if not self.training or self.drop_prob == 0.0:
+            return x
+        block = self.keep_mask(x.shape[0], x.shape[2], x.shape[3], x.device, rand)
         # (x * block) * numel / sum, evaluated in the reference's order (:49-50)
         return x * block[:, None, :, :] * block.numel() / block.sum()

@@ -20,6 +20,12 @@ class ROIWeakRegHead(nn.Module):
         self.DB_METHOD = cfg.DB.METHOD
         self.model_sim = Sim_Net(cfg, self.feature_extractor.out_channels)
 
+    head_grads_ready = None      # engine.FlatSGD installs its early-step callback here
+
+    def _on_pooled_grad(self, grad):
+        self.head_grads_ready()
+        return grad
+
     def set_rand(self, rand):
         """Install the counter-based random source for this step (dropout / DropBlock / noise)."""
         self.feature_extractor.rand = rand
@@ -41,6 +47,10 @@ class ROIWeakRegHead(nn.Module):
         if fe.rand is not None and self.DB_METHOD in ("dropblock", "none"):
             # clean pass + DropBlock pass as one stacked fc6/fc7 evaluation (same draws, same order)
             clean_pooled = fe.forward_pooler(features, proposals)
+            if self.head_grads_ready is not None and clean_pooled.requires_grad:
+                # every gradient of the head (fc6/fc7, Sim_Net, predictor) is final once d(loss)/d(pooled) is:
+                # the optimiser / all-reduce of those 600 MB can start while the backbone is still in backward
+                clean_pooled.register_hook(self._on_pooled_grad)
             clean_feats, aug_feats = fe.forward_clean_and_aug(clean_pooled)
             sim_feature = self.model_sim(clean_feats)
         else:

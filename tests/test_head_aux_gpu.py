@@ -1,0 +1,80 @@
+"""csrc/head_aux.hip: the stacked clean + DropBlock GEMM operand and its gradient against the straight PyTorch
+rendition of the reference's DropBlock2D.forward (modeling/dropblock/drop_block.py:45-50) + flatten + cat + cast."""
+import numpy as np
+import pytest
+import torch
+
+from od_wscl_amd.utils import rng
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(P, C, h, w, seed):
+    x = torch.from_numpy(rng.normal(seed, 1, P * C * h * w).reshape(P, C, h, w)).cuda()
+    keep = torch.from_numpy((rng.uniform(seed, 2, P * h * w) > 0.2).astype(np.float32).reshape(P, h, w)).cuda()
+    return x, keep
+
+
+@pytest.mark.parametrize("P,C,h,w", [(37, 64, 7, 7), (5, 512, 7, 7), (3, 16, 14, 14), (1, 64, 2, 2)])
+def test_stack_clean_aug_forward_backward(P, C, h, w):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.modeling.backbone.fc_extractor import _StackCleanAug
+    x, keep = _inputs(P, C, h, w, 5)
+    xs = x.clone().requires_grad_(True)
+    out = _StackCleanAug.apply(xs, keep, keep.sum())
+    aug = x * keep[:, None] * keep.numel() / keep.sum()                       # drop_block.py:49-50, same order
+    ref = torch.cat([x.reshape(P, -1), aug.reshape(P, -1)]).to(torch.bfloat16)
+    assert out.dtype == torch.bfloat16 and out.shape == (2 * P, C * h * w)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))          # bit-exact: same fp32 ops, same rounding
+    from od_wscl_amd import _lib as L
+    g32 = torch.from_numpy(rng.normal(6, 3, 2 * P * C * h * w).reshape(2 * P, -1)).cuda()
+    out.backward(g32)                       # autograd hands the node a gradient in the output's dtype (bf16)
+    for g, got in ((g32.to(torch.bfloat16), xs.grad), (g32, None)):
+        if got is None:                     # the fp32-gradient entry point of the kernel, called directly
+            got = torch.empty_like(x)
+            L.check(L.lib().odw_unstack_clean_aug_bwd(L.ptr(g), 1, g.stride(0), L.ptr(keep), L.ptr(keep.sum()), P, C,
+                                                      h * w, L.ptr(got), L.stream()), "unstack")
+        gf = g.float().reshape(2, P, C, h, w)
+        exp = gf[0] + gf[1] * keep[:, None] * keep.numel() / keep.sum()
+        np.testing.assert_allclose(got.cpu().numpy(), exp.cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_stacked_path_equals_unfused_path():
+    """forward_clean_and_aug: the fused operand path against the cat/DropBlock2D path on the bf16 back end --
+    identical random draws, identical bf16 operand, so identical fc outputs and pooled gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.config import make_defaults
+    from od_wscl_amd.layers import linear as ll
+    from od_wscl_amd.modeling.backbone import fc_extractor as fx
+    from od_wscl_amd.modeling.backbone.vgg16 import VGG16FC67ROIFeatureExtractor
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    cfg = make_defaults()
+    cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
+                         "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,), "DB.METHOD", "dropblock"])
+    ll.set_backend("hip_bf16")
+    try:
+        torch.manual_seed(0)
+        fe = VGG16FC67ROIFeatureExtractor(cfg, 512).cuda().train()
+        pooled = torch.randn(40, 512, 7, 7, device="cuda").relu_()
+        res = []
+        for fused in (True, False):
+            fe.rand = DeviceRand(77)
+            p = pooled.clone().requires_grad_(True)
+            real = fx.linear_layer.get_backend
+            if not fused:
+                fx.linear_layer.get_backend = lambda: "no-fusion"      # only steers the branch in forward_clean_and_aug
+            try:
+                c, a = fe.forward_clean_and_aug(p)
+            finally:
+                fx.linear_layer.get_backend = real
+            (c.float().square().sum() + a.float().sum()).backward()
+            res.append((c.float(), a.float(), p.grad.clone(), fe.rand.s.next))
+        assert res[0][3] == res[1][3]                                  # same number of random draws
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        # the unfused path hands fc6 an fp32 gradient, the fused one a bf16 gradient: 2^-8 relative
+        d = (res[0][2] - res[1][2]).abs().max().item()
+        assert d <= 1e-2 * res[1][2].abs().max().item(), d
+    finally:
+        ll.set_backend("torch")
