@@ -164,6 +164,17 @@ int odw_unstack_clean_aug_bwd(const void* dX, int dx_is_f32, int ld, const float
 /* Which kernel odw_gemm_nt_bf16 will launch for this product: 0 register-staged 128x128, 1 LDS-DMA 128x128,
  * 2 LDS-DMA 256x128 ring, 3 256x256 (per-kernel timing in bench.py names its roofline entry from this). */
 int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16);
+/* Split-K form: products with a small C and a long K (conv weight gradients, the fc6 pass over the sampled rows)
+ * fill the chip only when K is split.  odw_gemm_nt_bf16_workspace returns the bytes of fp32 partials the planner
+ * wants for this product (0 = no split) and the kernel variant it would use; odw_gemm_nt_bf16_ws takes that
+ * buffer (16-byte aligned; NULL / too small = unsplit, identical to odw_gemm_nt_bf16).  The reduction pass applies
+ * the same fused epilogue in a fixed summation order. */
+int64_t odw_gemm_nt_bf16_workspace(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16,
+                                   int* variant_out);
+int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C, int ldc,
+                        int c_is_bf16, const float* bias, int relu, float alpha, float drop_p, int nseg,
+                        const int* seg_rows, const uint32_t* seg_keys, int accumulate, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 int odw_linear_bwd_prep(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
                         float scale, void* dZ, int ld_z, void* dZT, int ld_t, float* db, void* stream);
 int odw_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,

@@ -43,6 +43,9 @@ SIGNATURES = {
     "odw_stack_clean_aug": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "odw_unstack_clean_aug_bwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "odw_gemm_nt_bf16_variant": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i]),
+    "odw_gemm_nt_bf16_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "odw_gemm_nt_bf16_ws": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_p, c_p, c_i,
+                                  c_p, c_l, c_p]),
     "odw_gemm_nt_bf16": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_p, c_p, c_i, c_p]),
     "odw_linear_bwd_prep": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_p, c_i, c_p, c_p]),
     "odw_transpose_to_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),

@@ -47,7 +47,18 @@ struct Epilogue {
     const unsigned short* mask;   // optional bf16 (M x ldmask): result forced to 0 where mask == 0 (ReLU backward)
     int ldmask;
     int pm;                // tile-order group height (tile_coords); 0 = the kernel's default
+    int kchunk;            // split-K: > 0 = this launch's blockIdx.y owns K range [y*kchunk, (y+1)*kchunk) and writes
+    long long split_stride;  //          its partial product split_stride bytes further into C (an fp32 workspace)
 };
+
+// split-K entry of a DMA kernel: narrow the operands / output to this workgroup's K range
+#define ODW_SPLITK_ENTER()                                                                 \
+    if (ep.kchunk > 0) {                                                                   \
+        const int ks_ = blockIdx.y * ep.kchunk;                                            \
+        A += ks_; B += ks_;                                                                \
+        K = K - ks_ < ep.kchunk ? K - ks_ : ep.kchunk;                                     \
+        Cv = reinterpret_cast<char*>(Cv) + (long long)blockIdx.y * ep.split_stride;        \
+    }
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * kChunksPerRow + (chunk ^ ((row >> 1) & 7)); }
 
@@ -328,6 +339,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [stage][A 256 rows | B 128 rows]
+    ODW_SPLITK_ENTER();
     int tm, tn;
     tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * RM, n0 = tn * RN;
@@ -567,6 +579,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [slot][A 256 rows | B 256 rows]
+    ODW_SPLITK_ENTER();
     int tm, tn;
     tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * GM, n0 = tn * GN;
@@ -876,35 +889,99 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
-// Which kernel serves a product.  0 = register-staged 128x128 (any alignment), 1 = LDS-DMA 128x128 (two workgroups
-// per CU), 2 = LDS-DMA 256x128 three-slot ring, 3 = 256x256 asm-scheduled.  The DMA kernels need operand rows
-// padded to a multiple of 64; the 256x256 kernel also 16-byte-aligned rows of C.  Among the eligible ones the
-// cheapest by (rounds of workgroups over 256 CUs) x (tile area) / (measured per-CU rate) wins: the big tiles are
-// ~25 % faster per FLOP but lose when their grid leaves CUs idle (e.g. M = 2000: 128 tiles of 256x256).
-// ODW_GEMM_VARIANT = reg | glds | ring | big forces one (tools/gemm_var.py).
-__host__ int pick_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16) {
+// Second pass of a split-K product: C = epilogue(sum_s partial[s]) with the full fused epilogue (bias, ReLU,
+// dropout keys, bf16 / fp32, accumulate) -- 4 consecutive columns per thread, fixed summation order (deterministic).
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long stride_f,
+                                                            int M, int N, void* __restrict__ Cv, int ldc, Epilogue ep) {
+    const int n4 = N / 4;
+    const long long total = (long long)M * n4;
+    const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
+        const float* p = ws + (size_t)m * N + n;
+        float4 a = *reinterpret_cast<const float4*>(p);
+        for (int sidx = 1; sidx < S; ++sidx) {
+            const float4 b = *reinterpret_cast<const float4*>(p + (size_t)sidx * stride_f);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float v[4] = {a.x, a.y, a.z, a.w};
+        int srow = ep.seg_row[0];
+        uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
+        if (ep.drop_p > 0.0f) {
+            if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
+            if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
+            if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = v[q] * ep.alpha;
+            if (ep.bias) x += ep.bias[n + q];
+            if (ep.relu) x = fmaxf(x, 0.0f);
+            if (ep.drop_p > 0.0f) {
+                const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)(n + q);
+                x = odw_uniform(idx, k0, k1) >= ep.drop_p ? x * keep_scale : 0.0f;
+            }
+            v[q] = x;
+        }
+        if (OUT_BF16) {
+            unsigned short* c = reinterpret_cast<unsigned short*>(Cv) + (size_t)m * ldc + n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = f2bf(v[q]);
+        } else {
+            float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = ep.accumulate ? c[q] + v[q] : v[q];
+        }
+    }
+}
+
+// Which kernel serves a product, and in how many K slices.  Variant 0 = register-staged 128x128 (any alignment),
+// 1 = LDS-DMA 128x128 (two workgroups per CU), 2 = LDS-DMA 256x128 three-slot ring, 3 = 256x256 asm-scheduled.
+// The DMA kernels need operand rows padded to a multiple of 64; the 256x256 kernel also 16-byte-aligned rows of C.
+// Cost model (seconds): rounds of workgroups over 256 CUs x tile FLOPs / measured per-CU rate, plus -- for a
+// split -- the reduction pass over the fp32 partials.  Big tiles are ~25 % faster per FLOP but lose when their
+// grid leaves CUs idle (M = 2000: 128 tiles of 256x256); products with a small C and a long K (the conv weight
+// gradients: 512 x 4608 x 5776 pixels = 72 tiles; the fc6 pass over the ~450 sampled rows) fill the chip only when
+// K is split.  ODW_GEMM_VARIANT = reg | glds | ring | big and ODW_GEMM_SPLITK = n force a choice (tools/gemm_var.py).
+struct Plan { int variant, splits, kchunk; };
+
+__host__ Plan pick_plan(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16, bool allow_split) {
     const int k64 = (K + 63) / 64 * 64;
     const bool dma_ok = lda >= k64 && ldb >= k64 && K > 0;
     const int c_el = c_is_bf16 ? 2 : 4;
     const bool big_ok = dma_ok && N % 8 == 0 && ((size_t)ldc * c_el) % 16 == 0 && (((uintptr_t)C) & 15) == 0;
     const char* force = getenv("ODW_GEMM_VARIANT");
+    const char* fsplit = getenv("ODW_GEMM_SPLITK");
+    int only = -1;
     if (force) {
-        if (force[0] == 'r' && force[1] == 'e') return 0;
-        if (force[0] == 'g') return dma_ok ? 1 : 0;
-        if (force[0] == 'r' && force[1] == 'i') return dma_ok ? 2 : 0;
-        if (force[0] == 'b') return big_ok ? 3 : (dma_ok ? 1 : 0);
+        if (force[0] == 'r' && force[1] == 'e') return {0, 1, 0};
+        if (force[0] == 'g') return {dma_ok ? 1 : 0, 1, 0};
+        if (force[0] == 'r' && force[1] == 'i') only = 2;
+        if (force[0] == 'b') only = big_ok ? 3 : 1;
     }
-    if (!dma_ok) return 0;
-    auto cost = [&](int tm, int tn, int per_cu, double rate) {
-        const long tiles = (long)((M + tm - 1) / tm) * ((N + tn - 1) / tn);
-        const long rounds = (tiles + 256L * per_cu - 1) / (256L * per_cu);
-        return (double)rounds * per_cu * tm * tn / rate;
-    };
-    int best = 1;
-    double c = cost(BM, BN, 2, 0.97);
-    const double cr = cost(RM, RN, 1, 1.0);
-    if (cr < c) { c = cr; best = 2; }
-    if (big_ok && cost(GM, GN, 1, 1.25) < c) best = 3;
+    if (!dma_ok) return {0, 1, 0};
+    const double kCuRate = 3.4e12;                       // FLOP/s of one CU inside the 256x128 ring kernel
+    const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    struct V { int id, tm, tn, per_cu; double rate; bool splittable; };
+    const V vs[] = {{1, BM, BN, 2, 0.97, false}, {2, RM, RN, 1, 1.0, true}, {3, GM, GN, 1, 1.25, true}};
+    Plan best = {1, 1, 0};
+    double best_t = 1e30;
+    for (const V& v : vs) {
+        if (v.id == 3 && !big_ok) continue;
+        if (only >= 0 && v.id != only) continue;
+        const long tiles = (long)((M + v.tm - 1) / v.tm) * ((N + v.tn - 1) / v.tn);
+        for (int sp : kSplits) {
+            if (sp > 1 && (!allow_split || !v.splittable || N % 4 != 0)) break;
+            if (fsplit && sp != atoi(fsplit) && !(sp == 1 && atoi(fsplit) <= 1)) continue;
+            const int kc = ((K + sp - 1) / sp + 63) / 64 * 64;
+            if (sp > 1 && (kc < 256 || (long)kc * (sp - 1) >= K)) break;
+            const long rounds = (tiles * sp + 256L * v.per_cu - 1) / (256L * v.per_cu);
+            double t = (double)rounds * v.per_cu * v.tm * v.tn * 2.0 * kc / (v.rate * kCuRate) + rounds * 2e-6;
+            if (sp > 1) t += ((double)sp * M * N * 4.0 + (double)M * N * c_el) / 2.5e12 + 4e-6;
+            if (t < best_t) { best_t = t; best = {v.id, sp, sp > 1 ? kc : 0}; }
+        }
+    }
     return best;
 }
 
@@ -912,13 +989,33 @@ __host__ int pick_variant(int M, int N, int K, int lda, int ldb, const void* C, 
 
 ODW_EXPORT int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc,
                                         int c_is_bf16) {
-    return pick_variant(M, N, K, lda, ldb, C, ldc, c_is_bf16);
+    return pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, false).variant;
 }
+
+ODW_EXPORT int64_t odw_gemm_nt_bf16_workspace(int M, int N, int K, int lda, int ldb, const void* C, int ldc,
+                                              int c_is_bf16, int* variant_out) {
+    const Plan p = pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, true);
+    if (variant_out) *variant_out = p.variant;
+    return p.splits > 1 ? (int64_t)p.splits * M * N * 4 : 0;
+}
+
+ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
+                                   int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
+                                   int nseg, const int* seg_rows, const uint32_t* seg_keys, int accumulate,
+                                   void* workspace, int64_t workspace_bytes, void* stream_);
 
 ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
                                 int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
                                 int nseg, const int* seg_rows, const uint32_t* seg_keys, int accumulate,
                                 void* stream_) {
+    return odw_gemm_nt_bf16_ws(A, lda, B, ldb, M, N, K, C, ldc, c_is_bf16, bias, relu, alpha, drop_p, nseg, seg_rows,
+                               seg_keys, accumulate, nullptr, 0, stream_);
+}
+
+ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
+                                   int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
+                                   int nseg, const int* seg_rows, const uint32_t* seg_keys, int accumulate,
+                                   void* workspace, int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_nt_bf16: bad dims M=%d N=%d K=%d", M, N, K);
     if (M == 0 || N == 0) return ODW_OK;
@@ -931,7 +1028,7 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     ODW_REQUIRE(!(accumulate && c_is_bf16), "gemm_nt_bf16: accumulate needs an fp32 C");
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = drop_p; ep.nseg = nseg; ep.accumulate = accumulate; ep.alpha = alpha;
-    ep.mask = nullptr; ep.ldmask = 0;
+    ep.mask = nullptr; ep.ldmask = 0; ep.kchunk = 0; ep.split_stride = 0;
     { const char* e = getenv("ODW_GEMM_PM"); ep.pm = e ? atoi(e) : 0; }
     for (int i = 0; i < kMaxSeg; ++i) {
         ep.seg_row[i] = (i < nseg && seg_rows) ? seg_rows[i] : 0;
@@ -941,7 +1038,45 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
     if (drop_p > 0.0f) ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_bf16: dropout needs row segments starting at 0");
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);   // 64 KB
-    const int variant = pick_variant(M, N, K, lda, ldb, C, ldc, c_is_bf16);
+    Plan plan = pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, workspace != nullptr);
+    if (plan.splits > 1 && workspace_bytes < (int64_t)plan.splits * M * N * 4)
+        plan = pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, false);
+    if (plan.splits > 1) {
+        // partial products (plain, fp32) into the workspace, then one reduction pass with the fused epilogue
+        ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "gemm_nt_bf16: workspace must be 16-byte aligned");
+        Epilogue pe = ep;
+        pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.accumulate = 0; pe.alpha = 1.0f;
+        pe.kchunk = plan.kchunk; pe.split_stride = (long long)M * N * 4;
+        const dim3 grid_r((unsigned)(((M + RM - 1) / RM) * ((N + RN - 1) / RN)), (unsigned)plan.splits);
+        const dim3 grid_b((unsigned)(((M + GM - 1) / GM) * ((N + GN - 1) / GN)), (unsigned)plan.splits);
+        if (plan.variant == 3) {
+            const size_t big_lds = (size_t)2 * kBigStageChunks * sizeof(uint4);
+            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 0>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr");
+            gemm_nt_bf16_big_kernel<false, 0><<<grid_b, kBigThreads, big_lds, stream>>>(
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, workspace, N, pe,
+                (M + GM - 1) / GM, (N + GN - 1) / GN);
+        } else {
+            const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
+            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "ring attr");
+            gemm_nt_bf16_ring_kernel<false><<<grid_r, kRingThreads, ring_lds, stream>>>(
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, workspace, N, pe,
+                (M + RM - 1) / RM, (N + RN - 1) / RN);
+        }
+        ODW_CHECK_HIP(hipGetLastError(), "gemm_nt_bf16 split-K launch");
+        const long long quads = (long long)M * (N / 4);
+        const int rblocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+        if (c_is_bf16)
+            splitk_reduce_kernel<true><<<rblocks, 256, 0, stream>>>((const float*)workspace, plan.splits,
+                                                                     (long long)M * N, M, N, C, ldc, ep);
+        else
+            splitk_reduce_kernel<false><<<rblocks, 256, 0, stream>>>((const float*)workspace, plan.splits,
+                                                                      (long long)M * N, M, N, C, ldc, ep);
+        ODW_CHECK_LAUNCH("splitk_reduce_kernel");
+        return ODW_OK;
+    }
+    const int variant = plan.variant;
     const bool use_big = variant == 3, use_ring = variant == 2, use_glds = variant >= 1;
     const int rtiles_m = (M + RM - 1) / RM, rtiles_n = (N + RN - 1) / RN;
     const int btiles_m = (M + GM - 1) / GM, btiles_n = (N + GN - 1) / GN;
@@ -1077,7 +1212,7 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16(const void* X, int n_pix, int H, int W, int
     while ((1 << g.logC) < C) ++g.logC;
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = 0.0f; ep.nseg = 0; ep.accumulate = 0; ep.alpha = 1.0f;
-    ep.mask = (const unsigned short*)mask; ep.ldmask = ldmask; ep.pm = 0;
+    ep.mask = (const unsigned short*)mask; ep.ldmask = ldmask; ep.pm = 0; ep.kchunk = 0; ep.split_stride = 0;
     for (int i = 0; i < kMaxSeg; ++i) { ep.seg_row[i] = 0; ep.seg_k0[i] = 0; ep.seg_k1[i] = 0; }
     const int tiles_m = (n_pix + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);

@@ -40,16 +40,21 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
     out_bf16 = out.dtype == torch.bfloat16
     # per-symbol timing for bench.py's roofline object (same names as rocprofv3's kernel trace)
-    var = L.lib().odw_gemm_nt_bf16_variant(M, N, K, a.stride(0), b.stride(0), L.ptr(out), out.stride(0),
-                                           1 if out_bf16 else 0)
-    sym = "gemm_nt_bf16_%skernel<%s>" % (_VARIANT_SYMBOL[var], ("true" if out_bf16 else "false") + (", 0" if var == 3 else ""))
+    var = ctypes.c_int(0)
+    ws_bytes = L.lib().odw_gemm_nt_bf16_workspace(M, N, K, a.stride(0), b.stride(0), L.ptr(out), out.stride(0),
+                                                  1 if out_bf16 else 0, ctypes.byref(var))
+    var = var.value
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None     # split-K partials
+    split = ws is not None
+    sym = "gemm_nt_bf16_%skernel<%s>%s" % (_VARIANT_SYMBOL[var], ("false" if split or not out_bf16 else "true")
+                                           + (", 0" if var == 3 else ""), " split-K+reduce" if split else "")
     with kernel_timer.region(sym, flops=2.0 * M * N * K):
-        L.check(L.lib().odw_gemm_nt_bf16(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out),
-                                         out.stride(0), 1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0,
-                                         float(alpha), float(drop_p), nseg,
-                                         ctypes.cast(rows, ctypes.c_void_p) if nseg else None,
-                                         ctypes.cast(keys, ctypes.c_void_p) if nseg else None,
-                                         1 if accumulate else 0, L.stream()), "gemm_nt_bf16")
+        L.check(L.lib().odw_gemm_nt_bf16_ws(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out),
+                                            out.stride(0), 1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0,
+                                            float(alpha), float(drop_p), nseg,
+                                            ctypes.cast(rows, ctypes.c_void_p) if nseg else None,
+                                            ctypes.cast(keys, ctypes.c_void_p) if nseg else None,
+                                            1 if accumulate else 0, L.ptr(ws), ws_bytes, L.stream()), "gemm_nt_bf16")
     return out
 
 

@@ -134,6 +134,47 @@ def test_gemm_256x256_variant(G, M, N, K, monkeypatch):
     assert (acc - (1 + ref)).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("M,N,K,forced", [(512, 4608, 5776, None), (256, 2304, 23104, None), (446, 4096, 25088, None),
+                                          (300, 200, 4096, 4), (130, 72, 1024, 3), (64, 576, 36864, None)])
+def test_gemm_split_k(G, M, N, K, forced, monkeypatch):
+    """Products with a small C and a long K are split along K (fp32 partials + one reduction pass that applies the
+    fused epilogue): conv weight-gradient shapes, the fc6 pass over the sampled rows, and forced splits on ragged
+    shapes; against the fp32 reference and against the unsplit kernel."""
+    import ctypes
+    from od_wscl_amd import _lib as L
+    if forced:
+        monkeypatch.setenv("ODW_GEMM_SPLITK", str(forced))
+    k64 = (K + 63) // 64 * 64
+    a = torch.zeros(M, k64, device="cuda").bfloat16()
+    b = torch.zeros(N, k64, device="cuda").bfloat16()
+    a[:, :K] = (rnd(41, (M, K)) * 0.1).bfloat16()
+    b[:, :K] = (rnd(42, (N, K)) * 0.1).bfloat16()
+    out = torch.empty(M, N, device="cuda")
+    var = ctypes.c_int(0)
+    ws = L.lib().odw_gemm_nt_bf16_workspace(M, N, K, k64, k64, L.ptr(out), N, 0, ctypes.byref(var))
+    assert ws > 0 and ws % (M * N * 4) == 0, "the planner should split this product"
+    ref = a.float() @ b.float().T
+    tol = 1e-5 * np.sqrt(K) * 4 * max(1.0, ref.abs().max().item())
+    G.gemm_nt(a, b, M, N, K, out)
+    assert (out - ref).abs().max().item() <= tol
+    bias = rnd(43, (N,))
+    s1 = M // 3
+    k1, k2 = rng.stream_key(9, 31), rng.stream_key(9, 32)
+    keep = np.concatenate([rng.uniform(9, 31, s1 * N).reshape(s1, N), rng.uniform(9, 32, (M - s1) * N).reshape(M - s1, N)]) >= 0.5
+    exp = torch.relu(ref * 0.5 + bias) * torch.from_numpy(keep).cuda() * 2.0
+    for dt, atol in ((torch.float32, 2e-3), (torch.bfloat16, 8e-3)):
+        o = torch.empty(M, N, device="cuda", dtype=dt)
+        G.gemm_nt(a, b, M, N, K, o, bias=bias, relu=True, alpha=0.5, drop_p=0.5, segs=[(0,) + k1, (s1,) + k2])
+        assert (o.float() - exp).abs().max().item() <= atol * max(1.0, exp.abs().max().item())
+    acc = torch.ones(M, N, device="cuda")
+    G.gemm_nt(a, b, M, N, K, acc, accumulate=True)
+    assert (acc - (1 + ref)).abs().max().item() <= tol
+    monkeypatch.setenv("ODW_GEMM_SPLITK", "1")                 # the same product unsplit
+    o1 = torch.empty(M, N, device="cuda")
+    G.gemm_nt(a, b, M, N, K, o1)
+    assert (o1 - out).abs().max().item() <= tol
+
+
 def test_transpose_and_convert(G):
     x = rnd(6, (70, 45))
     t = G.transpose_bf16(x, 70, 45)
