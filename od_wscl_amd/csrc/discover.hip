@@ -172,6 +172,10 @@ __device__ __forceinline__ bool before(float sa, int ia, float sb, int ib) {
     return (sa > sb) || (sa == sb && ia < ib);
 }
 
+// Phase 1 of object discovery, one workgroup per (image, refinement branch, positive class): similarity threshold,
+// candidate set, score sort and greedy NMS -> the instance list of loss.py:311-333.  These 3 x n_pos chains per
+// image are independent of each other; only the bookkeeping that follows (fresh = instances not yet in pgt_index,
+// which accumulates over the branches, and od_layer's pseudo-GT) is ordered, and it is cheap: phase 2 below.
 __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int ppow2, int sbox_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve
@@ -181,8 +185,6 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
     float* ks = fred + kThreads;                                          // ppow2 sort keys
     int* ki = reinterpret_cast<int*>(ks + ppow2);                         // ppow2 sort ids / candidate list
     unsigned char* close = reinterpret_cast<unsigned char*>(ki + ppow2);  // ppow2 flags (close / alive)
-    unsigned int* zeroed = reinterpret_cast<unsigned int*>(close + ppow2);  // W32 (od_layer zeroed rows)
-    int* scan = reinterpret_cast<int*>(zeroed + a.W32);                   // W32 + 1
     float4* sbox = reinterpret_cast<float4*>(smem + sbox_off);           // ppow2 candidate boxes, sorted order
     __shared__ int s_n, s_k;
     __shared__ float s_thr;
@@ -193,9 +195,11 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
     const float4* bx = reinterpret_cast<const float4*>(a.boxes) + base;
     const float* E = a.E + (size_t)base * kD;
 
-    for (int i = 0; i < 3; ++i) {
+    {
+        const int i = blockIdx.y / a.maxpos, ci = blockIdx.y - i * a.maxpos;
+        if (ci >= npos) return;
         const float* S = a.src[i] + (size_t)base * a.C;
-        for (int ci = 0; ci < npos; ++ci) {
+        {
             const int c = a.pos_cls[img * a.maxpos + ci];
             const int top = a.tops[(img * 3 + i) * a.maxpos + ci];
             const size_t slot = ((size_t)(img * 3 + i) * a.maxpos + ci);
@@ -314,10 +318,29 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
                 n_inst = 1;
             }
             if (threadIdx.x == 0) a.inst_cnt[slot] = n_inst;
-            __syncthreads();
+        }
+    }
+}
+
+// Phase 2, one workgroup per image, branches and classes in the reference's order.
+__global__ __launch_bounds__(kThreads) void discover_finish_kernel(SimArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ArgMax* red = reinterpret_cast<ArgMax*>(smem);                       // kThreads * 8
+    unsigned int* fresh_mask = reinterpret_cast<unsigned int*>(red + kThreads);   // W32
+    unsigned int* zeroed = fresh_mask + a.W32;                            // W32 (od_layer zeroed rows)
+    int* scan = reinterpret_cast<int*>(zeroed + a.W32);                   // W32 + 1
+    const int img = blockIdx.x;
+    const int base = a.img_off[img], P = a.img_off[img + 1] - base;
+    const int npos = a.n_pos[img];
+    for (int i = 0; i < 3; ++i) {
+        const float* S = a.src[i] + (size_t)base * a.C;
+        for (int ci = 0; ci < npos; ++ci) {
+            const int top = a.tops[(img * 3 + i) * a.maxpos + ci];
+            const size_t slot = ((size_t)(img * 3 + i) * a.maxpos + ci);
+            const int* inst = a.inst_idx + slot * a.pstride;
+            int n_inst = a.inst_cnt[slot];
             // ---- fresh = survivors not in pgt_index (ascending) ; fallback top ; pgt_index |= fresh
             unsigned int* pm = a.masks + ((size_t)img * a.maxpos + ci) * a.W32;
-            unsigned int* fresh_mask = reinterpret_cast<unsigned int*>(ks);   // sort keys are dead by now
             for (int w = threadIdx.x; w < a.W32; w += kThreads) fresh_mask[w] = 0;
             __syncthreads();
             for (int t = threadIdx.x; t < n_inst; t += kThreads) {
@@ -409,12 +432,15 @@ ODW_EXPORT int odw_discover_sim(const float* E, const float* s0, const float* s1
     a.gt_idx = gt_idx; a.gt_cls = gt_cls; a.gt_score = gt_score; a.gt_cnt = gt_cnt;
     const int ppow2 = pow2_at_least(max_p);
     size_t lds = kThreads * sizeof(ArgMax) + kD * 4 + kThreads * 4 + (size_t)ppow2 * 4 + (size_t)ppow2 * 4 +
-                 (size_t)ppow2 + (size_t)a.W32 * 4 + (size_t)(a.W32 + 1) * 4 + 64;
+                 (size_t)ppow2 + 64;
     const int sbox_off = (int)((lds + 15) / 16 * 16);
     lds = (size_t)sbox_off + (size_t)ppow2 * 16;
     ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(discover_sim_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "discover_sim attr");
-    discover_sim_kernel<<<n_img, kThreads, lds, (hipStream_t)stream_>>>(a, ppow2, sbox_off);
+    discover_sim_kernel<<<dim3(n_img, 3 * maxpos), kThreads, lds, (hipStream_t)stream_>>>(a, ppow2, sbox_off);
     ODW_CHECK_LAUNCH("discover_sim_kernel");
+    const size_t lds2 = kThreads * sizeof(ArgMax) + (size_t)a.W32 * 4 * 2 + (size_t)(a.W32 + 1) * 4;
+    discover_finish_kernel<<<n_img, kThreads, lds2, (hipStream_t)stream_>>>(a);
+    ODW_CHECK_LAUNCH("discover_finish_kernel");
     return ODW_OK;
 }
