@@ -46,11 +46,13 @@ class ROIWeakRegHead(nn.Module):
             return clean_feats, (final, torch.mean(torch.stack(boxes), dim=0)), {}, {}
         if fe.rand is not None and self.DB_METHOD in ("dropblock", "none"):
             # clean pass + DropBlock pass as one stacked fc6/fc7 evaluation (same draws, same order)
+            if self.head_grads_ready is not None and features[0].requires_grad:
+                # every gradient of the head (fc6/fc7, Sim_Net, predictor) is final once the ROI pooling node has
+                # produced d(loss)/d(features): the optimiser / all-reduce of those 600 MB can start while the
+                # backbone is still in backward.  (Hooked after the pooling backward, not before it: that kernel is
+                # as HBM-bound as the optimiser and the two would only slow each other down.)
+                features[0].register_hook(self._on_pooled_grad)
             clean_pooled = fe.forward_pooler(features, proposals)
-            if self.head_grads_ready is not None and clean_pooled.requires_grad:
-                # every gradient of the head (fc6/fc7, Sim_Net, predictor) is final once d(loss)/d(pooled) is:
-                # the optimiser / all-reduce of those 600 MB can start while the backbone is still in backward
-                clean_pooled.register_hook(self._on_pooled_grad)
             clean_feats, aug_feats = fe.forward_clean_and_aug(clean_pooled)
             sim_feature = self.model_sim(clean_feats)
         else:
