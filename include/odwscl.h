@@ -221,6 +221,13 @@ int odw_discover_sim(const float* E, const float* s0, const float* s1, const flo
 int odw_conv3x3_nhwc_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, int mirror, const void* Wk,
                           int ldw, int N, void* Y, int ldy, int y_is_bf16, const float* bias, int relu,
                           const void* mask, int ldmask, const void* zero_page, void* stream);
+/* Workspace form: for the deep layers (few output tiles, K = 9*C long) the launcher splits K over the grid and
+ * reduces fp32 partials with the same fused epilogue.  odw_conv3x3_workspace = bytes wanted (0 = no split). */
+int64_t odw_conv3x3_workspace(int n_pix, int C, int N);
+int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, int C, int dilation, int mirror, const void* Wk,
+                             int ldw, int N, void* Y, int ldy, int y_is_bf16, const float* bias, int relu,
+                             const void* mask, int ldmask, const void* zero_page, void* workspace,
+                             int64_t workspace_bytes, void* stream);
 int odw_conv_weight_prep(const float* w, int Co, int Ci, int Cp, void* wk, int ldk, void* wd, int ldd, void* stream);
 int odw_conv_wgrad_unpack(const float* dwk, int ld, int Co, int Ci, int Cp, float* dw, void* stream);
 int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm, void* stream);

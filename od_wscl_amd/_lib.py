@@ -54,6 +54,9 @@ SIGNATURES = {
     "odw_discover_iou": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p]),
     "odw_discover_sim": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_i,
                                c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "odw_conv3x3_workspace": (c_l, [c_i, c_i, c_i]),
+    "odw_conv3x3_nhwc_bf16_ws": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p,
+                                       c_p, c_l, c_p]),
     "odw_conv3x3_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_p]),
     "odw_conv_weight_prep": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p]),
     "odw_conv_wgrad_unpack": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),

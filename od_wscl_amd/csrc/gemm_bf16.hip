@@ -725,7 +725,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const int K = 9 * g.C;
+    int K = 9 * g.C, kbase = 0;
+    if (ep.kchunk > 0) {              // split-K: this workgroup's K range, fp32 partial into the workspace
+        kbase = blockIdx.y * ep.kchunk;
+        B += kbase;
+        K = K - kbase < ep.kchunk ? K - kbase : ep.kchunk;
+        Cv = reinterpret_cast<char*>(Cv) + (long long)blockIdx.y * ep.split_stride;
+    }
 
     int rm[4], rh[4], rw[4];          // this lane's 4 staging rows: pixel index, y, x
 #pragma unroll
@@ -745,7 +751,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     const int nk = (K + BK - 1) / BK;
-    dma_tile_conv(X, g, 0, lds, wave, lane, rm, rh, rw);
+    dma_tile_conv(X, g, kbase, lds, wave, lane, rm, rh, rw);
     dma_tile(B, ldb, N, n0, 0, lds + kTileChunks, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
         uint4* sb = sa + kTileChunks;
         if (kt + 1 < nk) {
             uint4* na = lds + (size_t)(stage ^ 1) * 2 * kTileChunks;
-            dma_tile_conv(X, g, (kt + 1) * BK, na, wave, lane, rm, rh, rw);
+            dma_tile_conv(X, g, kbase + (kt + 1) * BK, na, wave, lane, rm, rh, rw);
             dma_tile(B, ldb, N, n0, (kt + 1) * BK, na + kTileChunks, wave, lane);
         }
 #pragma unroll
@@ -918,6 +924,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             float x = v[q] * ep.alpha;
             if (ep.bias) x += ep.bias[n + q];
             if (ep.relu) x = fmaxf(x, 0.0f);
+            if (ep.mask && (ep.mask[(size_t)m * ep.ldmask + n + q] & 0x7fff) == 0) x = 0.0f;
             if (ep.drop_p > 0.0f) {
                 const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)(n + q);
                 x = odw_uniform(idx, k0, k1) >= ep.drop_p ? x * keep_scale : 0.0f;
@@ -1192,10 +1199,45 @@ ODW_EXPORT int odw_sgd_momentum(float* p, const float* g, float* buf, void* shad
     return ODW_OK;
 }
 
+namespace {
+// K slices of a convolution (1 = unsplit).  The deep layers of the backbone (76x76 pixels: M = 5776, N = 512,
+// K = 4608) are 184 tiles of 128x128: one workgroup on 184 of the 256 CUs, each alone on its CU with nothing to
+// overlap its barrier phases with.  Two K slices make 368 workgroups, all resident at two per CU: 72 -> 60 us per
+// layer including the reduction pass over the fp32 partials (which applies bias / ReLU / the ReLU-backward mask).
+// Measured and rejected: 3-4 slices (552+ workgroups = a second round), and the same on the 256x128 three-slot ring
+// pipeline (62 us at 2 slices, 86 at 3: the per-lane tap/bounds arithmetic of the operand DMA, not the depth of
+// the pipeline, is what the small layers pay for).
+int conv_splits(int n_pix, int N, int C) {
+    const char* f = getenv("ODW_CONV_SPLITK");
+    if (f) return atoi(f);
+    const long t128 = (long)((n_pix + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (t128 > 256 || N % 4 != 0 || 9 * C < 4096) return 1;
+    return 2;
+}
+}  // namespace
+
+ODW_EXPORT int64_t odw_conv3x3_workspace(int n_pix, int C, int N) {
+    const int sp = conv_splits(n_pix, N, C);
+    return sp > 1 ? (int64_t)sp * n_pix * N * 4 : 0;
+}
+
+ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, int C, int dilation, int mirror,
+                                        const void* Wk, int ldw, int N, void* Y, int ldy, int y_is_bf16,
+                                        const float* bias, int relu, const void* mask, int ldmask,
+                                        const void* zero_page, void* workspace, int64_t workspace_bytes, void* stream_);
+
 ODW_EXPORT int odw_conv3x3_nhwc_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, int mirror,
                                      const void* Wk, int ldw, int N, void* Y, int ldy, int y_is_bf16,
                                      const float* bias, int relu, const void* mask, int ldmask, const void* zero_page,
                                      void* stream_) {
+    return odw_conv3x3_nhwc_bf16_ws(X, n_pix, H, W, C, dilation, mirror, Wk, ldw, N, Y, ldy, y_is_bf16, bias, relu, mask,
+                                    ldmask, zero_page, nullptr, 0, stream_);
+}
+
+ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, int C, int dilation, int mirror,
+                                        const void* Wk, int ldw, int N, void* Y, int ldy, int y_is_bf16,
+                                        const float* bias, int relu, const void* mask, int ldmask,
+                                        const void* zero_page, void* workspace, int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(n_pix >= 0 && H > 0 && W > 0 && N > 0 && n_pix % (H * W) == 0, "conv3x3: bad dims");
     ODW_REQUIRE(C >= 8 && (C & (C - 1)) == 0, "conv3x3: channel count %d must be a power of two >= 8", C);
@@ -1214,6 +1256,31 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16(const void* X, int n_pix, int H, int W, int
     ep.bias = bias; ep.relu = relu; ep.drop_p = 0.0f; ep.nseg = 0; ep.accumulate = 0; ep.alpha = 1.0f;
     ep.mask = (const unsigned short*)mask; ep.ldmask = ldmask; ep.pm = 0; ep.kchunk = 0; ep.split_stride = 0;
     for (int i = 0; i < kMaxSeg; ++i) { ep.seg_row[i] = 0; ep.seg_k0[i] = 0; ep.seg_k1[i] = 0; }
+    const int sp = workspace ? conv_splits(n_pix, N, C) : 1;
+    if (sp > 1 && workspace_bytes >= (int64_t)sp * n_pix * N * 4) {
+        ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "conv3x3: workspace must be 16-byte aligned");
+        Epilogue pe = ep;
+        pe.bias = nullptr; pe.relu = 0; pe.mask = nullptr; pe.ldmask = 0;
+        pe.kchunk = ((K + sp - 1) / sp + 63) / 64 * 64;
+        pe.split_stride = (long long)n_pix * N * 4;
+        const int tm_ = (n_pix + BM - 1) / BM, tn_ = (N + BN - 1) / BN;
+        const size_t lds_b = (size_t)2 * 2 * kTileChunks * sizeof(uint4);
+        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_glds_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b), "conv attr");
+        conv3x3_glds_kernel<false><<<dim3((unsigned)(tm_ * tn_), (unsigned)sp), kThreads, lds_b, stream>>>(
+            (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_pix, N, workspace, N, pe, tm_, tn_);
+        ODW_CHECK_HIP(hipGetLastError(), "conv3x3 split launch");
+        const long long quads = (long long)n_pix * (N / 4);
+        const int rblocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+        if (y_is_bf16)
+            splitk_reduce_kernel<true><<<rblocks, 256, 0, stream>>>((const float*)workspace, sp, (long long)n_pix * N,
+                                                                     n_pix, N, Y, ldy, ep);
+        else
+            splitk_reduce_kernel<false><<<rblocks, 256, 0, stream>>>((const float*)workspace, sp, (long long)n_pix * N,
+                                                                      n_pix, N, Y, ldy, ep);
+        ODW_CHECK_LAUNCH("splitk_reduce_kernel");
+        return ODW_OK;
+    }
     const int tiles_m = (n_pix + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);
     if (y_is_bf16) {

@@ -44,6 +44,15 @@ def _layers_of(features):
     return out
 
 
+def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask, zero_page, st):
+    """One implicit-GEMM convolution; the launcher's split-K workspace (deep layers) comes from torch's allocator."""
+    ws_bytes = lib.odw_conv3x3_workspace(m, c, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=y.device) if ws_bytes else None
+    L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, w, c, dil, mirror, L.ptr(wk), wk.stride(0), n, L.ptr(y), n, 1,
+                                         L.ptr(bias), 1 if relu else 0, L.ptr(mask), ldmask, L.ptr(zero_page),
+                                         L.ptr(ws), ws_bytes, st), "conv3x3")
+
+
 class _VGGFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, net, *params):
@@ -59,9 +68,7 @@ class _VGGFn(torch.autograd.Function):
             m = B * h * w
             y = torch.empty((m, l.cout), dtype=torch.bfloat16, device=dev)
             with kernel_timer.region("conv3x3_glds_kernel<true>", flops=2.0 * m * l.cout * 9 * l.cin):
-                L.check(lib.odw_conv3x3_nhwc_bf16(L.ptr(x), m, h, w, l.cp, l.dil, 0, L.ptr(l.wk), l.wk.stride(0), l.cout,
-                                                  L.ptr(y), l.cout, 1, L.ptr(l.conv.bias), 1 if l.relu else 0, None, 0,
-                                                  L.ptr(net.zero_page), st), "conv3x3")
+                _conv3x3(lib, x, m, h, w, l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st)
             pre = None
             if l.pool:
                 pre = y
@@ -122,10 +129,8 @@ class _VGGFn(torch.autograd.Function):
                 dx = torch.empty((m, l.cin), dtype=torch.bfloat16, device=dev)
                 mask = x_in if (prev.relu and not prev.pool) else None
                 with kernel_timer.region("conv3x3_glds_kernel<true>", flops=2.0 * m * l.cout * 9 * l.cin):
-                    L.check(lib.odw_conv3x3_nhwc_bf16(L.ptr(dz), m, h, w, l.cout, l.dil, 1, L.ptr(l.wd), l.wd.stride(0),
-                                                      l.cin, L.ptr(dx), l.cin, 1, None, 0, L.ptr(mask),
-                                                      l.cin if mask is not None else 0, L.ptr(net.zero_page), st),
-                            "conv3x3 dgrad")
+                    _conv3x3(lib, dz, m, h, w, l.cout, l.dil, 1, l.wd, l.cin, dx, None, False, mask,
+                             l.cin if mask is not None else 0, net.zero_page, st)
                 dz = dx
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 

@@ -62,6 +62,42 @@ def test_conv3x3_forward_and_input_gradient(lib, B, Cin, Cout, H, W, dil, relu):
         assert (gotdx - xr.grad).abs().max().item() <= 2e-3 * max(1.0, xr.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,dil,forced", [(1, 512, 512, 12, 10, 2, 3), (1, 256, 512, 19, 13, 1, 2),
+                                                       (1, 512, 512, 76, 76, 2, None), (2, 128, 128, 9, 7, 1, 2)])
+def test_conv3x3_split_k_ring(lib, B, Cin, Cout, H, W, dil, forced, monkeypatch):
+    """The 256x128 ring form with K split over the grid + the reduction pass (bias, ReLU, ReLU-backward mask), bf16 and
+    fp32 outputs, against the unsplit 128x128 kernel and the PyTorch convolution."""
+    L = lib
+    if forced:
+        monkeypatch.setenv("ODW_CONV_SPLITK", str(forced))
+    m = B * H * W
+    x = rnd(11, (B, Cin, H, W)).bfloat16().float()
+    w = rnd(12, (Cout, Cin, 3, 3), 0.03).bfloat16().float()
+    b = rnd(13, (Cout,), 0.1)
+    zero = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
+    xn = torch.empty((m, Cin), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(x), B, H * W, Cin, Cin, L.ptr(xn), L.stream()), "to nhwc")
+    wk = torch.empty((Cout, r64(9 * Cin)), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_conv_weight_prep(L.ptr(w), Cout, Cin, Cin, L.ptr(wk), wk.stride(0), None, 0, L.stream()), "prep")
+    mask = (rnd(14, (m, Cout)) > 0).to(torch.bfloat16)
+    ws_bytes = L.lib().odw_conv3x3_workspace(m, Cin, Cout)
+    assert ws_bytes > 0 and ws_bytes % (m * Cout * 4) == 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    ref = torch.relu(F.conv2d(x, w, b, padding=dil, dilation=dil)).permute(0, 2, 3, 1).reshape(m, Cout) * mask.float()
+    for dt, tol in ((torch.float32, 2e-3), (torch.bfloat16, 1e-2)):
+        y = torch.empty((m, Cout), dtype=dt, device="cuda")
+        L.check(L.lib().odw_conv3x3_nhwc_bf16_ws(L.ptr(xn), m, H, W, Cin, dil, 0, L.ptr(wk), wk.stride(0), Cout, L.ptr(y), Cout,
+                                                 1 if dt == torch.bfloat16 else 0, L.ptr(b), 1, L.ptr(mask), Cout, L.ptr(zero),
+                                                 L.ptr(ws), ws_bytes, L.stream()), "conv ws")
+        y0 = torch.empty((m, Cout), dtype=dt, device="cuda")
+        L.check(L.lib().odw_conv3x3_nhwc_bf16(L.ptr(xn), m, H, W, Cin, dil, 0, L.ptr(wk), wk.stride(0), Cout, L.ptr(y0), Cout,
+                                              1 if dt == torch.bfloat16 else 0, L.ptr(b), 1, L.ptr(mask), Cout, L.ptr(zero),
+                                              L.stream()), "conv")
+        scale = max(1.0, ref.abs().max().item())
+        assert (y.float() - ref).abs().max().item() <= tol * scale
+        assert (y.float() - y0.float()).abs().max().item() <= tol * scale
+
+
 def test_maxpool_and_layout_kernels(lib):
     L = lib
     B, C, H, W = 2, 16, 8, 12

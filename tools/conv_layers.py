@@ -17,9 +17,11 @@ for li, (cin, cout, dil, h) in enumerate(layers):
     wk = torch.randn(cout, _r64(9 * cp), device="cuda").bfloat16()
     y = torch.empty(m, cout, device="cuda", dtype=torch.bfloat16)
     bias = torch.zeros(cout, device="cuda")
+    wsb = lib.odw_conv3x3_workspace(m, cp, cout)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
     def run():
-        L.check(lib.odw_conv3x3_nhwc_bf16(L.ptr(x), m, h, h, cp, dil, 0, L.ptr(wk), wk.stride(0), cout, L.ptr(y), cout, 1,
-                                          L.ptr(bias), 1, None, 0, L.ptr(zero), L.stream()), "conv")
+        L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, h, cp, dil, 0, L.ptr(wk), wk.stride(0), cout, L.ptr(y), cout, 1,
+                                             L.ptr(bias), 1, None, 0, L.ptr(zero), L.ptr(ws) if wsb else None, wsb, L.stream()), "conv")
     for _ in range(3): run()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -28,6 +30,6 @@ for li, (cin, cout, dil, h) in enumerate(layers):
     us = s.elapsed_time(e) * 100
     fl = 2.0 * m * cout * 9 * cin
     tot += us
-    print("conv%-2d  %4d->%4d dil %d  %3dx%-3d  M=%6d  %7.1f us  %6.1f TF (real FLOPs)  tiles %d" %
-          (li, cin, cout, dil, h, h, m, us, fl / us / 1e6, ((m + 127) // 128) * ((cout + 127) // 128)))
+    print("conv%-2d  %4d->%4d dil %d  %3dx%-3d  M=%6d  %7.1f us  %6.1f TF (real FLOPs)  tiles %d splits %d" %
+          (li, cin, cout, dil, h, h, m, us, fl / us / 1e6, ((m + 127) // 128) * ((cout + 127) // 128), wsb // (m * cout * 4)))
 print("forward total %.1f us" % tot)
