@@ -47,8 +47,10 @@ def parse():
     ap.add_argument("--arch", default="vgg16", choices=["vgg16", "r50"],
                     help="vgg16 = the headline workload (BASELINE.json configs[1]); r50 = the R-50-C5 config "
                          "(configs/voc/voc07_r50_c5_*.yaml), a secondary line")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="bracket the GEMM / conv launches of 1 timed step in N with HIP events (roofline object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-proposals", type=int, default=500)
+    ap.add_argument("--cpu-proposals", type=int, default=2000)
     return ap.parse_args()
 
 
@@ -153,10 +155,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
+        engine.kernel_timer.active = it % args.time_every == 0
         step_fn(images, targets, rois,
                 DeviceRand(seed + rank, first_stream=(1 << 20) + ((args.warmup + it) << 12), device=device))
     barrier()
     dt = time.perf_counter() - t0
+    engine.kernel_timer.active = True
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -166,6 +170,8 @@ def main():
 
     if rank == 0:
         roof = engine.kernel_timer.roofline(args.dtype, MFMA_PEAK_TFLOPS, HBM_PEAK_GBPS)
+        if roof is not None:
+            roof["timed_steps"] = "HIP events around every GEMM/conv launch of 1 timed step in %d" % args.time_every
         out = {
             "metric": "proposals/sec fwd+bwd (%s, %d proposals, %dpx)" % (ARCH_NAME[args.arch], args.proposals, args.size),
             "value": round(value, 1), "unit": "proposals/s", "n_gpus": world, "steps": args.steps,

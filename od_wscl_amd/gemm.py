@@ -116,8 +116,9 @@ class _FusedLinear(torch.autograd.Function):
         xb = x if x.dtype == torch.bfloat16 else to_bf16(x)
         xb = xb if xb.stride(1) == 1 and xb.stride(0) % 8 == 0 else xb.contiguous()
         y = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
-        with kernel_timer.region(timer_tag and "layer/" + timer_tag + "_fwd", flops=2.0 * M * N * K):
-            gemm_nt(xb, sh.w, M, N, K, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs)
+        kernel_timer.layer = timer_tag and timer_tag + "_fwd"
+        gemm_nt(xb, sh.w, M, N, K, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs)
+        kernel_timer.layer = None
         ctx.save_for_backward(xb, y if (relu or drop_p > 0) else None, weight, bias)
         ctx.cfg = (sh, relu, drop_p, x.dtype, timer_tag)
         return y
@@ -147,8 +148,9 @@ class _FusedLinear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=x_dtype, device=dy.device)
-            with kernel_timer.region(tag and "layer/" + tag + "_dgrad", flops=2.0 * M * N * K):
-                gemm_nt(dz, sh.wt, M, K, N, dx)
+            kernel_timer.layer = tag and tag + "_dgrad"
+            gemm_nt(dz, sh.wt, M, K, N, dx)
+            kernel_timer.layer = None
         dw = None
         if weight.requires_grad:
             xt = transpose_bf16(xb, M, K)
@@ -161,8 +163,9 @@ class _FusedLinear(torch.autograd.Function):
             else:                       # a derived weight (e.g. the concatenated predictor heads)
                 fresh = True
                 target = dw = torch.empty_like(weight)
-            with kernel_timer.region(tag and "layer/" + tag + "_wgrad", flops=2.0 * M * N * K):
-                gemm_nt(dzt, xt, N, K, M, target, accumulate=not fresh)
+            kernel_timer.layer = tag and tag + "_wgrad"
+            gemm_nt(dzt, xt, N, K, M, target, accumulate=not fresh)
+            kernel_timer.layer = None
         if bias is not None and not bias.is_leaf:
             raise RuntimeError("fused_linear: bias must be a leaf parameter or None")
         return dx, dw, None, None, None, None, None, None, None

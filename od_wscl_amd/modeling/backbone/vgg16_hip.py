@@ -44,13 +44,15 @@ def _layers_of(features):
     return out
 
 
-def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask, zero_page, st):
+def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask, zero_page, st, flops):
     """One implicit-GEMM convolution; the launcher's split-K workspace (deep layers) comes from torch's allocator."""
     ws_bytes = lib.odw_conv3x3_workspace(m, c, n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=y.device) if ws_bytes else None
-    L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, w, c, dil, mirror, L.ptr(wk), wk.stride(0), n, L.ptr(y), n, 1,
-                                         L.ptr(bias), 1 if relu else 0, L.ptr(mask), ldmask, L.ptr(zero_page),
-                                         L.ptr(ws), ws_bytes, st), "conv3x3")
+    sym = "conv3x3_glds_kernel<false> split-K+reduce" if ws_bytes else "conv3x3_glds_kernel<true>"
+    with kernel_timer.region(sym, flops=flops):
+        L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, w, c, dil, mirror, L.ptr(wk), wk.stride(0), n, L.ptr(y), n, 1,
+                                             L.ptr(bias), 1 if relu else 0, L.ptr(mask), ldmask, L.ptr(zero_page),
+                                             L.ptr(ws), ws_bytes, st), "conv3x3")
 
 
 class _VGGFn(torch.autograd.Function):
@@ -67,8 +69,8 @@ class _VGGFn(torch.autograd.Function):
         for l in net.layers:
             m = B * h * w
             y = torch.empty((m, l.cout), dtype=torch.bfloat16, device=dev)
-            with kernel_timer.region("conv3x3_glds_kernel<true>", flops=2.0 * m * l.cout * 9 * l.cin):
-                _conv3x3(lib, x, m, h, w, l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st)
+            _conv3x3(lib, x, m, h, w, l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
+                     2.0 * m * l.cout * 9 * l.cin)
             pre = None
             if l.pool:
                 pre = y
@@ -128,9 +130,8 @@ class _VGGFn(torch.autograd.Function):
                 prev = net.layers[li - 1]
                 dx = torch.empty((m, l.cin), dtype=torch.bfloat16, device=dev)
                 mask = x_in if (prev.relu and not prev.pool) else None
-                with kernel_timer.region("conv3x3_glds_kernel<true>", flops=2.0 * m * l.cout * 9 * l.cin):
-                    _conv3x3(lib, dz, m, h, w, l.cout, l.dil, 1, l.wd, l.cin, dx, None, False, mask,
-                             l.cin if mask is not None else 0, net.zero_page, st)
+                _conv3x3(lib, dz, m, h, w, l.cout, l.dil, 1, l.wd, l.cin, dx, None, False, mask,
+                         l.cin if mask is not None else 0, net.zero_page, st, 2.0 * m * l.cout * 9 * l.cin)
                 dz = dx
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 

@@ -8,10 +8,11 @@ import torch
 class _Region(object):
     """Context manager of one timed launch (a plain class: contextlib's generator wrapper costs more than the
     two event records it brackets)."""
-    __slots__ = ("timer", "name", "flops", "nbytes", "start")
+    __slots__ = ("timer", "name", "flops", "nbytes", "start", "layer")
 
     def __init__(self, timer, name, flops, nbytes):
         self.timer, self.name, self.flops, self.nbytes = timer, name, flops, nbytes
+        self.layer = timer.layer
 
     def __enter__(self):
         self.start = torch.cuda.Event(enable_timing=True)
@@ -21,7 +22,10 @@ class _Region(object):
     def __exit__(self, *exc):
         end = torch.cuda.Event(enable_timing=True)
         end.record()
-        self.timer.records.setdefault(self.name, []).append((self.start, end, self.flops, self.nbytes))
+        rec = (self.start, end, self.flops, self.nbytes)
+        self.timer.records.setdefault(self.name, []).append(rec)
+        if self.layer is not None:       # the same two events also feed the per-layer view
+            self.timer.records.setdefault("layer/" + self.layer, []).append(rec)
         return False
 
 
@@ -38,7 +42,9 @@ _NO_REGION = _NoRegion()
 
 class KernelTimer(object):
     def __init__(self):
-        self.enabled = False
+        self.enabled = False      # build-time switch (engine.build_training_step, ODW_NO_TIMER)
+        self.active = True        # per-step switch: bench.py times 1 step in `sample_every` (the event pairs cost
+        self.layer = None         # ~5 % of the step when every launch of every step carries them)
         self.reset()
 
     def reset(self):
@@ -46,7 +52,7 @@ class KernelTimer(object):
 
     def region(self, name, flops=0.0, nbytes=0.0):
         """with kernel_timer.region(symbol, flops=...): <one launch on torch's current stream>"""
-        if not self.enabled or name is None:
+        if not self.enabled or not self.active or name is None:
             return _NO_REGION
         return _Region(self, name, flops, nbytes)
 
