@@ -171,6 +171,14 @@ def main():
     if rank == 0:
         roof = engine.kernel_timer.roofline(args.dtype, MFMA_PEAK_TFLOPS, HBM_PEAK_GBPS)
         if roof is not None:
+            # memory-side bytes of the dominant launch from the committed PMC passes (rocprofv3 cannot run inside the
+            # timed region): FETCH_SIZE x 2 (gfx950 under-count of 16-B/lane reads) + WRITE_SIZE, per launch
+            tpath = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                t = json.load(open(tpath))
+                if t.get("kernel") == roof["kernel"]:
+                    roof["traffic"] = t["traffic_bytes"]
+                    roof["traffic_of"] = "%s; algorithmic %d B; %s" % (t["launch"], t["algorithmic_bytes"], t["source"])
             roof["timed_steps"] = "HIP events around every GEMM/conv launch of 1 timed step in %d" % args.time_every
         out = {
             "metric": "proposals/sec fwd+bwd (%s, %d proposals, %dpx)" % (ARCH_NAME[args.arch], args.proposals, args.size),

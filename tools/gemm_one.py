@@ -1,8 +1,12 @@
+"""The dominant launch of the step in isolation (for tools/pmc_gemm.sh): the stacked fc6 forward,
+gemm_nt_bf16_big_kernel<true, 0>, M=4000 N=4096 K=25088, bf16 output with bias + ReLU + dropout epilogue."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from od_wscl_amd import gemm
 M, N, K = 4000, 4096, 25088
 a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16(); b = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
-out = torch.empty(M, N, device="cuda")
-for _ in range(5): gemm.gemm_nt(a, b, M, N, K, out)
+bias = torch.randn(N, device="cuda")
+out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if os.environ.get("ODW_ONE_F32") != "1" else torch.float32)
+for _ in range(5):
+    gemm.gemm_nt(a, b, M, N, K, out, bias=bias, relu=True, drop_p=0.5, segs=[(0, 1, 2), (2000, 3, 4)])
 torch.cuda.synchronize()

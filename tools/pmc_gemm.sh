@@ -5,7 +5,8 @@ cd /tmp && export TMPDIR=/tmp
 var=${1:-ring}
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
-           "GRBM_GUI_ACTIVE GRBM_TA_BUSY TCC_HIT_sum TCC_MISS_sum" ; do
+           "GRBM_GUI_ACTIVE GRBM_TA_BUSY TCC_HIT_sum TCC_MISS_sum" \
+           "FETCH_SIZE" "WRITE_SIZE" ; do
   rm -rf /tmp/pmc_out
   ODW_GEMM_VARIANT=$var rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_out -o g -- python $root/tools/gemm_one.py > /dev/null 2>&1
   f=$(find /tmp/pmc_out -name "*counter_collection.csv" | head -1)
