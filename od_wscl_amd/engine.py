@@ -78,12 +78,26 @@ class FlatSGD(object):
         self.cfg, self.world = cfg, world
         self.momentum = cfg.SOLVER.MOMENTUM
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-        gemm_w = [(n, p) for n, p in named if self._is_gemm_weight(model, n, p)]
+        # the 8 predictor heads are evaluated as ONE GEMM (roi_weak_predictors.py): laid out back to back they ARE one
+        # (5C+12C) x 4096 matrix and one bias vector -- no torch.cat per step, one weight-gradient launch, one shadow
+        pred = getattr(getattr(model, "roi_heads", None), "predictor", None)
+        pred_w, pred_b = ([], [])
+        if (linear_layer.get_backend() == "hip_bf16" and hasattr(pred, "set_fused")
+                and os.environ.get("ODW_NO_PRED_FUSE") != "1"):
+            heads = [getattr(pred, h) for h in pred.head_names]
+            if all(h.weight.requires_grad and h.bias.requires_grad and h.weight.numel() % 4 == 0 for h in heads):
+                pred_w, pred_b = [h.weight for h in heads], [h.bias for h in heads]
+        pred_ids = set(id(p) for p in pred_w + pred_b)
+        name_of = {id(p): n for n, p in named}
+        gemm_w = [(n, p) for n, p in named if self._is_gemm_weight(model, n, p)] + [(name_of[id(p)], p) for p in pred_w]
         gemm_ids = set(id(p) for _, p in gemm_w)
         other_w = [(n, p) for n, p in named if id(p) not in gemm_ids and "bias" not in n]
-        biases = [(n, p) for n, p in named if "bias" in n]
+        biases = [(n, p) for n, p in named if "bias" in n and id(p) not in pred_ids] + [(name_of[id(p)], p) for p in pred_b]
         order = gemm_w + other_w + biases
-        sizes = [(p.numel() + 3) // 4 * 4 for _, p in order]     # keep every slice 16-byte aligned
+        # weights keep 16-byte-aligned slices (GEMM / conv operands); biases are packed back to back (only ever read
+        # as scalars or hit by atomics), which also makes the predictor's 8 bias vectors one contiguous vector
+        sizes = [p.numel() if "bias" in n else (p.numel() + 3) // 4 * 4 for n, p in order]
+        sizes[-1] += (-sum(sizes)) % 4
         total = sum(sizes)
         dev = order[0][1].device
         self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
@@ -116,16 +130,29 @@ class FlatSGD(object):
         self.shadows = []
         if gemm_w:
             from . import gemm
+
+            def managed_shadow(weight, o):
+                sh = gemm.Shadow(weight)
+                sh.w = self.flat_w16[o:o + weight.numel()].view(weight.shape)
+                sh.wt = torch.empty((weight.shape[1], (weight.shape[0] + 63) // 64 * 64), dtype=torch.bfloat16, device=dev)
+                sh.managed = True
+                self.shadows.append(sh)
+                return sh
+
             self.flat_w16 = torch.empty(n_gemm, dtype=torch.bfloat16, device=dev)
             for n, p in gemm_w:
-                mod = model.get_submodule(n.rsplit(".", 1)[0])
-                o, cnt = self.slices[n]
-                sh = gemm.Shadow(p)
-                sh.w = self.flat_w16[o:o + cnt].view(p.shape)
-                sh.wt = torch.empty((p.shape[1], (p.shape[0] + 63) // 64 * 64), dtype=torch.bfloat16, device=dev)
-                sh.managed = True
-                mod._shadow = sh
-                self.shadows.append(sh)
+                if id(p) in pred_ids:
+                    continue
+                model.get_submodule(n.rsplit(".", 1)[0])._shadow = managed_shadow(p, self.slices[n][0])
+            if pred_w:
+                ow, nw = self.slices[name_of[id(pred_w[0])]][0], sum(p.numel() for p in pred_w)
+                ob, nb = self.slices[name_of[id(pred_b[0])]][0], sum(p.numel() for p in pred_b)
+                w_cat = self.flat_p[ow:ow + nw].view(-1, pred_w[0].shape[1]).detach().requires_grad_(True)
+                b_cat = self.flat_p[ob:ob + nb].detach().requires_grad_(True)
+                w_cat.grad = self.flat_g[ow:ow + nw].view_as(w_cat)
+                b_cat.grad = self.flat_g[ob:ob + nb]
+                pred.set_fused(w_cat, b_cat, managed_shadow(w_cat, ow))
+                self.gemm_params.append(w_cat)
             self._refresh_shadows(initial=True)
 
     def _refresh_shadows(self, initial=False):

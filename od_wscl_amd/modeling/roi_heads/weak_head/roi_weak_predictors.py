@@ -27,15 +27,29 @@ class MISTPredictor(nn.Module):
                 nn.init.normal_(m.weight, mean=0, std=0.001)
                 nn.init.constant_(m.bias, 0)
 
+    head_names = _HEADS
+    _fused = None
+
+    def set_fused(self, w_cat, b_cat, shadow):
+        """engine.FlatSGD lays the 8 heads out back to back in its flat buffers and hands back the ONE
+        (5C+12C) x K weight / bias they form there (leaf tensors aliasing the heads' storage and gradients)."""
+        self._fused = (w_cat, b_cat, shadow)
+
     def forward(self, x, proposals):
         assert x.dim() == 2
         heads = [getattr(self, n) for n in _HEADS]
-        w = torch.cat([h.weight for h in heads], dim=0)
-        b = torch.cat([h.bias for h in heads], dim=0)
-        if get_backend() == "hip_bf16" and x.is_cuda:
+        if self._fused is not None and self.training and get_backend() == "hip_bf16" and x.is_cuda:
             from .... import gemm
+            w_cat, b_cat, shadow = self._fused
+            out = gemm.fused_linear(x, w_cat, b_cat, shadow, out_f32=True, tag="predictor")
+        elif get_backend() == "hip_bf16" and x.is_cuda:
+            from .... import gemm
+            w = torch.cat([h.weight for h in heads], dim=0)
+            b = torch.cat([h.bias for h in heads], dim=0)
             out = gemm.fused_linear(x, w, None, gemm.Shadow(w), out_f32=True, tag="predictor") + b
         else:
+            w = torch.cat([h.weight for h in heads], dim=0)
+            b = torch.cat([h.bias for h in heads], dim=0)
             out = F.linear(x, w, b)
         out = out.split([h.out_features for h in heads], dim=1)
         cls, det, r1, b1, r2, b2, r3, b3 = out

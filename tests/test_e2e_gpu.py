@@ -173,3 +173,38 @@ def test_bf16_mfma_backend_tracks_the_reference(name, weights_np):
         assert abs(gn - ref) <= 0.15 * ref, (gn, ref)
     finally:
         ll.set_backend("torch")
+
+
+def test_engine_step_fused_predictor_equals_unfused(monkeypatch):
+    """engine.FlatSGD lays the 8 predictor heads out as one matrix (one GEMM, no torch.cat, bias in the epilogue,
+    weight gradient written in place); the same two training steps with that layout switched off must give the
+    same losses and the same updated parameters up to bf16-GEMM re-association."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from od_wscl_amd import engine
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("ODW_NO_TIMER", "1")
+    out = {}
+    for fuse in (True, False):
+        monkeypatch.setenv("ODW_NO_PRED_FUSE", "0" if fuse else "1")
+        cfg = bench.build_cfg(21)
+        step, _ = engine.build_training_step(cfg, dev, dtype="bf16", world=1, seed=cfg.SEED, backend="hip")
+        images, targets, rois = bench.synthetic_batch(cfg.SEED, 0, 224, 150, 21, dev)
+        losses = []
+        for it in range(2):
+            l, _ = step(images, targets, rois, DeviceRand(cfg.SEED, first_stream=(1 << 20) + (it << 12), device=dev))
+            losses.append({k: float(v.detach()) for k, v in l.items()})
+        torch.cuda.synchronize()
+        opt = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, engine.FlatSGD)][0]
+        pred = {n: opt.flat_p[o:o + k].clone() for n, (o, k) in opt.slices.items() if "predictor" in n}
+        mom = {n: opt.flat_m[o:o + k].clone() for n, (o, k) in opt.slices.items() if "predictor" in n}
+        out[fuse] = (losses, pred, mom)
+    for it, (a, b) in enumerate(zip(out[True][0], out[False][0])):
+        for k in a:           # step 1: same weights, same draws; step 2 also carries the run-to-run noise of the atomics
+            assert abs(a[k] - b[k]) <= (1e-4, 1e-2)[it] * max(abs(b[k]), 1e-3), (it, k, a[k], b[k])
+    for n in out[True][1]:
+        ma, mb = out[True][2][n], out[False][2][n]                 # momentum after 2 steps = the gradients themselves
+        assert (ma - mb).abs().max().item() <= 2e-2 * mb.abs().max().item() + 1e-7, n
+        assert torch.allclose(out[True][1][n], out[False][1][n], rtol=0, atol=1e-6), n

@@ -14,5 +14,6 @@ find /tmp/prof_$name -name "*kernel_stats.csv" -exec cp {} $root/gpurun_out/$nam
 grep '^{"metric"' /tmp/prof_$name.log > $root/gpurun_out/$name/bench_line.txt
 trace=$(find /tmp/prof_$name -name "*kernel_trace.csv" | head -1)
 python $root/tools/trace_summary.py $trace $root/gpurun_out/$name/bench_line.txt > $root/gpurun_out/$name/steady_state.csv
+python $root/tools/trace_step.py $trace $root/gpurun_out/$name/bench_line.txt > $root/gpurun_out/$name/one_step.txt
 python $root/tools/trace_gaps.py $trace $root/gpurun_out/$name/bench_line.txt > $root/gpurun_out/$name/gaps.csv
 head -45 $root/gpurun_out/$name/steady_state.csv | cut -c1-200
