@@ -131,6 +131,11 @@ int odw_noise_mul(const float* x, float* out, int64_t n, uint32_t k0, uint32_t k
 int odw_od_assign(const float* boxes, int P, const float* gt_boxes, const int64_t* gt_classes,
                   const float* gt_scores, int G, float fg_thresh, float wx, float wy, float ww, float wh,
                   int64_t* labels, float* weights, float* targets, void* stream);
+/* Same assignment with the pseudo-GT given the way the discovery kernels emit them: int32 indices into `boxes` and
+ * int32 classes (no gather / widening kernels in between). */
+int odw_od_assign_indexed(const float* boxes, int P, const int* gt_index, const int* gt_classes,
+                          const float* gt_scores, int G, float fg_thresh, float wx, float wy, float ww, float wh,
+                          int64_t* labels, float* weights, float* targets, void* stream);
 
 /* ---- ROI-head GEMM on the bf16 matrix cores ---------------------------------------
  * C[M,N] (+)= epilogue( alpha * sum_k A[M,K] B[N,K] )   both operands bf16, K contiguous.

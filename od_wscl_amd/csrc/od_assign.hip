@@ -9,9 +9,12 @@ namespace {
 
 constexpr int kMaxGT = 2048;
 
+// INDEXED: the pseudo-GT are given as int32 indices into `boxes` (gt_boxes = the index list) with int32 classes --
+// the form the discovery kernels emit -- instead of gathered boxes + int64 classes.
+template <bool INDEXED>
 __global__ __launch_bounds__(256) void od_assign_kernel(const float* __restrict__ boxes, int P,
-                                                        const float* __restrict__ gt_boxes,
-                                                        const long long* __restrict__ gt_classes,
+                                                        const void* __restrict__ gt_boxes,
+                                                        const void* __restrict__ gt_classes,
                                                         const float* __restrict__ gt_scores, int G,
                                                         float fg_thresh, float wx, float wy, float ww, float wh,
                                                         long long* __restrict__ labels,
@@ -19,7 +22,8 @@ __global__ __launch_bounds__(256) void od_assign_kernel(const float* __restrict_
                                                         float* __restrict__ targets) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // G x 5: box + area
     for (int j = threadIdx.x; j < G; j += blockDim.x) {
-        float4 q = reinterpret_cast<const float4*>(gt_boxes)[j];
+        const float4 q = INDEXED ? reinterpret_cast<const float4*>(boxes)[reinterpret_cast<const int*>(gt_boxes)[j]]
+                                 : reinterpret_cast<const float4*>(gt_boxes)[j];
         sh[5 * j + 0] = q.x; sh[5 * j + 1] = q.y; sh[5 * j + 2] = q.z; sh[5 * j + 3] = q.w;
         sh[5 * j + 4] = (q.z - q.x + 1) * (q.w - q.y + 1);
     }
@@ -39,7 +43,9 @@ __global__ __launch_bounds__(256) void od_assign_kernel(const float* __restrict_
         const float iou = inter / (ap + sh[5 * j + 4] - inter);   // boxlist_ops.py:154-159
         if (iou > best) { best = iou; bj = j; }                    // first maximum (numpy argmax)
     }
-    labels[i] = best <= fg_thresh ? 0 : gt_classes[bj];            // bg test is <= (:183)
+    const long long cls = INDEXED ? (long long)reinterpret_cast<const int*>(gt_classes)[bj]
+                                  : reinterpret_cast<const long long*>(gt_classes)[bj];
+    labels[i] = best <= fg_thresh ? 0 : cls;                       // bg test is <= (:183)
     weights[i] = gt_scores[bj];
     // BoxCoder.encode(gt[bj], proposal i)
     const float ew = p.z - p.x + 1, eh = p.w - p.y + 1;
@@ -65,9 +71,24 @@ ODW_EXPORT int odw_od_assign(const float* boxes, int P, const float* gt_boxes, c
                 "od_assign: null pointer");
     ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)gt_boxes) & 15) == 0 &&
                 (((uintptr_t)targets) & 15) == 0, "od_assign: boxes/targets must be 16-byte aligned");
-    od_assign_kernel<<<(P + 255) / 256, 256, (size_t)G * 5 * 4, (hipStream_t)stream_>>>(
-        boxes, P, gt_boxes, (const long long*)gt_classes, gt_scores, G, fg_thresh, wx, wy, ww, wh,
+    od_assign_kernel<false><<<(P + 255) / 256, 256, (size_t)G * 5 * 4, (hipStream_t)stream_>>>(
+        boxes, P, gt_boxes, gt_classes, gt_scores, G, fg_thresh, wx, wy, ww, wh,
         (long long*)labels, weights, targets);
+    ODW_CHECK_LAUNCH("od_assign_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_od_assign_indexed(const float* boxes, int P, const int* gt_index, const int* gt_classes,
+                                     const float* gt_scores, int G, float fg_thresh, float wx, float wy, float ww,
+                                     float wh, int64_t* labels, float* weights, float* targets, void* stream_) {
+    ODW_REQUIRE(P >= 0 && G >= 1 && G <= kMaxGT, "od_assign_indexed: P=%d G=%d (1..%d pseudo-GT boxes)", P, G, kMaxGT);
+    if (P == 0) return ODW_OK;
+    ODW_REQUIRE(boxes && gt_index && gt_classes && gt_scores && labels && weights && targets,
+                "od_assign_indexed: null pointer");
+    ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)targets) & 15) == 0,
+                "od_assign_indexed: boxes/targets must be 16-byte aligned");
+    od_assign_kernel<true><<<(P + 255) / 256, 256, (size_t)G * 5 * 4, (hipStream_t)stream_>>>(
+        boxes, P, gt_index, gt_classes, gt_scores, G, fg_thresh, wx, wy, ww, wh, (long long*)labels, weights, targets);
     ODW_CHECK_LAUNCH("od_assign_kernel");
     return ODW_OK;
 }

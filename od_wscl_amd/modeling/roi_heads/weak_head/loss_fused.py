@@ -11,6 +11,7 @@ quirks Q1-Q12 kept) as `loss.RoIRegLossComputation`, restructured for the GPU:
   * SupCon features / weights are assembled with one gather each from the concatenated embedding
     matrix; the refinement losses use masked, fixed-shape expressions (no nonzero()).
 """
+import numpy as np
 import torch
 from torch.nn import functional as F
 
@@ -42,22 +43,30 @@ def _i32(values, device):
 
 
 class _Staging(object):
-    """Pinned host ring + device buffer for the few int32 values that DO change every step (bank offsets):
-    filled on the host, copied with a non-blocking in-stream memcpy."""
+    """Pinned host ring + device buffer for the int32 index lists that change every step (bank offsets, gather
+    indices built on the host from the lists the two blocking reads bring back): filled on the host, copied with ONE
+    non-blocking in-stream memcpy per stage."""
 
-    def __init__(self, device, slots=8, width=512):
+    def __init__(self, device, slots=8, width=1 << 16):
         self.host = torch.zeros((slots, width), dtype=torch.int32).pin_memory()
+        self.host_np = self.host.numpy()
         self.dev = torch.zeros((slots, width), dtype=torch.int32, device=device)
         self.slot, self.slots, self.width = 0, slots, width
 
-    def upload(self, values):
-        n = len(values)
-        assert n <= self.width
+    def upload(self, arrays):
+        """arrays: list of 1-D integer numpy arrays / lists -> list of int32 device views (one H2D copy)."""
         k = self.slot
         self.slot = (self.slot + 1) % self.slots
-        self.host[k, :n] = torch.tensor(values, dtype=torch.int32)
-        self.dev[k, :n].copy_(self.host[k, :n], non_blocking=True)
-        return self.dev[k, :n]
+        pos, views = 0, []
+        for a in arrays:
+            n = len(a)
+            if pos + n > self.width:
+                raise RuntimeError("fused loss: index staging buffer too small (%d > %d)" % (pos + n, self.width))
+            self.host_np[k, pos:pos + n] = a
+            views.append((pos, n))
+            pos += n
+        self.dev[k, :pos].copy_(self.host[k, :pos], non_blocking=True)
+        return [self.dev[k, o:o + n] for o, n in views]
 
 
 def _fused_base(tensors):
@@ -159,25 +168,34 @@ class RoIRegLossFused(RoIRegLossComputation):
         pos_cls = _i32([pc + [0] * (maxpos - len(pc)) for pc in pos_host], device)
         n_pos = _i32([len(pc) for pc in pos_host], device)
 
-        # ---- kernel A: tops + IoU-sampled row sets
+        # ---- kernel A: tops + IoU-sampled row sets.  One zero-filled int32 block holds its whole state; the part the
+        # host needs (counts, then the row lists) comes back in ONE blocking read, and every index list that depends
+        # on it is then built with numpy and uploaded in one copy -- not with a dozen 5-microsecond device kernels each
+        # of which the drained GPU would wait for
         w32 = (max_p + 31) // 32
-        tops = torch.zeros((n_img, 3, maxpos), dtype=torch.int32, device=device)
-        masks = torch.zeros((n_img, maxpos, w32), dtype=torch.int32, device=device)
-        rows = torch.empty((n_img, maxpos, max_p), dtype=torch.int32, device=device)
-        counts = torch.zeros((n_img, maxpos), dtype=torch.int32, device=device)
+        if getattr(self, "_staging", None) is None or self._staging.dev.device != device:
+            self._staging = _Staging(device)
+        n_cnt, n_rows, n_tops, n_masks = n_img * maxpos, n_img * maxpos * max_p, n_img * 3 * maxpos, n_img * maxpos * w32
+        state_a = torch.zeros(n_cnt + n_rows + n_tops + n_masks, dtype=torch.int32, device=device)
+        counts = state_a[:n_cnt].view(n_img, maxpos)
+        rows = state_a[n_cnt:n_cnt + n_rows].view(n_img, maxpos, max_p)
+        tops = state_a[n_cnt + n_rows:n_cnt + n_rows + n_tops].view(n_img, 3, maxpos)
+        masks = state_a[n_cnt + n_rows + n_tops:].view(n_img, maxpos, w32)
         L.check(lib.odw_discover_iou(L.ptr(srcs[0]), L.ptr(srcs[1]), L.ptr(srcs[2]), C, L.ptr(boxes_all),
                                      L.ptr(img_off), n_img, max_p, L.ptr(pos_cls), L.ptr(n_pos), maxpos,
                                      float(self.p_thres), L.ptr(tops), L.ptr(masks), L.ptr(rows), max_p,
                                      L.ptr(counts), L.stream()), "discover_iou")
-        counts_h = counts.tolist()                                            # host sync 1
+        host_a = state_a[:n_cnt + n_rows].cpu().numpy()                       # host sync 1
+        counts_h = host_a[:n_cnt].reshape(n_img, maxpos)
+        rows_h = host_a[n_cnt:].reshape(n_img, maxpos, max_p)
 
         # ---- stacked drop / noise passes of every (image, class)  (loss.py:292-305)
         parts, segs6, segs7, meta = [], [], [], []
         row0 = 0
         for idx in range(n_img):
             for ci, c in enumerate(pos_host[idx]):
-                k = counts_h[idx][ci]
-                r_img = rows[idx, ci, :k].long()
+                k = int(counts_h[idx][ci])
+                r_img = rows[idx, ci, :k]                    # int32 device view (index_select takes it as is)
                 # index_select, not x[rows]: the backward of advanced indexing (index_put_ with accumulate) sorts the
                 # indices and blocks the host on a device-to-host copy; index_select's backward is an atomic index_add_
                 picked = clean_pooled_feats[offs[idx]:offs[idx + 1]].index_select(0, r_img)
@@ -188,10 +206,10 @@ class RoIRegLossFused(RoIRegLossComputation):
                 parts += [drop.reshape(k, -1), noisy.reshape(k, -1)]
                 segs6 += [(row0,) + k6d, (row0 + k,) + k6n]
                 segs7 += [(row0,) + k7d, (row0 + k,) + k7n]
-                meta.append((idx, ci, c, k, row0, r_img))
+                meta.append((idx, ci, c, k, row0, rows_h[idx, ci, :k].astype(np.int64)))
                 row0 += 2 * k
                 if tr is not None:
-                    tr["iou_samples_%d_%d" % (idx, c)] = r_img.clone()
+                    tr["iou_samples_%d_%d" % (idx, c)] = r_img.long()
         n_seg = len(segs6)
         if n_seg > 4:       # more stacked passes than one launch carries dropout keys for: split
             emb = self._embed_in_chunks(feature_extractor, model_sim, parts, segs6, segs7)
@@ -200,35 +218,38 @@ class RoIRegLossFused(RoIRegLossComputation):
             emb = model_sim(feature_extractor._fc(x, segs6=segs6, segs7=segs7)).float()
         all_emb = torch.cat([sim_feature, emb], dim=0)            # rows: proposals, then the stacked views
 
-        # ---- class banks (pgt_collection, Q2: class-major over the images processed so far)
+        # ---- class banks (pgt_collection, Q2: class-major over the images processed so far): index lists on the host
         classes = sorted(set(c for pc in pos_host for c in pc))
         bank_parts = {c: [] for c in classes}
-        for (idx, ci, c, k, r0, r_img) in meta:
-            bank_parts[c] += [r_img + offs[idx], torch.arange(sum_p + r0, sum_p + r0 + 2 * k, device=device)]
-        bank_index, bank_off_h, bank_cnt_h = [], [0] * (C - 1), [0] * (C - 1)
+        for (idx, ci, c, k, r0, r_h) in meta:
+            bank_parts[c] += [r_h + offs[idx], np.arange(sum_p + r0, sum_p + r0 + 2 * k)]
+        bank_index_h, bank_off_h, bank_cnt_h = {}, [0] * (C - 1), [0] * (C - 1)
         pos = 0
         for c in classes:
-            ix = torch.cat(bank_parts[c])
-            bank_index.append(ix)
-            bank_off_h[c], bank_cnt_h[c] = pos, int(ix.numel())
-            pos += int(ix.numel())
-        bank_index_all = torch.cat(bank_index)
-        bank = all_emb.detach()[bank_index_all].contiguous()
-        if getattr(self, "_staging", None) is None or self._staging.dev.device != device:
-            self._staging = _Staging(device)
-        both = self._staging.upload(bank_off_h + bank_cnt_h)
-        bank_off, bank_cnt = both[:C - 1], both[C - 1:]
+            ix = np.concatenate(bank_parts[c])
+            bank_index_h[c] = ix
+            bank_off_h[c], bank_cnt_h[c] = pos, len(ix)
+            pos += len(ix)
+        bank_off, bank_cnt, bank_index_all = self._staging.upload(
+            [bank_off_h, bank_cnt_h, np.concatenate([bank_index_h[c] for c in classes])])
+        bank = all_emb.detach().index_select(0, bank_index_all)
 
-        # ---- kernel B: object discovery + pseudo-GT lists
+        # ---- kernel B: object discovery + pseudo-GT lists (state: one zero-filled block; counts + fresh lists first,
+        # they are what the host reads back)
         shp = (n_img, 3, maxpos)
-        inst_idx = torch.empty(shp + (max_p,), dtype=torch.int32, device=device)
-        fresh_idx = torch.empty(shp + (max_p,), dtype=torch.int32, device=device)
-        inst_cnt = torch.zeros(shp, dtype=torch.int32, device=device)
-        fresh_cnt = torch.zeros(shp, dtype=torch.int32, device=device)
-        gt_idx = torch.empty((n_img, 3, maxpos * max_p), dtype=torch.int32, device=device)
-        gt_cls = torch.empty((n_img, 3, maxpos * max_p), dtype=torch.int32, device=device)
+        nf = n_img * 3 * maxpos
+        n_gt = n_img * 3 * maxpos * max_p
+        state_b = torch.zeros(2 * nf + n_img * 3 + 2 * nf * max_p + 2 * n_gt, dtype=torch.int32, device=device)
+        o = 0
+        fresh_cnt = state_b[o:o + nf].view(shp); o += nf
+        gt_cnt = state_b[o:o + n_img * 3].view(n_img, 3); o += n_img * 3
+        inst_cnt = state_b[o:o + nf].view(shp); o += nf
+        fresh_idx = state_b[o:o + nf * max_p].view(shp + (max_p,)); o += nf * max_p
+        n_back = o
+        inst_idx = state_b[o:o + nf * max_p].view(shp + (max_p,)); o += nf * max_p
+        gt_idx = state_b[o:o + n_gt].view(n_img, 3, maxpos * max_p); o += n_gt
+        gt_cls = state_b[o:o + n_gt].view(n_img, 3, maxpos * max_p); o += n_gt
         gt_score = torch.empty((n_img, 3, maxpos * max_p), dtype=torch.float32, device=device)
-        gt_cnt = torch.zeros((n_img, 3), dtype=torch.int32, device=device)
         E = sim_feature.detach().contiguous()
         L.check(lib.odw_discover_sim(L.ptr(E), L.ptr(srcs[0]), L.ptr(srcs[1]), L.ptr(srcs[2]), C, L.ptr(boxes_all),
                                      L.ptr(img_off), n_img, max_p, L.ptr(pos_cls), L.ptr(n_pos), maxpos, L.ptr(tops),
@@ -236,38 +257,49 @@ class RoIRegLossFused(RoIRegLossComputation):
                                      max_p, L.ptr(inst_idx), L.ptr(inst_cnt), L.ptr(fresh_idx), L.ptr(fresh_cnt),
                                      L.ptr(gt_idx), L.ptr(gt_cls), L.ptr(gt_score), L.ptr(gt_cnt), L.stream()),
                 "discover_sim")
-        cnts_h = torch.cat([fresh_cnt.reshape(-1), gt_cnt.reshape(-1), inst_cnt.reshape(-1)]).tolist()   # host sync 2
-        nf = n_img * 3 * maxpos
-        fresh_h = [[cnts_h[(idx * 3 + i) * maxpos:(idx * 3 + i + 1) * maxpos] for i in range(3)] for idx in range(n_img)]
-        gt_h = [cnts_h[nf + idx * 3: nf + idx * 3 + 3] for idx in range(n_img)]
+        host_b = state_b[:n_back].cpu().numpy()                                # host sync 2
+        fresh_h = host_b[:nf].reshape(n_img, 3, maxpos)
+        gt_h = host_b[nf:nf + n_img * 3].reshape(n_img, 3)
+        inst_h = host_b[nf + n_img * 3:2 * nf + n_img * 3]
+        fresh_rows_h = host_b[2 * nf + n_img * 3:].reshape(n_img, 3, maxpos, max_p)
 
         # ---- SupCon inputs.  features: class-major (bank of the class, then its discoveries in loop
-        # order); weights: append order (Q1)
-        feat_index, feat_label = [], []
-        for c, bix in zip(classes, bank_index):
-            ix = [bix]
+        # order); weights: append order (Q1).  All gather indices are assembled on the host.
+        feat_parts, label_parts = [], []
+        for c in classes:
+            ix = [bank_index_h[c]]
             for idx in range(n_img):
                 if c in pos_host[idx]:
                     ci = pos_host[idx].index(c)
                     for i in range(3):
-                        ix.append(fresh_idx[idx, i, ci, :fresh_h[idx][i][ci]].long() + offs[idx])
-            ix = torch.cat(ix)
-            feat_index.append(ix)
-            feat_label.append(torch.full((ix.numel(),), c, dtype=torch.int32, device=device))
-        features = all_emb.index_select(0, torch.cat(feat_index))
-        labels = torch.cat(feat_label)
-        wparts = []
-        for (idx, ci, c, k, r0, r_img) in meta:                                      # loop 1 order
-            h = final_score[offs[idx]:offs[idx + 1]][r_img, c + 1] / colsum[idx][c + 1]   # Q12
-            wparts += [h, h, h]
+                        ix.append(fresh_rows_h[idx, i, ci, :fresh_h[idx, i, ci]].astype(np.int64) + offs[idx])
+            ix = np.concatenate(ix)
+            feat_parts.append(ix)
+            label_parts.append(np.full(len(ix), c, dtype=np.int64))
+        # weight of an entry = final_score[row, c+1] / colsum[image][c+1]  (Q12): flat indices into both tensors
+        fs_cols = final_score.shape[1]
+        if ybase is not None:
+            cs_flat, cs_ld, cs_off = colstat.view(-1), colstat.shape[1] * colstat.shape[2], 2 * colstat.shape[2]
+        else:
+            cs_mat = torch.stack(colsum)
+            cs_flat, cs_ld, cs_off = cs_mat.reshape(-1), cs_mat.shape[1], 0
+        w_fs, w_cs = [], []
+        for (idx, ci, c, k, r0, r_h) in meta:                                         # loop 1 order
+            f = (r_h + offs[idx]) * fs_cols + (c + 1)
+            w_fs += [f, f, f]
+            w_cs += [np.full(3 * k, idx * cs_ld + cs_off + c + 1, dtype=np.int64)]
         for idx in range(n_img):                                                      # loop 2 order
             for i in range(3):
                 for ci, c in enumerate(pos_host[idx]):
-                    f = fresh_idx[idx, i, ci, :fresh_h[idx][i][ci]].long()
-                    wparts.append(final_score[offs[idx]:offs[idx + 1]][f, c + 1] / colsum[idx][c + 1])
-        weights = torch.cat(wparts).detach()
+                    f = fresh_rows_h[idx, i, ci, :fresh_h[idx, i, ci]].astype(np.int64) + offs[idx]
+                    w_fs.append(f * fs_cols + (c + 1))
+                    w_cs.append(np.full(len(f), idx * cs_ld + cs_off + c + 1, dtype=np.int64))
+        feat_index, labels, w_fs_d, w_cs_d = self._staging.upload(
+            [np.concatenate(feat_parts), np.concatenate(label_parts), np.concatenate(w_fs), np.concatenate(w_cs)])
+        features = all_emb.index_select(0, feat_index)
+        weights = (final_score.detach().reshape(-1).index_select(0, w_fs_d)
+                   / cs_flat.detach().index_select(0, w_cs_d))
         if tr is not None:
-            inst_h = cnts_h[nf + n_img * 3:]
             for idx in range(n_img):
                 for i in range(3):
                     for ci, c in enumerate(pos_host[idx]):
@@ -287,10 +319,14 @@ class RoIRegLossFused(RoIRegLossComputation):
             sl = slice(offs[idx], offs[idx + 1])
             bx = boxes_all[sl]
             for i in range(n_ref):
-                g = gt_h[idx][i]
-                gi = gt_idx[idx, i, :g].long()
-                _C.od_assign(bx, bx[gi], gt_cls[idx, i, :g].long(), gt_score[idx, i, :g], self.od_layer.fg_thresh,
-                             self.od_layer.weights, out=(pseudo_all[i, sl], weight_all[i, sl], target_all[i, sl]))
+                g = int(gt_h[idx][i])
+                # pseudo-GT boxes are gathered inside the kernel from their int32 proposal indices
+                wts = self.od_layer.weights
+                L.check(lib.odw_od_assign_indexed(L.ptr(bx), bx.shape[0], L.ptr(gt_idx[idx, i]), L.ptr(gt_cls[idx, i]),
+                                                  L.ptr(gt_score[idx, i]), g, float(self.od_layer.fg_thresh),
+                                                  float(wts[0]), float(wts[1]), float(wts[2]), float(wts[3]),
+                                                  L.ptr(pseudo_all[i, sl]), L.ptr(weight_all[i, sl]),
+                                                  L.ptr(target_all[i, sl]), L.stream()), "od_assign_indexed")
                 if tr is not None:
                     tr["pseudo_%d_%d" % (idx, i)] = pseudo_all[i, sl].clone()
                     tr["weights_%d_%d" % (idx, i)] = weight_all[i, sl].clone()
