@@ -166,6 +166,18 @@ int odw_stack_clean_aug(const float* pooled, const float* block, const float* bl
                         void* out_bf16, int ld, void* stream);
 int odw_unstack_clean_aug_bwd(const void* dX, int dx_is_f32, int ld, const float* block, const float* block_sum,
                               int P, int C, int S, float* dpooled, void* stream);
+/* The two contrastive views of k sampled proposals of one (image, class) (loss.py:292-305: drop_pool and noise_pool
+ * of pooled[rows], vgg16.py:169-180) written straight into the bf16 GEMM operand: rows [out_row0, +k) =
+ * ((x * keep) * numel) / sum with keep = !(u < gamma), u the counter-based uniform draw (kd0,kd1) over (k, S) and
+ * sum = sum(keep) (left in keep_sum, a device scalar), rows [out_row0 + k, +k) = z*x + x with z the normal draw
+ * (kn0,kn1) over (k, C, S).  rows = int32 indices relative to row_base.  _bwd folds the gradient of those 2k rows
+ * back: dpooled[row_base + rows[r]] += ...  (launches on one stream are ordered; rows of one call are distinct). */
+int odw_rows_drop_noise(const float* pooled, const int* rows, int row_base, int k, int C, int S, float gamma,
+                        uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1, float* keep_sum, void* out_bf16,
+                        int ld, int out_row0, void* stream);
+int odw_rows_drop_noise_bwd(const void* dX, int dx_is_f32, int ld, int dx_row0, const int* rows, int row_base, int k,
+                            int C, int S, float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1,
+                            const float* keep_sum, float* dpooled, void* stream);
 /* Which kernel odw_gemm_nt_bf16 will launch for this product: 0 register-staged 128x128, 1 LDS-DMA 128x128,
  * 2 LDS-DMA 256x128 ring, 3 256x256 (per-kernel timing in bench.py names its roofline entry from this). */
 int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16);

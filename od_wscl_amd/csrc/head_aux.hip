@@ -9,6 +9,7 @@
 //   unstack : dX (2P, ld) bf16|fp32 --> d pooled fp32 (P, C, S) = dX[p] + ((dX[P+p] * block) * numel) / sum
 // `block` is the (P, S) keep mask after dilation (S = 7*7), `block_sum` its sum on the device (no host sync).
 #include "odw_common.h"
+#include "odw_rng.h"
 
 namespace {
 
@@ -95,6 +96,107 @@ __global__ __launch_bounds__(256) void unstack_clean_aug_kernel(const void* __re
     }
 }
 
+
+// ---- the contrastive views of the sampled rows (loss.py:292-305: drop_pool + noise_pool of pooled[rows]) ----------
+// For one (image, class): k sampled proposals -> 2k rows of the bf16 GEMM operand, rows [out_row0, +k) the
+// DropBlock(block 1) view ((x * keep) * numel) / sum with keep = !(u < gamma) drawn per (row, cell), rows
+// [out_row0 + k, +k) the noise view z*x + x with z ~ N(0,1) per element (Box-Muller on pairs, as noise_kernel).
+// The PyTorch rendition is 14 launches per class (gather, uniform, compare, cast, max-pool, 1-x, mul, mul, sum,
+// div, noise, cat, cast) in a phase where the GPU is drained and waits for each of them.
+__global__ __launch_bounds__(256) void rows_keep_sum_kernel(int n, float gamma, uint32_t k0, uint32_t k1,
+                                                            float* __restrict__ sum_out) {
+    __shared__ float red[256];
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += odw_uniform((uint32_t)i, k0, k1) < gamma ? 0.0f : 1.0f;
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *sum_out = red[0];          // a count <= 2^24: exact in fp32 whatever the order
+}
+
+__device__ __forceinline__ void normal_pair(uint32_t p, uint32_t k0, uint32_t k1, float& z0, float& z1) {
+    const float u1 = 1.0f - odw_uniform(2 * p, k0, k1);
+    const float t = 6.283185307179586f * odw_uniform(2 * p + 1, k0, k1);
+    const float r = sqrtf(-2.0f * logf(u1));
+    z0 = r * cosf(t);
+    z1 = r * sinf(t);
+}
+
+// BWD = false: out rows from pooled;  BWD = true: dpooled[rows[r]] += d(drop row) and d(noise row) folded back
+template <bool BWD, bool DX_F32>
+__global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __restrict__ pooled, const void* __restrict__ dXv,
+                                                              const int* __restrict__ rows, int row_base, int k, int CS,
+                                                              int S, float gamma, uint32_t kd0, uint32_t kd1,
+                                                              uint32_t kn0, uint32_t kn1,
+                                                              const float* __restrict__ keep_sum,
+                                                              unsigned short* __restrict__ out, int ld, int row0,
+                                                              float* __restrict__ dpooled) {
+    __shared__ float keep[kMaxS];
+    const int r = blockIdx.x;
+    for (int s = threadIdx.x; s < S; s += blockDim.x)
+        keep[s] = odw_uniform((uint32_t)(r * S + s), kd0, kd1) < gamma ? 0.0f : 1.0f;
+    __syncthreads();
+    const float sum = *keep_sum, numel = (float)((double)k * S);
+    const size_t src_row = (size_t)(row_base + rows[r]);
+    for (int q = threadIdx.x; q < CS / 4; q += blockDim.x) {
+        const int s0 = (q * 4) % S;
+        const uint32_t e = (uint32_t)r * (uint32_t)CS + (uint32_t)q * 4u;       // element index in the (k, C, S) draw
+        float z[4];
+        normal_pair(e / 2, kn0, kn1, z[0], z[1]);
+        normal_pair(e / 2 + 1, kn0, kn1, z[2], z[3]);
+        if (!BWD) {
+            const float4 v = *reinterpret_cast<const float4*>(pooled + src_row * CS + q * 4);
+            const float x[4] = {v.x, v.y, v.z, v.w};
+            unsigned short d[4], n[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int sidx = s0 + t;
+                sidx = sidx >= S ? sidx - S : sidx;
+                d[t] = f2bf(((x[t] * keep[sidx]) * numel) / sum);
+                n[t] = f2bf(z[t] * x[t] + x[t]);
+            }
+            *reinterpret_cast<uint2*>(out + (size_t)(row0 + r) * ld + q * 4) =
+                make_uint2((unsigned)d[0] | ((unsigned)d[1] << 16), (unsigned)d[2] | ((unsigned)d[3] << 16));
+            *reinterpret_cast<uint2*>(out + (size_t)(row0 + k + r) * ld + q * 4) =
+                make_uint2((unsigned)n[0] | ((unsigned)n[1] << 16), (unsigned)n[2] | ((unsigned)n[3] << 16));
+        } else {
+            float gd[4], gn[4];
+            if (DX_F32) {
+                const float* dX = reinterpret_cast<const float*>(dXv);
+                const float4 a = *reinterpret_cast<const float4*>(dX + (size_t)(row0 + r) * ld + q * 4);
+                const float4 b = *reinterpret_cast<const float4*>(dX + (size_t)(row0 + k + r) * ld + q * 4);
+                gd[0] = a.x; gd[1] = a.y; gd[2] = a.z; gd[3] = a.w;
+                gn[0] = b.x; gn[1] = b.y; gn[2] = b.z; gn[3] = b.w;
+            } else {
+                const unsigned short* dX = reinterpret_cast<const unsigned short*>(dXv);
+                const uint2 a = *reinterpret_cast<const uint2*>(dX + (size_t)(row0 + r) * ld + q * 4);
+                const uint2 b = *reinterpret_cast<const uint2*>(dX + (size_t)(row0 + k + r) * ld + q * 4);
+                gd[0] = bf2f(a.x & 0xffff); gd[1] = bf2f(a.x >> 16); gd[2] = bf2f(a.y & 0xffff); gd[3] = bf2f(a.y >> 16);
+                gn[0] = bf2f(b.x & 0xffff); gn[1] = bf2f(b.x >> 16); gn[2] = bf2f(b.y & 0xffff); gn[3] = bf2f(b.y >> 16);
+            }
+            float4* dst = reinterpret_cast<float4*>(dpooled + src_row * CS + q * 4);
+            float4 acc = *dst;                       // rows of one launch are distinct; launches are stream-ordered
+            float add[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int sidx = s0 + t;
+                sidx = sidx >= S ? sidx - S : sidx;
+                add[t] = ((gd[t] * keep[sidx]) * numel) / sum + (z[t] * gn[t] + gn[t]);
+            }
+            acc.x += add[0]; acc.y += add[1]; acc.z += add[2]; acc.w += add[3];
+            *dst = acc;
+        }
+    }
+    if (!BWD)
+        for (int c = CS + threadIdx.x; c < ld; c += blockDim.x) {
+            out[(size_t)(row0 + r) * ld + c] = 0;
+            out[(size_t)(row0 + k + r) * ld + c] = 0;
+        }
+}
+
 }  // namespace
 
 ODW_EXPORT int odw_stack_clean_aug(const float* pooled, const float* block, const float* block_sum, int P, int C,
@@ -127,5 +229,43 @@ ODW_EXPORT int odw_unstack_clean_aug_bwd(const void* dX, int dx_is_f32, int ld, 
     else
         unstack_clean_aug_kernel<false><<<P, 256, 0, stream>>>(dX, ld, block, block_sum, P, (int)cs, S, numel, dpooled);
     ODW_CHECK_LAUNCH("unstack_clean_aug_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_rows_drop_noise(const float* pooled, const int* rows, int row_base, int k, int C, int S,
+                                   float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1,
+                                   float* keep_sum, void* out_bf16, int ld, int out_row0, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(k >= 0 && C > 0 && S >= 4 && S <= kMaxS && row_base >= 0 && out_row0 >= 0, "rows_drop_noise: bad dims");
+    if (k == 0) return ODW_OK;
+    const long cs = (long)C * S;
+    ODW_REQUIRE(pooled && rows && keep_sum && out_bf16, "rows_drop_noise: null pointer");
+    ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0 && (long)k * cs < (1ll << 32), "rows_drop_noise: C*S=%ld, ld=%d", cs, ld);
+    ODW_REQUIRE((((uintptr_t)pooled) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0, "rows_drop_noise: alignment");
+    rows_keep_sum_kernel<<<1, 256, 0, stream>>>(k * S, gamma, kd0, kd1, keep_sum);
+    rows_drop_noise_kernel<false, false><<<k, 256, 0, stream>>>(pooled, nullptr, rows, row_base, k, (int)cs, S, gamma, kd0,
+                                                                kd1, kn0, kn1, keep_sum, (unsigned short*)out_bf16, ld,
+                                                                out_row0, nullptr);
+    ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_rows_drop_noise_bwd(const void* dX, int dx_is_f32, int ld, int dx_row0, const int* rows, int row_base,
+                                       int k, int C, int S, float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0,
+                                       uint32_t kn1, const float* keep_sum, float* dpooled, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(k >= 0 && C > 0 && S >= 4 && S <= kMaxS && row_base >= 0 && dx_row0 >= 0, "rows_drop_noise_bwd: bad dims");
+    if (k == 0) return ODW_OK;
+    const long cs = (long)C * S;
+    ODW_REQUIRE(dX && rows && keep_sum && dpooled, "rows_drop_noise_bwd: null pointer");
+    ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0, "rows_drop_noise_bwd: C*S=%ld, ld=%d", cs, ld);
+    ODW_REQUIRE((((uintptr_t)dX) & 15) == 0 && (((uintptr_t)dpooled) & 15) == 0, "rows_drop_noise_bwd: alignment");
+    if (dx_is_f32)
+        rows_drop_noise_kernel<true, true><<<k, 256, 0, stream>>>(nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1,
+                                                                  kn0, kn1, keep_sum, nullptr, ld, dx_row0, dpooled);
+    else
+        rows_drop_noise_kernel<true, false><<<k, 256, 0, stream>>>(nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1,
+                                                                   kn0, kn1, keep_sum, nullptr, ld, dx_row0, dpooled);
+    ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
     return ODW_OK;
 }

@@ -20,7 +20,7 @@ class _StackCleanAug(torch.autograd.Function):
     clean features, rows P..2P-1 the DropBlock view), one pass each way (csrc/head_aux.hip)."""
 
     @staticmethod
-    def forward(ctx, pooled, block, block_sum):
+    def forward(ctx, pooled, block, block_sum, holder):
         P, C, h, w = pooled.shape
         S = h * w
         pooled = pooled.contiguous()
@@ -29,6 +29,7 @@ class _StackCleanAug(torch.autograd.Function):
                                             out.stride(0), L.stream()), "stack_clean_aug")
         ctx.save_for_backward(block, block_sum)
         ctx.shape = (P, C, h, w)
+        ctx.holder = holder
         return out
 
     @staticmethod
@@ -40,7 +41,63 @@ class _StackCleanAug(torch.autograd.Function):
         L.check(L.lib().odw_unstack_clean_aug_bwd(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
                                                   L.ptr(block), L.ptr(block_sum), P, C, h * w, L.ptr(dp), L.stream()),
                 "unstack_clean_aug_bwd")
-        return dp, None, None
+        if ctx.holder is not None:          # gradients of the sampled-row views parked by _RowViews.backward
+            for fold in ctx.holder.pending:
+                fold(dp)
+            ctx.holder.pending = []
+            ctx.holder.done = True
+        return dp, None, None, None
+
+
+class _GradHolder(object):
+    """Where the gradient of `pooled` is assembled for one step: the sampled-row views (a later, smaller autograd
+    node that the engine runs first) park their contribution here and the stacked node folds it into the one dense
+    tensor it produces anyway -- instead of a second dense (P,C,7,7) tensor, a fill and a 600 MB add."""
+
+    def __init__(self):
+        self.pending, self.done = [], False
+
+
+class _RowViews(torch.autograd.Function):
+    """pooled[rows] of every (image, class) -> drop view and noise view, stacked as the bf16 GEMM operand
+    (csrc/head_aux.hip: rows_drop_noise_kernel); groups = [(row_base, rows int32 device view, k, keys...)]."""
+
+    @staticmethod
+    def forward(ctx, pooled, groups, holder, gamma):
+        _, C, h, w = pooled.shape
+        S = h * w
+        pooled = pooled.contiguous()
+        total = sum(g[2] for g in groups)
+        out = torch.empty((2 * total, C * S), dtype=torch.bfloat16, device=pooled.device)
+        sums = torch.empty(len(groups), dtype=torch.float32, device=pooled.device)
+        lib, st, row0 = L.lib(), L.stream(), 0
+        for gi, (base, rows, k, kd, kn) in enumerate(groups):
+            L.check(lib.odw_rows_drop_noise(L.ptr(pooled), L.ptr(rows), base, k, C, S, gamma, kd[0], kd[1], kn[0], kn[1],
+                                            L.ptr(sums[gi:]), L.ptr(out), out.stride(0), row0, st), "rows_drop_noise")
+            row0 += 2 * k
+        ctx.args = (groups, holder, gamma, tuple(pooled.shape), sums)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        groups, holder, gamma, shape, sums = ctx.args
+        _, C, h, w = shape
+        dx = dx if dx.stride(1) == 1 else dx.contiguous()
+
+        def fold(dp):
+            lib, st, row0 = L.lib(), L.stream(), 0
+            for gi, (base, rows, k, kd, kn) in enumerate(groups):
+                L.check(lib.odw_rows_drop_noise_bwd(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0), row0,
+                                                    L.ptr(rows), base, k, C, h * w, gamma, kd[0], kd[1], kn[0], kn[1],
+                                                    L.ptr(sums[gi:]), L.ptr(dp), st), "rows_drop_noise_bwd")
+                row0 += 2 * k
+
+        if holder is not None and not holder.done:
+            holder.pending.append(fold)          # the stacked node has not produced d(pooled) yet: it will fold this in
+            return None, None, None, None
+        dp = torch.zeros(shape, dtype=torch.float32, device=dx.device)
+        fold(dp)
+        return dp, None, None, None
 
 
 class TwoFCROIFeatureExtractor(nn.Module):
@@ -57,6 +114,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
             self.dropblock = DropBlock2D(block_size=3, drop_prob=0.3)
         self.sim_drop = DropBlock2D(block_size=1, drop_prob=0.3)
         self.rand = None
+        self._grad_holder = None
 
     def init_fc(self):
         for m in self.modules():
@@ -101,7 +159,11 @@ class TwoFCROIFeatureExtractor(nn.Module):
             # bf16 GEMM operand, one kernel folds both halves of its gradient back (same draws, same arithmetic)
             block = self.dropblock.keep_mask(P, pooled.shape[2], pooled.shape[3], pooled.device, self.rand)
             k4, k5 = self.rand.key(), self.rand.key()
-            x = _StackCleanAug.apply(pooled, block.contiguous(), block.sum())
+            if self._grad_holder is not None and self._grad_holder.pending:
+                raise RuntimeError("the gradient of the previous step's sampled-row views was parked for the stacked "
+                                   "fc6 node, whose backward never ran")
+            self._grad_holder = _GradHolder()
+            x = _StackCleanAug.apply(pooled, block.contiguous(), block.sum(), self._grad_holder)
             h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5])
             return h[:P], h[P:]
         aug = self.forward_dropblock(pooled) if hasattr(self, "dropblock") else pooled
@@ -109,6 +171,30 @@ class TwoFCROIFeatureExtractor(nn.Module):
         x = torch.cat([pooled.reshape(P, -1), aug.reshape(P, -1)], dim=0)
         h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5])
         return h[:P], h[P:]
+
+    _grad_holder = None
+
+    def sampled_row_views(self, pooled, groups):
+        """drop_pool and noise_pool of pooled[rows] for every (image, class) of the step, stacked for ONE
+        fc6/fc7 evaluation (loss.py:292-305).  groups = [(row_base, rows int32 device tensor, k)].  Returns
+        (x, segs6, segs7) with the random draws numbered in the reference's order (per group: drop mask, fc6, fc7 of
+        the drop view; noise, fc6, fc7 of the noise view), or None when the fused kernels do not apply."""
+        if not (linear_layer.get_backend() == "hip_bf16" and self.rand is not None and pooled.is_cuda
+                and pooled.dtype == torch.float32 and self.sim_drop.block_size == 1
+                and (pooled.shape[1] * pooled.shape[2] * pooled.shape[3]) % 64 == 0 and hasattr(self.rand, "key")):
+            return None
+        specs, segs6, segs7, row0 = [], [], [], 0
+        for base, rows, k in groups:
+            kd = self.rand.key()
+            k6d, k7d = self.rand.key(), self.rand.key()
+            kn = self.rand.key()
+            k6n, k7n = self.rand.key(), self.rand.key()
+            specs.append((base, rows, k, kd, kn))
+            segs6 += [(row0,) + k6d, (row0 + k,) + k6n]
+            segs7 += [(row0,) + k7d, (row0 + k,) + k7n]
+            row0 += 2 * k
+        x = _RowViews.apply(pooled, specs, self._grad_holder, float(self.sim_drop.drop_prob))
+        return x, segs6, segs7
 
     def forward(self, x, proposals):
         pooled = self.pooler(x, proposals)

@@ -190,32 +190,43 @@ class RoIRegLossFused(RoIRegLossComputation):
         rows_h = host_a[n_cnt:].reshape(n_img, maxpos, max_p)
 
         # ---- stacked drop / noise passes of every (image, class)  (loss.py:292-305)
-        parts, segs6, segs7, meta = [], [], [], []
+        meta, groups = [], []
         row0 = 0
         for idx in range(n_img):
             for ci, c in enumerate(pos_host[idx]):
                 k = int(counts_h[idx][ci])
-                r_img = rows[idx, ci, :k]                    # int32 device view (index_select takes it as is)
-                # index_select, not x[rows]: the backward of advanced indexing (index_put_ with accumulate) sorts the
-                # indices and blocks the host on a device-to-host copy; index_select's backward is an atomic index_add_
-                picked = clean_pooled_feats[offs[idx]:offs[idx + 1]].index_select(0, r_img)
+                groups.append((offs[idx], rows[idx, ci, :k], k))          # rows: int32 device view
+                meta.append((idx, ci, c, k, row0, rows_h[idx, ci, :k].astype(np.int64)))
+                row0 += 2 * k
+                if tr is not None:
+                    tr["iou_samples_%d_%d" % (idx, c)] = rows[idx, ci, :k].long()
+        views = feature_extractor.sampled_row_views(clean_pooled_feats, groups)
+        if views is not None:       # production path: gather + both views + bf16 cast = two launches per class
+            x, segs6, segs7 = views
+            embs = []
+            for s0 in range(0, len(segs6), 4):          # a GEMM launch carries the dropout keys of 4 stacked passes
+                a = segs6[s0][0]
+                b = segs6[s0 + 4][0] if s0 + 4 < len(segs6) else x.shape[0]
+                s6 = [(r - a, k0, k1) for (r, k0, k1) in segs6[s0:s0 + 4]]
+                s7 = [(r - a, k0, k1) for (r, k0, k1) in segs7[s0:s0 + 4]]
+                embs.append(model_sim(feature_extractor._fc(x[a:b], segs6=s6, segs7=s7)).float())
+            emb = embs[0] if len(embs) == 1 else torch.cat(embs, dim=0)
+        else:
+            parts, segs6, segs7 = [], [], []
+            for (base, r_img, k), m in zip(groups, meta):
+                picked = clean_pooled_feats[base:base + sizes[m[0]]].index_select(0, r_img)
                 drop = feature_extractor.drop_pool(picked)
                 k6d, k7d = rand.key(), rand.key()
                 noisy = feature_extractor.noise_pool(picked)
                 k6n, k7n = rand.key(), rand.key()
                 parts += [drop.reshape(k, -1), noisy.reshape(k, -1)]
-                segs6 += [(row0,) + k6d, (row0 + k,) + k6n]
-                segs7 += [(row0,) + k7d, (row0 + k,) + k7n]
-                meta.append((idx, ci, c, k, row0, rows_h[idx, ci, :k].astype(np.int64)))
-                row0 += 2 * k
-                if tr is not None:
-                    tr["iou_samples_%d_%d" % (idx, c)] = r_img.long()
-        n_seg = len(segs6)
-        if n_seg > 4:       # more stacked passes than one launch carries dropout keys for: split
-            emb = self._embed_in_chunks(feature_extractor, model_sim, parts, segs6, segs7)
-        else:
-            x = torch.cat(parts, dim=0)
-            emb = model_sim(feature_extractor._fc(x, segs6=segs6, segs7=segs7)).float()
+                segs6 += [(m[4],) + k6d, (m[4] + k,) + k6n]
+                segs7 += [(m[4],) + k7d, (m[4] + k,) + k7n]
+            if len(segs6) > 4:       # more stacked passes than one launch carries dropout keys for: split
+                emb = self._embed_in_chunks(feature_extractor, model_sim, parts, segs6, segs7)
+            else:
+                x = torch.cat(parts, dim=0)
+                emb = model_sim(feature_extractor._fc(x, segs6=segs6, segs7=segs7)).float()
         all_emb = torch.cat([sim_feature, emb], dim=0)            # rows: proposals, then the stacked views
 
         # ---- class banks (pgt_collection, Q2: class-major over the images processed so far): index lists on the host

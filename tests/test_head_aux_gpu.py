@@ -22,7 +22,7 @@ def test_stack_clean_aug_forward_backward(P, C, h, w):
     from od_wscl_amd.modeling.backbone.fc_extractor import _StackCleanAug
     x, keep = _inputs(P, C, h, w, 5)
     xs = x.clone().requires_grad_(True)
-    out = _StackCleanAug.apply(xs, keep, keep.sum())
+    out = _StackCleanAug.apply(xs, keep, keep.sum(), None)
     aug = x * keep[:, None] * keep.numel() / keep.sum()                       # drop_block.py:49-50, same order
     ref = torch.cat([x.reshape(P, -1), aug.reshape(P, -1)]).to(torch.bfloat16)
     assert out.dtype == torch.bfloat16 and out.shape == (2 * P, C * h * w)
@@ -76,5 +76,61 @@ def test_stacked_path_equals_unfused_path():
         # the unfused path hands fc6 an fp32 gradient, the fused one a bf16 gradient: 2^-8 relative
         d = (res[0][2] - res[1][2]).abs().max().item()
         assert d <= 1e-2 * res[1][2].abs().max().item(), d
+    finally:
+        ll.set_backend("torch")
+
+
+def test_sampled_row_views_equal_the_unfused_ops():
+    """sampled_row_views (gather + DropBlock(1) view + noise view + bf16 cast in two launches per class, gradient
+    folded into the stacked node's d(pooled)) against index_select -> drop_pool -> noise_pool -> cat: identical
+    draws, bit-identical bf16 operand, equal pooled gradient."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.config import make_defaults
+    from od_wscl_amd.layers import linear as ll
+    from od_wscl_amd.modeling.backbone.vgg16 import VGG16FC67ROIFeatureExtractor
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    cfg = make_defaults()
+    cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
+                         "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,), "DB.METHOD", "dropblock"])
+    ll.set_backend("hip_bf16")
+    try:
+        torch.manual_seed(1)
+        fe = VGG16FC67ROIFeatureExtractor(cfg, 512).cuda().train()
+        P = 60
+        pooled0 = torch.randn(P, 512, 7, 7, device="cuda").relu_()
+        rows_a = torch.tensor([3, 17, 18, 40, 59], dtype=torch.int32, device="cuda")
+        rows_b = torch.tensor([0, 17, 33], dtype=torch.int32, device="cuda")          # row 17 in both classes
+        groups = [(0, rows_a, 5), (0, rows_b, 3)]
+        gout = torch.randn(16, 512 * 49, device="cuda")
+        # fused: stacked node + row views sharing one gradient holder
+        fe.rand = DeviceRand(5)
+        p1 = pooled0.clone().requires_grad_(True)
+        c, a = fe.forward_clean_and_aug(p1)
+        x, s6, s7 = fe.sampled_row_views(p1, groups)
+        n1 = fe.rand.s.next
+        ((x.float() * gout).sum() + c.float().sum() + a.float().sum()).backward()
+        # unfused: the torch ops on gathered rows
+        fe.rand = DeviceRand(5)
+        p2 = pooled0.clone().requires_grad_(True)
+        c2, a2 = fe.forward_clean_and_aug(p2)
+        parts, t6 = [], []
+        for base, rows, k in groups:
+            picked = p2.index_select(0, rows)
+            drop = fe.drop_pool(picked)
+            k6, k7 = fe.rand.key(), fe.rand.key()
+            noisy = fe.noise_pool(picked)
+            k6n, k7n = fe.rand.key(), fe.rand.key()
+            parts += [drop.reshape(k, -1), noisy.reshape(k, -1)]
+            t6 += [k6, k6n]
+        x2 = torch.cat(parts).to(torch.bfloat16)
+        assert fe.rand.s.next == n1
+        assert [s[1:] for s in s6] == t6
+        assert torch.equal(x.view(torch.int16), x2.view(torch.int16))
+        ((torch.cat(parts) * gout.to(torch.bfloat16).float()).sum() + c2.float().sum() + a2.float().sum()).backward()
+        d = (p1.grad - p2.grad).abs().max().item()
+        assert d <= 2e-2 * p2.grad.abs().max().item(), d             # bf16 gradient of the stacked half on both sides
+        sel = torch.tensor([3, 17, 18, 33, 40], device="cuda")
+        assert (p1.grad[sel] - p2.grad[sel]).abs().max().item() <= 2e-2 * p2.grad[sel].abs().max().item()
     finally:
         ll.set_backend("torch")
