@@ -178,6 +178,11 @@ int odw_rows_drop_noise(const float* pooled, const int* rows, int row_base, int 
 int odw_rows_drop_noise_bwd(const void* dX, int dx_is_f32, int ld, int dx_row0, const int* rows, int row_base, int k,
                             int C, int S, float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1,
                             const float* keep_sum, float* dpooled, void* stream);
+/* Row-wise L2 normalisation of the (R x D) embeddings (Sim_Net.forward, sim_head/sim_net.py:25-26, F.normalize with
+ * eps): y = x / max(||x||, eps), norm[r] = ||x_r||; bwd: dx = (g - y (g.y)) / max(||x||, eps). */
+int odw_l2norm_rows(const float* x, int R, int D, float eps, float* y, float* norm, void* stream);
+int odw_l2norm_rows_bwd(const float* g, const float* y, const float* norm, int R, int D, float eps, float* dx,
+                        void* stream);
 /* Which kernel odw_gemm_nt_bf16 will launch for this product: 0 register-staged 128x128, 1 LDS-DMA 128x128,
  * 2 LDS-DMA 256x128 ring, 3 256x256 (per-kernel timing in bench.py names its roofline entry from this). */
 int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16);

@@ -44,6 +44,8 @@ SIGNATURES = {
     "odw_unstack_clean_aug_bwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "odw_rows_drop_noise": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_i, c_i, c_p]),
     "odw_rows_drop_noise_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_p]),
+    "odw_l2norm_rows": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "odw_l2norm_rows_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     "odw_gemm_nt_bf16_variant": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i]),
     "odw_gemm_nt_bf16_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "odw_gemm_nt_bf16_ws": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_p, c_p, c_i,

@@ -197,6 +197,41 @@ __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __res
         }
 }
 
+// ---- row-wise L2 normalisation of the 128-d embeddings (Sim_Net.forward, sim_head/sim_net.py:25-26: F.normalize) ------
+// y = x / max(||x||, eps); backward dx = (g - y (g.y)) / max(||x||, eps).  One wavefront per row; the PyTorch
+// rendition is 3 launches forward and ~12 backward, twice per step, in the latency-bound part of the step.
+template <bool BWD>
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ a, const float* __restrict__ y_in,
+                                                          const float* __restrict__ norm_in, int R, int D, float eps,
+                                                          float* __restrict__ out, float* __restrict__ norm_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* src = a + (size_t)row * D;
+    float acc = 0.0f;
+    if (!BWD) {
+        for (int j = lane; j < D; j += 64) acc += src[j] * src[j];
+    } else {
+        const float* y = y_in + (size_t)row * D;
+        for (int j = lane; j < D; j += 64) acc += src[j] * y[j];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (!BWD) {
+        const float n = sqrtf(acc);
+        const float d = fmaxf(n, eps);
+        for (int j = lane; j < D; j += 64) out[(size_t)row * D + j] = src[j] / d;
+        if (lane == 0) norm_out[row] = n;
+    } else {
+        const float n = norm_in[row];
+        const float d = fmaxf(n, eps);
+        const float* y = y_in + (size_t)row * D;
+        // below eps the forward is x / eps (no dependence on the norm): the projection term drops out
+        const float dot = n > eps ? acc : 0.0f;
+        for (int j = lane; j < D; j += 64) out[(size_t)row * D + j] = (src[j] - y[j] * dot) / d;
+    }
+}
+
 }  // namespace
 
 ODW_EXPORT int odw_stack_clean_aug(const float* pooled, const float* block, const float* block_sum, int P, int C,
@@ -267,5 +302,24 @@ ODW_EXPORT int odw_rows_drop_noise_bwd(const void* dX, int dx_is_f32, int ld, in
         rows_drop_noise_kernel<true, false><<<k, 256, 0, stream>>>(nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1,
                                                                    kn0, kn1, keep_sum, nullptr, ld, dx_row0, dpooled);
     ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_l2norm_rows(const float* x, int R, int D, float eps, float* y, float* norm, void* stream_) {
+    ODW_REQUIRE(R >= 0 && D >= 1, "l2norm_rows: bad dims R=%d D=%d", R, D);
+    if (R == 0) return ODW_OK;
+    ODW_REQUIRE(x && y && norm, "l2norm_rows: null pointer");
+    l2norm_rows_kernel<false><<<(R + 3) / 4, 256, 0, (hipStream_t)stream_>>>(x, nullptr, nullptr, R, D, eps, y, norm);
+    ODW_CHECK_LAUNCH("l2norm_rows_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_l2norm_rows_bwd(const float* g, const float* y, const float* norm, int R, int D, float eps,
+                                   float* dx, void* stream_) {
+    ODW_REQUIRE(R >= 0 && D >= 1, "l2norm_rows_bwd: bad dims R=%d D=%d", R, D);
+    if (R == 0) return ODW_OK;
+    ODW_REQUIRE(g && y && norm && dx, "l2norm_rows_bwd: null pointer");
+    l2norm_rows_kernel<true><<<(R + 3) / 4, 256, 0, (hipStream_t)stream_>>>(g, y, norm, R, D, eps, dx, nullptr);
+    ODW_CHECK_LAUNCH("l2norm_rows_kernel");
     return ODW_OK;
 }

@@ -253,7 +253,9 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             opt.begin_step()
             losses, accs = model(images, targets, rois, rand=rand)
             mark("forward")
-            loss = sum(losses.values())
+            loss = getattr(losses, "total", None)
+            if loss is None:
+                loss = sum(losses.values())
             loss.backward()
             mark("backward")
             opt.all_reduce()

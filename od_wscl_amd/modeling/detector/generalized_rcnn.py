@@ -33,5 +33,5 @@ class GeneralizedRCNN(nn.Module):
             features = self.backbone(images.tensors)
         x, result, losses, accuracy = self.roi_heads(features, rois, targets, model_cdb, iteration)
         if self.training:
-            return dict(losses), accuracy
+            return (losses if isinstance(losses, dict) else dict(losses)), accuracy
         return result

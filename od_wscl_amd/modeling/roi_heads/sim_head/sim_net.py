@@ -1,10 +1,36 @@
 """Sim_Net (wetectron/modeling/roi_heads/sim_head/sim_net.py:7-26): 4096 -> 4096 -> 128,
 L2-normalised rows.  On the gfx950 back end both Linears run on the MFMA GEMM (ReLU fused into
 the first epilogue, fp32 output from the second so the normalisation sees full precision)."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .... import _lib as L
 from ....layers.linear import Linear, get_backend
+
+
+class _L2NormRows(torch.autograd.Function):
+    """F.normalize(x, dim=1) of the (R, 128) embeddings as one launch each way (csrc/head_aux.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = x.contiguous()
+        R, D = x.shape
+        y = torch.empty_like(x)
+        norm = torch.empty(R, dtype=torch.float32, device=x.device)
+        L.check(L.lib().odw_l2norm_rows(L.ptr(x), R, D, eps, L.ptr(y), L.ptr(norm), L.stream()), "l2norm_rows")
+        ctx.save_for_backward(y, norm)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, norm = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        L.check(L.lib().odw_l2norm_rows_bwd(L.ptr(g), L.ptr(y), L.ptr(norm), y.shape[0], y.shape[1], ctx.eps, L.ptr(dx),
+                                            L.stream()), "l2norm_rows_bwd")
+        return dx, None
 
 
 class Sim_Net(nn.Module):
@@ -19,5 +45,8 @@ class Sim_Net(nn.Module):
     def forward(self, roi_feat):
         if get_backend() == "hip_bf16":
             h = self.mlp[0].fused(roi_feat, relu=True)
-            return F.normalize(self.mlp[2].fused(h, out_f32=True), dim=1)
+            e = self.mlp[2].fused(h, out_f32=True)
+            if e.is_cuda and e.dtype == torch.float32:
+                return _L2NormRows.apply(e, 1e-12)
+            return F.normalize(e, dim=1)
         return F.normalize(self.mlp(roi_feat), dim=1)

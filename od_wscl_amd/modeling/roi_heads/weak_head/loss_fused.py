@@ -85,6 +85,13 @@ def _fused_base(tensors):
     return base, offs
 
 
+class LossDict(dict):
+    """The loss dictionary of the reference plus `total`: the same sum, taken once over the kernel's loss vector
+    (sum(losses.values()) is 7 add kernels forward and 21 fill/copy/add kernels backward in the part of the step
+    where the GPU waits for every launch)."""
+    total = None
+
+
 class _DenseLossFn(torch.autograd.Function):
     """7 dense losses as one autograd node: the kernel already produced d(sum of losses)/dY; backward scales
     each head's columns by the incoming gradient of its loss."""
@@ -359,9 +366,10 @@ class RoIRegLossFused(RoIRegLossComputation):
             tot = out.sum(dim=0)
             col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
             dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
-            losses = {"loss_img": dense[0], "loss_sim": loss_sim}
+            losses = LossDict({"loss_img": dense[0], "loss_sim": loss_sim})
             for k in range(1, 7):
                 losses[names[k]] = dense[k]
+            losses.total = dense.sum() + loss_sim
             accs = {"acc_img": tot[7], "acc_ref0": tot[8], "acc_ref1": tot[9], "acc_ref2": tot[10]}
             return losses, accs
 

@@ -134,3 +134,24 @@ def test_sampled_row_views_equal_the_unfused_ops():
         assert (p1.grad[sel] - p2.grad[sel]).abs().max().item() <= 2e-2 * p2.grad[sel].abs().max().item()
     finally:
         ll.set_backend("torch")
+
+
+def test_l2norm_rows_kernels():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.nn.functional as F
+    from od_wscl_amd.modeling.roi_heads.sim_head.sim_net import _L2NormRows
+    x = torch.from_numpy(rng.normal(8, 1, 333 * 128).reshape(333, 128)).cuda()
+    x[5] = 0                                                   # all-zero row: y = 0, gradient g / eps
+    x[6] *= 1e-20
+    xs = x.clone().requires_grad_(True)
+    y = _L2NormRows.apply(xs, 1e-12)
+    xr = x.clone().requires_grad_(True)
+    ref = F.normalize(xr, dim=1)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+    g = torch.from_numpy(rng.normal(9, 1, 333 * 128).reshape(333, 128)).cuda()
+    g[5] = 0
+    g[6] = 0
+    y.backward(g)
+    ref.backward(g)
+    np.testing.assert_allclose(xs.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=2e-4, atol=2e-6)
