@@ -51,6 +51,18 @@ int odw_roi_pool_forward(const float* feat, const float* rois, float spatial_sca
 int odw_roi_pool_backward(const float* grad_out, const int32_t* argmax, const float* rois,
                           int B, int C, int H, int W, int R, int PH, int PW,
                           float* grad_in, void* stream);
+/* ROIPool fused with the operand staging of the first head GEMM (same pooling semantics as odw_roi_pool_forward:
+ * csrc/cuda/ROIPool_cuda.cu:17-108): X (2R x ld) bf16, row n = pooled features of ROI n flattened (C, PH, PW), row
+ * R+n = ((x * keep[n][bin]) * R*PH*PW) / *keep_sum (DropBlock2D.forward, drop_block.py:45-50; keep = NULL: only
+ * the R clean rows); argmax 16-bit (0xFFFF = empty bin; H*W < 65535).  _backward scatters the gradient of both halves
+ * of X -- plus E parked fp32 gradient rows `extra` belonging to ROIs `extra_roi` (the sampled-row views of the
+ * contrastive loss) -- through the argmax into grad_in (B, C, H, W) fp32. */
+int odw_roi_pool_stack_forward(const float* feat, const float* rois, float spatial_scale, int B, int C, int H, int W,
+                               int R, int PH, int PW, const float* keep, const float* keep_sum, void* X_bf16, int ld,
+                               void* argmax_u16, void* workspace, int64_t workspace_bytes, void* stream);
+int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld, const void* argmax_u16, const float* rois,
+                                const float* keep, const float* keep_sum, const float* extra, const int* extra_roi,
+                                int E, int B, int C, int H, int W, int R, int PH, int PW, float* grad_in, void* stream);
 
 /* ---- ROIAlign -------------------------------------------------------------
  * replaces _C.roi_align_forward / roi_align_backward
@@ -170,9 +182,10 @@ int odw_unstack_clean_aug_bwd(const void* dX, int dx_is_f32, int ld, const float
  * of pooled[rows], vgg16.py:169-180) written straight into the bf16 GEMM operand: rows [out_row0, +k) =
  * ((x * keep) * numel) / sum with keep = !(u < gamma), u the counter-based uniform draw (kd0,kd1) over (k, S) and
  * sum = sum(keep) (left in keep_sum, a device scalar), rows [out_row0 + k, +k) = z*x + x with z the normal draw
- * (kn0,kn1) over (k, C, S).  rows = int32 indices relative to row_base.  _bwd folds the gradient of those 2k rows
+ * (kn0,kn1) over (k, C, S).  rows = int32 indices relative to row_base; pooled = fp32 (P, C, S), or (src_is_bf16) the
+ * bf16 rows of a stacked operand with the output's row stride.  _bwd folds the gradient of those 2k rows
  * back: dpooled[row_base + rows[r]] += ...  (launches on one stream are ordered; rows of one call are distinct). */
-int odw_rows_drop_noise(const float* pooled, const int* rows, int row_base, int k, int C, int S, float gamma,
+int odw_rows_drop_noise(const void* pooled, int src_is_bf16, const int* rows, int row_base, int k, int C, int S, float gamma,
                         uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1, float* keep_sum, void* out_bf16,
                         int ld, int out_row0, void* stream);
 int odw_rows_drop_noise_bwd(const void* dX, int dx_is_f32, int ld, int dx_row0, const int* rows, int row_base, int k,

@@ -126,7 +126,7 @@ __device__ __forceinline__ void normal_pair(uint32_t p, uint32_t k0, uint32_t k1
 }
 
 // BWD = false: out rows from pooled;  BWD = true: dpooled[rows[r]] += d(drop row) and d(noise row) folded back
-template <bool BWD, bool DX_F32>
+template <bool BWD, bool DX_F32, bool SRC_BF16 = false>
 __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __restrict__ pooled, const void* __restrict__ dXv,
                                                               const int* __restrict__ rows, int row_base, int k, int CS,
                                                               int S, float gamma, uint32_t kd0, uint32_t kd1,
@@ -148,8 +148,14 @@ __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __res
         normal_pair(e / 2, kn0, kn1, z[0], z[1]);
         normal_pair(e / 2 + 1, kn0, kn1, z[2], z[3]);
         if (!BWD) {
-            const float4 v = *reinterpret_cast<const float4*>(pooled + src_row * CS + q * 4);
-            const float x[4] = {v.x, v.y, v.z, v.w};
+            float x[4];
+            if (SRC_BF16) {          // rows of the stacked bf16 operand itself (row stride ld)
+                const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(pooled) + src_row * ld + q * 4);
+                x[0] = bf2f(v.x & 0xffff); x[1] = bf2f(v.x >> 16); x[2] = bf2f(v.y & 0xffff); x[3] = bf2f(v.y >> 16);
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(pooled + src_row * CS + q * 4);
+                x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+            }
             unsigned short d[4], n[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -267,8 +273,8 @@ ODW_EXPORT int odw_unstack_clean_aug_bwd(const void* dX, int dx_is_f32, int ld, 
     return ODW_OK;
 }
 
-ODW_EXPORT int odw_rows_drop_noise(const float* pooled, const int* rows, int row_base, int k, int C, int S,
-                                   float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1,
+ODW_EXPORT int odw_rows_drop_noise(const void* pooled, int src_is_bf16, const int* rows, int row_base, int k, int C,
+                                   int S, float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1,
                                    float* keep_sum, void* out_bf16, int ld, int out_row0, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(k >= 0 && C > 0 && S >= 4 && S <= kMaxS && row_base >= 0 && out_row0 >= 0, "rows_drop_noise: bad dims");
@@ -278,9 +284,14 @@ ODW_EXPORT int odw_rows_drop_noise(const float* pooled, const int* rows, int row
     ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0 && (long)k * cs < (1ll << 32), "rows_drop_noise: C*S=%ld, ld=%d", cs, ld);
     ODW_REQUIRE((((uintptr_t)pooled) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0, "rows_drop_noise: alignment");
     rows_keep_sum_kernel<<<1, 256, 0, stream>>>(k * S, gamma, kd0, kd1, keep_sum);
-    rows_drop_noise_kernel<false, false><<<k, 256, 0, stream>>>(pooled, nullptr, rows, row_base, k, (int)cs, S, gamma, kd0,
-                                                                kd1, kn0, kn1, keep_sum, (unsigned short*)out_bf16, ld,
-                                                                out_row0, nullptr);
+    if (src_is_bf16)          // source rows have the same stride as the output (rows of one (2R x ld) operand)
+        rows_drop_noise_kernel<false, false, true><<<k, 256, 0, stream>>>((const float*)pooled, nullptr, rows, row_base, k,
+                                                                          (int)cs, S, gamma, kd0, kd1, kn0, kn1, keep_sum,
+                                                                          (unsigned short*)out_bf16, ld, out_row0, nullptr);
+    else
+        rows_drop_noise_kernel<false, false><<<k, 256, 0, stream>>>((const float*)pooled, nullptr, rows, row_base, k, (int)cs,
+                                                                    S, gamma, kd0, kd1, kn0, kn1, keep_sum,
+                                                                    (unsigned short*)out_bf16, ld, out_row0, nullptr);
     ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
     return ODW_OK;
 }

@@ -18,6 +18,7 @@
 //   * planes that do not fit in LDS fall back to direct global kernels.
 #include "odw_common.h"
 #include <float.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -185,6 +186,154 @@ __global__ void roi_pool_bwd_direct(const float* __restrict__ grad_out, const in
     }
 }
 
+
+// ---- ROIPool fused with the operand staging of the first head GEMM -------------------------------------------
+// Same plane-resident pooling, but the results leave the CU in the form the consumer wants: the bf16 (2R x C*nb)
+// stacked operand of fc6 (row n = pooled features of ROI n, row R+n = their DropBlock view ((x*keep)*numel)/sum,
+// head_aux.hip) and a 16-bit argmax -- 300 MB of writes instead of 400 MB fp32/int32 here plus 400 MB for the
+// separate stacking pass.  blockIdx.y splits the ROI list so that 128 channel groups x 4 chunks fill the chip.
+__device__ __forceinline__ unsigned short rp_f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float rp_bf2f(unsigned int h) { return __uint_as_float(h << 16); }
+
+constexpr int kStackThreads = 512;
+
+// The feature map of this path holds bf16 values (it comes from the bf16 backbone), so value and position fit ONE
+// 32-bit key: (order-preserving image of the 16 value bits) << 16 | (0xFFFF - cell).  The window scan is then one
+// LDS read + one v_max_u32 per cell -- max value AND first row-major position of it -- instead of read, compare,
+// two selects and a branch.  0 = "no cell" (every real key is >= 0x00800000).
+__device__ __forceinline__ unsigned rp_key(float v, int cell) {
+    const unsigned b = __float_as_uint(v) >> 16;
+    const unsigned ord = (b & 0x8000u) ? (~b & 0xFFFFu) : (b | 0x8000u);
+    return (ord << 16) | (0xFFFFu - (unsigned)cell);
+}
+
+// One workgroup = one channel plane (+ an ROI chunk).  Next to the keys T0 the plane's LDS holds three more
+// levels of a row-wise range-max table (T1/T2/T3[i] = max of the 2/4/8 keys starting at i): the maximum of a bin row
+// [ws, we) is max(Tk[ws], Tk[we - 2^k]) -- two LDS reads per bin row instead of one per cell, and no divergent
+// inner loop.  (Measured before: a straight per-cell scan, fp32 compare or key max, 2-byte or packed 8-byte stores:
+// 600-710 us for P = 2000 on 76x76x512 -- ~1 G cell visits at 15 % of the LDS read rate; the scan, not the
+// output traffic, bounds ROI pooling.)
+template <int PW_T>
+__global__ __launch_bounds__(kPlaneThreads) void roi_pool_stack_fwd_plane(
+    const float* __restrict__ feat, const int* __restrict__ tab, int C, int H, int W, int R, int PH, int PW_rt,
+    const float* __restrict__ keep, const float* __restrict__ keep_sum, unsigned short* __restrict__ X, int ld,
+    unsigned short* __restrict__ argmax) {
+    extern __shared__ __attribute__((aligned(16))) unsigned keys[];
+    const int PW = PW_T > 0 ? PW_T : PW_rt;
+    const int b = blockIdx.x / C;
+    const int c = blockIdx.x % C;
+    const int HW = H * W;
+    unsigned* T0 = keys;
+    unsigned* T1 = keys + HW;
+    unsigned* T2 = keys + 2 * HW;
+    unsigned* T3 = keys + 3 * HW;
+    {
+        const float* src = feat + ((size_t)b * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) T0[i] = rp_key(src[i], i);
+        __syncthreads();
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) T1[i] = max(T0[i], T0[min(i + 1, HW - 1)]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) T2[i] = max(T1[i], T1[min(i + 2, HW - 1)]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) T3[i] = max(T2[i], T2[min(i + 4, HW - 1)]);
+        __syncthreads();
+    }
+    const int nb = PH * PW;
+    const int ts = 1 + 2 * PH + 2 * PW;
+    const int n_lo = (int)((long long)R * blockIdx.y / gridDim.y), n_hi = (int)((long long)R * (blockIdx.y + 1) / gridDim.y);
+    const float numel = (float)((double)R * nb);
+    const float sum = keep ? *keep_sum : 1.0f;
+    int n = n_lo + threadIdx.x / nb;
+    int bin = threadIdx.x % nb;
+    const int dn = blockDim.x / nb, dr = blockDim.x % nb;
+    for (; n < n_hi; n += dn, bin += dr) {
+        if (bin >= nb) { bin -= nb; ++n; if (n >= n_hi) break; }
+        const int* t = tab + (size_t)n * ts;
+        if (t[0] != b) continue;
+        const int ph = bin / PW, pw = bin - ph * PW;
+        const int hs = t[1 + ph], he = t[1 + PH + ph];
+        const int ws = t[1 + 2 * PH + pw], we = t[1 + 2 * PH + PW + pw];
+        const int bw = we - ws;
+        unsigned best = 0;
+        if (bw > 0) {
+            if (bw >= 8) {
+                for (int h = hs; h < he; ++h) {
+                    const unsigned* row = T3 + h * W;
+                    for (int w = ws; w + 8 <= we; w += 8) best = max(best, row[w]);
+                    best = max(best, row[we - 8]);
+                }
+            } else {
+                const unsigned* tbl = bw >= 4 ? T2 : (bw >= 2 ? T1 : T0);
+                const int span = bw >= 4 ? 4 : (bw >= 2 ? 2 : 1);
+                for (int h = hs; h < he; ++h) best = max(best, max(tbl[h * W + ws], tbl[h * W + we - span]));
+            }
+        }
+        unsigned short vbits = 0, a = 0xFFFF;            // empty bin -> 0, no argmax (ROIPool_cuda.cu:47-56)
+        if (best) {
+            const unsigned ord = best >> 16;
+            vbits = (unsigned short)((ord & 0x8000u) ? (ord & 0x7FFFu) : (~ord & 0xFFFFu));
+            a = (unsigned short)(0xFFFFu - (best & 0xFFFFu));
+        }
+        const size_t col = (size_t)c * nb + bin;
+        X[(size_t)n * ld + col] = vbits;
+        if (keep) X[(size_t)(R + n) * ld + col] = rp_f2bf(((rp_bf2f(vbits) * keep[(size_t)n * nb + bin]) * numel) / sum);
+        argmax[(size_t)n * C * nb + col] = a;
+    }
+}
+
+// gradient of the stacked operand (both halves) + the parked gradients of the sampled-row views (E rows of fp32,
+// extra_roi[e] = ROI they belong to) scattered through the argmax into the feature planes, NCHW fp32 out
+template <int CG, bool DX_F32>
+__global__ __launch_bounds__(kPlaneThreads) void roi_pool_stack_bwd_plane(
+    const void* __restrict__ dXv, int ld, const unsigned short* __restrict__ argmax, const float* __restrict__ rois,
+    const float* __restrict__ keep, const float* __restrict__ keep_sum, const float* __restrict__ extra,
+    const int* __restrict__ extra_roi, int E, int C, int H, int W, int R, int nb, float* __restrict__ grad_in) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int groups = (C + CG - 1) / CG;
+    const int b = blockIdx.x / groups;
+    const int c0 = (blockIdx.x % groups) * CG;
+    const int nc = min(CG, C - c0);
+    const int HW = H * W;
+    for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) acc[i] = 0.0f;
+    __syncthreads();
+    const float numel = (float)((double)R * nb);
+    const float sum = keep ? *keep_sum : 1.0f;
+    const int per_roi = nc * nb;
+    int n = threadIdx.x / per_roi;
+    int r = threadIdx.x % per_roi;
+    const int dn = kPlaneThreads / per_roi, dr = kPlaneThreads % per_roi;
+    for (; n < R + E; n += dn, r += dr) {
+        if (r >= per_roi) { r -= per_roi; ++n; if (n >= R + E) break; }
+        const int roi = n < R ? n : extra_roi[n - R];
+        if ((int)rois[(size_t)roi * 5] != b) continue;
+        const int cl = r / nb, bin = r - cl * nb;
+        const size_t col = (size_t)(c0 + cl) * nb + bin;
+        const unsigned short a = argmax[(size_t)roi * C * nb + col];
+        if (a == 0xFFFF) continue;
+        float g;
+        if (n >= R) {
+            g = extra[(size_t)(n - R) * C * nb + col];
+        } else if (DX_F32) {
+            const float* dX = reinterpret_cast<const float*>(dXv);
+            g = dX[(size_t)n * ld + col];
+            if (keep) g += ((dX[(size_t)(R + n) * ld + col] * keep[(size_t)n * nb + bin]) * numel) / sum;
+        } else {
+            const unsigned short* dX = reinterpret_cast<const unsigned short*>(dXv);
+            g = rp_bf2f(dX[(size_t)n * ld + col]);
+            if (keep) g += ((rp_bf2f(dX[(size_t)(R + n) * ld + col]) * keep[(size_t)n * nb + bin]) * numel) / sum;
+        }
+        atomicAdd(&acc[cl * HW + a], g);
+    }
+    __syncthreads();
+    float* dst = grad_in + ((size_t)b * C + c0) * HW;
+    for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) dst[i] = acc[i];
+}
+
 // channels per workgroup: as many as fit while still giving every CU a workgroup
 int pick_cg(int B, int C, int HW) {
     const int cands[3] = {4, 2, 1};
@@ -300,5 +449,70 @@ ODW_EXPORT int odw_roi_pool_backward(const float* grad_out, const int32_t* argma
             break;
     }
     ODW_CHECK_LAUNCH("roi_pool_bwd_plane");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_roi_pool_stack_forward(const float* feat, const float* rois, float spatial_scale, int B, int C,
+                                          int H, int W, int R, int PH, int PW, const float* keep, const float* keep_sum,
+                                          void* X_bf16, int ld, void* argmax_u16, void* workspace,
+                                          int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(B >= 1 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 0, "roi_pool_stack_forward: bad dims");
+    if (R == 0) return ODW_OK;
+    ODW_REQUIRE(feat && rois && X_bf16 && argmax_u16 && (!keep || keep_sum), "roi_pool_stack_forward: null pointer");
+    ODW_REQUIRE((long)H * W < 65535, "roi_pool_stack_forward: %dx%d feature map does not fit a 16-bit argmax", H, W);
+    ODW_REQUIRE(ld >= C * PH * PW && PH * PW <= kStackThreads / 4, "roi_pool_stack_forward: ld=%d / pooled size", ld);
+    if (workspace_bytes < odw_roi_pool_workspace(R, PH, PW) || !workspace) {
+        odw_set_error("roi_pool_stack_forward: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                      (long long)odw_roi_pool_workspace(R, PH, PW));
+        return ODW_EWORKSPACE;
+    }
+    int* tab = (int*)workspace;
+    roi_bins_kernel<<<(R + 255) / 256, 256, 0, stream>>>(rois, spatial_scale, R, PH, PW, H, W, tab);
+    ODW_CHECK_LAUNCH("roi_bins_kernel");
+    const int HW = H * W;
+    ODW_REQUIRE((int64_t)4 * HW * 4 <= ODW_LDS_BYTES, "roi_pool_stack_forward: the 4-level table of a %dx%d plane does not fit in LDS", H, W);
+    const int groups = B * C;
+    int chunks = (ODW_NUM_CU + groups - 1) / groups;
+    chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
+    const size_t lds = (size_t)4 * HW * 4;
+    const dim3 grid((unsigned)groups, (unsigned)chunks);
+    if (PW == 7) {
+        ODW_CHECK_HIP(allow_lds(roi_pool_stack_fwd_plane<7>, lds), "roi_pool_stack_fwd_plane<7> attr");
+        roi_pool_stack_fwd_plane<7><<<grid, kPlaneThreads, lds, stream>>>(feat, tab, C, H, W, R, PH, PW, keep, keep_sum,
+                                                                         (unsigned short*)X_bf16, ld, (unsigned short*)argmax_u16);
+    } else {
+        ODW_CHECK_HIP(allow_lds(roi_pool_stack_fwd_plane<0>, lds), "roi_pool_stack_fwd_plane<0> attr");
+        roi_pool_stack_fwd_plane<0><<<grid, kPlaneThreads, lds, stream>>>(feat, tab, C, H, W, R, PH, PW, keep, keep_sum,
+                                                                         (unsigned short*)X_bf16, ld, (unsigned short*)argmax_u16);
+    }
+    ODW_CHECK_LAUNCH("roi_pool_stack_fwd_plane");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
+                                           const float* rois, const float* keep, const float* keep_sum,
+                                           const float* extra, const int* extra_roi, int E, int B, int C, int H, int W,
+                                           int R, int PH, int PW, float* grad_in, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(B >= 1 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 1 && E >= 0,
+                "roi_pool_stack_backward: bad dims");
+    ODW_REQUIRE(dX && argmax_u16 && rois && grad_in && (!keep || keep_sum) && (E == 0 || (extra && extra_roi)),
+                "roi_pool_stack_backward: null pointer");
+    const int HW = H * W, nb = PH * PW;
+    ODW_REQUIRE((int64_t)HW * 4 <= ODW_LDS_BYTES && nb <= kPlaneThreads / 4, "roi_pool_stack_backward: plane / pooled size");
+    const int cg = ((int64_t)2 * HW * 4 <= ODW_LDS_BYTES && (int64_t)B * ((C + 1) / 2) >= 2 * ODW_NUM_CU) ? 2 : 1;
+    const int grid = B * ((C + cg - 1) / cg);
+    const size_t lds = (size_t)cg * HW * 4;
+#define ODW_RPS_BWD(CGV, F32)                                                                                       \
+    do {                                                                                                            \
+        ODW_CHECK_HIP(allow_lds(roi_pool_stack_bwd_plane<CGV, F32>, lds), "roi_pool_stack_bwd_plane attr");         \
+        roi_pool_stack_bwd_plane<CGV, F32><<<grid, kPlaneThreads, lds, stream>>>(                                   \
+            dX, ld, (const unsigned short*)argmax_u16, rois, keep, keep_sum, extra, extra_roi, E, C, H, W, R, nb, grad_in); \
+    } while (0)
+    if (cg == 2) { if (dx_is_f32) ODW_RPS_BWD(2, true); else ODW_RPS_BWD(2, false); }
+    else { if (dx_is_f32) ODW_RPS_BWD(1, true); else ODW_RPS_BWD(1, false); }
+#undef ODW_RPS_BWD
+    ODW_CHECK_LAUNCH("roi_pool_stack_bwd_plane");
     return ODW_OK;
 }

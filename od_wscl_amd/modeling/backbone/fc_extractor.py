@@ -4,6 +4,8 @@ roi_heads/box_head/roi_box_feature_extractors.py:13-122 are the same code apart 
 positions of the Linear layers inside `classifier`).
 
 `rand` (a DeviceRand) carries the counter-based streams; every method draws in the reference's order."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -43,7 +45,7 @@ class _StackCleanAug(torch.autograd.Function):
                 "unstack_clean_aug_bwd")
         if ctx.holder is not None:          # gradients of the sampled-row views parked by _RowViews.backward
             for fold in ctx.holder.pending:
-                fold(dp)
+                fold(dp, False)
             ctx.holder.pending = []
             ctx.holder.done = True
         return dp, None, None, None
@@ -54,50 +56,123 @@ class _GradHolder(object):
     node that the engine runs first) park their contribution here and the stacked node folds it into the one dense
     tensor it produces anyway -- instead of a second dense (P,C,7,7) tensor, a fill and a 600 MB add."""
 
-    def __init__(self):
-        self.pending, self.done = [], False
+    def __init__(self, kind="dense"):
+        # kind "dense": folds accumulate into the (P,C,h,w) fp32 gradient of `pooled` (at row_base + rows);
+        # kind "extra": there is no pooled tensor (ROI pooling writes the stacked operand itself) -- folds fill an
+        #               (E, C*h*w) fp32 side buffer, one row per sampled entry, roi_index[e] = the ROI it belongs to
+        self.kind, self.pending, self.done, self.roi_index = kind, [], False, None
+
+
+_IOTA = {}
+
+
+def _iota(n, device):
+    """int32 0..n-1 on the device (cached, grown geometrically): identity row lists for the side buffer."""
+    t = _IOTA.get(str(device))
+    if t is None or t.numel() < n:
+        t = _IOTA[str(device)] = torch.arange(max(n, 4096), dtype=torch.int32, device=device)
+    return t[:n]
 
 
 class _RowViews(torch.autograd.Function):
-    """pooled[rows] of every (image, class) -> drop view and noise view, stacked as the bf16 GEMM operand
-    (csrc/head_aux.hip: rows_drop_noise_kernel); groups = [(row_base, rows int32 device view, k, keys...)]."""
+    """src[rows] of every (image, class) -> drop view and noise view, stacked as the bf16 GEMM operand
+    (csrc/head_aux.hip: rows_drop_noise_kernel); groups = [(row_base, rows int32 device view, k, keys...)];
+    src = the fp32 pooled tensor (P,C,h,w), or the bf16 stacked operand of _PoolStack (its first P rows)."""
 
     @staticmethod
-    def forward(ctx, pooled, groups, holder, gamma):
-        _, C, h, w = pooled.shape
-        S = h * w
-        pooled = pooled.contiguous()
+    def forward(ctx, src, groups, holder, gamma, S):
+        src = src.contiguous()
+        from_bf16 = src.dtype == torch.bfloat16
+        CS = src.shape[1] if from_bf16 else src.shape[1] * src.shape[2] * src.shape[3]
+        C = CS // S
         total = sum(g[2] for g in groups)
-        out = torch.empty((2 * total, C * S), dtype=torch.bfloat16, device=pooled.device)
-        sums = torch.empty(len(groups), dtype=torch.float32, device=pooled.device)
+        out = torch.empty((2 * total, CS), dtype=torch.bfloat16, device=src.device)
+        sums = torch.empty(len(groups), dtype=torch.float32, device=src.device)
         lib, st, row0 = L.lib(), L.stream(), 0
         for gi, (base, rows, k, kd, kn) in enumerate(groups):
-            L.check(lib.odw_rows_drop_noise(L.ptr(pooled), L.ptr(rows), base, k, C, S, gamma, kd[0], kd[1], kn[0], kn[1],
-                                            L.ptr(sums[gi:]), L.ptr(out), out.stride(0), row0, st), "rows_drop_noise")
+            L.check(lib.odw_rows_drop_noise(L.ptr(src), 1 if from_bf16 else 0, L.ptr(rows), base, k, C, S, gamma, kd[0],
+                                            kd[1], kn[0], kn[1], L.ptr(sums[gi:]), L.ptr(out), out.stride(0), row0, st),
+                    "rows_drop_noise")
             row0 += 2 * k
-        ctx.args = (groups, holder, gamma, tuple(pooled.shape), sums)
+        ctx.args = (groups, holder, gamma, tuple(src.shape), sums, C, S, from_bf16)
         return out
 
     @staticmethod
     def backward(ctx, dx):
-        groups, holder, gamma, shape, sums = ctx.args
-        _, C, h, w = shape
+        groups, holder, gamma, shape, sums, C, S, from_bf16 = ctx.args
         dx = dx if dx.stride(1) == 1 else dx.contiguous()
+        f32 = 1 if dx.dtype == torch.float32 else 0
 
-        def fold(dp):
-            lib, st, row0 = L.lib(), L.stream(), 0
+        def fold(target, identity_rows):
+            """accumulate d(src rows) into `target`: the dense fp32 gradient of pooled at the sampled rows, or
+            (identity_rows) the (E, C*S) side buffer at consecutive entries"""
+            lib, st, row0, e0 = L.lib(), L.stream(), 0, 0
             for gi, (base, rows, k, kd, kn) in enumerate(groups):
-                L.check(lib.odw_rows_drop_noise_bwd(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0), row0,
-                                                    L.ptr(rows), base, k, C, h * w, gamma, kd[0], kd[1], kn[0], kn[1],
-                                                    L.ptr(sums[gi:]), L.ptr(dp), st), "rows_drop_noise_bwd")
+                r = _iota(k, dx.device) if identity_rows else rows
+                L.check(lib.odw_rows_drop_noise_bwd(L.ptr(dx), f32, dx.stride(0), row0, L.ptr(r),
+                                                    e0 if identity_rows else base, k, C, S, gamma, kd[0], kd[1], kn[0],
+                                                    kn[1], L.ptr(sums[gi:]), L.ptr(target), st), "rows_drop_noise_bwd")
                 row0 += 2 * k
+                e0 += k
 
         if holder is not None and not holder.done:
-            holder.pending.append(fold)          # the stacked node has not produced d(pooled) yet: it will fold this in
-            return None, None, None, None
+            holder.pending.append(fold)          # the stacked node has not produced its gradient yet: it folds this in
+            return None, None, None, None, None
+        if from_bf16:      # (never taken in the training step) dense gradient of the stacked operand itself
+            d = torch.zeros((shape[0], C * S), dtype=torch.float32, device=dx.device)
+            fold(d, False)
+            return d.to(torch.bfloat16), None, None, None, None
         dp = torch.zeros(shape, dtype=torch.float32, device=dx.device)
-        fold(dp)
-        return dp, None, None, None
+        fold(dp, False)
+        return dp, None, None, None, None
+
+
+class _PoolStack(torch.autograd.Function):
+    """ROIPool of the feature map written directly as the stacked bf16 operand of the first head GEMM (rows 0..R-1
+    the pooled features, rows R..2R-1 their DropBlock view) with a 16-bit argmax; backward scatters the gradient of
+    both halves plus the parked gradients of the sampled-row views into d(features) (csrc/roi_pool.hip)."""
+
+    @staticmethod
+    def forward(ctx, feat, rois5, keep, keep_sum, holder, scale, ph, pw):
+        feat = feat.contiguous()
+        rois5 = rois5.contiguous().float()
+        B, C, H, W = feat.shape
+        R, nb = rois5.shape[0], ph * pw
+        x = torch.empty((2 * R, C * nb), dtype=torch.bfloat16, device=feat.device)
+        argmax = torch.empty((R, C * nb), dtype=torch.int16, device=feat.device)
+        lib = L.lib()
+        ws_bytes = lib.odw_roi_pool_workspace(R, ph, pw)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=feat.device)
+        L.check(lib.odw_roi_pool_stack_forward(L.ptr(feat), L.ptr(rois5), scale, B, C, H, W, R, ph, pw, L.ptr(keep),
+                                               L.ptr(keep_sum), L.ptr(x), x.stride(0), L.ptr(argmax), L.ptr(ws), ws_bytes,
+                                               L.stream()), "roi_pool_stack_forward")
+        ctx.save_for_backward(rois5, keep, keep_sum, argmax)
+        ctx.dims = (B, C, H, W, R, ph, pw)
+        ctx.holder = holder
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        rois5, keep, keep_sum, argmax = ctx.saved_tensors
+        B, C, H, W, R, ph, pw = ctx.dims
+        dx = dx if dx.stride(1) == 1 else dx.contiguous()
+        holder = ctx.holder
+        extra, roi_index, E = None, None, 0
+        if holder is not None and holder.pending:
+            roi_index = holder.roi_index
+            E = int(roi_index.numel())
+            extra = torch.zeros((E, C * ph * pw), dtype=torch.float32, device=dx.device)
+            for fold in holder.pending:
+                fold(extra, True)
+            holder.pending = []
+        if holder is not None:
+            holder.done = True
+        dfeat = torch.empty((B, C, H, W), dtype=torch.float32, device=dx.device)
+        L.check(L.lib().odw_roi_pool_stack_backward(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
+                                                    L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
+                                                    L.ptr(extra), L.ptr(roi_index), E, B, C, H, W, R, ph, pw,
+                                                    L.ptr(dfeat), L.stream()), "roi_pool_stack_backward")
+        return dfeat, None, None, None, None, None, None, None
 
 
 class TwoFCROIFeatureExtractor(nn.Module):
@@ -174,15 +249,26 @@ class TwoFCROIFeatureExtractor(nn.Module):
 
     _grad_holder = None
 
-    def sampled_row_views(self, pooled, groups):
+    def sampled_row_views(self, pooled, groups, roi_index=None):
         """drop_pool and noise_pool of pooled[rows] for every (image, class) of the step, stacked for ONE
-        fc6/fc7 evaluation (loss.py:292-305).  groups = [(row_base, rows int32 device tensor, k)].  Returns
-        (x, segs6, segs7) with the random draws numbered in the reference's order (per group: drop mask, fc6, fc7 of
-        the drop view; noise, fc6, fc7 of the noise view), or None when the fused kernels do not apply."""
+        fc6/fc7 evaluation (loss.py:292-305).  groups = [(row_base, rows int32 device tensor, k)]; `pooled` = the
+        fp32 pooled tensor, or the stacked bf16 operand forward_pool_clean_and_aug returned (then roi_index = the
+        int32 device list of the sampled ROIs, group after group).  Returns (x, segs6, segs7) with the random
+        draws numbered in the reference's order (per group: drop mask, fc6, fc7 of the drop view; noise, fc6, fc7
+        of the noise view), or None when the fused kernels do not apply."""
+        stacked = pooled.dim() == 2 and pooled.dtype == torch.bfloat16
+        res = self.pooler.output_size
+        S = res[0] * res[1]
         if not (linear_layer.get_backend() == "hip_bf16" and self.rand is not None and pooled.is_cuda
-                and pooled.dtype == torch.float32 and self.sim_drop.block_size == 1
-                and (pooled.shape[1] * pooled.shape[2] * pooled.shape[3]) % 64 == 0 and hasattr(self.rand, "key")):
+                and (stacked or pooled.dtype == torch.float32) and self.sim_drop.block_size == 1 and S >= 4
+                and (pooled[0].numel() % 64 == 0) and hasattr(self.rand, "key")):
+            if stacked:
+                raise RuntimeError("sampled_row_views: the stacked pooling path needs the fused kernels")
             return None
+        holder = self._grad_holder
+        if stacked:
+            assert holder is not None and holder.kind == "extra" and roi_index is not None
+            holder.roi_index = roi_index
         specs, segs6, segs7, row0 = [], [], [], 0
         for base, rows, k in groups:
             kd = self.rand.key()
@@ -193,8 +279,40 @@ class TwoFCROIFeatureExtractor(nn.Module):
             segs6 += [(row0,) + k6d, (row0 + k,) + k6n]
             segs7 += [(row0,) + k7d, (row0 + k,) + k7n]
             row0 += 2 * k
-        x = _RowViews.apply(pooled, specs, self._grad_holder, float(self.sim_drop.drop_prob))
+        x = _RowViews.apply(pooled, specs, holder, float(self.sim_drop.drop_prob), S)
         return x, segs6, segs7
+
+    def can_pool_stack(self, features):
+        """ROI pooling may write the stacked bf16 operand directly (csrc/roi_pool.hip: roi_pool_stack_*)."""
+        if not (linear_layer.get_backend() == "hip_bf16" and self.rand is not None and hasattr(self, "dropblock")
+                and self.training and len(features) == 1 and os.environ.get("ODW_NO_POOL_STACK") != "1"):
+            return False
+        f = features[0]
+        pool = self.pooler.poolers[0]
+        res = self.pooler.output_size
+        return (type(pool).__name__ == "ROIPool" and f.is_cuda and f.dtype == torch.float32 and f.dim() == 4
+                and f.shape[2] * f.shape[3] < 65535 and 4 * f.shape[2] * f.shape[3] * 4 <= 160 * 1024
+                and (f.shape[1] * res[0] * res[1]) % 64 == 0 and res[0] * res[1] <= 128)
+
+    def forward_pool_clean_and_aug(self, features, proposals):
+        """forward_pooler + forward_clean_and_aug with NO pooled tensor in between: the pooling kernel writes the
+        stacked (2P x C*7*7) bf16 operand (clean rows, DropBlock rows) and a 16-bit argmax.  Same random draws in
+        the same order.  Returns (clean_feats, aug_feats, stacked operand) -- the operand stands in for
+        `clean_pooled` in the loss (sampled_row_views reads its first P rows)."""
+        feat = features[0]
+        rois5 = self.pooler.convert_to_roi_format(proposals)
+        P = rois5.shape[0]
+        res = self.pooler.output_size
+        k1, k2 = self.rand.key(), self.rand.key()
+        block = self.dropblock.keep_mask(P, res[0], res[1], feat.device, self.rand)
+        k4, k5 = self.rand.key(), self.rand.key()
+        if self._grad_holder is not None and self._grad_holder.pending:
+            raise RuntimeError("the gradient of the previous step's sampled-row views was never folded")
+        self._grad_holder = _GradHolder("extra")
+        x = _PoolStack.apply(feat, rois5, block.contiguous(), block.sum(), self._grad_holder,
+                             float(self.pooler.poolers[0].spatial_scale), res[0], res[1])
+        h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5])
+        return h[:P], h[P:], x
 
     def forward(self, x, proposals):
         pooled = self.pooler(x, proposals)

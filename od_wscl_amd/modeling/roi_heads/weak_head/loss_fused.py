@@ -207,7 +207,23 @@ class RoIRegLossFused(RoIRegLossComputation):
                 row0 += 2 * k
                 if tr is not None:
                     tr["iou_samples_%d_%d" % (idx, c)] = rows[idx, ci, :k].long()
-        views = feature_extractor.sampled_row_views(clean_pooled_feats, groups)
+        # ---- class banks (pgt_collection, Q2: class-major over the images processed so far): index lists on the host,
+        # uploaded together with the list of sampled ROIs before the views are launched
+        classes = sorted(set(c for pc in pos_host for c in pc))
+        bank_parts = {c: [] for c in classes}
+        for (idx, ci, c, k, r0, r_h) in meta:
+            bank_parts[c] += [r_h + offs[idx], np.arange(sum_p + r0, sum_p + r0 + 2 * k)]
+        bank_index_h, bank_off_h, bank_cnt_h = {}, [0] * (C - 1), [0] * (C - 1)
+        pos = 0
+        for c in classes:
+            ix = np.concatenate(bank_parts[c])
+            bank_index_h[c] = ix
+            bank_off_h[c], bank_cnt_h[c] = pos, len(ix)
+            pos += len(ix)
+        bank_off, bank_cnt, bank_index_all, roi_index = self._staging.upload(
+            [bank_off_h, bank_cnt_h, np.concatenate([bank_index_h[c] for c in classes]),
+             np.concatenate([m[5] + offs[m[0]] for m in meta]) if meta else []])
+        views = feature_extractor.sampled_row_views(clean_pooled_feats, groups, roi_index)
         if views is not None:       # production path: gather + both views + bf16 cast = two launches per class
             x, segs6, segs7 = views
             embs = []
@@ -236,20 +252,6 @@ class RoIRegLossFused(RoIRegLossComputation):
                 emb = model_sim(feature_extractor._fc(x, segs6=segs6, segs7=segs7)).float()
         all_emb = torch.cat([sim_feature, emb], dim=0)            # rows: proposals, then the stacked views
 
-        # ---- class banks (pgt_collection, Q2: class-major over the images processed so far): index lists on the host
-        classes = sorted(set(c for pc in pos_host for c in pc))
-        bank_parts = {c: [] for c in classes}
-        for (idx, ci, c, k, r0, r_h) in meta:
-            bank_parts[c] += [r_h + offs[idx], np.arange(sum_p + r0, sum_p + r0 + 2 * k)]
-        bank_index_h, bank_off_h, bank_cnt_h = {}, [0] * (C - 1), [0] * (C - 1)
-        pos = 0
-        for c in classes:
-            ix = np.concatenate(bank_parts[c])
-            bank_index_h[c] = ix
-            bank_off_h[c], bank_cnt_h[c] = pos, len(ix)
-            pos += len(ix)
-        bank_off, bank_cnt, bank_index_all = self._staging.upload(
-            [bank_off_h, bank_cnt_h, np.concatenate([bank_index_h[c] for c in classes])])
         bank = all_emb.detach().index_select(0, bank_index_all)
 
         # ---- kernel B: object discovery + pseudo-GT lists (state: one zero-filled block; counts + fresh lists first,

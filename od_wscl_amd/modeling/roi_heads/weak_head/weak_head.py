@@ -52,8 +52,12 @@ class ROIWeakRegHead(nn.Module):
                 # backbone is still in backward.  (Hooked after the pooling backward, not before it: that kernel is
                 # as HBM-bound as the optimiser and the two would only slow each other down.)
                 features[0].register_hook(self._on_pooled_grad)
-            clean_pooled = fe.forward_pooler(features, proposals)
-            clean_feats, aug_feats = fe.forward_clean_and_aug(clean_pooled)
+            if self.DB_METHOD == "dropblock" and fe.can_pool_stack(features):
+                # pooling writes the stacked bf16 fc6 operand itself; it stands in for `clean_pooled` in the loss
+                clean_feats, aug_feats, clean_pooled = fe.forward_pool_clean_and_aug(features, proposals)
+            else:
+                clean_pooled = fe.forward_pooler(features, proposals)
+                clean_feats, aug_feats = fe.forward_clean_and_aug(clean_pooled)
             sim_feature = self.model_sim(clean_feats)
         else:
             clean_feats, clean_pooled = fe.forward(features, proposals)

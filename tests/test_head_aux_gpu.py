@@ -155,3 +155,59 @@ def test_l2norm_rows_kernels():
     y.backward(g)
     ref.backward(g)
     np.testing.assert_allclose(xs.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_pool_stack_equals_pool_then_stack():
+    """forward_pool_clean_and_aug (ROIPool writing the stacked bf16 operand + 16-bit argmax, sampled-row views read
+    from it, all gradients scattered by one kernel) against forward_pooler -> forward_clean_and_aug -> views on the
+    fp32 pooled tensor: identical draws, bit-identical operands and fc outputs, equal feature gradient."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.config import make_defaults
+    from od_wscl_amd.layers import linear as ll
+    from od_wscl_amd.modeling.backbone.vgg16 import VGG16FC67ROIFeatureExtractor
+    from od_wscl_amd.structures import BoxList
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    from od_wscl_amd import synthetic
+    cfg = make_defaults()
+    cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
+                         "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,), "DB.METHOD", "dropblock"])
+    ll.set_backend("hip_bf16")
+    try:
+        torch.manual_seed(2)
+        fe = VGG16FC67ROIFeatureExtractor(cfg, 512).cuda().train()
+        H = W = 160
+        feat0 = torch.randn(2, 512, H // 8, W // 8, device="cuda").relu_().bfloat16().float()   # bf16-valued, like the backbone's
+        props = []
+        for k, n in enumerate((37, 29)):
+            bx = torch.from_numpy(synthetic.make_proposals(3, k, n, H, W, min_size=12)).cuda()
+            bx[0] = torch.tensor([150.0, 150.0, 150.4, 150.3])          # degenerate box: single-cell / empty bins
+            props.append(BoxList(bx, (W, H), "xyxy"))
+        rows_a = torch.tensor([1, 5, 20], dtype=torch.int32, device="cuda")
+        rows_b = torch.tensor([0, 5, 28], dtype=torch.int32, device="cuda")
+        groups = [(0, rows_a, 3), (37, rows_b, 3)]
+        roi_index = torch.tensor([1, 5, 20, 37, 42, 65], dtype=torch.int32, device="cuda")
+        gx = torch.randn(12, 512 * 49, device="cuda")
+        out = {}
+        for fused in (True, False):
+            fe.rand = DeviceRand(11)
+            f = feat0.clone().requires_grad_(True)
+            if fused:
+                assert fe.can_pool_stack([f])
+                c, a, pooled = fe.forward_pool_clean_and_aug([f], props)
+                x, s6, s7 = fe.sampled_row_views(pooled, groups, roi_index)
+                stacked = pooled
+            else:
+                pooled = fe.forward_pooler([f], props)
+                c, a = fe.forward_clean_and_aug(pooled)
+                x, s6, s7 = fe.sampled_row_views(pooled, groups)
+                stacked = None
+            ((x.float() * gx).sum() + (c.float() ** 2).sum() + a.float().sum()).backward()
+            out[fused] = (c.float(), a.float(), x.clone(), f.grad.clone(), fe.rand.s.next, s6, stacked)
+        assert out[True][4] == out[False][4] and out[True][5] == out[False][5]
+        assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+        assert torch.equal(out[True][2].view(torch.int16), out[False][2].view(torch.int16))
+        ga, gb = out[True][3], out[False][3]
+        assert (ga - gb).abs().max().item() <= 1e-4 * gb.abs().max().item() + 1e-6, (ga - gb).abs().max().item()
+    finally:
+        ll.set_backend("torch")
