@@ -203,7 +203,7 @@ def test_engine_step_fused_predictor_equals_unfused(monkeypatch):
         out[fuse] = (losses, pred, mom)
     for it, (a, b) in enumerate(zip(out[True][0], out[False][0])):
         for k in a:           # step 1: same weights, same draws; step 2 also carries the run-to-run noise of the atomics
-            assert abs(a[k] - b[k]) <= (1e-4, 1e-2)[it] * max(abs(b[k]), 1e-3), (it, k, a[k], b[k])
+            assert abs(a[k] - b[k]) <= (1e-4, 5e-2)[it] * max(abs(b[k]), 1e-3), (it, k, a[k], b[k])
     for n in out[True][1]:
         ma, mb = out[True][2][n], out[False][2][n]                 # momentum after 2 steps = the gradients themselves
         assert (ma - mb).abs().max().item() <= 2e-2 * mb.abs().max().item() + 1e-7, n
