@@ -240,6 +240,22 @@ int odw_discover_sim(const float* E, const float* s0, const float* s1, const flo
                      float nms_thr, int pstride, int* inst_idx, int* inst_cnt, int* fresh_idx, int* fresh_cnt,
                      int* gt_idx, int* gt_cls, float* gt_score, int* gt_cnt, void* stream);
 
+/* ---- inference tail of the ROI head ------------------------------------------------------------
+ * replaces PostProcessor.forward + filter_results (modeling/roi_heads/box_head/inference.py:41-90,216-258; the
+ * weak variant roi_heads/weak_head/inference.py with reg = NULL) reached from ROIWeakRegHead.testing_forward
+ * (weak_head.py:124-145): BoxCoder.decode (box_coder.py:52-95, weights wx..wh, dw/dh clamped to xform_clip),
+ * BoxList.clip_to_image (bounding_box.py:218-229), per class j >= 1: candidates prob[:, j] > score_thresh,
+ * torchvision-semantics NMS (boxlist_ops.py:13-36).  One workgroup per (image, class).
+ *   prob (sumP, C) fp32; reg (sumP, ld_reg) fp32 (4*C columns, or 4 with cls_agnostic, or NULL = no decoding);
+ *   boxes (sumP, 4) xyxy; img_off (n_img+1) int32; img_wh (n_img, 2) fp32 = (width, height); max_p <= 4096
+ *   out_* : (n_img, C-1, pstride[, 4]) survivors of each class in kept order (descending score), out_count
+ *   (n_img, C-1).  The final "best max_det over all classes" (kthvalue, ties kept) is the caller's. */
+int odw_detect_postprocess(const float* prob, int C, const float* reg, int ld_reg, int cls_agnostic,
+                           const float* boxes, const int* img_off, const float* img_wh, int n_img, int max_p,
+                           float wx, float wy, float ww, float wh, float xform_clip, float score_thresh,
+                           float nms_thr, int pstride, float* out_boxes, float* out_scores, int* out_index,
+                           int* out_count, void* stream);
+
 /* ---- backbone convolutions (NHWC bf16, implicit GEMM on the MFMA tile) ----------------------
  * replaces the cuDNN convolutions behind torch.nn.Conv2d in VGG_Base
  * (modeling/backbone/vgg16.py:34-36,58-83: 3x3, stride 1, padding = dilation).

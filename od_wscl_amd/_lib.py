@@ -76,6 +76,8 @@ SIGNATURES = {
     "odw_wsddn_scores": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p]),
     "odw_refine_losses": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
                                 c_p, c_l, c_p]),
+    "odw_detect_postprocess": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
+                                     c_p, c_p, c_p, c_p, c_p]),
     "odw_od_assign_indexed": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
     "odw_od_assign": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
 }

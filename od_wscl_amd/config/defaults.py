@@ -72,6 +72,9 @@ def make_defaults():
     c.iou = 0.5          # unused by the loss (Q9)
     c.temp = 0.2
     c.loss = "supconv2"
+    c.TEST = CN()
+    c.TEST.BBOX_AUG = CN()
+    c.TEST.BBOX_AUG.ENABLED = False                           # :500
     c.OUTPUT_DIR = "."
     c.DTYPE = "float32"  # :559
     # build-specific switches (not in the reference)

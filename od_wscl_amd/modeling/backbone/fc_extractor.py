@@ -211,6 +211,8 @@ class TwoFCROIFeatureExtractor(nn.Module):
         several passes are stacked along the row dimension."""
         fc6, fc7 = self.fc6, self.fc7
         if not self.training:
+            if linear_layer.get_backend() == "hip_bf16" and x.is_cuda:      # inference: MFMA GEMMs, ReLU in the epilogue
+                return fc7.fused(fc6.fused(x, relu=True), relu=True)
             return torch.relu(fc7(torch.relu(fc6(x))))
         if self.rand is None:
             x = F.dropout(torch.relu(fc6(x)), 0.5, True)

@@ -1,0 +1,99 @@
+"""PostProcessor -- detections from class scores, box regression and proposals
+(wetectron/modeling/roi_heads/box_head/inference.py:12-90,216-282; the weak variant without regression:
+roi_heads/weak_head/inference.py:10-134).
+
+decode -> clip -> per-class (score > thresh, NMS) -> labels -> keep the best `detections_per_img` over all classes.
+On the GPU the first four stages are ONE kernel launch (csrc/detect.hip, one workgroup per (image, class)) and
+one small blocking read of the per-class counts; the reference runs a Python loop over the classes with a
+nonzero() synchronisation and an NMS launch per class."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .... import _lib as L
+from ....structures import BoxList
+from ...box_coder import BoxCoder
+
+
+class PostProcessor(nn.Module):
+    def __init__(self, score_thresh=0.05, nms=0.5, detections_per_img=100, box_coder=None,
+                 cls_agnostic_bbox_reg=False, bbox_aug_enabled=False, regression=True):
+        super().__init__()
+        self.score_thresh, self.nms, self.detections_per_img = score_thresh, nms, detections_per_img
+        self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(10.0, 10.0, 5.0, 5.0))
+        self.cls_agnostic_bbox_reg, self.bbox_aug_enabled, self.regression = cls_agnostic_bbox_reg, bbox_aug_enabled, regression
+
+    def forward(self, x, boxes, softmax_on=True):
+        """x = (class scores (sumP, C), box regression (sumP, 4C | 4)) -- or the scores alone for the weak variant;
+        boxes: list[BoxList] proposals.  Returns one BoxList per image with fields `scores`, `labels`."""
+        if self.regression:
+            class_logits, box_regression = x
+        else:
+            class_logits, box_regression, softmax_on = x, None, False
+        class_prob = F.softmax(class_logits, -1) if softmax_on else class_logits
+        L.need_gpu(class_prob, boxes[0].bbox)
+        if self.bbox_aug_enabled:
+            raise NotImplementedError("test-time augmentation merges un-filtered boxlists (engine/bbox_aug.py): not on this path yet")
+        if self.nms <= 0:
+            raise ValueError("MODEL.ROI_HEADS.NMS must be > 0")
+        dev = class_prob.device
+        sizes = [len(b) for b in boxes]
+        n_img, C, max_p = len(boxes), class_prob.shape[1], max(sizes)
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+        concat = torch.cat([b.bbox for b in boxes], dim=0).float().contiguous()
+        prob = class_prob.float().contiguous()
+        reg = None
+        if box_regression is not None:
+            reg = box_regression.reshape(offs[-1], -1).float()
+            if self.cls_agnostic_bbox_reg:
+                reg = reg[:, -4:]
+            reg = reg.contiguous()
+        img_off = torch.tensor(offs, dtype=torch.int32, device=dev)
+        img_wh = torch.tensor([[float(b.size[0]), float(b.size[1])] for b in boxes], dtype=torch.float32, device=dev)
+        out_boxes = torch.empty((n_img, C - 1, max_p, 4), dtype=torch.float32, device=dev)
+        out_scores = torch.empty((n_img, C - 1, max_p), dtype=torch.float32, device=dev)
+        out_index = torch.empty((n_img, C - 1, max_p), dtype=torch.int32, device=dev)
+        out_count = torch.zeros((n_img, C - 1), dtype=torch.int32, device=dev)
+        w = self.box_coder.weights
+        L.check(L.lib().odw_detect_postprocess(L.ptr(prob), C, L.ptr(reg), reg.shape[1] if reg is not None else 0,
+                                               1 if self.cls_agnostic_bbox_reg else 0, L.ptr(concat), L.ptr(img_off),
+                                               L.ptr(img_wh), n_img, max_p, float(w[0]), float(w[1]), float(w[2]), float(w[3]),
+                                               float(self.box_coder.bbox_xform_clip), float(self.score_thresh), float(self.nms),
+                                               max_p, L.ptr(out_boxes), L.ptr(out_scores), L.ptr(out_index), L.ptr(out_count),
+                                               L.stream()), "detect_postprocess")
+        counts = out_count.cpu().numpy()                               # the one blocking read
+        results = []
+        for i, b in enumerate(boxes):
+            bx, sc, lab, idx = [], [], [], []
+            for j in range(1, C):
+                k = int(counts[i, j - 1])
+                if k:
+                    bx.append(out_boxes[i, j - 1, :k])
+                    sc.append(out_scores[i, j - 1, :k])
+                    idx.append(out_index[i, j - 1, :k])
+                    lab.append(torch.full((k,), j, dtype=torch.int64, device=dev))
+            if bx:
+                bx, sc, lab, idx = torch.cat(bx), torch.cat(sc), torch.cat(lab), torch.cat(idx)
+            else:
+                bx, sc = torch.zeros((0, 4), device=dev), torch.zeros((0,), device=dev)
+                lab, idx = torch.zeros((0,), dtype=torch.int64, device=dev), torch.zeros((0,), dtype=torch.int32, device=dev)
+            n = int(sc.numel())
+            if n > self.detections_per_img > 0:                        # inference.py:246-255: ties at the cut are kept
+                thresh, _ = torch.kthvalue(sc.cpu(), n - self.detections_per_img + 1)
+                keep = torch.nonzero(sc >= thresh.item(), as_tuple=False).squeeze(1)
+                bx, sc, lab, idx = bx[keep], sc[keep], lab[keep], idx[keep]
+            r = BoxList(bx, b.size, mode="xyxy")
+            r.add_field("scores", sc)
+            r.add_field("labels", lab)
+            r.add_field("proposal_index", idx.long())
+            results.append(r)
+        return results
+
+
+def make_roi_box_post_processor(cfg, regression=True):
+    """box_head/inference.py:268-282 (regression) and weak_head/inference.py:136-146 (scores only)."""
+    return PostProcessor(cfg.MODEL.ROI_HEADS.SCORE_THRESH, cfg.MODEL.ROI_HEADS.NMS, cfg.MODEL.ROI_HEADS.DETECTIONS_PER_IMG,
+                         BoxCoder(weights=cfg.MODEL.ROI_HEADS.BBOX_REG_WEIGHTS), cfg.MODEL.CLS_AGNOSTIC_BBOX_REG,
+                         cfg.TEST.BBOX_AUG.ENABLED, regression=regression)

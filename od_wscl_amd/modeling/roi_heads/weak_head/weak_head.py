@@ -5,6 +5,7 @@ from torch import nn
 
 from ... import registry
 from ..sim_head.sim_net import Sim_Net
+from ..box_head.inference import make_roi_box_post_processor
 from .loss import make_roi_weak_loss_evaluator
 from .roi_weak_predictors import make_roi_weak_predictor
 
@@ -19,6 +20,8 @@ class ROIWeakRegHead(nn.Module):
         self.HEUR = cfg.MODEL.ROI_WEAK_HEAD.REGRESS_HEUR
         self.DB_METHOD = cfg.DB.METHOD
         self.model_sim = Sim_Net(cfg, self.feature_extractor.out_channels)
+        self.weak_post_processor = make_roi_box_post_processor(cfg, regression=False)
+        self.strong_post_processor = make_roi_box_post_processor(cfg, regression=True)
 
     head_grads_ready = None      # engine.FlatSGD installs its early-step callback here
 
@@ -37,13 +40,24 @@ class ROIWeakRegHead(nn.Module):
             return self.feature_extractor.forward_dropblock(pooled, proposals)
         raise ValueError("DB.METHOD %r is outside the OD-WSCL hot path" % self.DB_METHOD)
 
+    def testing_forward(self, cls_score, det_score, proposals, ref_scores=None, ref_bbox_preds=None):
+        """weak_head.py:124-145: scores already softmax-ed by the predictor's eval branch."""
+        if self.HEUR == "WSDDN":
+            return self.weak_post_processor(cls_score * det_score, proposals)
+        if self.HEUR == "CLS-AVG":
+            return self.weak_post_processor(torch.mean(torch.stack(ref_scores), dim=0), proposals)
+        if self.HEUR == "AVG":
+            final_score = torch.mean(torch.stack(ref_scores), dim=0)
+            final_regression = torch.mean(torch.stack(ref_bbox_preds), dim=0)
+            return self.strong_post_processor((final_score, final_regression), proposals, softmax_on=False)
+        raise ValueError("REGRESS_HEUR %r is outside the OD-WSCL path" % self.HEUR)
+
     def forward(self, features, proposals, targets=None, model_cdb=None, iteration=None):
         fe = self.feature_extractor
         if not self.training:
             clean_feats, clean_pooled = fe.forward(features, proposals)
             cls, det, refs, boxes = self.predictor(clean_feats, proposals)
-            final = torch.mean(torch.stack(refs), dim=0)
-            return clean_feats, (final, torch.mean(torch.stack(boxes), dim=0)), {}, {}
+            return clean_feats, self.testing_forward(cls, det, proposals, refs, boxes), {}, {}
         if fe.rand is not None and self.DB_METHOD in ("dropblock", "none"):
             # clean pass + DropBlock pass as one stacked fc6/fc7 evaluation (same draws, same order)
             if self.head_grads_ready is not None and features[0].requires_grad:

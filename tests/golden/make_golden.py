@@ -308,6 +308,56 @@ def gen_e2e(name, spec, out):
     return rec
 
 
+def gen_infer(name, spec, out):
+    """Eval-mode forward of the imported reference (single scale: TEST.BBOX_AUG.ENABLED False): the detections
+    PostProcessor returns for each image."""
+    from oracle import hotpath_ref as H
+    from oracle import inference_ref as I
+    refimport.load_reference()
+    from wetectron.structures.bounding_box import BoxList
+    from wetectron.structures.image_list import to_image_list
+    cfg = refimport.reference_cfg(opts=CFG_OPTS + ["MODEL.ROI_BOX_HEAD.POOLER_METHOD", spec["pooler"],
+                                                    "TEST.BBOX_AUG.ENABLED", False])
+    model = refimport.build_reference_model(cfg)
+    model.eval()
+    seed = spec["seed"]
+    shapes = [(n, tuple(p.shape)) for n, p in model.named_parameters()]
+    sd = synthetic.init_state_dict(shapes, WEIGHT_SEED, overrides=OVERRIDES)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(sd[n]))
+    imgs, rois, boxes_np = [], [], []
+    for k, (h, w, pcount) in enumerate(spec["images"]):
+        imgs.append(torch.from_numpy(synthetic.make_image(seed, k, h, w)[:, :h, :w].copy()))
+        bx = synthetic.make_proposals(seed, k, pcount, h, w, min_size=12)
+        boxes_np.append(bx)
+        rois.append(BoxList(torch.from_numpy(bx), (w, h), "xyxy"))
+    images = to_image_list(imgs, 32)
+    with torch.no_grad():
+        result = model(images, rois=rois)
+    rec = {"spec_seed": np.array(seed), "spec_images": np.array(spec["images"]), "spec_pooler": np.array(spec["pooler"]),
+           "score_thresh": np.array(cfg.MODEL.ROI_HEADS.SCORE_THRESH), "nms": np.array(cfg.MODEL.ROI_HEADS.NMS),
+           "max_det": np.array(cfg.MODEL.ROI_HEADS.DETECTIONS_PER_IMG)}
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.no_grad():
+        ora = I.forward_eval(images.tensors, [torch.from_numpy(b) for b in boxes_np], [(w, h) for h, w, _ in spec["images"]], sdt,
+                             dict(score_thresh=float(rec["score_thresh"]), nms_test=float(rec["nms"]), max_det=int(rec["max_det"])))
+    for i, r in enumerate(result):
+        rec["det_boxes_%d" % i] = r.bbox.numpy()
+        rec["det_scores_%d" % i] = r.get_field("scores").numpy()
+        rec["det_labels_%d" % i] = r.get_field("labels").numpy()
+        ob, os_, ol = ora[i]
+        assert np.array_equal(ol.numpy(), rec["det_labels_%d" % i]), "oracle != reference (labels)"
+        np.testing.assert_allclose(ob.numpy(), rec["det_boxes_%d" % i], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(os_.numpy(), rec["det_scores_%d" % i], rtol=1e-6, atol=1e-8)
+        print("   image %d: %d detections, classes %s" % (i, len(r), sorted(set(rec["det_labels_%d" % i].tolist()))[:8]))
+    np.savez_compressed(out, **rec)
+    print("wrote", out)
+
+
+INFER_CASES = {"infer_voc_2img": dict(seed=58, images=[(96, 128, 48), (80, 112, 40)], pooler="ROIPool")}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops"] + list(E2E_CASES)
     if "ops" in which:
@@ -315,3 +365,6 @@ if __name__ == "__main__":
     for name, spec in E2E_CASES.items():
         if name in which:
             gen_e2e(name, spec, os.path.join(HERE, name + ".npz"))
+    for name, spec in INFER_CASES.items():
+        if name in which or not sys.argv[1:]:
+            gen_infer(name, spec, os.path.join(HERE, name + ".npz"))

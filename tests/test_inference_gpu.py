@@ -1,0 +1,66 @@
+"""The inference tail on the GPU (csrc/detect.hip behind modeling/roi_heads/box_head/inference.py:PostProcessor):
+against the CPU oracle on random scores / regressions, and the whole eval forward against the detections the
+imported reference produced (tests/golden/infer_voc_2img.npz).  `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_e2e, weights_for
+from test_oracle_vs_reference import e2e_inputs_infer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("P,C,thresh,nms,regress", [(300, 21, 0.0, 0.4, True), (1000, 21, 0.03, 0.3, True),
+                                                    (257, 5, 0.0, 0.5, False), (64, 81, 0.01, 0.4, True)])
+def test_postprocessor_matches_oracle(P, C, thresh, nms, regress):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import inference_ref as I
+    from od_wscl_amd import synthetic
+    from od_wscl_amd.modeling.box_coder import BoxCoder
+    from od_wscl_amd.modeling.roi_heads.box_head.inference import PostProcessor
+    from od_wscl_amd.structures import BoxList
+    from od_wscl_amd.utils import rng
+    W, H = 320, 240
+    sizes = [P - P // 3, P // 3]
+    boxes = [torch.from_numpy(synthetic.make_proposals(7, k, n, H, W, min_size=8)) for k, n in enumerate(sizes)]
+    prob = torch.softmax(torch.from_numpy(rng.normal(7, 3, P * C).reshape(P, C)) * 2, dim=1)
+    reg = torch.from_numpy(rng.normal(7, 4, P * 4 * C).reshape(P, 4 * C)) * 0.5
+    reg[5, 6] = 50.0                                                 # exercises the exp clamp (bbox_xform_clip)
+    pp = PostProcessor(thresh, nms, 100, BoxCoder((10.0, 10.0, 5.0, 5.0)), False, False, regression=regress)
+    bl = [BoxList(b.cuda(), (W, H), "xyxy") for b in boxes]
+    res = pp((prob.cuda(), reg.cuda()), bl, softmax_on=False) if regress else pp(prob.cuda(), bl)
+    o = 0
+    for i, b in enumerate(boxes):
+        n = b.shape[0]
+        dec = I.decode(reg[o:o + n], b) if regress else b.repeat(1, C)
+        d = dec.reshape(-1, 4).clone()
+        d[:, 0].clamp_(min=0, max=W - 1); d[:, 1].clamp_(min=0, max=H - 1)
+        d[:, 2].clamp_(min=0, max=W - 1); d[:, 3].clamp_(min=0, max=H - 1)
+        ob, os_, ol = I.filter_results(d.reshape(n, -1), prob[o:o + n], (W, H), thresh, nms, 100)
+        r = res[i]
+        np.testing.assert_array_equal(r.get_field("labels").cpu().numpy(), ol.numpy())
+        np.testing.assert_allclose(r.get_field("scores").cpu().numpy(), os_.numpy(), rtol=0, atol=0)
+        np.testing.assert_allclose(r.bbox.cpu().numpy(), ob.numpy(), rtol=2e-6, atol=2e-4)
+        o += n
+
+
+def test_eval_forward_matches_reference_detections():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from test_e2e_gpu import build_model
+    from od_wscl_amd.structures import BoxList, to_image_list
+    g = load_e2e("infer_voc_2img")
+    seed, batch, boxes, _, _ = e2e_inputs_infer(g)
+    model = build_model(str(g["spec_pooler"]), weights_for("vgg16"), "fused")
+    model.roi_heads.strong_post_processor.score_thresh = float(g["score_thresh"])
+    model.roi_heads.strong_post_processor.nms = float(g["nms"])
+    model.eval()
+    rois = [BoxList(boxes[k].cuda(), (int(w), int(h)), "xyxy") for k, (h, w, p) in enumerate(g["spec_images"])]
+    with torch.no_grad():
+        res = model(to_image_list(batch.cuda()), rois=rois)
+    for i, r in enumerate(res):
+        np.testing.assert_array_equal(r.get_field("labels").cpu().numpy(), g["det_labels_%d" % i])
+        np.testing.assert_allclose(r.get_field("scores").cpu().numpy(), g["det_scores_%d" % i], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(r.bbox.cpu().numpy(), g["det_boxes_%d" % i], rtol=1e-4, atol=1e-3)

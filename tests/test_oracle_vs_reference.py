@@ -181,3 +181,35 @@ def test_reference_build_exports_expected_functions():
         assert hasattr(m, fn)
     with pytest.raises(RuntimeError):
         m.roi_pool_forward(torch.zeros(1, 1, 4, 4), torch.zeros(1, 5), 1.0, 2, 2)
+
+
+def test_inference_tail_matches_imported_reference(weights_np):
+    """Eval forward + PostProcessor of the restated path vs the detections the imported reference returned."""
+    from oracle import inference_ref as I
+    from od_wscl_amd import synthetic
+    g = load_e2e("infer_voc_2img")
+    seed, batch, boxes, _, cfg = e2e_inputs_infer(g)
+    sd = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    with torch.no_grad():
+        out = I.forward_eval(batch, boxes, [(int(w), int(h)) for h, w, _ in g["spec_images"]], sd,
+                             dict(score_thresh=float(g["score_thresh"]), nms_test=float(g["nms"]), max_det=int(g["max_det"])))
+    for i, (b, s, l) in enumerate(out):
+        np.testing.assert_array_equal(l.numpy(), g["det_labels_%d" % i])
+        np.testing.assert_allclose(b.numpy(), g["det_boxes_%d" % i], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(s.numpy(), g["det_scores_%d" % i], rtol=1e-6, atol=1e-8)
+
+
+def e2e_inputs_infer(g):
+    import torch as _t
+    from od_wscl_amd import synthetic
+    seed = int(g["spec_seed"])
+    specs = g["spec_images"]
+    hm = max(synthetic.pad_to(int(h)) for h, w, p in specs)
+    wm = max(synthetic.pad_to(int(w)) for h, w, p in specs)
+    batch = _t.zeros(len(specs), 3, hm, wm)
+    boxes = []
+    for k, (h, w, p) in enumerate(specs):
+        h, w, p = int(h), int(w), int(p)
+        batch[k, :, :h, :w] = _t.from_numpy(synthetic.make_image(seed, k, h, w)[:, :h, :w].copy())
+        boxes.append(_t.from_numpy(synthetic.make_proposals(seed, k, p, h, w, min_size=12)))
+    return seed, batch, boxes, None, {}
