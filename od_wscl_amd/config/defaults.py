@@ -63,6 +63,11 @@ def make_defaults():
     c.SOLVER.WEIGHT_DECAY = 0.0005
     c.SOLVER.WEIGHT_DECAY_BIAS = 0
     c.SOLVER.IMS_PER_BATCH = 16
+    c.SOLVER.GAMMA = 0.1                                      # :445-450
+    c.SOLVER.STEPS = (30000,)
+    c.SOLVER.WARMUP_FACTOR = 1.0 / 3
+    c.SOLVER.WARMUP_ITERS = 500
+    c.SOLVER.WARMUP_METHOD = "linear"
     c.SOLVER.CONTRA = False
     # OD-WSCL hyper-parameters, lower-case top-level keys (:540-551)
     c.nms = 0.1

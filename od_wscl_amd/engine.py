@@ -56,6 +56,33 @@ def make_optimizer(cfg, model):
     return torch.optim.SGD(groups, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
 
 
+def lr_factor(cfg, iteration):
+    """WarmupMultiStepLR.get_lr / base_lr (solver/lr_scheduler.py:14-56) after `iteration` scheduler steps -- the
+    trainer steps the scheduler BEFORE the forward of (1-based) iteration i, so step i runs at lr_factor(cfg, i)
+    (engine/trainer.py:199-204)."""
+    from bisect import bisect_right
+    s = cfg.SOLVER
+    warm = 1.0
+    if iteration < s.WARMUP_ITERS:
+        if s.WARMUP_METHOD == "constant":
+            warm = s.WARMUP_FACTOR
+        elif s.WARMUP_METHOD == "linear":
+            alpha = float(iteration) / s.WARMUP_ITERS
+            warm = s.WARMUP_FACTOR * (1 - alpha) + alpha
+        else:
+            raise ValueError("Only 'constant' or 'linear' warmup_method accepted, got %s" % s.WARMUP_METHOD)
+    return warm * s.GAMMA ** bisect_right(list(s.STEPS), iteration)
+
+
+def momentum_correction(cur_lr, new_lr, threshold=1.1, eps=1e-10):
+    """update_momentum (engine/trainer.py:38-51): when the learning rate jumps by more than 10 % the momentum
+    buffers are rescaled by new_lr / cur_lr; returns that factor or None."""
+    if not (cur_lr > 1e-7 and cur_lr != new_lr):
+        return None
+    ratio = max(new_lr / max(cur_lr, eps), cur_lr / max(new_lr, eps))
+    return new_lr / cur_lr if ratio > threshold else None
+
+
 def all_reduce_flat(flat, world, chunk_elems=64 * 1024 * 1024, group=None):
     """Sum-all-reduce a flat gradient buffer in place over `world` ranks as a few large contiguous
     collectives (256 MB of fp32 each by default: large messages for RCCL's rings over xGMI, and
@@ -124,6 +151,7 @@ class FlatSGD(object):
         self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.early_done = False
         self.first = True
+        self.lr_scale = 1.0
         self.total = total
         # bf16 shadows of the GEMM weights: one flat buffer the SGD kernel refreshes in the same pass
         self.flat_w16 = None
@@ -171,6 +199,22 @@ class FlatSGD(object):
         mod = model.get_submodule(name.rsplit(".", 1)[0])
         return isinstance(mod, linear_layer.Linear)
 
+    def sync_from_params(self):
+        """After weights were loaded into the model (utils/checkpoint.load_checkpoint copies into the flat views):
+        rebuild the bf16 shadows the matrix cores read."""
+        if self.flat_w16 is not None:
+            self._refresh_shadows(initial=True)
+
+    def set_iteration(self, iteration):
+        """Learning-rate schedule + momentum correction for (1-based) training iteration `iteration`."""
+        f = lr_factor(self.cfg, iteration)
+        if f != self.lr_scale:
+            base = self.cfg.SOLVER.BASE_LR
+            corr = momentum_correction(base * self.lr_scale, base * f)
+            if corr is not None and not self.first:
+                self.flat_m.mul_(corr)
+            self.lr_scale = f
+
     def begin_step(self):
         """Gradient buffer state for a new step: GEMM weights are overwritten by their first wgrad
         launch; everything autograd accumulates into (convs, predictor heads, biases) is zeroed."""
@@ -185,7 +229,7 @@ class FlatSGD(object):
             return
         shadow = self.flat_w16 if (i == 0 and self.flat_w16 is not None) else None
         L.check(L.lib().odw_sgd_momentum(L.ptr(self.flat_p[start:]), L.ptr(self.flat_g[start:]),
-                                         L.ptr(self.flat_m[start:]), L.ptr(shadow), n, lr, wd, self.momentum,
+                                         L.ptr(self.flat_m[start:]), L.ptr(shadow), n, lr * self.lr_scale, wd, self.momentum,
                                          1.0 / self.world, 1 if self.first else 0, L.stream()), "sgd_momentum")
 
     def head_grads_ready(self):
@@ -249,7 +293,9 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         opt = FlatSGD(cfg, model, world)
         model.roi_heads.head_grads_ready = opt.head_grads_ready
 
-        def step(images, targets, rois, rand):
+        def step(images, targets, rois, rand, iteration=None):
+            if iteration is not None:           # WarmupMultiStepLR + update_momentum (solver/lr_scheduler.py, trainer.py:38-51)
+                opt.set_iteration(iteration)
             opt.begin_step()
             losses, accs = model(images, targets, rois, rand=rand)
             mark("forward")

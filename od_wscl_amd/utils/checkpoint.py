@@ -1,0 +1,57 @@
+"""Checkpoint compatibility with the reference (wetectron/utils/checkpoint.py:41-104,156-178 and
+utils/model_serialization.py:11-80): `.pth` files hold {"model": state_dict, "optimizer": ..., "scheduler": ...,
+"iteration": ...}; keys may carry DistributedDataParallel's "module." prefix; pretrained backbones carry SHORTER
+keys that are matched to the model's keys by longest suffix.  Parameter and buffer names of this build equal the
+reference's, so its checkpoints load unchanged (and ours load into wetectron)."""
+from collections import OrderedDict
+
+import torch
+
+
+def strip_prefix_if_present(state_dict, prefix="module."):
+    keys = sorted(state_dict.keys())
+    if not keys or not all(k.startswith(prefix) for k in keys):
+        return state_dict
+    return OrderedDict((k.replace(prefix, ""), v) for k, v in state_dict.items())
+
+
+def align_and_update_state_dicts(model_state_dict, loaded_state_dict):
+    """For every model key take the loaded key that is its LONGEST suffix (model_serialization.py:11-62)."""
+    loaded_keys = sorted(loaded_state_dict.keys())
+    matched = {}
+    for key in sorted(model_state_dict.keys()):
+        best = None
+        for lk in loaded_keys:
+            if key.endswith(lk) and (best is None or len(lk) > len(best)):
+                best = lk
+        if best is not None:
+            model_state_dict[key] = loaded_state_dict[best]
+            matched[key] = best
+    return matched
+
+
+def load_state_dict(model, loaded_state_dict):
+    """model_serialization.py:73-80.  Parameters that live in engine.FlatSGD's flat buffers are updated in place
+    (copy_ into the views); call FlatSGD.sync_from_params() afterwards to refresh the bf16 shadows."""
+    model_state_dict = model.state_dict()
+    loaded_state_dict = strip_prefix_if_present(loaded_state_dict, prefix="module.")
+    matched = align_and_update_state_dicts(model_state_dict, loaded_state_dict)
+    model.load_state_dict(model_state_dict)
+    return matched
+
+
+def load_checkpoint(model, path, map_location="cpu"):
+    """DetectronCheckpointer._load_file + _load_model for native `.pth` files (checkpoint.py:169-178): a bare
+    state-dict is wrapped as {"model": ...}.  Returns the rest of the checkpoint (optimizer, scheduler, iteration)."""
+    loaded = torch.load(path, map_location=map_location)
+    if "model" not in loaded:
+        loaded = dict(model=loaded)
+    load_state_dict(model, loaded.pop("model"))
+    return loaded
+
+
+def save_checkpoint(model, path, **extra):
+    """Checkpointer.save (checkpoint.py:41-63): the reference's layout, loadable by wetectron."""
+    data = {"model": model.state_dict()}
+    data.update(extra)
+    torch.save(data, path)

@@ -68,3 +68,66 @@ def test_world_one_is_a_noop():
     g = torch.ones(10)
     engine.all_reduce_flat(g, 1)
     assert torch.equal(g, torch.ones(10))
+
+
+def test_lr_schedule_and_momentum_correction():
+    """engine.lr_factor == WarmupMultiStepLR (solver/lr_scheduler.py:14-56); momentum_correction == update_momentum's
+    rule (engine/trainer.py:38-51)."""
+    from od_wscl_amd import engine
+    from od_wscl_amd.config import make_defaults
+    cfg = make_defaults()
+    cfg.merge_from_list(["SOLVER.STEPS", (20, 30), "SOLVER.WARMUP_ITERS", 10, "SOLVER.BASE_LR", 0.01])
+    assert abs(engine.lr_factor(cfg, 0) - 1.0 / 3) < 1e-12
+    assert abs(engine.lr_factor(cfg, 5) - (1.0 / 3 * 0.5 + 0.5)) < 1e-12
+    assert engine.lr_factor(cfg, 10) == 1.0 and engine.lr_factor(cfg, 19) == 1.0
+    assert abs(engine.lr_factor(cfg, 20) - 0.1) < 1e-12 and abs(engine.lr_factor(cfg, 30) - 0.01) < 1e-12
+    assert engine.momentum_correction(0.01, 0.0101) is None                    # < 10 % change
+    assert abs(engine.momentum_correction(0.01, 0.001) - 0.1) < 1e-12          # milestone
+    assert engine.momentum_correction(1e-8, 0.01) is None                      # cur_lr <= 1e-7
+    if os.path.isdir("/root/reference/wetectron"):                            # the reference class itself, when present
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        import refimport
+        refimport.load_reference()
+        from wetectron.solver.lr_scheduler import WarmupMultiStepLR
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=0.01)
+        sch = WarmupMultiStepLR(opt, (20, 30), 0.1, warmup_factor=1.0 / 3, warmup_iters=10, warmup_method="linear")
+        for it in range(1, 40):
+            opt.step()
+            sch.step()
+            assert abs(opt.param_groups[0]["lr"] - 0.01 * engine.lr_factor(cfg, it)) < 1e-12, it
+
+
+def test_checkpoint_layout_and_suffix_matching(tmp_path):
+    """utils/checkpoint: the reference's `.pth` layout, the "module." prefix of DDP checkpoints and the
+    longest-suffix matching of pretrained backbone keys (utils/model_serialization.py:11-80)."""
+    from od_wscl_amd.utils import checkpoint as ck
+
+    class Body(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(3, 4, 3)
+            self.layer1 = torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1))
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Sequential()
+            self.backbone.add_module("body", Body())
+            self.head = torch.nn.Linear(4, 2)
+
+    a, b = Net(), Net()
+    ck.save_checkpoint(a, str(tmp_path / "m.pth"), iteration=7)
+    rest = ck.load_checkpoint(b, str(tmp_path / "m.pth"))
+    assert rest["iteration"] == 7
+    for (n1, p1), (n2, p2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    # DDP prefix + a pretrained body with short keys: "conv1.weight" must go to body.conv1, "layer1.0.weight" to layer1
+    c = Net()
+    short = {"module.conv1.weight": torch.full((4, 3, 3, 3), 2.0), "module.layer1.0.weight": torch.full((4, 4, 1, 1), 3.0)}
+    matched = ck.load_state_dict(c, short)
+    assert matched == {"backbone.body.conv1.weight": "conv1.weight", "backbone.body.layer1.0.weight": "layer1.0.weight"}
+    assert (c.backbone.body.conv1.weight == 2).all() and (c.backbone.body.layer1[0].weight == 3).all()
+    torch.save({"w": 1}, str(tmp_path / "bare.pth"))            # a bare state-dict is wrapped as {"model": ...}
+    assert ck.load_checkpoint(Net(), str(tmp_path / "bare.pth")) == {}

@@ -213,3 +213,28 @@ def e2e_inputs_infer(g):
         batch[k, :, :h, :w] = _t.from_numpy(synthetic.make_image(seed, k, h, w)[:, :h, :w].copy())
         boxes.append(_t.from_numpy(synthetic.make_proposals(seed, k, p, h, w, min_size=12)))
     return seed, batch, boxes, None, {}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/wetectron"), reason="reference tree not present")
+@pytest.mark.parametrize("yaml_rel,arch", [("configs/voc/voc07_contra_db_b8_lr0.01_mcg.yaml", "vgg16"),
+                                           ("configs/voc/voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml", "r50")])
+def test_state_dict_layout_equals_the_reference_model(yaml_rel, arch):
+    """Checkpoint compatibility: the imported reference model and ours, built from the same
+    yaml, expose the same state-dict keys with the same shapes, so `.pth` files travel both ways."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import refimport
+    from od_wscl_amd.config import cfg as base
+    from od_wscl_amd.modeling.detector import build_detection_model
+    from od_wscl_amd.utils import checkpoint as ck
+    ref = refimport.build_reference_model(refimport.reference_cfg(yaml_rel))
+    cfg = base.clone()
+    cfg.merge_from_file(os.path.join("/root/reference", yaml_rel))
+    ours = build_detection_model(cfg)
+    a = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    assert a == b
+    matched = ck.load_state_dict(ours, {"module." + k: v for k, v in ref.state_dict().items()})
+    assert len(matched) == len(a)
+    for (k, v) in ours.state_dict().items():
+        assert torch.equal(v, ref.state_dict()[k]), k
