@@ -203,17 +203,26 @@ int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* 
  * fill the chip only when K is split.  odw_gemm_nt_bf16_workspace returns the bytes of fp32 partials the planner
  * wants for this product (0 = no split) and the kernel variant it would use; odw_gemm_nt_bf16_ws takes that
  * buffer (16-byte aligned; NULL / too small = unsplit, identical to odw_gemm_nt_bf16).  The reduction pass applies
- * the same fused epilogue in a fixed summation order. */
+ * the same fused epilogue in a fixed summation order.  row_ids (device int32[M], nullable): A holds a GATHERED
+ * subset of the rows of a larger pass -- the dropout draw of GEMM row m is the one logical row row_ids[m] had there
+ * (segment 0's key), so re-evaluating a few rows reproduces their original masks. */
 int64_t odw_gemm_nt_bf16_workspace(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16,
                                    int* variant_out);
 int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C, int ldc,
                         int c_is_bf16, const float* bias, int relu, float alpha, float drop_p, int nseg,
-                        const int* seg_rows, const uint32_t* seg_keys, int accumulate, void* workspace,
-                        int64_t workspace_bytes, void* stream);
+                        const int* seg_rows, const uint32_t* seg_keys, const int* row_ids, int accumulate,
+                        void* workspace, int64_t workspace_bytes, void* stream);
 int odw_linear_bwd_prep(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
                         float scale, void* dZ, int ld_z, void* dZT, int ld_t, float* db, void* stream);
 int odw_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
                           void* stream);
+/* "_part" forms: the transposed output is a column block [0, cols) (zero padded from R / M up to cols) of a wider
+ * matrix with row stride ld -- several evaluations of one Linear lay their dZ^T / X^T blocks side by side so that
+ * ONE weight-gradient GEMM (K = all their rows) replaces one read-modify-write pass over the gradient per evaluation. */
+int odw_transpose_to_bf16_part(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
+                               int out_cols, void* stream);
+int odw_linear_bwd_prep_part(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
+                             float scale, void* dZ, int ld_z, void* dZT, int ld_t, int t_cols, float* db, void* stream);
 int odw_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int odw_sgd_momentum(float* p, const float* g, float* buf, void* shadow_bf16, int64_t n, float lr, float wd,
                      float momentum, float grad_scale, int first_step, void* stream);

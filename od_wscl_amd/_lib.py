@@ -51,10 +51,12 @@ SIGNATURES = {
     "odw_l2norm_rows_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     "odw_gemm_nt_bf16_variant": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i]),
     "odw_gemm_nt_bf16_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
-    "odw_gemm_nt_bf16_ws": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_p, c_p, c_i,
-                                  c_p, c_l, c_p]),
+    "odw_gemm_nt_bf16_ws": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_p, c_p, c_p,
+                                  c_i, c_p, c_l, c_p]),
     "odw_gemm_nt_bf16": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_p, c_p, c_i, c_p]),
     "odw_linear_bwd_prep": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_p, c_i, c_p, c_p]),
+    "odw_linear_bwd_prep_part": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_p, c_i, c_i, c_p, c_p]),
+    "odw_transpose_to_bf16_part": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "odw_transpose_to_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "odw_f32_to_bf16": (c_i, [c_p, c_p, c_l, c_p]),
     "odw_sgd_momentum": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_p]),

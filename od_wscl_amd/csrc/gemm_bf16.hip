@@ -47,6 +47,7 @@ struct Epilogue {
     const unsigned short* mask;   // optional bf16 (M x ldmask): result forced to 0 where mask == 0 (ReLU backward)
     int ldmask;
     int pm;                // tile-order group height (tile_coords); 0 = the kernel's default
+    const int* row_ids;    // dropout of a gathered row subset: logical row of GEMM row m (with segment 0's key); null = m
     int kchunk;            // split-K: > 0 = this launch's blockIdx.y owns K range [y*kchunk, (y+1)*kchunk) and writes
     long long split_stride;  //          its partial product split_stride bytes further into C (an fp32 workspace)
 };
@@ -127,7 +128,8 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[MI][NJ], void
                     if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
                     if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
                     if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
-                    const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)n;
+                    const uint32_t lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
+                    const uint32_t idx = lrow * (uint32_t)N + (uint32_t)n;
                     v = odw_uniform(idx, k0, k1) >= ep.drop_p ? v * (1.0f / (1.0f - ep.drop_p)) : 0.0f;
                 }
                 if (OUT_BF16) {
@@ -523,6 +525,7 @@ __device__ __forceinline__ void big_store(const f32x16 (&acc)[4][2], void* __res
             if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
             if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
         }
+        const uint32_t lrow = (ep.row_ids && m < M) ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -537,7 +540,7 @@ __device__ __forceinline__ void big_store(const f32x16 (&acc)[4][2], void* __res
                     if (ep.relu) x = fmaxf(x, 0.0f);
                     if (ep.mask && m < M && n + q < N && (ep.mask[(size_t)m * ep.ldmask + n + q] & 0x7fff) == 0) x = 0.0f;
                     if (ep.drop_p > 0.0f) {
-                        const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)(n + q);
+                        const uint32_t idx = lrow * (uint32_t)N + (uint32_t)(n + q);
                         x = odw_uniform(idx, k0, k1) >= ep.drop_p ? x * keep_scale : 0.0f;
                     }
                     v[q] = x;
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
 template <bool IN_F32>
 __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __restrict__ in, int ld_in, int R,
                                                                 int Cc, unsigned short* __restrict__ out,
-                                                                int ld_out) {
+                                                                int ld_out, int out_cols) {
     __shared__ unsigned short t[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __re
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = c0 + ty + 8 * k, r = r0 + tx;
-        if (c < Cc && r < ld_out) out[(size_t)c * ld_out + r] = r < R ? t[tx][ty + 8 * k] : (unsigned short)0;
+        if (c < Cc && r < out_cols) out[(size_t)c * ld_out + r] = r < R ? t[tx][ty + 8 * k] : (unsigned short)0;
     }
 }
 
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __rest
                                                               const unsigned short* __restrict__ Y, int ld_y,
                                                               int M, int N, float scale,
                                                               unsigned short* __restrict__ dZ, int ld_z,
-                                                              unsigned short* __restrict__ dZT, int ld_t,
+                                                              unsigned short* __restrict__ dZT, int ld_t, int t_cols,
                                                               float* __restrict__ db) {
     __shared__ float t[32][33];
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __rest
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int n = n0 + ty + 8 * k, m = m0 + tx;
-        if (n < N && m < ld_t) dZT[(size_t)n * ld_t + m] = f2bf(t[tx][ty + 8 * k]);
+        if (n < N && m < t_cols) dZT[(size_t)n * ld_t + m] = f2bf(t[tx][ty + 8 * k]);
     }
     if (db && ty == 0) {
         float sum = 0.0f;
@@ -926,7 +929,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             if (ep.relu) x = fmaxf(x, 0.0f);
             if (ep.mask && (ep.mask[(size_t)m * ep.ldmask + n + q] & 0x7fff) == 0) x = 0.0f;
             if (ep.drop_p > 0.0f) {
-                const uint32_t idx = (uint32_t)(m - srow) * (uint32_t)N + (uint32_t)(n + q);
+                const uint32_t lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
+                const uint32_t idx = lrow * (uint32_t)N + (uint32_t)(n + q);
                 x = odw_uniform(idx, k0, k1) >= ep.drop_p ? x * keep_scale : 0.0f;
             }
             v[q] = x;
@@ -1008,21 +1012,21 @@ ODW_EXPORT int64_t odw_gemm_nt_bf16_workspace(int M, int N, int K, int lda, int 
 
 ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
                                    int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
-                                   int nseg, const int* seg_rows, const uint32_t* seg_keys, int accumulate,
-                                   void* workspace, int64_t workspace_bytes, void* stream_);
+                                   int nseg, const int* seg_rows, const uint32_t* seg_keys, const int* row_ids,
+                                   int accumulate, void* workspace, int64_t workspace_bytes, void* stream_);
 
 ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
                                 int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
                                 int nseg, const int* seg_rows, const uint32_t* seg_keys, int accumulate,
                                 void* stream_) {
     return odw_gemm_nt_bf16_ws(A, lda, B, ldb, M, N, K, C, ldc, c_is_bf16, bias, relu, alpha, drop_p, nseg, seg_rows,
-                               seg_keys, accumulate, nullptr, 0, stream_);
+                               seg_keys, nullptr, accumulate, nullptr, 0, stream_);
 }
 
 ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
                                    int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
-                                   int nseg, const int* seg_rows, const uint32_t* seg_keys, int accumulate,
-                                   void* workspace, int64_t workspace_bytes, void* stream_) {
+                                   int nseg, const int* seg_rows, const uint32_t* seg_keys, const int* row_ids,
+                                   int accumulate, void* workspace, int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_nt_bf16: bad dims M=%d N=%d K=%d", M, N, K);
     if (M == 0 || N == 0) return ODW_OK;
@@ -1035,7 +1039,7 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
     ODW_REQUIRE(!(accumulate && c_is_bf16), "gemm_nt_bf16: accumulate needs an fp32 C");
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = drop_p; ep.nseg = nseg; ep.accumulate = accumulate; ep.alpha = alpha;
-    ep.mask = nullptr; ep.ldmask = 0; ep.kchunk = 0; ep.split_stride = 0;
+    ep.mask = nullptr; ep.ldmask = 0; ep.kchunk = 0; ep.split_stride = 0; ep.row_ids = row_ids;
     { const char* e = getenv("ODW_GEMM_PM"); ep.pm = e ? atoi(e) : 0; }
     for (int i = 0; i < kMaxSeg; ++i) {
         ep.seg_row[i] = (i < nseg && seg_rows) ? seg_rows[i] : 0;
@@ -1052,7 +1056,7 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
         // partial products (plain, fp32) into the workspace, then one reduction pass with the fused epilogue
         ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "gemm_nt_bf16: workspace must be 16-byte aligned");
         Epilogue pe = ep;
-        pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.accumulate = 0; pe.alpha = 1.0f;
+        pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.accumulate = 0; pe.alpha = 1.0f; pe.row_ids = nullptr;
         pe.kchunk = plan.kchunk; pe.split_stride = (long long)M * N * 4;
         const dim3 grid_r((unsigned)(((M + RM - 1) / RM) * ((N + RN - 1) / RN)), (unsigned)plan.splits);
         const dim3 grid_b((unsigned)(((M + GM - 1) / GM) * ((N + GN - 1) / GN)), (unsigned)plan.splits);
@@ -1143,17 +1147,25 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
     return ODW_OK;
 }
 
+ODW_EXPORT int odw_transpose_to_bf16_part(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
+                                          int out_cols, void* stream_);
+
 ODW_EXPORT int odw_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
                                      void* stream_) {
+    return odw_transpose_to_bf16_part(in, in_is_f32, ld_in, R, Cc, out, ld_out, ld_out, stream_);
+}
+
+ODW_EXPORT int odw_transpose_to_bf16_part(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
+                                          int out_cols, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    ODW_REQUIRE(R >= 0 && Cc >= 0 && ld_in >= Cc && ld_out >= R, "transpose_to_bf16: bad dims");
+    ODW_REQUIRE(R >= 0 && Cc >= 0 && ld_in >= Cc && out_cols >= R && ld_out >= out_cols, "transpose_to_bf16: bad dims");
     if (R == 0 || Cc == 0) return ODW_OK;
     ODW_REQUIRE(in && out, "transpose_to_bf16: null pointer");
-    dim3 grid((Cc + 31) / 32, (ld_out + 31) / 32);   // covers the zero padding up to ld_out
+    dim3 grid((Cc + 31) / 32, (out_cols + 31) / 32);   // covers the zero padding up to out_cols
     if (in_is_f32)
-        transpose_to_bf16_kernel<true><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out);
+        transpose_to_bf16_kernel<true><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out, out_cols);
     else
-        transpose_to_bf16_kernel<false><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out);
+        transpose_to_bf16_kernel<false><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out, out_cols);
     ODW_CHECK_LAUNCH("transpose_to_bf16_kernel");
     return ODW_OK;
 }
@@ -1168,19 +1180,29 @@ ODW_EXPORT int odw_f32_to_bf16(const float* in, void* out, int64_t n, void* stre
     return ODW_OK;
 }
 
+ODW_EXPORT int odw_linear_bwd_prep_part(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
+                                        float scale, void* dZ, int ld_z, void* dZT, int ld_t, int t_cols, float* db,
+                                        void* stream_);
+
 ODW_EXPORT int odw_linear_bwd_prep(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
                                    float scale, void* dZ, int ld_z, void* dZT, int ld_t, float* db, void* stream_) {
+    return odw_linear_bwd_prep_part(dY, dy_is_f32, ld_dy, Y, ld_y, M, N, scale, dZ, ld_z, dZT, ld_t, ld_t, db, stream_);
+}
+
+ODW_EXPORT int odw_linear_bwd_prep_part(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
+                                        float scale, void* dZ, int ld_z, void* dZT, int ld_t, int t_cols, float* db,
+                                        void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    ODW_REQUIRE(M >= 0 && N >= 0 && ld_z >= N && ld_t >= M && ld_dy >= N, "linear_bwd_prep: bad dims");
+    ODW_REQUIRE(M >= 0 && N >= 0 && ld_z >= N && t_cols >= M && ld_t >= t_cols && ld_dy >= N, "linear_bwd_prep: bad dims");
     if (M == 0 || N == 0) return ODW_OK;
     ODW_REQUIRE(dY && dZ && dZT, "linear_bwd_prep: null pointer");
-    dim3 grid((ld_z + 31) / 32, (ld_t + 31) / 32);     // covers the zero padding of both outputs
+    dim3 grid((ld_z + 31) / 32, (t_cols + 31) / 32);     // covers the zero padding of both outputs
     if (dy_is_f32)
         linear_bwd_prep_kernel<true><<<grid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
-                                                               (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, db);
+                                                               (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db);
     else
         linear_bwd_prep_kernel<false><<<grid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
-                                                                (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, db);
+                                                                (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db);
     ODW_CHECK_LAUNCH("linear_bwd_prep_kernel");
     return ODW_OK;
 }
@@ -1254,7 +1276,7 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
     while ((1 << g.logC) < C) ++g.logC;
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = 0.0f; ep.nseg = 0; ep.accumulate = 0; ep.alpha = 1.0f;
-    ep.mask = (const unsigned short*)mask; ep.ldmask = ldmask; ep.pm = 0; ep.kchunk = 0; ep.split_stride = 0;
+    ep.mask = (const unsigned short*)mask; ep.ldmask = ldmask; ep.pm = 0; ep.kchunk = 0; ep.split_stride = 0; ep.row_ids = nullptr;
     for (int i = 0; i < kMaxSeg; ++i) { ep.seg_row[i] = 0; ep.seg_k0[i] = 0; ep.seg_k1[i] = 0; }
     const int sp = workspace ? conv_splits(n_pix, N, C) : 1;
     if (sp > 1 && workspace_bytes >= (int64_t)sp * n_pix * N * 4) {

@@ -164,6 +164,9 @@ class FlatSGD(object):
                 sh.w = self.flat_w16[o:o + weight.numel()].view(weight.shape)
                 sh.wt = torch.empty((weight.shape[1], (weight.shape[0] + 63) // 64 * 64), dtype=torch.bfloat16, device=dev)
                 sh.managed = True
+                # Linears whose gradient is large enough for its read-modify-write to matter get ONE weight-gradient
+                # GEMM per step over all their evaluations (gemm.WgradBatch)
+                sh.batch = gemm.WgradBatch() if (weight.numel() >= (8 << 20) and os.environ.get("ODW_NO_WGRAD_BATCH") != "1") else None
                 self.shadows.append(sh)
                 return sh
 
@@ -237,6 +240,7 @@ class FlatSGD(object):
         all-reduce + SGD + shadow refresh of the head on the side stream, overlapping the backbone's backward."""
         if self.side is None or self.n_gemm == 0 or self.early_done or os.environ.get("ODW_NO_OVERLAP") == "1":
             return
+        self.flush_wgrad()
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
             all_reduce_flat(self.flat_g[:self.n_gemm], self.world)
@@ -248,7 +252,16 @@ class FlatSGD(object):
         """Whatever has not been exchanged by head_grads_ready (the backbone and the biases, or everything)."""
         all_reduce_flat(self.flat_g[self.n_gemm:] if self.early_done else self.flat_g, self.world)
 
+    def flush_wgrad(self):
+        """Weight-gradient batches whose last registered evaluation never ran its backward (e.g. a loss that does not
+        reach every pass): run the GEMM over what was filled."""
+        for sh in self.shadows:
+            b = getattr(sh, "batch", None)
+            if b is not None and b.rows:
+                b.flush(sh.weight)
+
     def step(self):
+        self.flush_wgrad()
         if not self.early_done:
             self._sgd_region(0)
             self._refresh_shadows()

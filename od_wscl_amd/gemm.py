@@ -29,7 +29,7 @@ def _r64(n):
 _VARIANT_SYMBOL = {0: "", 1: "glds_", 2: "ring_", 3: "big_"}      # names as rocprofv3's kernel trace prints them
 
 
-def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, segs=None, accumulate=False):
+def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, segs=None, accumulate=False, row_ids=None):
     """out[M,N] (+)= epilogue(alpha * a[M,K] @ b[N,K]^T); a, b bf16 2-D tensors (row stride % 8 == 0)."""
     L.need_gpu(a, b, out)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
@@ -53,7 +53,7 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
                                             out.stride(0), 1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0,
                                             float(alpha), float(drop_p), nseg,
                                             ctypes.cast(rows, ctypes.c_void_p) if nseg else None,
-                                            ctypes.cast(keys, ctypes.c_void_p) if nseg else None,
+                                            ctypes.cast(keys, ctypes.c_void_p) if nseg else None, L.ptr(row_ids),
                                             1 if accumulate else 0, L.ptr(ws), ws_bytes, L.stream()), "gemm_nt_bf16")
     return out
 
@@ -86,6 +86,7 @@ class Shadow(object):
         self.w = None
         self.wt = None
         self.managed = False      # True: the optimiser refreshes w / wt itself (engine.FlatSGD)
+        self.batch = None         # gemm.WgradBatch: one weight-gradient GEMM per step over all evaluations
 
     def refresh(self):
         w = self.weight
@@ -100,6 +101,55 @@ class Shadow(object):
         return self
 
 
+class WgradBatch(object):
+    """One weight-gradient GEMM per step for a Linear that is evaluated several times (fc6: the stacked pass, the
+    sampled-row views, the re-evaluated clean rows).  dW = sum_e dZ_e^T X_e = [dZ_1; dZ_2; ...]^T [X_1; X_2; ...]:
+    every evaluation's backward lays its dZ^T and X^T as a column block of two shared matrices and the LAST one
+    runs the GEMM over all rows -- instead of one read-modify-write pass over the (411 MB for fc6) gradient per
+    evaluation.  Evaluations register at forward time; engine.FlatSGD flushes a step that ended early."""
+
+    def __init__(self):
+        self.rows, self.filled, self.dzt, self.xt, self.kpad = [], 0, None, None, 0
+
+    def register(self, m):
+        self.rows.append(_r64(m))
+        return len(self.rows) - 1
+
+    def offset(self, slot):
+        return sum(self.rows[:slot])
+
+    def buffers(self, n_out, k_in, device):
+        if self.dzt is None:
+            self.kpad = sum(self.rows)
+            self.dzt = torch.empty((n_out, self.kpad), dtype=torch.bfloat16, device=device)
+            self.xt = torch.empty((k_in, self.kpad), dtype=torch.bfloat16, device=device)
+            self.done = [False] * len(self.rows)
+        return self.dzt, self.xt
+
+    def reset(self):
+        self.rows, self.filled, self.dzt, self.xt, self.kpad = [], 0, None, None, 0
+
+    def flush(self, weight, tag=None):
+        """Run the GEMM over whatever was filled (blocks of evaluations whose backward never ran are zeroed)."""
+        if self.dzt is None:
+            self.reset()
+            return
+        off = 0
+        for r, d in zip(self.rows, self.done):
+            if not d:                       # 0 x garbage would still be NaN: clear both operands' blocks
+                self.dzt[:, off:off + r].zero_()
+                self.xt[:, off:off + r].zero_()
+            off += r
+        fresh = weight.grad is None or getattr(weight, "_odw_fresh", False)
+        if weight.grad is None:
+            weight.grad = torch.empty_like(weight)
+        weight._odw_fresh = False
+        kernel_timer.layer = tag and tag + "_wgrad"
+        gemm_nt(self.dzt, self.xt, weight.shape[0], weight.shape[1], self.kpad, weight.grad, accumulate=not fresh)
+        kernel_timer.layer = None
+        self.reset()
+
+
 class _FusedLinear(torch.autograd.Function):
     """y = dropout(relu(x W^T + b)) on the matrix cores, bf16 in / bf16 or fp32 out.
 
@@ -109,7 +159,11 @@ class _FusedLinear(torch.autograd.Function):
     materialised twice."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, shadow, relu, drop_p, segs, out_f32, timer_tag):
+    def forward(ctx, x, weight, bias, shadow, relu, drop_p, segs, out_f32, timer_tag, grad_rows=None, row_ids=None,
+                grad_mode=True):
+        """grad_rows = (a, b): only rows [a, b) of this evaluation take part in backward (the clean half of the
+        stacked pass carries gradient for a few hundred rows only, which are re-evaluated separately);
+        row_ids: x holds gathered rows of a larger pass -- their dropout draws are those of the original rows."""
         sh = shadow.refresh()
         M, K = x.shape
         N = weight.shape[0]
@@ -117,22 +171,38 @@ class _FusedLinear(torch.autograd.Function):
         xb = xb if xb.stride(1) == 1 and xb.stride(0) % 8 == 0 else xb.contiguous()
         y = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
         kernel_timer.layer = timer_tag and timer_tag + "_fwd"
-        gemm_nt(xb, sh.w, M, N, K, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs)
+        gemm_nt(xb, sh.w, M, N, K, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs, row_ids=row_ids)
         kernel_timer.layer = None
         ctx.save_for_backward(xb, y if (relu or drop_p > 0) else None, weight, bias)
-        ctx.cfg = (sh, relu, drop_p, x.dtype, timer_tag)
+        slot = None
+        batch = getattr(sh, "batch", None)
+        if batch is not None and weight.is_leaf and weight.requires_grad and grad_mode:    # not under torch.no_grad()
+            slot = batch.register((grad_rows[1] - grad_rows[0]) if grad_rows is not None else M)
+        ctx.cfg = (sh, relu, drop_p, x.dtype, timer_tag, grad_rows, slot)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xb, y, weight, bias = ctx.saved_tensors
-        sh, relu, drop_p, x_dtype, tag = ctx.cfg
-        M, K = xb.shape
+        sh, relu, drop_p, x_dtype, tag, grad_rows, slot = ctx.cfg
+        M_all, K = xb.shape
         N = weight.shape[0]
         dy = dy.contiguous()
+        if grad_rows is not None:           # rows outside [a, b) neither send nor receive gradient
+            ra, rb = grad_rows
+            dy, xb = dy[ra:rb], xb[ra:rb]
+            y = y[ra:rb] if y is not None else None
+        M = xb.shape[0]
         n8, m8 = _r64(N), _r64(M)
         dz = torch.empty((M, n8), dtype=torch.bfloat16, device=dy.device)
-        dzt = torch.empty((N, m8), dtype=torch.bfloat16, device=dy.device)
+        batch = sh.batch if slot is not None else None
+        if batch is not None:                  # this evaluation's column block of the shared dZ^T / X^T matrices
+            dzt_all, xt_all = batch.buffers(N, K, dy.device)
+            off = batch.offset(slot)
+            dzt, ld_t, t_cols = dzt_all[:, off:], dzt_all.stride(0), m8
+        else:
+            dzt = torch.empty((N, m8), dtype=torch.bfloat16, device=dy.device)
+            ld_t, t_cols = m8, m8
         if bias is not None:
             if bias.grad is None:
                 bias.grad = torch.zeros_like(bias)
@@ -142,17 +212,31 @@ class _FusedLinear(torch.autograd.Function):
         scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
         if y is not None and y.dtype != torch.bfloat16:
             y = y.to(torch.bfloat16)
-        L.check(L.lib().odw_linear_bwd_prep(L.ptr(dy), 1 if dy.dtype == torch.float32 else 0, dy.stride(0),
-                                            L.ptr(y), y.stride(0) if y is not None else 0, M, N, scale,
-                                            L.ptr(dz), n8, L.ptr(dzt), m8, L.ptr(db), L.stream()), "linear_bwd_prep")
+        L.check(L.lib().odw_linear_bwd_prep_part(L.ptr(dy), 1 if dy.dtype == torch.float32 else 0, dy.stride(0),
+                                                 L.ptr(y), y.stride(0) if y is not None else 0, M, N, scale,
+                                                 L.ptr(dz), n8, L.ptr(dzt), ld_t, t_cols, L.ptr(db), L.stream()),
+                "linear_bwd_prep")
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), dtype=x_dtype, device=dy.device)
+            dx_all = torch.empty((M_all, K), dtype=x_dtype, device=dy.device)
+            dx = dx_all
+            if grad_rows is not None:
+                dx_all[:ra].zero_()
+                dx_all[rb:].zero_()
+                dx = dx_all[ra:rb]
             kernel_timer.layer = tag and tag + "_dgrad"
             gemm_nt(dz, sh.wt, M, K, N, dx)
             kernel_timer.layer = None
+            dx = dx_all
         dw = None
-        if weight.requires_grad:
+        if weight.requires_grad and batch is not None:
+            L.check(L.lib().odw_transpose_to_bf16_part(L.ptr(xb), 0, xb.stride(0), M, K, L.ptr(xt_all[:, off:]),
+                                                       xt_all.stride(0), m8, L.stream()), "transpose_to_bf16")
+            batch.done[slot] = True
+            batch.filled += 1
+            if batch.filled == len(batch.rows):
+                batch.flush(weight, tag)
+        elif weight.requires_grad:
             xt = transpose_bf16(xb, M, K)
             if weight.is_leaf:          # accumulate straight into the parameter's gradient buffer
                 fresh = weight.grad is None or getattr(weight, "_odw_fresh", False)
@@ -168,8 +252,10 @@ class _FusedLinear(torch.autograd.Function):
             kernel_timer.layer = None
         if bias is not None and not bias.is_leaf:
             raise RuntimeError("fused_linear: bias must be a leaf parameter or None")
-        return dx, dw, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None, None, None
 
 
-def fused_linear(x, weight, bias, shadow, relu=False, drop_p=0.0, segs=None, out_f32=False, tag=None):
-    return _FusedLinear.apply(x, weight, bias, shadow, relu, drop_p, segs, out_f32, tag)
+def fused_linear(x, weight, bias, shadow, relu=False, drop_p=0.0, segs=None, out_f32=False, tag=None, grad_rows=None,
+                 row_ids=None):
+    return _FusedLinear.apply(x, weight, bias, shadow, relu, drop_p, segs, out_f32, tag, grad_rows, row_ids,
+                              torch.is_grad_enabled())      # (grad mode is always off INSIDE Function.forward)

@@ -30,7 +30,7 @@ class Linear(nn.Linear):
     tag = None
     _shadow = None
 
-    def fused(self, x, relu=False, drop_p=0.0, key=None, segs=None, out_f32=False):
+    def fused(self, x, relu=False, drop_p=0.0, key=None, segs=None, out_f32=False, grad_rows=None, row_ids=None):
         """dropout(relu(x W^T + b)); `key` = (k0,k1) of one counter-based draw or `segs` =
         [(first_row, k0, k1), ...] when several logical passes are stacked along M."""
         if _BACKEND == "hip_bf16":
@@ -40,7 +40,8 @@ class Linear(nn.Linear):
             if drop_p > 0 and segs is None:
                 segs = [(0, key[0], key[1])]
             return gemm.fused_linear(x, self.weight, self.bias, self._shadow, relu=relu, drop_p=drop_p,
-                                     segs=segs if drop_p > 0 else None, out_f32=out_f32, tag=self.tag)
+                                     segs=segs if drop_p > 0 else None, out_f32=out_f32, tag=self.tag,
+                                     grad_rows=grad_rows, row_ids=row_ids)
         y = self.forward(x)
         if relu:
             y = torch.relu(y)

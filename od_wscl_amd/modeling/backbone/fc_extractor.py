@@ -127,6 +127,28 @@ class _RowViews(torch.autograd.Function):
         return dp, None, None, None, None
 
 
+class _RowGather(torch.autograd.Function):
+    """rows of the stacked bf16 operand as a new (R, C*S) operand; the gradient of those rows is parked for the
+    pooling node (entries [e0, e0+R) of its fp32 side buffer)."""
+
+    @staticmethod
+    def forward(ctx, stacked, rows, holder, e0):
+        ctx.args = (holder, e0, int(rows.numel()))
+        return stacked.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, dx):
+        holder, e0, n = ctx.args
+
+        def fold(extra, identity_rows):
+            extra[e0:e0 + n].add_(dx)
+
+        if holder is None or holder.done:
+            raise RuntimeError("_RowGather: the pooling node already ran its backward")
+        holder.pending.append(fold)
+        return None, None, None, None
+
+
 class _PoolStack(torch.autograd.Function):
     """ROIPool of the feature map written directly as the stacked bf16 operand of the first head GEMM (rows 0..R-1
     the pooled features, rows R..2R-1 their DropBlock view) with a 16-bit argmax; backward scatters the gradient of
@@ -160,6 +182,8 @@ class _PoolStack(torch.autograd.Function):
         extra, roi_index, E = None, None, 0
         if holder is not None and holder.pending:
             roi_index = holder.roi_index
+            if isinstance(roi_index, (list, tuple)):
+                roi_index = roi_index[0] if len(roi_index) == 1 else torch.cat(list(roi_index))
             E = int(roi_index.numel())
             extra = torch.zeros((E, C * ph * pw), dtype=torch.float32, device=dx.device)
             for fold in holder.pending:
@@ -190,6 +214,8 @@ class TwoFCROIFeatureExtractor(nn.Module):
         self.sim_drop = DropBlock2D(block_size=1, drop_prob=0.3)
         self.rand = None
         self._grad_holder = None
+        self.sparse_clean = False
+        self._clean_keys = None
 
     def init_fc(self):
         for m in self.modules():
@@ -205,7 +231,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
     def fc7(self):
         return self.classifier[self.fc_index[1]]
 
-    def _fc(self, x, segs6=None, segs7=None):
+    def _fc(self, x, segs6=None, segs7=None, grad_rows=None, row_ids=None):
         """Linear, ReLU, Dropout, Linear, ReLU, Dropout (vgg16.py:121-127).  With a counter-based `rand`
         the two dropouts are fused into the GEMM epilogues; `segs*` carry per-pass keys when
         several passes are stacked along the row dimension."""
@@ -220,8 +246,8 @@ class TwoFCROIFeatureExtractor(nn.Module):
         if segs6 is None:
             k6, k7 = self.rand.key(), self.rand.key()
             segs6, segs7 = [(0, k6[0], k6[1])], [(0, k7[0], k7[1])]
-        x = fc6.fused(x, relu=True, drop_p=0.5, segs=segs6)
-        return fc7.fused(x, relu=True, drop_p=0.5, segs=segs7)
+        x = fc6.fused(x, relu=True, drop_p=0.5, segs=segs6, grad_rows=grad_rows, row_ids=row_ids)
+        return fc7.fused(x, relu=True, drop_p=0.5, segs=segs7, grad_rows=grad_rows, row_ids=row_ids)
 
     def forward_clean_and_aug(self, pooled):
         """The clean pass and the DropBlock pass of ROIWeakRegHead.forward (weak_head.py:107-112) as
@@ -270,7 +296,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
         holder = self._grad_holder
         if stacked:
             assert holder is not None and holder.kind == "extra" and roi_index is not None
-            holder.roi_index = roi_index
+            holder.roi_index = [roi_index]
         specs, segs6, segs7, row0 = [], [], [], 0
         for base, rows, k in groups:
             kd = self.rand.key()
@@ -313,8 +339,22 @@ class TwoFCROIFeatureExtractor(nn.Module):
         self._grad_holder = _GradHolder("extra")
         x = _PoolStack.apply(feat, rois5, block.contiguous(), block.sum(), self._grad_holder,
                              float(self.pooler.poolers[0].spatial_scale), res[0], res[1])
-        h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5])
-        return h[:P], h[P:], x
+        # The clean half feeds only Sim_Net, and the contrastive loss touches a few hundred of its P rows: the stacked
+        # evaluation takes part in backward with its DropBlock half only (grad_rows); the clean rows the loss ends
+        # up using are re-evaluated by recompute_clean_rows with their original dropout draws (row_ids).
+        self.sparse_clean = os.environ.get("ODW_NO_SPARSE") != "1"
+        self._clean_keys = (k1, k2)
+        h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5],
+                     grad_rows=(P, 2 * P) if self.sparse_clean else None)
+        return (h[:P].detach() if self.sparse_clean else h[:P]), h[P:], x
+
+    def recompute_clean_rows(self, stacked, rows, first_entry):
+        """fc6/fc7 of the clean rows `rows` (int32 device list, ascending) of the stacked operand, WITH autograd and
+        with the dropout draws those rows had in the stacked pass; their input gradient is parked as extra rows
+        [first_entry, first_entry + len(rows)) of the pooling node's side buffer."""
+        k1, k2 = self._clean_keys
+        x = _RowGather.apply(stacked, rows, self._grad_holder, first_entry)
+        return self._fc(x, segs6=[(0,) + k1], segs7=[(0,) + k2], row_ids=rows)
 
     def forward(self, x, proposals):
         pooled = self.pooler(x, proposals)

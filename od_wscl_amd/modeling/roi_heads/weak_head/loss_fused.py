@@ -314,9 +314,26 @@ class RoIRegLossFused(RoIRegLossComputation):
                     f = fresh_rows_h[idx, i, ci, :fresh_h[idx, i, ci]].astype(np.int64) + offs[idx]
                     w_fs.append(f * fs_cols + (c + 1))
                     w_cs.append(np.full(len(f), idx * cs_ld + cs_off + c + 1, dtype=np.int64))
-        feat_index, labels, w_fs_d, w_cs_d = self._staging.upload(
-            [np.concatenate(feat_parts), np.concatenate(label_parts), np.concatenate(w_fs), np.concatenate(w_cs)])
-        features = all_emb.index_select(0, feat_index)
+        feat_all = np.concatenate(feat_parts)
+        sparse = bool(getattr(feature_extractor, "sparse_clean", False)) and clean_pooled_feats.dim() == 2
+        if sparse:
+            # only the proposal rows the contrastive loss references carry gradient into the clean pass: re-evaluate
+            # exactly those (ascending, unique) with autograd and index a compact table [their embeddings; the views]
+            is_prop = feat_all < sum_p
+            act_rows = np.unique(feat_all[is_prop])
+            remap = np.where(is_prop, np.searchsorted(act_rows, np.minimum(feat_all, sum_p - 1)),
+                             feat_all - sum_p + len(act_rows))
+            feat_index, labels, w_fs_d, w_cs_d, act_d = self._staging.upload(
+                [remap, np.concatenate(label_parts), np.concatenate(w_fs), np.concatenate(w_cs), act_rows])
+            holder = feature_extractor._grad_holder
+            first_entry = int(sum(m[3] for m in meta))
+            holder.roi_index = list(holder.roi_index or []) + [act_d]
+            e_act = model_sim(feature_extractor.recompute_clean_rows(clean_pooled_feats, act_d, first_entry)).float()
+            features = torch.cat([e_act, emb], dim=0).index_select(0, feat_index)
+        else:
+            feat_index, labels, w_fs_d, w_cs_d = self._staging.upload(
+                [feat_all, np.concatenate(label_parts), np.concatenate(w_fs), np.concatenate(w_cs)])
+            features = all_emb.index_select(0, feat_index)
         weights = (final_score.detach().reshape(-1).index_select(0, w_fs_d)
                    / cs_flat.detach().index_select(0, w_cs_d))
         if tr is not None:

@@ -72,7 +72,11 @@ class ROIWeakRegHead(nn.Module):
             else:
                 clean_pooled = fe.forward_pooler(features, proposals)
                 clean_feats, aug_feats = fe.forward_clean_and_aug(clean_pooled)
-            sim_feature = self.model_sim(clean_feats)
+            if getattr(fe, "sparse_clean", False) and clean_pooled.dim() == 2:
+                with torch.no_grad():       # all P embeddings drive the selection; the rows the loss differentiates
+                    sim_feature = self.model_sim(clean_feats)      # are re-evaluated (fe.recompute_clean_rows)
+            else:
+                sim_feature = self.model_sim(clean_feats)
         else:
             clean_feats, clean_pooled = fe.forward(features, proposals)
             sim_feature = self.model_sim(clean_feats)

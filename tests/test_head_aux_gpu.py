@@ -157,7 +157,7 @@ def test_l2norm_rows_kernels():
     np.testing.assert_allclose(xs.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=2e-4, atol=2e-6)
 
 
-def test_pool_stack_equals_pool_then_stack():
+def test_pool_stack_equals_pool_then_stack(monkeypatch):
     """forward_pool_clean_and_aug (ROIPool writing the stacked bf16 operand + 16-bit argmax, sampled-row views read
     from it, all gradients scattered by one kernel) against forward_pooler -> forward_clean_and_aug -> views on the
     fp32 pooled tensor: identical draws, bit-identical operands and fc outputs, equal feature gradient."""
@@ -173,6 +173,7 @@ def test_pool_stack_equals_pool_then_stack():
     cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
                          "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,), "DB.METHOD", "dropblock"])
     ll.set_backend("hip_bf16")
+    monkeypatch.setenv("ODW_NO_SPARSE", "1")      # this test differentiates the clean features themselves
     try:
         torch.manual_seed(2)
         fe = VGG16FC67ROIFeatureExtractor(cfg, 512).cuda().train()
