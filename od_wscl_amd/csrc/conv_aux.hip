@@ -47,32 +47,49 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ dwk, int ld, int C
     }
 }
 
-// out[(t*C + ci)][m] = X[m + shift(t)][ci] (0 in the padding), m < ldm zero padded.  32(m) x 32(ci) tiles.
+// out[(t*C + ci)][m] = X[m + shift(t)][ci] (0 in the padding), m < ldm zero padded.
+// 64(m) x 64(ci) tiles, 16 bytes per lane both ways: a pixel's 64 channels are one 128-byte read (8 lanes x 16 B),
+// an output row's 64 pixels one 128-byte write; the transposition happens in LDS (rows padded to 72 elements).
+// (The first version moved 32x32 tiles with 2-byte accesses: 64-byte segments, 0.55 ms per step; this one ~0.2.)
 __global__ __launch_bounds__(256) void im2col_t_kernel(const unsigned short* __restrict__ X, int M, int H, int W,
                                                        int C, int dil, unsigned short* __restrict__ out, int ldm) {
-    __shared__ unsigned short tile[32][33];
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];
     const int t = blockIdx.z;
     const int ty9 = t / 3, tx9 = t - 3 * ty9;
     const int dh = (ty9 - 1) * dil, dw = (tx9 - 1) * dil;
-    const int c0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
     const int hw = H * W;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int m = m0 + ty + 8 * k, c = c0 + tx;
-        unsigned short v = 0;
+    for (int k = 0; k < 2; ++k) {
+        const int item = threadIdx.x + 256 * k;              // 64 pixels x 8 chunks of 8 channels
+        const int ml = item >> 3, ch = item & 7;
+        const int m = m0 + ml, c = c0 + ch * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
         if (m < M && c < C) {
             const int p = m % hw;
             const int y = p / W + dh, x = p % W + dw;
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = X[(size_t)(m + dh * W + dw) * C + c];
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                v = *reinterpret_cast<const uint4*>(X + (size_t)(m + dh * W + dw) * C + c);
         }
-        tile[ty + 8 * k][tx] = v;
+        *reinterpret_cast<uint4*>(&tile[ml][ch * 8]) = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + ty + 8 * k, m = m0 + tx;
-        if (c < C && m < ldm) out[((size_t)t * C + c) * ldm + m] = tile[tx][ty + 8 * k];
+    for (int k = 0; k < 2; ++k) {
+        const int item = threadIdx.x + 256 * k;              // 64 channels x 8 chunks of 8 pixels
+        const int cl = item >> 3, mc = item & 7;
+        const int c = c0 + cl, m = m0 + mc * 8;
+        if (c < C && m < ldm) {
+            unsigned short v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = tile[mc * 8 + q][cl];
+            uint4 o;
+            o.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+            o.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+            o.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
+            o.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
+            *reinterpret_cast<uint4*>(out + ((size_t)t * C + c) * ldm + m) = o;
+        }
     }
 }
 
@@ -208,7 +225,9 @@ ODW_EXPORT int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, 
                                  void* stream_) {
     ODW_REQUIRE(n_pix > 0 && H > 0 && W > 0 && C > 0 && ldm >= n_pix && n_pix % (H * W) == 0 && X && out,
                 "im2col_t: bad arguments");
-    dim3 grid((C + 31) / 32, (ldm + 31) / 32, 9);
+    ODW_REQUIRE(C % 8 == 0 && ldm % 8 == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
+                "im2col_t: C=%d and ldm=%d must be multiples of 8, pointers 16-byte aligned", C, ldm);
+    dim3 grid((C + 63) / 64, (ldm + 63) / 64, 9);
     im2col_t_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X, n_pix, H, W, C, dilation,
                                                             (unsigned short*)out, ldm);
     ODW_CHECK_LAUNCH("im2col_t_kernel");

@@ -813,6 +813,42 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __re
     }
 }
 
+// bf16 -> bf16 transpose with 16-byte accesses both ways: 64 x 64 tiles through LDS (rows padded to 72 elements);
+// needs Cc, ld_in, ld_out, out_cols multiples of 8 and 16-byte-aligned pointers (every operand of the head's GEMMs).
+__global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const unsigned short* __restrict__ in, int ld_in, int R,
+                                                                 int Cc, unsigned short* __restrict__ out, int ld_out,
+                                                                 int out_cols) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = threadIdx.x + 256 * k;
+        const int rl = item >> 3, ch = item & 7;
+        const int r = r0 + rl, c = c0 + ch * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < R && c < Cc) v = *reinterpret_cast<const uint4*>(in + (size_t)r * ld_in + c);
+        *reinterpret_cast<uint4*>(&tile[rl][ch * 8]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = threadIdx.x + 256 * k;
+        const int cl = item >> 3, rc = item & 7;
+        const int c = c0 + cl, r = r0 + rc * 8;
+        if (c < Cc && r < out_cols) {
+            unsigned short v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = tile[rc * 8 + q][cl];
+            uint4 o;
+            o.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+            o.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+            o.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
+            o.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
+            *reinterpret_cast<uint4*>(out + (size_t)c * ld_out + r) = o;
+        }
+    }
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n) {
     const size_t n4 = n / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -862,6 +898,78 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __rest
 #pragma unroll
         for (int r = 0; r < 32; ++r) sum += t[r][tx];
         if (n0 + tx < N) atomicAdd(db + n0 + tx, sum);
+    }
+}
+
+// The same prologue with 16-byte accesses: 64 x 64 tiles, fp32 tile in LDS (column sums for the bias gradient in
+// fp32 before any rounding, as above), dZ written as it is loaded, dZ^T as 8 transposed values per lane.
+template <bool DY_F32>
+__global__ __launch_bounds__(256) void linear_bwd_prep_vec_kernel(const void* __restrict__ dY, int ld_dy,
+                                                                  const unsigned short* __restrict__ Y, int ld_y,
+                                                                  int M, int N, float scale,
+                                                                  unsigned short* __restrict__ dZ, int ld_z,
+                                                                  unsigned short* __restrict__ dZT, int ld_t, int t_cols,
+                                                                  float* __restrict__ db) {
+    __shared__ float t[64][65];
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = threadIdx.x + 256 * k;
+        const int ml = item >> 3, ch = item & 7;
+        const int m = m0 + ml, n = n0 + ch * 8;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m < M && n < N) {            // N % 8 == 0: a chunk is all-in or all-out
+            if (DY_F32) {
+                const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dY) + (size_t)m * ld_dy + n);
+                const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dY) + (size_t)m * ld_dy + n + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+                const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(dY) + (size_t)m * ld_dy + n);
+                const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+            }
+            if (Y) {
+                const uint4 yv = *reinterpret_cast<const uint4*>(Y + (size_t)m * ld_y + n);
+                const unsigned w[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] = (w[q] & 0x7fffu) ? v[2 * q] * scale : 0.0f;
+                    v[2 * q + 1] = (w[q] & 0x7fff0000u) ? v[2 * q + 1] * scale : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[ml][ch * 8 + q] = v[q];
+        if (m < M && n < ld_z) {         // ld_z % 8 == 0 as well; beyond N the chunk is zero padding
+            uint4 o;
+            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+            o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+            *reinterpret_cast<uint4*>(dZ + (size_t)m * ld_z + n) = o;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = threadIdx.x + 256 * k;
+        const int nl = item >> 3, mc = item & 7;
+        const int n = n0 + nl, m = m0 + mc * 8;
+        if (n < N && m < t_cols) {
+            uint4 o;
+            o.x = (unsigned)f2bf(t[mc * 8 + 0][nl]) | ((unsigned)f2bf(t[mc * 8 + 1][nl]) << 16);
+            o.y = (unsigned)f2bf(t[mc * 8 + 2][nl]) | ((unsigned)f2bf(t[mc * 8 + 3][nl]) << 16);
+            o.z = (unsigned)f2bf(t[mc * 8 + 4][nl]) | ((unsigned)f2bf(t[mc * 8 + 5][nl]) << 16);
+            o.w = (unsigned)f2bf(t[mc * 8 + 6][nl]) | ((unsigned)f2bf(t[mc * 8 + 7][nl]) << 16);
+            *reinterpret_cast<uint4*>(dZT + (size_t)n * ld_t + m) = o;
+        }
+    }
+    if (db && threadIdx.x < 64) {
+        float sum = 0.0f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) sum += t[r][threadIdx.x];
+        if (n0 + (int)threadIdx.x < N) atomicAdd(db + n0 + threadIdx.x, sum);
     }
 }
 
@@ -1161,6 +1269,14 @@ ODW_EXPORT int odw_transpose_to_bf16_part(const void* in, int in_is_f32, int ld_
     ODW_REQUIRE(R >= 0 && Cc >= 0 && ld_in >= Cc && out_cols >= R && ld_out >= out_cols, "transpose_to_bf16: bad dims");
     if (R == 0 || Cc == 0) return ODW_OK;
     ODW_REQUIRE(in && out, "transpose_to_bf16: null pointer");
+    if (!in_is_f32 && Cc % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && out_cols % 8 == 0 &&
+        (((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 15) == 0) {
+        dim3 vgrid((Cc + 63) / 64, (out_cols + 63) / 64);
+        transpose_bf16_vec_kernel<<<vgrid, 256, 0, stream>>>((const unsigned short*)in, ld_in, R, Cc, (unsigned short*)out,
+                                                             ld_out, out_cols);
+        ODW_CHECK_LAUNCH("transpose_bf16_vec_kernel");
+        return ODW_OK;
+    }
     dim3 grid((Cc + 31) / 32, (out_cols + 31) / 32);   // covers the zero padding up to out_cols
     if (in_is_f32)
         transpose_to_bf16_kernel<true><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out, out_cols);
@@ -1196,6 +1312,22 @@ ODW_EXPORT int odw_linear_bwd_prep_part(const void* dY, int dy_is_f32, int ld_dy
     ODW_REQUIRE(M >= 0 && N >= 0 && ld_z >= N && t_cols >= M && ld_t >= t_cols && ld_dy >= N, "linear_bwd_prep: bad dims");
     if (M == 0 || N == 0) return ODW_OK;
     ODW_REQUIRE(dY && dZ && dZT, "linear_bwd_prep: null pointer");
+    const bool vec = N % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_t % 8 == 0 && t_cols % 8 == 0 && (!Y || ld_y % 8 == 0) &&
+                     (((uintptr_t)dY) & 15) == 0 && (((uintptr_t)Y) & 15) == 0 && (((uintptr_t)dZ) & 15) == 0 &&
+                     (((uintptr_t)dZT) & 15) == 0;
+    if (vec) {
+        dim3 vgrid((ld_z + 63) / 64, (t_cols + 63) / 64);
+        if (dy_is_f32)
+            linear_bwd_prep_vec_kernel<true><<<vgrid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
+                                                                        (unsigned short*)dZ, ld_z, (unsigned short*)dZT,
+                                                                        ld_t, t_cols, db);
+        else
+            linear_bwd_prep_vec_kernel<false><<<vgrid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
+                                                                         (unsigned short*)dZ, ld_z, (unsigned short*)dZT,
+                                                                         ld_t, t_cols, db);
+        ODW_CHECK_LAUNCH("linear_bwd_prep_vec_kernel");
+        return ODW_OK;
+    }
     dim3 grid((ld_z + 31) / 32, (t_cols + 31) / 32);     // covers the zero padding of both outputs
     if (dy_is_f32)
         linear_bwd_prep_kernel<true><<<grid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
