@@ -241,3 +241,35 @@ def test_row_sparse_clean_backward_equals_dense(monkeypatch):
         rel = (ga - gb).abs().max().item() / (gb.abs().max().item() + 1e-6)     # floor: analytically-zero gradients
         worst = max(worst, rel)
         assert rel <= 3e-2, (n, rel)          # bf16 GEMMs over different row sets: re-association + bf16 rounding
+
+
+def test_engine_steps_over_changing_shapes(monkeypatch):
+    """Consecutive training steps on images of different sizes, proposal counts and label sets (the reference trains
+    multi-scale: INPUT.MIN_SIZE_TRAIN has six sizes): every per-step buffer, index upload, split-K plan and
+    weight-gradient batch is sized per step; losses stay finite and parameters move."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from od_wscl_amd import engine, synthetic
+    from od_wscl_amd.structures import BoxList, to_image_list
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("ODW_NO_TIMER", "1")
+    cfg = bench.build_cfg(21)
+    step, _ = engine.build_training_step(cfg, dev, dtype="bf16", world=1, seed=cfg.SEED, backend="hip")
+    opt = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, engine.FlatSGD)][0]
+    p0 = opt.flat_p.clone()
+    cases = [(224, 320, 180, [3]), (352, 256, 90, [1, 7, 12]), (224, 320, 180, [3]), (160, 192, 40, [20, 5])]
+    for it, (h, w, p, labs) in enumerate(cases):
+        img = torch.from_numpy(synthetic.make_image(11, it, h, w))[:, :h, :w]
+        boxes = torch.from_numpy(synthetic.make_proposals(11, it, p, h, w, min_size=16))
+        images = to_image_list([img], 32).to(dev)
+        rois = [BoxList(boxes.to(dev), (w, h), "xyxy")]
+        t = BoxList(torch.zeros((len(labs), 4), device=dev), (w, h), "xyxy")
+        t.add_field("labels", torch.tensor(labs, device=dev))
+        t.add_field("labels_host", labs)
+        losses, accs = step(images, [t], rois, DeviceRand(5, first_stream=(1 << 20) + (it << 12), device=dev), iteration=it + 1)
+        vals = [float(v.detach()) for v in losses.values()]
+        assert all(np.isfinite(v) for v in vals), (it, losses)
+    torch.cuda.synchronize()
+    assert torch.isfinite(opt.flat_p).all() and not torch.equal(opt.flat_p, p0)
