@@ -63,6 +63,7 @@ def make_defaults():
     c.SOLVER.WEIGHT_DECAY = 0.0005
     c.SOLVER.WEIGHT_DECAY_BIAS = 0
     c.SOLVER.IMS_PER_BATCH = 16
+    c.SOLVER.CHECKPOINT_PERIOD = 2500                         # :454
     c.SOLVER.GAMMA = 0.1                                      # :445-450
     c.SOLVER.STEPS = (30000,)
     c.SOLVER.WARMUP_FACTOR = 1.0 / 3

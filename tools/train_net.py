@@ -1,0 +1,122 @@
+"""Counterpart of the reference's tools/train_net.py for the MI355X build: same command line
+(--config-file <yaml> [KEY VALUE ...]), same yaml files, same flow (build model -> optimiser + WarmupMultiStepLR
+-> load cfg.MODEL.WEIGHT if it is a local .pth -> train loop with periodic checkpoints in the reference's layout),
+one process per GPU under torch.distributed.run (RCCL).
+
+The data side of wetectron (datasets, transforms, proposal files) is outside this build:
+batches come from --synthetic (formula-generated images / proposals / image labels of the configured shape) or from
+a user-supplied iterable yielding (ImageList, [BoxList targets], [BoxList proposals]).
+
+    python tools/train_net.py --config-file /path/to/voc07_contra_db_b8_lr0.01_mcg.yaml --synthetic \\
+        SOLVER.MAX_ITER 50 SOLVER.CHECKPOINT_PERIOD 25 OUTPUT_DIR /tmp/odw_run
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def synthetic_loader(cfg, rank, device, size, proposals, max_iter):
+    from od_wscl_amd import synthetic
+    from od_wscl_amd.structures import BoxList, to_image_list
+    classes = cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES
+    div = cfg.DATALOADER.SIZE_DIVISIBILITY or 32
+    for it in range(max_iter):
+        key = it * 1000 + rank                       # a different image per (iteration, rank)
+        img = torch.from_numpy(synthetic.make_image(cfg.SEED, key, size, size))[:, :size, :size]
+        boxes = torch.from_numpy(synthetic.make_proposals(cfg.SEED, key, proposals, size, size))
+        labels = synthetic.make_labels(cfg.SEED, key, classes).tolist()
+        t = BoxList(torch.zeros((len(labels), 4), device=device), (size, size), "xyxy")
+        t.add_field("labels", torch.tensor(labels, device=device))
+        t.add_field("labels_host", labels)
+        yield to_image_list([img], div).to(device), [t], [BoxList(boxes.to(device), (size, size), "xyxy")]
+
+
+def main():
+    ap = argparse.ArgumentParser(description="OD-WSCL training on MI355X")
+    ap.add_argument("--config-file", default="", metavar="FILE")
+    ap.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))
+    ap.add_argument("--synthetic", action="store_true", help="formula-generated batches (no datasets in this build)")
+    ap.add_argument("--size", type=int, default=600)
+    ap.add_argument("--proposals", type=int, default=2000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--log-period", type=int, default=20)
+    ap.add_argument("opts", default=None, nargs=argparse.REMAINDER)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("tools/train_net.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(args.local_rank)
+    device = torch.device("cuda", args.local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from od_wscl_amd import engine
+    from od_wscl_amd.config import cfg as base
+    from od_wscl_amd.utils import checkpoint as ck
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    cfg = base.clone()
+    if args.config_file:
+        cfg.merge_from_file(args.config_file)
+    cfg.merge_from_list(args.opts or [])
+    if cfg.SEED < 0:
+        cfg.merge_from_list(["SEED", 1234])
+    if not args.synthetic:
+        raise SystemExit("only --synthetic batches are available: the dataset / proposal-file side of wetectron is "
+                         "outside this build (pass your own loader to engine.build_training_step's step function)")
+
+    step, info = engine.build_training_step(cfg, device, dtype=args.dtype, world=world, seed=cfg.SEED, backend="hip")
+    opt = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, engine.FlatSGD)][0]
+    model = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, torch.nn.Module)][0]
+    start_iter = 0
+    weight = cfg.MODEL.WEIGHT
+    if weight and os.path.isfile(weight):           # catalog:// and http:// sources need the network: not here
+        rest = ck.load_checkpoint(model, weight)
+        opt.sync_from_params()
+        start_iter = int(rest.get("iteration", 0))
+        if rank == 0:
+            print("loaded %s (iteration %d)" % (weight, start_iter), flush=True)
+    elif weight and rank == 0:
+        print("MODEL.WEIGHT %r is not a local file: training from the formula initialisation" % weight, flush=True)
+
+    max_iter = cfg.SOLVER.MAX_ITER
+    period = getattr(cfg.SOLVER, "CHECKPOINT_PERIOD", 0)
+    out_dir = cfg.OUTPUT_DIR
+    if rank == 0 and out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+    loader = synthetic_loader(cfg, rank, device, args.size, args.proposals, max_iter)
+    t0, seen = time.time(), 0
+    for iteration, (images, targets, rois) in enumerate(loader, start_iter):
+        iteration += 1                                             # engine/trainer.py:94
+        if iteration > max_iter:
+            break
+        rand = DeviceRand(cfg.SEED + rank, first_stream=(1 << 20) + (iteration << 12), device=device)
+        losses, accs = step(images, targets, rois, rand, iteration=iteration)
+        seen += sum(len(r) for r in rois)
+        if rank == 0 and (iteration % args.log_period == 0 or iteration == max_iter):
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            txt = "  ".join("%s: %.4f" % (k, float(v.detach())) for k, v in losses.items())
+            print("iter: %d  lr: %.6f  %s  | %.0f proposals/s/GPU" % (
+                iteration, cfg.SOLVER.BASE_LR * opt.lr_scale, txt, seen / dt), flush=True)
+            t0, seen = time.time(), 0
+        if rank == 0 and out_dir and period and (iteration % period == 0 or iteration == max_iter):
+            path = os.path.join(out_dir, "model_%07d.pth" % iteration if iteration != max_iter else "model_final.pth")
+            ck.save_checkpoint(model, path, iteration=iteration)
+            with open(os.path.join(out_dir, "last_checkpoint"), "w") as f:      # utils/checkpoint.py:120-123
+                f.write(path)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
