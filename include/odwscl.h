@@ -56,13 +56,15 @@ int odw_roi_pool_backward(const float* grad_out, const int32_t* argmax, const fl
  * R+n = ((x * keep[n][bin]) * R*PH*PW) / *keep_sum (DropBlock2D.forward, drop_block.py:45-50; keep = NULL: only
  * the R clean rows); argmax 16-bit (0xFFFF = empty bin; H*W < 65535).  _backward scatters the gradient of both halves
  * of X -- plus E parked fp32 gradient rows `extra` belonging to ROIs `extra_roi` (the sampled-row views of the
- * contrastive loss) -- through the argmax into grad_in (B, C, H, W) fp32. */
+ * contrastive loss) -- through the argmax into grad_in (B, C, H, W) fp32; skip_clean: rows [0, R) of dX are not read
+ * (row-sparse backward: their gradient arrives through `extra`). */
 int odw_roi_pool_stack_forward(const float* feat, const float* rois, float spatial_scale, int B, int C, int H, int W,
                                int R, int PH, int PW, const float* keep, const float* keep_sum, void* X_bf16, int ld,
                                void* argmax_u16, void* workspace, int64_t workspace_bytes, void* stream);
 int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld, const void* argmax_u16, const float* rois,
                                 const float* keep, const float* keep_sum, const float* extra, const int* extra_roi,
-                                int E, int B, int C, int H, int W, int R, int PH, int PW, float* grad_in, void* stream);
+                                int E, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW, float* grad_in,
+                                void* stream);
 
 /* ---- ROIAlign -------------------------------------------------------------
  * replaces _C.roi_align_forward / roi_align_backward

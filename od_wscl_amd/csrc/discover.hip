@@ -75,12 +75,14 @@ __device__ __forceinline__ bool tv_overlap(const float4 a, const float4 b, float
 
 // <X[r], v> for one row handled by a whole wave: lanes read the 512-byte row coalesced (2 floats each),
 // butterfly-reduce.  v is in LDS.  All 64 lanes return the sum.
-__device__ __forceinline__ float wave_row_dot(const float* __restrict__ row, const float* __restrict__ v, int lane) {
-    const float2 x = reinterpret_cast<const float2*>(row)[lane];
+__device__ __forceinline__ float wave_dot_loaded(const float2 x, const float* __restrict__ v, int lane) {
     float d = x.x * v[2 * lane] + x.y * v[2 * lane + 1];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
     return d;
+}
+__device__ __forceinline__ float wave_row_dot(const float* __restrict__ row, const float* __restrict__ v, int lane) {
+    return wave_dot_loaded(reinterpret_cast<const float2*>(row)[lane], v, lane);
 }
 
 // sorted list of the set bits of mask[0..W) (32-bit words) -> out, returns count.  scan: LDS int[W+1]
@@ -206,12 +208,26 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
             if (threadIdx.x < kD) etop[threadIdx.x] = E[(size_t)top * kD + threadIdx.x];
             __syncthreads();
             // ---- threshold: mean_j <e_top, bank_c[j]>   (loss.py:320)
+            // (the dot loops keep four rows of loads in flight per wave: one row per iteration is pure L2 latency;
+            //  per-row arithmetic and the order of the running sums are unchanged)
             {
                 const int nb = a.bank_cnt[c];
                 const float* bk = a.bank + (size_t)a.bank_off[c] * kD;
                 const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                constexpr int kW = kThreads / 64;
                 float acc = 0.0f;
-                for (int j = wave; j < nb; j += kThreads / 64) {
+                int j = wave;
+                for (; j + 3 * kW < nb; j += 4 * kW) {
+                    float2 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = reinterpret_cast<const float2*>(bk + (size_t)(j + u * kW) * kD)[lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float d = wave_dot_loaded(x[u], etop, lane);
+                        if (lane == 0) acc += d;
+                    }
+                }
+                for (; j < nb; j += kW) {
                     const float d = wave_row_dot(bk + (size_t)j * kD, etop, lane);
                     if (lane == 0) acc += d;
                 }
@@ -228,7 +244,19 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
             // ---- close = sim_mat[top] >= thr
             {
                 const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-                for (int r = wave; r < P; r += kThreads / 64) {
+                constexpr int kW = kThreads / 64;
+                int r = wave;
+                for (; r + 3 * kW < P; r += 4 * kW) {
+                    float2 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = reinterpret_cast<const float2*>(E + (size_t)(r + u * kW) * kD)[lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float d = wave_dot_loaded(x[u], etop, lane);
+                        if (lane == 0) close[r + u * kW] = d >= thr ? 1 : 0;
+                    }
+                }
+                for (; r < P; r += kW) {
                     const float d = wave_row_dot(E + (size_t)r * kD, etop, lane);
                     if (lane == 0) close[r] = d >= thr ? 1 : 0;
                 }
@@ -243,7 +271,19 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
                     __syncthreads();
                     {
                         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-                        for (int r = wave; r < P; r += kThreads / 64) {
+                        constexpr int kW = kThreads / 64;
+                        int r = wave;
+                        for (; r + 3 * kW < P; r += 4 * kW) {
+                            float2 x[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) x[u] = reinterpret_cast<const float2*>(E + (size_t)(r + u * kW) * kD)[lane];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float d = wave_dot_loaded(x[u], etop, lane);
+                                if (lane == 0) close[r + u * kW] = ((close[r + u * kW] ? 1.0f : 0.0f) >= d) ? 1 : 0;
+                            }
+                        }
+                        for (; r < P; r += kW) {
                             const float d = wave_row_dot(E + (size_t)r * kD, etop, lane);
                             if (lane == 0) close[r] = ((close[r] ? 1.0f : 0.0f) >= d) ? 1 : 0;
                         }

@@ -292,7 +292,8 @@ template <int CG, bool DX_F32>
 __global__ __launch_bounds__(kPlaneThreads) void roi_pool_stack_bwd_plane(
     const void* __restrict__ dXv, int ld, const unsigned short* __restrict__ argmax, const float* __restrict__ rois,
     const float* __restrict__ keep, const float* __restrict__ keep_sum, const float* __restrict__ extra,
-    const int* __restrict__ extra_roi, int E, int C, int H, int W, int R, int nb, float* __restrict__ grad_in) {
+    const int* __restrict__ extra_roi, int E, int skip_clean, int C, int H, int W, int R, int nb,
+    float* __restrict__ grad_in) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const int groups = (C + CG - 1) / CG;
     const int b = blockIdx.x / groups;
@@ -320,11 +321,11 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_pool_stack_bwd_plane(
             g = extra[(size_t)(n - R) * C * nb + col];
         } else if (DX_F32) {
             const float* dX = reinterpret_cast<const float*>(dXv);
-            g = dX[(size_t)n * ld + col];
+            g = skip_clean ? 0.0f : dX[(size_t)n * ld + col];
             if (keep) g += ((dX[(size_t)(R + n) * ld + col] * keep[(size_t)n * nb + bin]) * numel) / sum;
         } else {
             const unsigned short* dX = reinterpret_cast<const unsigned short*>(dXv);
-            g = rp_bf2f(dX[(size_t)n * ld + col]);
+            g = skip_clean ? 0.0f : rp_bf2f(dX[(size_t)n * ld + col]);
             if (keep) g += ((rp_bf2f(dX[(size_t)(R + n) * ld + col]) * keep[(size_t)n * nb + bin]) * numel) / sum;
         }
         atomicAdd(&acc[cl * HW + a], g);
@@ -492,8 +493,8 @@ ODW_EXPORT int odw_roi_pool_stack_forward(const float* feat, const float* rois, 
 
 ODW_EXPORT int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
                                            const float* rois, const float* keep, const float* keep_sum,
-                                           const float* extra, const int* extra_roi, int E, int B, int C, int H, int W,
-                                           int R, int PH, int PW, float* grad_in, void* stream_) {
+                                           const float* extra, const int* extra_roi, int E, int skip_clean, int B, int C,
+                                           int H, int W, int R, int PH, int PW, float* grad_in, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(B >= 1 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 1 && E >= 0,
                 "roi_pool_stack_backward: bad dims");
@@ -508,7 +509,8 @@ ODW_EXPORT int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld
     do {                                                                                                            \
         ODW_CHECK_HIP(allow_lds(roi_pool_stack_bwd_plane<CGV, F32>, lds), "roi_pool_stack_bwd_plane attr");         \
         roi_pool_stack_bwd_plane<CGV, F32><<<grid, kPlaneThreads, lds, stream>>>(                                   \
-            dX, ld, (const unsigned short*)argmax_u16, rois, keep, keep_sum, extra, extra_roi, E, C, H, W, R, nb, grad_in); \
+            dX, ld, (const unsigned short*)argmax_u16, rois, keep, keep_sum, extra, extra_roi, E, skip_clean, C, H, W, R, nb, \
+            grad_in);                                                                                               \
     } while (0)
     if (cg == 2) { if (dx_is_f32) ODW_RPS_BWD(2, true); else ODW_RPS_BWD(2, false); }
     else { if (dx_is_f32) ODW_RPS_BWD(1, true); else ODW_RPS_BWD(1, false); }

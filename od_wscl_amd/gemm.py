@@ -189,7 +189,7 @@ class _FusedLinear(torch.autograd.Function):
         N = weight.shape[0]
         dy = dy.contiguous()
         if grad_rows is not None:           # rows outside [a, b) neither send nor receive gradient
-            ra, rb = grad_rows
+            ra, rb = grad_rows[0], grad_rows[1]
             dy, xb = dy[ra:rb], xb[ra:rb]
             y = y[ra:rb] if y is not None else None
         M = xb.shape[0]
@@ -221,8 +221,9 @@ class _FusedLinear(torch.autograd.Function):
             dx_all = torch.empty((M_all, K), dtype=x_dtype, device=dy.device)
             dx = dx_all
             if grad_rows is not None:
-                dx_all[:ra].zero_()
-                dx_all[rb:].zero_()
+                if len(grad_rows) < 3 or grad_rows[2]:      # (a, b, False): the consumer ignores rows outside [a, b)
+                    dx_all[:ra].zero_()
+                    dx_all[rb:].zero_()
                 dx = dx_all[ra:rb]
             kernel_timer.layer = tag and tag + "_dgrad"
             gemm_nt(dz, sh.wt, M, K, N, dx)

@@ -61,6 +61,7 @@ class _GradHolder(object):
         # kind "extra": there is no pooled tensor (ROI pooling writes the stacked operand itself) -- folds fill an
         #               (E, C*h*w) fp32 side buffer, one row per sampled entry, roi_index[e] = the ROI it belongs to
         self.kind, self.pending, self.done, self.roi_index = kind, [], False, None
+        self.clean_rows = None      # _PoolStack: number of leading rows of dX whose gradient is meaningful (None = all)
 
 
 _IOTA = {}
@@ -192,9 +193,10 @@ class _PoolStack(torch.autograd.Function):
         if holder is not None:
             holder.done = True
         dfeat = torch.empty((B, C, H, W), dtype=torch.float32, device=dx.device)
+        skip_clean = 1 if (holder is not None and holder.clean_rows == 0) else 0      # sparse backward: clean half unset
         L.check(L.lib().odw_roi_pool_stack_backward(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
                                                     L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
-                                                    L.ptr(extra), L.ptr(roi_index), E, B, C, H, W, R, ph, pw,
+                                                    L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph, pw,
                                                     L.ptr(dfeat), L.stream()), "roi_pool_stack_backward")
         return dfeat, None, None, None, None, None, None, None
 
@@ -345,7 +347,8 @@ class TwoFCROIFeatureExtractor(nn.Module):
         self.sparse_clean = os.environ.get("ODW_NO_SPARSE") != "1"
         self._clean_keys = (k1, k2)
         h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5],
-                     grad_rows=(P, 2 * P) if self.sparse_clean else None)
+                     grad_rows=(P, 2 * P, False) if self.sparse_clean else None)   # consumers skip the clean half:
+        self._grad_holder.clean_rows = 0 if self.sparse_clean else P                       # fc6's slices it, pooling below
         return (h[:P].detach() if self.sparse_clean else h[:P]), h[P:], x
 
     def recompute_clean_rows(self, stacked, rows, first_entry):

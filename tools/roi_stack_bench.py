@@ -18,7 +18,7 @@ def fwd():
     L.check(lib.odw_roi_pool_stack_forward(L.ptr(feat), L.ptr(rois), 0.125, 1, C, H, W, P, 7, 7, L.ptr(keep), L.ptr(ks), L.ptr(x),
                                            x.stride(0), L.ptr(am), L.ptr(ws), wsb, L.stream()), "fwd")
 def bwd():
-    L.check(lib.odw_roi_pool_stack_backward(L.ptr(dx), 0, dx.stride(0), L.ptr(am), L.ptr(rois), L.ptr(keep), L.ptr(ks), None, None, 0,
+    L.check(lib.odw_roi_pool_stack_backward(L.ptr(dx), 0, dx.stride(0), L.ptr(am), L.ptr(rois), L.ptr(keep), L.ptr(ks), None, None, 0, 0,
                                             1, C, H, W, P, 7, 7, L.ptr(dfeat), L.stream()), "bwd")
 def timeit(fn, n=10):
     for _ in range(3): fn()
