@@ -237,7 +237,9 @@ class FlatSGD(object):
 
     def head_grads_ready(self):
         """Called from backward (tensor hook on the pooled features) once every gradient of region 0 is final:
-        all-reduce + SGD + shadow refresh of the head on the side stream, overlapping the backbone's backward."""
+        all-reduce + SGD + shadow refresh of the head on the side stream, overlapping the backbone's backward.
+        (Measured alternative: SGD deferred to overlap the NEXT step's backbone forward instead -- same step time:
+        the optimiser pass is 3.4 GB of HBM traffic wherever it runs.)"""
         if self.side is None or self.n_gemm == 0 or self.early_done or os.environ.get("ODW_NO_OVERLAP") == "1":
             return
         self.flush_wgrad()
