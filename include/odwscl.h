@@ -317,6 +317,20 @@ int odw_refine_losses(const float* Y, int ldy, const int* head_offsets, int C, c
                       const float* weights, const float* targets, const int* n_pos, float eps, float* out, float* dY,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- data boundary: decoded uint8 image -> its slot of the normalised, zero-padded batch -----------
+ * Replaces, for the pixels, the reference's CPU-worker transform chain data/transforms/transforms.py:33-150
+ * (Resize = torchvision F.resize on a PIL image = Pillow's Image.resize(BILINEAR), :62-70; RandomHorizontalFlip /
+ * RandomVerticalFlip :72-98; ToTensor :116-118; Lighting :133-150; Normalize :120-131) and the padding copy of
+ * structures/image_list.py:60-72, and engine/bbox_aug.py:81-137 at test time (one call per scale / flip).
+ * rgb = DEVICE uint8 (in_h, in_w, 3), RGB order, as PIL decodes it; (out_h, out_w) = Resize.get_size();
+ * lighting_rgb / mean / std = HOST float[3] (lighting_rgb may be NULL); out = DEVICE fp32 plane (3, Hp, Wp) of the
+ * batch tensor, pixels outside (out_h, out_w) are written as 0.  The resampling is bit-identical to Pillow's 8-bit
+ * path (22-bit fixed-point coefficients, horizontal pass rounded to uint8 first). */
+int64_t odw_image_preprocess_workspace(int in_h, int in_w, int out_h, int out_w);
+int odw_image_preprocess(const uint8_t* rgb, int in_h, int in_w, int out_h, int out_w, int hflip, int vflip,
+                         const float* lighting_rgb, const float* mean, const float* std, int to_bgr255, float* out,
+                         int Hp, int Wp, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

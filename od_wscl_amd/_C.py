@@ -168,3 +168,31 @@ def od_assign(boxes, gt_boxes, gt_classes, gt_scores, fg_thresh=0.5, weights=(10
                                   float(fg_thresh), *[float(w) for w in weights], L.ptr(labels), L.ptr(lw),
                                   L.ptr(tg), L.stream()), "od_assign")
     return labels, lw, tg
+
+
+def image_preprocess(pixels, out_hw, out_plane, mean, std, to_bgr255=True, hflip=False, vflip=False, lighting=None):
+    """Decoded uint8 image (H,W,3 RGB, on the GPU) -> its normalised, zero-padded fp32 slot (3,Hp,Wp) of the batch:
+    Pillow-exact bilinear resize to out_hw, flips, /255, + lighting, BGR*255, (x-mean)/std in one pass
+    (data/transforms/transforms.py:33-150 + structures/image_list.py:60-72)."""
+    import ctypes
+    import numpy as np
+    L.need_gpu(pixels, out_plane)
+    if pixels.dtype != torch.uint8 or pixels.dim() != 3 or pixels.shape[2] != 3 or not pixels.is_contiguous():
+        raise ValueError("image_preprocess: pixels must be a contiguous uint8 (H,W,3) tensor")
+    if out_plane.dtype != torch.float32 or out_plane.dim() != 3 or out_plane.shape[0] != 3 or not out_plane.is_contiguous():
+        raise ValueError("image_preprocess: out_plane must be a contiguous fp32 (3,Hp,Wp) tensor")
+    in_h, in_w = int(pixels.shape[0]), int(pixels.shape[1])
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    f3 = ctypes.c_float * 3
+    mean_c = f3(*[float(np.float32(v)) for v in mean])
+    std_c = f3(*[float(np.float32(v)) for v in std])
+    light_c = f3(*[float(np.float32(v)) for v in lighting]) if lighting is not None else None
+    nbytes = L.lib().odw_image_preprocess_workspace(in_h, in_w, oh, ow)
+    ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=pixels.device)
+    L.check(L.lib().odw_image_preprocess(
+        L.ptr(pixels), in_h, in_w, oh, ow, int(bool(hflip)), int(bool(vflip)),
+        ctypes.cast(light_c, ctypes.c_void_p) if light_c is not None else ctypes.c_void_p(0),
+        ctypes.cast(mean_c, ctypes.c_void_p), ctypes.cast(std_c, ctypes.c_void_p), int(bool(to_bgr255)),
+        L.ptr(out_plane), int(out_plane.shape[1]), int(out_plane.shape[2]), L.ptr(ws), int(nbytes), L.stream()),
+        "image_preprocess")
+    return out_plane

@@ -26,6 +26,18 @@ def boxlist_nms_index(boxlist, nms_thresh, max_proposals=-1, score_field="scores
     return boxlist[keep].convert(mode), keep
 
 
+def remove_small_boxes(boxlist, min_size):
+    """Keep boxes whose width AND height (+1 convention) are >= min_size (boxlist_ops.py:96-113)."""
+    wh = boxlist.convert("xywh").bbox
+    keep = torch.nonzero((wh[:, 2] >= min_size) & (wh[:, 3] >= min_size)).squeeze(1)
+    return boxlist[keep]
+
+
+def remove_small_area(boxlist, min_area):
+    keep = torch.nonzero(boxlist.area() >= min_area).squeeze(1)
+    return boxlist[keep], keep
+
+
 def cat_boxlist(bboxes):
     size, mode = bboxes[0].size, bboxes[0].mode
     out = BoxList(torch.cat([b.bbox for b in bboxes], dim=0), size, mode)

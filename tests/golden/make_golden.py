@@ -355,6 +355,70 @@ def gen_infer(name, spec, out):
     print("wrote", out)
 
 
+def gen_data(name, spec, out):
+    """The imported reference's data boundary on a miniature VOC devkit: PascalVOCDataset.__getitem__ (proposal
+    preparation, transforms) and BatchCollator, in training and in test mode, under fixed `random` / `torch` seeds."""
+    import pickle
+    import random
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    import voc_fixture
+    from oracle import data_ref as D
+    refimport.load_reference()
+    from wetectron.data.transforms import build_transforms
+    from wetectron.data.datasets.voc import PascalVOCDataset
+    from wetectron.data.collate_batch import BatchCollator
+    images, objects, proposals = voc_fixture.make_case(spec["seed"], spec["shapes"])
+    ids = spec["ids"]
+    rec = {"spec_seed": np.array(spec["seed"]), "spec_shapes": np.array(spec["shapes"]), "spec_ids": np.array(ids),
+           "min_train": np.array(spec["min_train"]), "max_train": np.array(spec["max_train"]),
+           "min_test": np.array(spec["min_test"]), "max_test": np.array(spec["max_test"])}
+    cfg = refimport.reference_cfg(opts=["INPUT.MIN_SIZE_TRAIN", tuple(spec["min_train"]), "INPUT.MAX_SIZE_TRAIN",
+                                        spec["max_train"], "INPUT.MIN_SIZE_TEST", spec["min_test"],
+                                        "INPUT.MAX_SIZE_TEST", spec["max_test"], "DATALOADER.SIZE_DIVISIBILITY", 32])
+    rec["pixel_mean"] = np.array(cfg.INPUT.PIXEL_MEAN, np.float32)
+    rec["pixel_std"] = np.array(cfg.INPUT.PIXEL_STD, np.float32)
+    rec["to_bgr255"] = np.array(cfg.INPUT.TO_BGR255)
+    rec["pca"] = np.array(cfg.INPUT.PCA)
+    with tempfile.TemporaryDirectory() as root:
+        voc_fixture.write_devkit(root, "trainval", ids, images, objects)
+        pkl = os.path.join(root, "props.pkl")
+        with open(pkl, "wb") as f:
+            pickle.dump(dict(boxes=proposals, scores=[np.ones(len(b), np.float32) for b in proposals],
+                             indexes=[int(i) for i in ids]), f, pickle.HIGHEST_PROTOCOL)
+        for mode, is_train in (("train", True), ("test", False)):
+            ds = PascalVOCDataset(root, "trainval", use_difficult=not is_train,
+                                  transforms=build_transforms(cfg, is_train), proposal_file=pkl)
+            random.seed(spec["seed"])
+            torch.manual_seed(spec["seed"])
+            samples = [ds[i] for i in range(len(ids))]
+            batch = BatchCollator(32)(samples)
+            rec[mode + "_batch"] = batch[0].tensors.numpy()
+            rec[mode + "_image_sizes"] = np.array([tuple(s) for s in batch[0].image_sizes])
+            for i, (img, target, rois, index) in enumerate(samples):
+                rec["%s_target_boxes_%d" % (mode, i)] = target.bbox.numpy()
+                rec["%s_target_size_%d" % (mode, i)] = np.array(target.size)
+                rec["%s_target_labels_%d" % (mode, i)] = target.get_field("labels").numpy()
+                rec["%s_target_difficult_%d" % (mode, i)] = target.get_field("difficult").numpy()
+                rec["%s_rois_%d" % (mode, i)] = rois.bbox.numpy()
+                print("   %s image %d: %s -> %s, %d proposals of %d, %d objects" % (
+                    mode, i, images[i].shape[:2], tuple(img.shape[1:]), len(rois), len(proposals[i]), len(target)))
+        raw = PascalVOCDataset(root, "trainval", use_difficult=False, transforms=None, proposal_file=pkl)
+        for i in range(len(ids)):
+            _, _, rois, _ = raw[i]
+            rec["raw_rois_%d" % i] = rois.bbox.numpy()
+            np.testing.assert_array_equal(D.prepare_proposals(proposals[i], (images[i].shape[1], images[i].shape[0])),
+                                          rec["raw_rois_%d" % i])
+            info = raw.get_img_info(i)
+            rec["info_%d" % i] = np.array([info["height"], info["width"]])
+    np.savez_compressed(out, **rec)
+    print("wrote", out)
+
+
+DATA_CASES = {"data_voc": dict(seed=11, shapes=[(60, 80), (75, 50), (64, 64), (48, 96)],
+                               ids=["000005", "000007", "000009", "000012"], min_train=(48, 64, 80), max_train=100,
+                               min_test=64, max_test=120)}
+
 INFER_CASES = {"infer_voc_2img": dict(seed=58, images=[(96, 128, 48), (80, 112, 40)], pooler="ROIPool")}
 
 
@@ -368,3 +432,6 @@ if __name__ == "__main__":
     for name, spec in INFER_CASES.items():
         if name in which or not sys.argv[1:]:
             gen_infer(name, spec, os.path.join(HERE, name + ".npz"))
+    for name, spec in DATA_CASES.items():
+        if name in which or not sys.argv[1:]:
+            gen_data(name, spec, os.path.join(HERE, name + ".npz"))

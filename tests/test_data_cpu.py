@@ -1,0 +1,135 @@
+"""Data boundary on the CPU: the oracle against the golden vectors of the imported reference
+and against the installed Pillow; the host half of the product (datasets, transforms' geometry and RNG consumption,
+collation) against the same goldens.  The pixel half of the product only exists on the GPU (tests/test_data_gpu.py);
+here its recorded plan is executed by the oracle."""
+import os
+import pickle
+import random
+
+import numpy as np
+import pytest
+import torch
+from yacs_like import cfg_for_data  # noqa: E402  (tests/yacs_like.py)
+
+import voc_fixture
+from oracle import data_ref as D
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "data_voc.npz"))
+
+
+def _devkit(tmp_path, g):
+    shapes = [tuple(s) for s in g["spec_shapes"].tolist()]
+    ids = [str(i) for i in g["spec_ids"].tolist()]
+    images, objects, proposals = voc_fixture.make_case(int(g["spec_seed"]), shapes)
+    root = str(tmp_path)
+    voc_fixture.write_devkit(root, "trainval", ids, images, objects)
+    from od_wscl_amd.data.datasets import ProposalFile
+    pkl = os.path.join(root, "props.pkl")
+    ProposalFile.write(pkl, proposals, [np.ones(len(b), np.float32) for b in proposals], [int(i) for i in ids])
+    return root, pkl, images, proposals, ids
+
+
+def test_resample_restatement_is_pillow_bit_for_bit():
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for it in range(30):
+        h, w = (int(v) for v in rng.integers(5, 90, 2))
+        oh, ow = (int(v) for v in rng.integers(3, 140, 2))
+        if it % 7 == 0:
+            ow = w
+        if it % 11 == 0:
+            oh = h
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img, "RGB").resize((ow, oh), Image.BILINEAR))
+        np.testing.assert_array_equal(D.pil_bilinear_resize(img, oh, ow), ref)
+
+
+def test_get_size_known_answers():
+    # transforms.py:41-61: short side = size unless the long side would exceed max_size; truncating division
+    assert D.get_size((500, 375), 600, 2000) == (600, 800)
+    assert D.get_size((375, 500), 600, 2000) == (800, 600)
+    assert D.get_size((500, 375), 1200, 1000) == (750, 1000)
+    assert D.get_size((500, 333), 480, 2000) == (480, 720)
+    assert D.get_size((333, 500), 333, 2000) == (500, 333)
+
+
+def test_proposal_preparation_matches_the_reference(golden, tmp_path):
+    root, pkl, images, proposals, ids = _devkit(tmp_path, golden)
+    from od_wscl_amd.data.datasets import PascalVOCDataset, prepare_proposals
+    ds = PascalVOCDataset(root, "trainval", use_difficult=False, transforms=None, proposal_file=pkl)
+    assert len(ds) == len(ids)
+    for i in range(len(ids)):
+        size = (images[i].shape[1], images[i].shape[0])
+        np.testing.assert_array_equal(D.prepare_proposals(proposals[i], size), golden["raw_rois_%d" % i])
+        np.testing.assert_array_equal(prepare_proposals(proposals[i], size).bbox.numpy(), golden["raw_rois_%d" % i])
+        img, target, rois, index = ds[i]
+        assert index == i and img.size == size
+        np.testing.assert_array_equal(rois.bbox.numpy(), golden["raw_rois_%d" % i])
+        info = ds.get_img_info(i)
+        assert [info["height"], info["width"]] == golden["info_%d" % i].tolist()
+
+
+@pytest.mark.parametrize("mode", ["train", "test"])
+def test_dataset_transforms_collate_match_the_reference(golden, tmp_path, mode):
+    root, pkl, images, proposals, ids = _devkit(tmp_path, golden)
+    from od_wscl_amd.data import BatchCollator, build_transforms
+    from od_wscl_amd.data.datasets import PascalVOCDataset
+    is_train = mode == "train"
+    cfg = cfg_for_data(golden)
+    ds = PascalVOCDataset(root, "trainval", use_difficult=not is_train, transforms=build_transforms(cfg, is_train),
+                          proposal_file=pkl)
+    random.seed(int(golden["spec_seed"]))
+    torch.manual_seed(int(golden["spec_seed"]))
+    samples = [ds[i] for i in range(len(ids))]
+    pending, targets, rois, idx = BatchCollator(32)(samples)
+    assert list(idx) == list(range(len(ids)))
+    assert [tuple(s) for s in pending.image_sizes] == [tuple(s) for s in golden[mode + "_image_sizes"].tolist()]
+    assert (len(pending), 3) + pending.padded_hw == golden[mode + "_batch"].shape
+    for i in range(len(ids)):
+        np.testing.assert_array_equal(targets[i].bbox.numpy(), golden["%s_target_boxes_%d" % (mode, i)])
+        assert list(targets[i].size) == golden["%s_target_size_%d" % (mode, i)].tolist()
+        np.testing.assert_array_equal(targets[i].get_field("labels").numpy(), golden["%s_target_labels_%d" % (mode, i)])
+        np.testing.assert_array_equal(targets[i].get_field("difficult").numpy(),
+                                      golden["%s_target_difficult_%d" % (mode, i)])
+        np.testing.assert_array_equal(rois[i].bbox.numpy(), golden["%s_rois_%d" % (mode, i)])
+    # the recorded pixel plans, executed by the oracle (Pillow and the written-out resampler), give the reference batch
+    for use_pillow in (True, False):
+        outs = []
+        for im in pending.images:
+            mean, std, bgr = im.norm
+            outs.append(D.pixel_chain(im.pixels, im.shape[-2:], im.hflip, im.vflip, im.light, mean, std, bgr,
+                                      use_pillow=use_pillow))
+        batch, sizes = D.to_image_list(outs, 32)
+        np.testing.assert_array_equal(batch, golden[mode + "_batch"])
+    with pytest.raises(RuntimeError):
+        pending.to("cpu")
+
+
+def test_boxlist_geometry_known_answers():
+    from od_wscl_amd.structures.bounding_box import BoxList, FLIP_LEFT_RIGHT, FLIP_TOP_BOTTOM
+    b = BoxList(torch.tensor([[10.0, 20.0, 30.0, 50.0]]), (100, 80))
+    assert b.transpose(FLIP_LEFT_RIGHT).bbox.tolist() == [[69.0, 20.0, 89.0, 50.0]]       # W - x - 1
+    assert b.transpose(FLIP_TOP_BOTTOM).bbox.tolist() == [[10.0, 30.0, 30.0, 60.0]]       # H - y (no -1)
+    assert b.resize((200, 160)).bbox.tolist() == [[20.0, 40.0, 60.0, 100.0]]
+    assert b.resize((200, 80)).bbox.tolist() == [[20.0, 20.0, 60.0, 50.0]]
+    np.testing.assert_array_equal(D.boxes_transpose(b.bbox.numpy(), (100, 80), 0), b.transpose(0).bbox.numpy())
+    np.testing.assert_array_equal(D.boxes_resize(b.bbox.numpy(), (100, 80), (150, 90)), b.resize((150, 90)).bbox.numpy())
+    c = BoxList(torch.tensor([[-5.0, 3.0, 120.0, 90.0], [4.0, 4.0, 4.0, 9.0]]), (100, 80)).clip_to_image()
+    assert c.bbox.tolist() == [[0.0, 3.0, 99.0, 79.0]]
+
+
+def test_live_reference_agrees_with_the_golden(golden, tmp_path):
+    from oracle import refimport
+    if not refimport.reference_available():
+        pytest.skip("reference tree not present")
+    refimport.load_reference()
+    from wetectron.data.datasets.voc import PascalVOCDataset as RefVOC
+    root, pkl, images, proposals, ids = _devkit(tmp_path, golden)
+    ds = RefVOC(root, "trainval", use_difficult=False, transforms=None, proposal_file=pkl)
+    for i in range(len(ids)):
+        np.testing.assert_array_equal(ds[i][2].bbox.numpy(), golden["raw_rois_%d" % i])
