@@ -266,6 +266,17 @@ int odw_detect_postprocess(const float* prob, int C, const float* reg, int ld_re
                            float wx, float wy, float ww, float wh, float xform_clip, float score_thresh,
                            float nms_thr, int pstride, float* out_boxes, float* out_scores, int* out_index,
                            int* out_count, void* stream);
+/* The same tail in the two halves test-time augmentation needs (engine/bbox_aug.py:11-77):
+ * odw_detect_decode = PostProcessor.forward with bbox_aug_enabled (inference.py:57-90): BoxCoder.decode + clip_to_image
+ *   for every (proposal, class), nothing filtered -> out_boxes (sumP, C, 4);
+ * odw_detect_filter = PostProcessor.filter_results (inference.py:216-258) on a merged boxlist: boxes_pc (sumP, C, 4) are
+ *   used as given (no decode, no clip), prob (sumP, C); outputs as odw_detect_postprocess. */
+int odw_detect_decode(const float* reg, int ld_reg, int cls_agnostic, const float* boxes, const int* img_off,
+                      const float* img_wh, int n_img, int sum_p, int C, float wx, float wy, float ww, float wh,
+                      float xform_clip, float* out_boxes, void* stream);
+int odw_detect_filter(const float* prob, int C, const float* boxes_pc, const int* img_off, int n_img, int max_p,
+                      float score_thresh, float nms_thr, int pstride, float* out_boxes, float* out_scores,
+                      int* out_index, int* out_count, void* stream);
 
 /* ---- backbone convolutions (NHWC bf16, implicit GEMM on the MFMA tile) ----------------------
  * replaces the cuDNN convolutions behind torch.nn.Conv2d in VGG_Base

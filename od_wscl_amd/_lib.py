@@ -80,6 +80,8 @@ SIGNATURES = {
                                 c_p, c_l, c_p]),
     "odw_detect_postprocess": (c_i, [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i,
                                      c_p, c_p, c_p, c_p, c_p]),
+    "odw_detect_decode": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "odw_detect_filter": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p]),
     "odw_image_preprocess_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "odw_image_preprocess": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_l, c_p]),
     "odw_od_assign_indexed": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),

@@ -19,10 +19,10 @@ constexpr int kThreads = 512;
 struct DetArgs {
     const float* prob;      // (sumP, C)
     const float* reg;       // (sumP, 4*C) or (sumP, 4) class-agnostic, or null (boxes are used as they are)
-    const float* boxes;     // (sumP, 4) xyxy
+    const float* boxes;     // (sumP, 4) xyxy -- or (sumP, C, 4) already decoded per class (per_class)
     const int* img_off;     // (n_img + 1)
     const float* img_wh;    // (n_img, 2)
-    int C, ld_reg, cls_agnostic;
+    int C, ld_reg, cls_agnostic, per_class;
     float wx, wy, ww, wh, xform_clip, score_thresh, nms_thr;
     int pstride;            // output slots per (image, class)
     float* out_boxes;       // (n_img, C-1, pstride, 4)
@@ -53,15 +53,23 @@ __global__ __launch_bounds__(kThreads) void detect_classes_kernel(DetArgs a, int
 
     const int img = blockIdx.x, j = blockIdx.y + 1;                 // class 0 = background is skipped
     const int base = a.img_off[img], P = a.img_off[img + 1] - base;
-    const float iw = a.img_wh[2 * img], ih = a.img_wh[2 * img + 1];
+    const float iw = a.per_class ? 0.0f : a.img_wh[2 * img], ih = a.per_class ? 0.0f : a.img_wh[2 * img + 1];
     int cnt_local = 0;
     for (int r = threadIdx.x; r < ppow2; r += kThreads) {
         float s = -__builtin_inff();
         int id = 0x40000000 + r;
         if (r < P) {
             const float sc = a.prob[(size_t)(base + r) * a.C + j];
-            const float4 b = reinterpret_cast<const float4*>(a.boxes)[base + r];
+            const float4 b = reinterpret_cast<const float4*>(a.boxes)[a.per_class ? (size_t)(base + r) * a.C + j
+                                                                                   : (size_t)(base + r)];
             float4 o = b;
+            if (a.per_class) {          // filter_results on a merged boxlist (engine/bbox_aug.py:70-75): boxes as given
+                sbox[r] = o;
+                if (sc > a.score_thresh) { s = sc; id = r; ++cnt_local; }
+                ks[r] = s;
+                ki[r] = id;
+                continue;
+            }
             if (a.reg) {
                 const float* rc = a.reg + (size_t)(base + r) * a.ld_reg + (a.cls_agnostic ? 0 : 4 * j);
                 const float w = b.z - b.x + 1.0f, h = b.w - b.y + 1.0f;
@@ -142,7 +150,48 @@ __global__ __launch_bounds__(kThreads) void detect_classes_kernel(DetArgs a, int
     (void)s_n;
 }
 
+// PostProcessor.forward with bbox_aug_enabled (inference.py:57-90): every proposal decoded for every class and clipped,
+// nothing filtered -- the (sumP, C, 4) boxlist the test-time augmentation merges.  One thread per (proposal, class).
+__global__ __launch_bounds__(256) void detect_decode_kernel(DetArgs a, int n_img, int sum_p, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sum_p * a.C) return;
+    const int r = t / a.C, j = t - r * a.C;
+    int img = 0;
+    while (img + 1 < n_img && r >= a.img_off[img + 1]) ++img;
+    const float iw = a.img_wh[2 * img], ih = a.img_wh[2 * img + 1];
+    const float4 b = reinterpret_cast<const float4*>(a.boxes)[r];
+    float4 o = b;
+    if (a.reg) {
+        const float* rc = a.reg + (size_t)r * a.ld_reg + (a.cls_agnostic ? 0 : 4 * j);
+        const float w = b.z - b.x + 1.0f, h = b.w - b.y + 1.0f;
+        const float cx = b.x + 0.5f * w, cy = b.y + 0.5f * h;
+        const float dx = rc[0] / a.wx, dy = rc[1] / a.wy;
+        const float dw = fminf(rc[2] / a.ww, a.xform_clip), dh = fminf(rc[3] / a.wh, a.xform_clip);
+        const float pcx = dx * w + cx, pcy = dy * h + cy;
+        const float pw = expf(dw) * w, ph = expf(dh) * h;
+        o.x = pcx - 0.5f * pw;
+        o.y = pcy - 0.5f * ph;
+        o.z = pcx + 0.5f * pw - 1.0f;
+        o.w = pcy + 0.5f * ph - 1.0f;
+    }
+    o.x = fminf(fmaxf(o.x, 0.0f), iw - 1.0f);
+    o.y = fminf(fmaxf(o.y, 0.0f), ih - 1.0f);
+    o.z = fminf(fmaxf(o.z, 0.0f), iw - 1.0f);
+    o.w = fminf(fmaxf(o.w, 0.0f), ih - 1.0f);
+    reinterpret_cast<float4*>(out)[t] = o;
+}
+
 int pow2_at_least(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+int launch_detect(DetArgs a, int n_img, int max_p, void* stream_) {
+    const int ppow2 = pow2_at_least(max_p);
+    const size_t lds = (size_t)ppow2 * (16 + 16 + 4 + 4 + 1) + 64;
+    ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(detect_classes_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "detect attr");
+    detect_classes_kernel<<<dim3((unsigned)n_img, (unsigned)(a.C - 1)), kThreads, lds, (hipStream_t)stream_>>>(a, ppow2);
+    ODW_CHECK_LAUNCH("detect_classes_kernel");
+    return ODW_OK;
+}
 
 }  // namespace
 
@@ -160,14 +209,40 @@ ODW_EXPORT int odw_detect_postprocess(const float* prob, int C, const float* reg
     ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)out_boxes) & 15) == 0, "detect_postprocess: 16-byte alignment");
     DetArgs a;
     a.prob = prob; a.reg = reg; a.boxes = boxes; a.img_off = img_off; a.img_wh = img_wh; a.C = C; a.ld_reg = ld_reg;
-    a.cls_agnostic = cls_agnostic; a.wx = wx; a.wy = wy; a.ww = ww; a.wh = wh; a.xform_clip = xform_clip;
+    a.cls_agnostic = cls_agnostic; a.per_class = 0; a.wx = wx; a.wy = wy; a.ww = ww; a.wh = wh; a.xform_clip = xform_clip;
     a.score_thresh = score_thresh; a.nms_thr = nms_thr; a.pstride = pstride; a.out_boxes = out_boxes;
     a.out_scores = out_scores; a.out_index = out_index; a.out_count = out_count;
-    const int ppow2 = pow2_at_least(max_p);
-    const size_t lds = (size_t)ppow2 * (16 + 16 + 4 + 4 + 1) + 64;
-    ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(detect_classes_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "detect attr");
-    detect_classes_kernel<<<dim3((unsigned)n_img, (unsigned)(C - 1)), kThreads, lds, (hipStream_t)stream_>>>(a, ppow2);
-    ODW_CHECK_LAUNCH("detect_classes_kernel");
+    return launch_detect(a, n_img, max_p, stream_);
+}
+
+ODW_EXPORT int odw_detect_decode(const float* reg, int ld_reg, int cls_agnostic, const float* boxes, const int* img_off,
+                                 const float* img_wh, int n_img, int sum_p, int C, float wx, float wy, float ww, float wh,
+                                 float xform_clip, float* out_boxes, void* stream_) {
+    ODW_REQUIRE(n_img >= 1 && C >= 2 && sum_p >= 0, "detect_decode: bad dims");
+    if (sum_p == 0) return ODW_OK;
+    ODW_REQUIRE(boxes && img_off && img_wh && out_boxes, "detect_decode: null pointer");
+    ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)out_boxes) & 15) == 0, "detect_decode: 16-byte alignment");
+    DetArgs a = {};
+    a.reg = reg; a.boxes = boxes; a.img_off = img_off; a.img_wh = img_wh; a.C = C; a.ld_reg = ld_reg;
+    a.cls_agnostic = cls_agnostic; a.wx = wx; a.wy = wy; a.ww = ww; a.wh = wh; a.xform_clip = xform_clip;
+    const long long total = (long long)sum_p * C;
+    detect_decode_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream_>>>(a, n_img, sum_p, out_boxes);
+    ODW_CHECK_LAUNCH("detect_decode_kernel");
     return ODW_OK;
+}
+
+ODW_EXPORT int odw_detect_filter(const float* prob, int C, const float* boxes_pc, const int* img_off, int n_img, int max_p,
+                                 float score_thresh, float nms_thr, int pstride, float* out_boxes, float* out_scores,
+                                 int* out_index, int* out_count, void* stream_) {
+    ODW_REQUIRE(n_img >= 0 && C >= 2 && max_p >= 1 && max_p <= 4096 && pstride >= max_p,
+                "detect_filter: bad dims (at most 4096 boxes per image and class, got %d)", max_p);
+    if (n_img == 0) return ODW_OK;
+    ODW_REQUIRE(prob && boxes_pc && img_off && out_boxes && out_scores && out_index && out_count, "detect_filter: null pointer");
+    ODW_REQUIRE(nms_thr > 0.0f, "detect_filter: nms threshold must be > 0");
+    ODW_REQUIRE((((uintptr_t)boxes_pc) & 15) == 0 && (((uintptr_t)out_boxes) & 15) == 0, "detect_filter: 16-byte alignment");
+    DetArgs a = {};
+    a.prob = prob; a.boxes = boxes_pc; a.img_off = img_off; a.img_wh = nullptr; a.C = C; a.per_class = 1;
+    a.score_thresh = score_thresh; a.nms_thr = nms_thr; a.pstride = pstride; a.out_boxes = out_boxes;
+    a.out_scores = out_scores; a.out_index = out_index; a.out_count = out_count;
+    return launch_detect(a, n_img, max_p, stream_);
 }

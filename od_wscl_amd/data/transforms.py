@@ -28,6 +28,16 @@ class DeferredImage(object):
         self.tensor = False         # ToTensor seen
         self.light = None           # Lighting offset per RGB channel (fp32[3])
         self.norm = None            # (mean[3], std[3], to_bgr255)
+        self.device_pixels = {}     # device -> uploaded copy of `pixels` (shared by forks: one upload, many plans)
+
+    def fork(self):
+        """A fresh plan over the same pixels (test-time augmentation runs many plans per image)."""
+        if self.out_hw is not None or self.hflip or self.vflip or self.tensor:
+            raise RuntimeError("fork() is for an image no transform has touched yet")
+        twin = DeferredImage.__new__(DeferredImage)
+        twin.pixels, twin.device_pixels = self.pixels, self.device_pixels
+        twin.out_hw, twin.hflip, twin.vflip, twin.tensor, twin.light, twin.norm = None, False, False, False, None, None
+        return twin
 
     @property
     def size(self):
@@ -179,6 +189,7 @@ class ColorJitter(object):
             factor = torch.tensor(1.0).uniform_(rng[0], rng[1]).item()
             image._eager_only("ColorJitter")
             image.pixels = _jitter(image.pixels, fn_id, factor)
+            image.device_pixels = {}
         return image, target, rois
 
 

@@ -32,10 +32,6 @@ class PostProcessor(nn.Module):
             class_logits, box_regression, softmax_on = x, None, False
         class_prob = F.softmax(class_logits, -1) if softmax_on else class_logits
         L.need_gpu(class_prob, boxes[0].bbox)
-        if self.bbox_aug_enabled:
-            raise NotImplementedError("test-time augmentation merges un-filtered boxlists (engine/bbox_aug.py): not on this path yet")
-        if self.nms <= 0:
-            raise ValueError("MODEL.ROI_HEADS.NMS must be > 0")
         dev = class_prob.device
         sizes = [len(b) for b in boxes]
         n_img, C, max_p = len(boxes), class_prob.shape[1], max(sizes)
@@ -52,20 +48,65 @@ class PostProcessor(nn.Module):
             reg = reg.contiguous()
         img_off = torch.tensor(offs, dtype=torch.int32, device=dev)
         img_wh = torch.tensor([[float(b.size[0]), float(b.size[1])] for b in boxes], dtype=torch.float32, device=dev)
-        out_boxes = torch.empty((n_img, C - 1, max_p, 4), dtype=torch.float32, device=dev)
-        out_scores = torch.empty((n_img, C - 1, max_p), dtype=torch.float32, device=dev)
-        out_index = torch.empty((n_img, C - 1, max_p), dtype=torch.int32, device=dev)
-        out_count = torch.zeros((n_img, C - 1), dtype=torch.int32, device=dev)
         w = self.box_coder.weights
+        if self.bbox_aug_enabled:
+            # inference.py:78-88: decoded + clipped (P*C) boxlists, filtered later by the test-time augmentation
+            decoded = torch.empty((offs[-1], C, 4), dtype=torch.float32, device=dev)
+            L.check(L.lib().odw_detect_decode(L.ptr(reg), reg.shape[1] if reg is not None else 0,
+                                              1 if self.cls_agnostic_bbox_reg else 0, L.ptr(concat), L.ptr(img_off),
+                                              L.ptr(img_wh), n_img, offs[-1], C, float(w[0]), float(w[1]), float(w[2]),
+                                              float(w[3]), float(self.box_coder.bbox_xform_clip), L.ptr(decoded),
+                                              L.stream()), "detect_decode")
+            results = []
+            for i, b in enumerate(boxes):
+                r = BoxList(decoded[offs[i]:offs[i + 1]].reshape(-1, 4), b.size, mode="xyxy")
+                r.add_field("scores", prob[offs[i]:offs[i + 1]].reshape(-1))
+                results.append(r)
+            return results
+        if self.nms <= 0:
+            raise ValueError("MODEL.ROI_HEADS.NMS must be > 0")
+        out = self._outputs(n_img, C, max_p, dev)
         L.check(L.lib().odw_detect_postprocess(L.ptr(prob), C, L.ptr(reg), reg.shape[1] if reg is not None else 0,
                                                1 if self.cls_agnostic_bbox_reg else 0, L.ptr(concat), L.ptr(img_off),
                                                L.ptr(img_wh), n_img, max_p, float(w[0]), float(w[1]), float(w[2]), float(w[3]),
                                                float(self.box_coder.bbox_xform_clip), float(self.score_thresh), float(self.nms),
-                                               max_p, L.ptr(out_boxes), L.ptr(out_scores), L.ptr(out_index), L.ptr(out_count),
+                                               max_p, L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]),
                                                L.stream()), "detect_postprocess")
+        return self._collect(out, [b.size for b in boxes], C)
+
+    @staticmethod
+    def _outputs(n_img, C, max_p, dev):
+        return (torch.empty((n_img, C - 1, max_p, 4), dtype=torch.float32, device=dev),
+                torch.empty((n_img, C - 1, max_p), dtype=torch.float32, device=dev),
+                torch.empty((n_img, C - 1, max_p), dtype=torch.int32, device=dev),
+                torch.zeros((n_img, C - 1), dtype=torch.int32, device=dev))
+
+    def filter_results(self, boxlist, num_classes):
+        """inference.py:216-258 on one (P*C)-box list with (P*C) scores -- what the test-time augmentation hands over
+        after merging its passes: per class score > thresh, NMS, labels, best `detections_per_img` overall."""
+        boxes_pc = boxlist.bbox.reshape(-1, num_classes, 4).float().contiguous()
+        prob = boxlist.get_field("scores").reshape(-1, num_classes).float().contiguous()
+        L.need_gpu(boxes_pc, prob)
+        if self.nms <= 0:
+            raise ValueError("MODEL.ROI_HEADS.NMS must be > 0")
+        P = boxes_pc.shape[0]
+        if P > 4096:
+            raise NotImplementedError("filter_results: %d boxes per class exceed the kernel's 4096 (the UNION heuristic "
+                                      "of TEST.BBOX_AUG concatenates every pass; the shipped configs use AVG)" % P)
+        dev = prob.device
+        img_off = torch.tensor([0, P], dtype=torch.int32, device=dev)
+        out = self._outputs(1, num_classes, P, dev)
+        L.check(L.lib().odw_detect_filter(L.ptr(prob), num_classes, L.ptr(boxes_pc), L.ptr(img_off), 1, P,
+                                          float(self.score_thresh), float(self.nms), P, L.ptr(out[0]), L.ptr(out[1]),
+                                          L.ptr(out[2]), L.ptr(out[3]), L.stream()), "detect_filter")
+        return self._collect(out, [boxlist.size], num_classes)[0]
+
+    def _collect(self, out, image_sizes, C):
+        out_boxes, out_scores, out_index, out_count = out
+        dev = out_boxes.device
         counts = out_count.cpu().numpy()                               # the one blocking read
         results = []
-        for i, b in enumerate(boxes):
+        for i, size in enumerate(image_sizes):
             bx, sc, lab, idx = [], [], [], []
             for j in range(1, C):
                 k = int(counts[i, j - 1])
@@ -84,7 +125,7 @@ class PostProcessor(nn.Module):
                 thresh, _ = torch.kthvalue(sc.cpu(), n - self.detections_per_img + 1)
                 keep = torch.nonzero(sc >= thresh.item(), as_tuple=False).squeeze(1)
                 bx, sc, lab, idx = bx[keep], sc[keep], lab[keep], idx[keep]
-            r = BoxList(bx, b.size, mode="xyxy")
+            r = BoxList(bx, size, mode="xyxy")
             r.add_field("scores", sc)
             r.add_field("labels", lab)
             r.add_field("proposal_index", idx.long())

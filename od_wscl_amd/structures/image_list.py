@@ -73,7 +73,10 @@ class PendingImageList(object):
                 if not im.tensor or im.norm is None:
                     raise RuntimeError("the transform chain has to end with ToTensor + Normalize")
                 mean, std, bgr = im.norm
-                _C.image_preprocess(_RING.stage(im.pixels, device), im.shape[-2:], slot, mean, std, bgr,
+                pixels = im.device_pixels.get(device)
+                if pixels is None:
+                    pixels = im.device_pixels[device] = _RING.stage(im.pixels, device)
+                _C.image_preprocess(pixels, im.shape[-2:], slot, mean, std, bgr,
                                     hflip=im.hflip, vflip=im.vflip, lighting=im.light)
         return ImageList(batch, self.image_sizes)
 

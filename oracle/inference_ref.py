@@ -58,7 +58,7 @@ def filter_results(boxes, scores, size, score_thresh, nms_thr, max_det):
     return b, s, l
 
 
-def forward_eval(images, boxes_per_image, sizes_wh, sd, cfg):
+def forward_eval(images, boxes_per_image, sizes_wh, sd, cfg, raw=False):
     """GeneralizedRCNN.forward in eval mode with precomputed proposals: backbone -> ROIPool -> fc6/fc7 (dropout is
     the identity) -> MISTPredictor eval branch (softmax-ed refinement scores, roi_weak_predictors.py:167-181) ->
     testing_forward "AVG" -> PostProcessor."""
@@ -84,7 +84,60 @@ def forward_eval(images, boxes_per_image, sizes_wh, sd, cfg):
         d[:, 1].clamp_(min=0, max=h - 1)
         d[:, 2].clamp_(min=0, max=w - 1)
         d[:, 3].clamp_(min=0, max=h - 1)
-        out.append(filter_results(d.reshape(n, -1), final_score[o:o + n], (w, h), cfg.get("score_thresh", 0.0),
-                                  cfg.get("nms_test", 0.4), cfg.get("max_det", 100)))
+        if raw:     # PostProcessor with bbox_aug_enabled (inference.py:85-88): decoded + clipped, not filtered
+            out.append((d.reshape(n, -1), final_score[o:o + n]))
+        else:
+            out.append(filter_results(d.reshape(n, -1), final_score[o:o + n], (w, h), cfg.get("score_thresh", 0.0),
+                                      cfg.get("nms_test", 0.4), cfg.get("max_det", 100)))
         o += n
+    return out
+
+
+def tta(pixels_list, raw_boxes_list, sd, cfg, aug):
+    """im_detect_bbox_aug (wetectron/engine/bbox_aug.py:11-77) for a BATCH of images (the passes run on the whole
+    batch, so the zero padding to the batch's common size is part of the result): the identity pass, its flip, every
+    scale (+ flip); boxes un-flipped (W - x - 1) and resized to the first pass's frame; "AVG" merge; filter_results.
+    pixels uint8 (H,W,3) per image; raw_boxes (n,4) fp32 in the original frame; aug = dict(min_test, max_test, h_flip,
+    scales, max_size, scale_h_flip, mean, std, to_bgr255, size_divisible)."""
+    import numpy as np
+    from . import data_ref as D
+    passes = [(aug["min_test"], aug["max_test"], False)]
+    if aug["h_flip"]:
+        passes.append((aug["min_test"], aug["max_test"], True))
+    for s in aug["scales"]:
+        passes.append((s, aug["max_size"], False))
+        if aug["scale_h_flip"]:
+            passes.append((s, aug["max_size"], True))
+    n_img = len(pixels_list)
+    merged_b, merged_s, first = [[] for _ in range(n_img)], [[] for _ in range(n_img)], [None] * n_img
+    for size, max_size, flip in passes:
+        imgs, boxes, sizes = [], [], []
+        for pixels, raw_boxes in zip(pixels_list, raw_boxes_list):
+            h0, w0 = pixels.shape[:2]
+            oh, ow = D.get_size((w0, h0), size, max_size)
+            imgs.append(D.pixel_chain(pixels, (oh, ow), flip, False, None, aug["mean"], aug["std"], aug["to_bgr255"]))
+            b = D.boxes_resize(raw_boxes, (w0, h0), (ow, oh))
+            if flip:
+                b = D.boxes_transpose(b, (ow, oh), 0)
+            boxes.append(torch.from_numpy(np.ascontiguousarray(b)))
+            sizes.append((ow, oh))
+        batch, _ = D.to_image_list(imgs, aug["size_divisible"])
+        raw = forward_eval(torch.from_numpy(batch), boxes, sizes, sd, cfg, raw=True)
+        for i, (dec, sc) in enumerate(raw):
+            dec = dec.reshape(-1, 4).numpy()
+            if flip:
+                dec = D.boxes_transpose(dec, sizes[i], 0)
+            if first[i] is None:
+                first[i] = sizes[i]
+            else:
+                dec = D.boxes_resize(dec, sizes[i], first[i])
+            merged_b[i].append(torch.from_numpy(np.ascontiguousarray(dec)))
+            merged_s[i].append(sc.reshape(-1))
+            C = sc.shape[1]
+    out = []
+    for i in range(n_img):
+        bbox = torch.mean(torch.stack(merged_b[i]), dim=0)
+        scores = torch.mean(torch.stack(merged_s[i]), dim=0)
+        out.append(filter_results(bbox.reshape(-1, C * 4), scores.reshape(-1, C), first[i], cfg.get("score_thresh", 0.0),
+                                  cfg.get("nms_test", 0.4), cfg.get("max_det", 100)))
     return out

@@ -415,6 +415,66 @@ def gen_data(name, spec, out):
     print("wrote", out)
 
 
+def gen_tta(name, spec, out):
+    """im_detect_bbox_aug of the imported reference (engine/bbox_aug.py): eval model with TEST.BBOX_AUG.ENABLED,
+    "AVG" merge over the identity pass, its flip and two extra scales with flips."""
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(HERE))
+    import voc_fixture
+    from oracle import inference_ref as I
+    refimport.load_reference()
+    from wetectron.structures.bounding_box import BoxList
+    from wetectron.engine.bbox_aug import im_detect_bbox_aug
+    aug = spec["aug"]
+    cfg = refimport.reference_cfg(opts=CFG_OPTS + [
+        "MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "TEST.BBOX_AUG.ENABLED", True, "TEST.BBOX_AUG.HEUR", "AVG",
+        "TEST.BBOX_AUG.H_FLIP", aug["h_flip"], "TEST.BBOX_AUG.SCALES", tuple(aug["scales"]),
+        "TEST.BBOX_AUG.MAX_SIZE", aug["max_size"], "TEST.BBOX_AUG.SCALE_H_FLIP", aug["scale_h_flip"],
+        "INPUT.MIN_SIZE_TEST", aug["min_test"], "INPUT.MAX_SIZE_TEST", aug["max_test"],
+        "DATALOADER.SIZE_DIVISIBILITY", 32])
+    model = refimport.build_reference_model(cfg)
+    model.eval()
+    shapes = [(n, tuple(p.shape)) for n, p in model.named_parameters()]
+    sd = synthetic.init_state_dict(shapes, WEIGHT_SEED, overrides=OVERRIDES)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(sd[n]))
+    pixels, _, _ = voc_fixture.make_case(spec["seed"], [(h, w) for h, w, _ in spec["images"]])
+    rois, boxes_np = [], []
+    for k, (h, w, pcount) in enumerate(spec["images"]):
+        bx = synthetic.make_proposals(spec["seed"], k, pcount, h, w, min_size=12)
+        boxes_np.append(bx)
+        rois.append(BoxList(torch.from_numpy(bx), (w, h), "xyxy"))
+    with torch.no_grad():
+        result = im_detect_bbox_aug(model, [Image.fromarray(p, "RGB") for p in pixels], torch.device("cpu"), rois)
+    rec = {"spec_seed": np.array(spec["seed"]), "spec_images": np.array(spec["images"]),
+           "score_thresh": np.array(cfg.MODEL.ROI_HEADS.SCORE_THRESH), "nms": np.array(cfg.MODEL.ROI_HEADS.NMS),
+           "max_det": np.array(cfg.MODEL.ROI_HEADS.DETECTIONS_PER_IMG), "pixel_mean": np.array(cfg.INPUT.PIXEL_MEAN, np.float32),
+           "pixel_std": np.array(cfg.INPUT.PIXEL_STD, np.float32), "to_bgr255": np.array(cfg.INPUT.TO_BGR255)}
+    for k, v in aug.items():
+        rec["aug_" + k] = np.array(v)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    ocfg = dict(score_thresh=float(rec["score_thresh"]), nms_test=float(rec["nms"]), max_det=int(rec["max_det"]))
+    oaug = dict(aug, mean=rec["pixel_mean"], std=rec["pixel_std"], to_bgr255=bool(rec["to_bgr255"]), size_divisible=32)
+    with torch.no_grad():
+        ora = I.tta(pixels, boxes_np, sdt, ocfg, oaug)
+    for i, r in enumerate(result):
+        rec["det_boxes_%d" % i] = r.bbox.numpy()
+        rec["det_scores_%d" % i] = r.get_field("scores").numpy()
+        rec["det_labels_%d" % i] = r.get_field("labels").numpy()
+        ob, os_, ol = ora[i]
+        assert np.array_equal(ol.numpy(), rec["det_labels_%d" % i]), "oracle != reference (labels)"
+        np.testing.assert_allclose(ob.numpy(), rec["det_boxes_%d" % i], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(os_.numpy(), rec["det_scores_%d" % i], rtol=1e-6, atol=1e-8)
+        print("   image %d: %d detections, classes %s" % (i, len(r), sorted(set(rec["det_labels_%d" % i].tolist()))[:8]))
+    np.savez_compressed(out, **rec)
+    print("wrote", out)
+
+
+TTA_CASES = {"tta_voc_2img": dict(seed=23, images=[(96, 128, 48), (112, 80, 40)],
+                                  aug=dict(min_test=96, max_test=160, h_flip=True, scales=(64, 128), max_size=176,
+                                           scale_h_flip=True))}
+
 DATA_CASES = {"data_voc": dict(seed=11, shapes=[(60, 80), (75, 50), (64, 64), (48, 96)],
                                ids=["000005", "000007", "000009", "000012"], min_train=(48, 64, 80), max_train=100,
                                min_test=64, max_test=120)}
@@ -432,6 +492,9 @@ if __name__ == "__main__":
     for name, spec in INFER_CASES.items():
         if name in which or not sys.argv[1:]:
             gen_infer(name, spec, os.path.join(HERE, name + ".npz"))
+    for name, spec in TTA_CASES.items():
+        if name in which or not sys.argv[1:]:
+            gen_tta(name, spec, os.path.join(HERE, name + ".npz"))
     for name, spec in DATA_CASES.items():
         if name in which or not sys.argv[1:]:
             gen_data(name, spec, os.path.join(HERE, name + ".npz"))

@@ -199,6 +199,36 @@ def test_inference_tail_matches_imported_reference(weights_np):
         np.testing.assert_allclose(s.numpy(), g["det_scores_%d" % i], rtol=1e-6, atol=1e-8)
 
 
+def tta_inputs(g):
+    """pixels, proposals and the augmentation settings of a tests/golden/tta_*.npz case."""
+    import voc_fixture
+    from od_wscl_amd import synthetic
+    seed = int(g["spec_seed"])
+    specs = [(int(h), int(w), int(p)) for h, w, p in g["spec_images"]]
+    pixels, _, _ = voc_fixture.make_case(seed, [(h, w) for h, w, _ in specs])
+    boxes = [synthetic.make_proposals(seed, k, p, h, w, min_size=12) for k, (h, w, p) in enumerate(specs)]
+    aug = dict(min_test=int(g["aug_min_test"]), max_test=int(g["aug_max_test"]), h_flip=bool(g["aug_h_flip"]),
+               scales=tuple(int(v) for v in g["aug_scales"].tolist()), max_size=int(g["aug_max_size"]),
+               scale_h_flip=bool(g["aug_scale_h_flip"]), mean=g["pixel_mean"], std=g["pixel_std"],
+               to_bgr255=bool(g["to_bgr255"]), size_divisible=32)
+    return specs, pixels, boxes, aug
+
+
+def test_test_time_augmentation_matches_imported_reference(weights_np):
+    """im_detect_bbox_aug (engine/bbox_aug.py) restated: 6 passes over a 2-image batch, AVG merge, filter."""
+    from oracle import inference_ref as I
+    g = load_e2e("tta_voc_2img")
+    specs, pixels, boxes, aug = tta_inputs(g)
+    sd = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    with torch.no_grad():
+        out = I.tta(pixels, boxes, sd, dict(score_thresh=float(g["score_thresh"]), nms_test=float(g["nms"]),
+                                            max_det=int(g["max_det"])), aug)
+    for i, (b, s, l) in enumerate(out):
+        np.testing.assert_array_equal(l.numpy(), g["det_labels_%d" % i])
+        np.testing.assert_allclose(b.numpy(), g["det_boxes_%d" % i], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(s.numpy(), g["det_scores_%d" % i], rtol=1e-6, atol=1e-8)
+
+
 def e2e_inputs_infer(g):
     import torch as _t
     from od_wscl_amd import synthetic
