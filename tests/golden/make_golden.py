@@ -471,6 +471,103 @@ def gen_tta(name, spec, out):
     print("wrote", out)
 
 
+class _ListSampler(torch.utils.data.sampler.Sampler):
+    def __init__(self, order):
+        self.order = list(order)
+
+    def __iter__(self):
+        return iter(self.order)
+
+    def __len__(self):
+        return len(self.order)
+
+
+def gen_sampler(name, spec, out):
+    """The imported reference's GroupedBatchSampler: aspect-ratio grouping and the class-pair batches of
+    SOLVER.CLASS_BATCH, on a two-split miniature VOC devkit under a fixed numpy seed."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    import voc_fixture
+    refimport.load_reference()
+    from wetectron.data.datasets import PascalVOCDataset, ConcatDataset
+    from wetectron.data.samplers import GroupedBatchSampler, DistributedSampler, IterationBasedBatchSampler
+    from wetectron.data.build import _quantize, _compute_aspect_ratios
+    n = spec["n"]
+    images, objects = voc_fixture.make_pair_case(spec["seed"], n)
+    ids = ["%06d" % (k + 1) for k in range(n)]
+    rec = {"spec_seed": np.array(spec["seed"]), "spec_n": np.array(n)}
+    with tempfile.TemporaryDirectory() as root:
+        half = n // 2
+        voc_fixture.write_devkit(root, "train", ids[:half], images[:half], objects[:half])
+        voc_fixture.write_devkit(root, "val", ids[half:], images[half:], objects[half:])
+        args = [dict(data_dir=root, split="train", use_difficult=False, transforms=None),
+                dict(data_dir=root, split="val", use_difficult=False, transforms=None)]
+        ds = ConcatDataset([PascalVOCDataset(**a) for a in args])
+        group_ids = _quantize(_compute_aspect_ratios(ds), [1])
+        rec["group_ids"] = np.array(group_ids)
+        order = np.random.RandomState(spec["seed"]).permutation(n).tolist()
+        rec["order"] = np.array(order)
+        for bs in (2, 3):
+            b = list(GroupedBatchSampler(_ListSampler(order), group_ids, bs, bs * 2, ds, False, data_args=[args]))
+            rec["grouped_bs%d" % bs] = np.array([x + [-1] * (bs - len(x)) for x in b])
+        np.random.seed(spec["seed"])
+        pairs = list(GroupedBatchSampler(_ListSampler(order), group_ids, 2, 4, ds, True, data_args=[args]))
+        rec["class_pairs"] = np.array(pairs)
+        rec["labels"] = np.array([(sorted(set(ds.datasets[ds.get_idxs(d)[0]].get_groundtruth(ds.get_idxs(d)[1])
+                                             .get_field("labels").tolist())) + [-1, -1])[:2] for d in range(n)])
+        for rank in range(2):
+            s_ = DistributedSampler(ds, num_replicas=2, rank=rank, shuffle=True)
+            s_.set_epoch(3)
+            rec["dist_rank%d_epoch3" % rank] = np.array(list(s_))
+        it = IterationBasedBatchSampler(GroupedBatchSampler(_ListSampler(order), group_ids, 2, 4, ds, False,
+                                                            data_args=[args]), num_iterations=11, start_iter=4)
+        rec["iteration_based"] = np.array([x + [-1] * (2 - len(x)) for x in it])
+        print("   %d grouped batches, %d class pairs, %d iteration-based" % (len(b), len(pairs), len(rec["iteration_based"])))
+    np.savez_compressed(out, **rec)
+    print("wrote", out)
+
+
+def gen_voc_eval(name, spec, out):
+    """The imported reference's VOC metric (data/datasets/evaluation/voc/voc_eval.py) on random detections against a
+    miniature devkit's annotations (difficult objects, duplicates, misses, empty images)."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    import voc_fixture
+    refimport.load_reference()
+    from wetectron.data.datasets import PascalVOCDataset
+    from wetectron.structures.bounding_box import BoxList
+    from wetectron.data.datasets.evaluation.voc.voc_eval import eval_detection_voc
+    n = spec["n"]
+    images, objects = voc_fixture.make_pair_case(spec["seed"], n)
+    objects = [[(nm, int((k + j) % 4 == 0), x1, y1, x2, y2) for j, (nm, d, x1, y1, x2, y2) in enumerate(o)]
+               for k, o in enumerate(objects)]
+    ids = ["%06d" % (k + 1) for k in range(n)]
+    preds = voc_fixture.make_detections(spec["seed"], images, objects)
+    rec = {"spec_seed": np.array(spec["seed"]), "spec_n": np.array(n)}
+    with tempfile.TemporaryDirectory() as root:
+        voc_fixture.write_devkit(root, "test", ids, images, objects)
+        ds = PascalVOCDataset(root, "test", use_difficult=True)
+        pl, gl = [], []
+        for k, (b, s, l) in enumerate(preds):
+            info = ds.get_img_info(k)
+            p = BoxList(torch.from_numpy(b), (info["width"], info["height"]), "xyxy")
+            p.add_field("scores", torch.from_numpy(s))
+            p.add_field("labels", torch.from_numpy(l))
+            pl.append(p)
+            gl.append(ds.get_groundtruth(k))
+        for tag, m07 in (("07", True), ("area", False)):
+            r = eval_detection_voc(pl, gl, iou_thresh=0.5, use_07_metric=m07)
+            rec["ap_" + tag] = r["ap"]
+            rec["map_" + tag] = np.array(r["map"])
+            print("   %s: mAP %.4f" % (tag, r["map"]))
+    np.savez_compressed(out, **rec)
+    print("wrote", out)
+
+
+EVAL_CASES = {"voc_eval": dict(seed=31, n=24)}
+
+SAMPLER_CASES = {"sampler_voc": dict(seed=5, n=14)}
+
 TTA_CASES = {"tta_voc_2img": dict(seed=23, images=[(96, 128, 48), (112, 80, 40)],
                                   aug=dict(min_test=96, max_test=160, h_flip=True, scales=(64, 128), max_size=176,
                                            scale_h_flip=True))}
@@ -492,6 +589,12 @@ if __name__ == "__main__":
     for name, spec in INFER_CASES.items():
         if name in which or not sys.argv[1:]:
             gen_infer(name, spec, os.path.join(HERE, name + ".npz"))
+    for name, spec in EVAL_CASES.items():
+        if name in which or not sys.argv[1:]:
+            gen_voc_eval(name, spec, os.path.join(HERE, name + ".npz"))
+    for name, spec in SAMPLER_CASES.items():
+        if name in which or not sys.argv[1:]:
+            gen_sampler(name, spec, os.path.join(HERE, name + ".npz"))
     for name, spec in TTA_CASES.items():
         if name in which or not sys.argv[1:]:
             gen_tta(name, spec, os.path.join(HERE, name + ".npz"))

@@ -133,3 +133,107 @@ def test_live_reference_agrees_with_the_golden(golden, tmp_path):
     ds = RefVOC(root, "trainval", use_difficult=False, transforms=None, proposal_file=pkl)
     for i in range(len(ids)):
         np.testing.assert_array_equal(ds[i][2].bbox.numpy(), golden["raw_rois_%d" % i])
+
+
+class _ListSampler(torch.utils.data.sampler.Sampler):
+    def __init__(self, order):
+        self.order = list(order)
+
+    def __iter__(self):
+        return iter(self.order)
+
+    def __len__(self):
+        return len(self.order)
+
+
+def test_samplers_match_the_reference(tmp_path):
+    """Aspect-ratio grouping, SOLVER.CLASS_BATCH pairs, rank sharding and iteration-based resampling against what the
+    imported reference's sampler classes produced on the same miniature two-split devkit."""
+    g = np.load(os.path.join(HERE, "golden", "sampler_voc.npz"))
+    n, seed = int(g["spec_n"]), int(g["spec_seed"])
+    images, objects = voc_fixture.make_pair_case(seed, n)
+    ids = ["%06d" % (k + 1) for k in range(n)]
+    root = str(tmp_path)
+    voc_fixture.write_devkit(root, "train", ids[: n // 2], images[: n // 2], objects[: n // 2])
+    voc_fixture.write_devkit(root, "val", ids[n // 2:], images[n // 2:], objects[n // 2:])
+    from od_wscl_amd.data import build as B
+    from od_wscl_amd.data.datasets import ConcatDataset, PascalVOCDataset
+    from od_wscl_amd.data.samplers import DistributedSampler, GroupedBatchSampler, IterationBasedBatchSampler
+    ds = ConcatDataset([PascalVOCDataset(root, "train"), PascalVOCDataset(root, "val")])
+    group_ids = B._quantize(B._compute_aspect_ratios(ds), [1])
+    assert group_ids == g["group_ids"].tolist()
+    order = g["order"].tolist()
+    for bs in (2, 3):
+        got = list(GroupedBatchSampler(_ListSampler(order), group_ids, bs))
+        assert [x + [-1] * (bs - len(x)) for x in got] == g["grouped_bs%d" % bs].tolist()
+    np.random.seed(seed)
+    pairs = list(GroupedBatchSampler(_ListSampler(order), group_ids, 2, 4, ds, True))
+    assert pairs == g["class_pairs"].tolist()
+    labels = [set(ds.get_groundtruth(d).get_field("labels").tolist()) for d in range(n)]
+    assert all(labels[a] & labels[b] for a, b in pairs)                   # every pair shares a class
+    for rank in range(2):
+        s = DistributedSampler(ds, num_replicas=2, rank=rank, shuffle=True)
+        s.set_epoch(3)
+        assert list(s) == g["dist_rank%d_epoch3" % rank].tolist()
+    it = IterationBasedBatchSampler(GroupedBatchSampler(_ListSampler(order), group_ids, 2), num_iterations=11, start_iter=4)
+    assert [x + [-1] * (2 - len(x)) for x in it] == g["iteration_based"].tolist() and len(it) == 11
+
+
+def test_make_data_loader_end_to_end_on_a_devkit(golden, tmp_path):
+    """cfg -> catalog -> datasets -> samplers -> workers -> collated pending batch (host half only)."""
+    root, pkl, images, proposals, ids = _devkit(tmp_path, golden)
+    from od_wscl_amd.data import make_data_loader
+
+    class Catalog(object):
+        @staticmethod
+        def get(name):
+            return dict(factory="PascalVOCDataset", args=dict(data_dir=root, split="trainval"))
+
+    cfg = cfg_for_data(golden)
+    cfg.merge_from_list(["DATASETS.TRAIN", ("voc_2007_trainval",), "DATASETS.TEST", ("voc_2007_trainval",),
+                         "PROPOSAL_FILES.TRAIN", (pkl,), "PROPOSAL_FILES.TEST", (pkl,), "SOLVER.IMS_PER_BATCH", 2,
+                         "SOLVER.MAX_ITER", 5, "TEST.IMS_PER_BATCH", 2, "DATALOADER.NUM_WORKERS", 2,
+                         "DATALOADER.SIZE_DIVISIBILITY", 32])
+    loader = make_data_loader(cfg, is_train=True, dataset_catalog=Catalog, num_gpus=1)
+    batches = list(loader)
+    assert len(batches) == 5
+    for pending, targets, rois, idx in batches:
+        assert 1 <= len(pending) <= 2 and len(targets) == len(rois) == len(idx) == len(pending)
+        assert pending.padded_hw[0] % 32 == 0 and pending.padded_hw[1] % 32 == 0
+        for im, r in zip(pending.images, rois):
+            assert im.pixels.dtype == np.uint8 and r.size == im.size and im.norm is not None
+    test_loaders = make_data_loader(cfg, is_train=False, dataset_catalog=Catalog, num_gpus=1)
+    assert len(test_loaders) == 1 and sum(len(b[0]) for b in test_loaders[0]) == len(ids)
+    cfg.merge_from_list(["TEST.BBOX_AUG.ENABLED", True])
+    raw = next(iter(make_data_loader(cfg, is_train=False, dataset_catalog=Catalog, num_gpus=1)[0]))
+    assert hasattr(raw[0][0], "size") and raw[2][0].size == raw[0][0].size       # PIL images + proposals, untransformed
+
+
+def test_voc_metric_matches_the_reference(tmp_path):
+    """mAP / per-class AP (VOC07 11-point and area rule) on random detections == the imported reference's
+    eval_detection_voc on the same inputs; do_voc_evaluation end to end."""
+    from od_wscl_amd.data.datasets import PascalVOCDataset
+    from od_wscl_amd.data.evaluation import do_voc_evaluation, eval_detection_voc
+    from od_wscl_amd.structures.bounding_box import BoxList
+    g = np.load(os.path.join(HERE, "golden", "voc_eval.npz"))
+    n, seed = int(g["spec_n"]), int(g["spec_seed"])
+    images, objects = voc_fixture.make_pair_case(seed, n)
+    objects = [[(nm, int((k + j) % 4 == 0), x1, y1, x2, y2) for j, (nm, d, x1, y1, x2, y2) in enumerate(o)]
+               for k, o in enumerate(objects)]
+    ids = ["%06d" % (k + 1) for k in range(n)]
+    voc_fixture.write_devkit(str(tmp_path), "test", ids, images, objects)
+    ds = PascalVOCDataset(str(tmp_path), "test", use_difficult=True)
+    preds, gts = [], []
+    for k, (b, s, l) in enumerate(voc_fixture.make_detections(seed, images, objects)):
+        info = ds.get_img_info(k)
+        p = BoxList(torch.from_numpy(b), (info["width"], info["height"]), "xyxy")
+        p.add_field("scores", torch.from_numpy(s))
+        p.add_field("labels", torch.from_numpy(l))
+        preds.append(p)
+        gts.append(ds.get_groundtruth(k))
+    for tag, m07 in (("07", True), ("area", False)):
+        r = eval_detection_voc(preds, gts, iou_thresh=0.5, use_07_metric=m07)
+        np.testing.assert_allclose(r["ap"], g["ap_" + tag], rtol=0, atol=1e-12, equal_nan=True)
+        assert abs(r["map"] - float(g["map_" + tag])) < 1e-12
+    out = do_voc_evaluation(ds, preds, str(tmp_path))
+    assert abs(out["map"] - float(g["map_07"])) < 1e-12 and os.path.exists(os.path.join(str(tmp_path), "result.txt"))

@@ -55,3 +55,43 @@ def write_devkit(root, split, ids, images, objects):
         xml.append("</annotation>")
         with open(os.path.join(root, "Annotations", i + ".xml"), "w") as f:
             f.write("".join(xml))
+
+
+def make_pair_case(seed, n):
+    """n tiny images (wide and tall) whose objects come from a 5-class pool, so that many images share a class:
+    input of the aspect-grouping / class-pair sampler tests."""
+    rng = np.random.RandomState(seed)
+    images, objects = [], []
+    pool = ("bird", "cat", "dog", "horse", "sheep")
+    for k in range(n):
+        h, w = (16, 24) if rng.randint(2) else (24, 16)
+        images.append(rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8))
+        names = sorted(set(pool[c] for c in rng.randint(0, 5, size=1 + rng.randint(2))))
+        objects.append([(nm, 0, 2, 2, 10 + j, 12 + j) for j, nm in enumerate(names)])
+    return images, objects
+
+
+def make_detections(seed, images, objects):
+    """Per image (boxes fp32 (k,4), scores (k), labels int64 (k)): jittered copies of the annotated objects (hits and
+    near misses, duplicates), plus random false positives; some images get none."""
+    rng = np.random.RandomState(seed + 1000)
+    cls_index = {c: i + 1 for i, c in enumerate(CLASSES)}
+    out = []
+    for k, (img, objs) in enumerate(zip(images, objects)):
+        h, w = img.shape[:2]
+        boxes, scores, labels = [], [], []
+        if k % 7 != 3:
+            for name, difficult, x1, y1, x2, y2 in objs:
+                for rep in range(1 + rng.randint(3)):
+                    j = rng.randint(-3, 4, size=4) if rng.rand() < 0.7 else rng.randint(-9, 10, size=4)
+                    boxes.append([x1 - 1 + j[0], y1 - 1 + j[1], x2 - 1 + j[2], y2 - 1 + j[3]])
+                    scores.append(rng.rand())
+                    labels.append(cls_index[name] if rng.rand() < 0.85 else 1 + rng.randint(20))
+            for _ in range(rng.randint(3)):
+                x1, y1 = rng.randint(0, w - 6), rng.randint(0, h - 6)
+                boxes.append([x1, y1, x1 + rng.randint(3, 6), y1 + rng.randint(3, 6)])
+                scores.append(rng.rand() * 0.6)
+                labels.append(1 + rng.randint(20))
+        out.append((np.asarray(boxes, np.float32).reshape(-1, 4), np.asarray(scores, np.float32),
+                    np.asarray(labels, np.int64)))
+    return out

@@ -3,9 +3,9 @@
 -> load cfg.MODEL.WEIGHT if it is a local .pth -> train loop with periodic checkpoints in the reference's layout),
 one process per GPU under torch.distributed.run (RCCL).
 
-The data side of wetectron (datasets, transforms, proposal files) is outside this build:
-batches come from --synthetic (formula-generated images / proposals / image labels of the configured shape) or from
-a user-supplied iterable yielding (ImageList, [BoxList targets], [BoxList proposals]).
+Batches come from the configured datasets (DATASETS.TRAIN + PROPOSAL_FILES.TRAIN under --data-dir, VOC devkit layout;
+DataLoader workers decode and plan, the GPU preprocesses -- od_wscl_amd/data) or, with --synthetic, from
+formula-generated images / proposals / image labels of the configured shape (no dataset needed).
 
     python tools/train_net.py --config-file /path/to/voc07_contra_db_b8_lr0.01_mcg.yaml --synthetic \\
         SOLVER.MAX_ITER 50 SOLVER.CHECKPOINT_PERIOD 25 OUTPUT_DIR /tmp/odw_run
@@ -38,11 +38,27 @@ def synthetic_loader(cfg, rank, device, size, proposals, max_iter):
         yield to_image_list([img], div).to(device), [t], [BoxList(boxes.to(device), (size, size), "xyxy")]
 
 
+def dataset_loader(cfg, device, world, start_iter, data_dir):
+    """(images on the device, targets, proposals) from make_data_loader: the pending batch is materialised by the GPU
+    preprocessing kernel in `.to(device)`; image labels stay on the host for the loss."""
+    from od_wscl_amd.data import DatasetCatalog, make_data_loader
+    if data_dir:
+        DatasetCatalog.DATA_DIR = data_dir
+    loader = make_data_loader(cfg, is_train=True, is_distributed=world > 1, start_iter=start_iter)
+    for images, targets, rois, _ in loader:
+        out_t = []
+        for t in targets:
+            t.add_field("labels_host", t.get_field("labels").tolist())
+            out_t.append(t.to(device))
+        yield images.to(device), out_t, [r.to(device) for r in rois]
+
+
 def main():
     ap = argparse.ArgumentParser(description="OD-WSCL training on MI355X")
     ap.add_argument("--config-file", default="", metavar="FILE")
     ap.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))
-    ap.add_argument("--synthetic", action="store_true", help="formula-generated batches (no datasets in this build)")
+    ap.add_argument("--synthetic", action="store_true", help="formula-generated batches instead of DATASETS.TRAIN")
+    ap.add_argument("--data-dir", default="", help="root of the dataset catalog (default: ./datasets)")
     ap.add_argument("--size", type=int, default=600)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -70,9 +86,8 @@ def main():
     cfg.merge_from_list(args.opts or [])
     if cfg.SEED < 0:
         cfg.merge_from_list(["SEED", 1234])
-    if not args.synthetic:
-        raise SystemExit("only --synthetic batches are available: the dataset / proposal-file side of wetectron is "
-                         "outside this build (pass your own loader to engine.build_training_step's step function)")
+    if not args.synthetic and not cfg.DATASETS.TRAIN:
+        raise SystemExit("DATASETS.TRAIN is empty: pass a config that names a dataset, or --synthetic")
 
     step, info = engine.build_training_step(cfg, device, dtype=args.dtype, world=world, seed=cfg.SEED, backend="hip")
     opt = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, engine.FlatSGD)][0]
@@ -93,7 +108,8 @@ def main():
     out_dir = cfg.OUTPUT_DIR
     if rank == 0 and out_dir:
         os.makedirs(out_dir, exist_ok=True)
-    loader = synthetic_loader(cfg, rank, device, args.size, args.proposals, max_iter)
+    loader = synthetic_loader(cfg, rank, device, args.size, args.proposals, max_iter) if args.synthetic else \
+        dataset_loader(cfg, device, world, start_iter, args.data_dir)
     t0, seen = time.time(), 0
     for iteration, (images, targets, rois) in enumerate(loader, start_iter):
         iteration += 1                                             # engine/trainer.py:94
