@@ -48,48 +48,48 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ dwk, int ld, int C
 }
 
 // out[(t*C + ci)][m] = X[m + shift(t)][ci] (0 in the padding), m < ldm zero padded.
-// 64(m) x 64(ci) tiles, 16 bytes per lane both ways: a pixel's 64 channels are one 128-byte read (8 lanes x 16 B),
-// an output row's 64 pixels one 128-byte write; the transposition happens in LDS (rows padded to 72 elements).
-// (The first version moved 32x32 tiles with 2-byte accesses: 64-byte segments, 0.55 ms per step; this one ~0.2.)
+// LDS-free: a thread owns an 8(pixel) x 8(channel) block -- eight 16-byte loads (one per pixel), an in-register 8x8
+// transposition of the 16-bit elements (32 v_perm_b32), eight 16-byte stores (one per channel).  A wave covers
+// 16 pixel groups x 4 channel chunks: 64-byte read segments (L2 hits: every tap re-reads X) and 256-byte write runs
+// (the writes are 9/10 of the traffic).  History: 32x32 LDS tiles with 2-byte accesses; 64x64 LDS tiles with 16-byte
+// global accesses but 2-byte, 8-way bank-conflicted LDS reads: 88 us per launch inside the step (1 TB/s); this one
+// 45-50 us.  Inside the step the saving is mostly absorbed: the old kernel was LDS-bound and overlapped the
+// HBM-bound side-stream optimiser for free, now the weight-gradient GEMMs that follow share HBM with it instead
+// (GPU-busy per step 9.11 -> 8.96 ms on the same box class).
 __global__ __launch_bounds__(256) void im2col_t_kernel(const unsigned short* __restrict__ X, int M, int H, int W,
                                                        int C, int dil, unsigned short* __restrict__ out, int ldm) {
-    __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];
     const int t = blockIdx.z;
     const int ty9 = t / 3, tx9 = t - 3 * ty9;
     const int dh = (ty9 - 1) * dil, dw = (tx9 - 1) * dil;
-    const int c0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
     const int hw = H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pg = lane & 15, ch = lane >> 4;                 // pixel group (8 pixels), channel chunk (8 channels)
+    const int m0 = (blockIdx.y * 4 + wave) * 128 + pg * 8;    // block = 4 waves x 128 pixels
+    const int c0 = blockIdx.x * 32 + ch * 8;
+    if (c0 >= C || m0 >= ldm) return;
+    unsigned int r[8][4];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int item = threadIdx.x + 256 * k;              // 64 pixels x 8 chunks of 8 channels
-        const int ml = item >> 3, ch = item & 7;
-        const int m = m0 + ml, c = c0 + ch * 8;
+    for (int q = 0; q < 8; ++q) {
+        const int m = m0 + q;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (m < M && c < C) {
+        if (m < M) {
             const int p = m % hw;
             const int y = p / W + dh, x = p % W + dw;
             if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                v = *reinterpret_cast<const uint4*>(X + (size_t)(m + dh * W + dw) * C + c);
+                v = *reinterpret_cast<const uint4*>(X + (size_t)(m + dh * W + dw) * C + c0);
         }
-        *reinterpret_cast<uint4*>(&tile[ml][ch * 8]) = v;
+        r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w;
     }
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int item = threadIdx.x + 256 * k;              // 64 channels x 8 chunks of 8 pixels
-        const int cl = item >> 3, mc = item & 7;
-        const int c = c0 + cl, m = m0 + mc * 8;
-        if (c < C && m < ldm) {
-            unsigned short v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = tile[mc * 8 + q][cl];
-            uint4 o;
-            o.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
-            o.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
-            o.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
-            o.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
-            *reinterpret_cast<uint4*>(out + ((size_t)t * C + c) * ldm + m) = o;
-        }
+    for (int j = 0; j < 8; ++j) {
+        // channel j of pixels (2p, 2p+1): low halves (selector 0x05040100) or high halves (0x07060302) of dword j/2
+        const unsigned int sel = (j & 1) ? 0x07060302u : 0x05040100u;
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(r[1][j >> 1], r[0][j >> 1], sel);
+        o.y = __builtin_amdgcn_perm(r[3][j >> 1], r[2][j >> 1], sel);
+        o.z = __builtin_amdgcn_perm(r[5][j >> 1], r[4][j >> 1], sel);
+        o.w = __builtin_amdgcn_perm(r[7][j >> 1], r[6][j >> 1], sel);
+        *reinterpret_cast<uint4*>(out + ((size_t)t * C + c0 + j) * ldm + m0) = o;
     }
 }
 
@@ -227,7 +227,7 @@ ODW_EXPORT int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, 
                 "im2col_t: bad arguments");
     ODW_REQUIRE(C % 8 == 0 && ldm % 8 == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
                 "im2col_t: C=%d and ldm=%d must be multiples of 8, pointers 16-byte aligned", C, ldm);
-    dim3 grid((C + 63) / 64, (ldm + 63) / 64, 9);
+    dim3 grid((C + 31) / 32, (ldm + 511) / 512, 9);
     im2col_t_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X, n_pix, H, W, C, dilation,
                                                             (unsigned short*)out, ldm);
     ODW_CHECK_LAUNCH("im2col_t_kernel");
