@@ -35,3 +35,7 @@ for mode in sys.argv[1].split(","):
 os.environ["ODW_RPS_MODE"] = "0"
 fwd()
 print("bwd %.1f us" % timeit(bwd))
+def bwd_skip():
+    L.check(lib.odw_roi_pool_stack_backward(L.ptr(dx), 0, dx.stride(0), L.ptr(am), L.ptr(rois), L.ptr(keep), L.ptr(ks), None, None, 0, 1,
+                                            1, C, H, W, P, 7, 7, L.ptr(dfeat), L.stream()), "bwd")
+print("bwd skip_clean %.1f us" % timeit(bwd_skip))
