@@ -1006,6 +1006,56 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+
+// The streaming form of the same update (n % 4 == 0): nontemporal loads / stores and two float4 per lane in flight.
+// 153 M parameters x 22 B: 606 us (5.55 TB/s) with the plain kernel on 8192 workgroups, 528 us (6.37 TB/s) with
+// MODE 3 on 65536 (MODE bit 0 = nontemporal, bit 1 = two vectors in flight; ODW_SGD_MODE / ODW_SGD_GRID to compare).
+template <int MODE>
+__global__ __launch_bounds__(256) void sgd_kernel_x(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                    unsigned short* __restrict__ shadow, size_t n4, float lr, float wd,
+                                                    float mu, float gscale, int first) {
+    constexpr bool NT = (MODE & 1) != 0;
+    constexpr int U = (MODE & 2) ? 2 : 1;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * U) {
+        f4 pv[U], gv[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = i0 + u * stride;
+            if (i < n4) {
+                pv[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<f4*>(p) + i) : reinterpret_cast<f4*>(p)[i];
+                gv[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i) : reinterpret_cast<const f4*>(g)[i];
+                bv[u] = first ? (f4)(0.0f) : (NT ? __builtin_nontemporal_load(reinterpret_cast<f4*>(buf) + i) : reinterpret_cast<f4*>(buf)[i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = i0 + u * stride;
+            if (i < n4) {
+                us4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = gv[u][k] * gscale + wd * pv[u][k];
+                    bv[u][k] = first ? d : mu * bv[u][k] + d;
+                    pv[u][k] -= lr * bv[u][k];
+                    o[k] = f2bf(pv[u][k]);
+                }
+                if (NT) {
+                    __builtin_nontemporal_store(pv[u], reinterpret_cast<f4*>(p) + i);
+                    __builtin_nontemporal_store(bv[u], reinterpret_cast<f4*>(buf) + i);
+                    if (shadow) __builtin_nontemporal_store(o, reinterpret_cast<us4*>(shadow) + i);
+                } else {
+                    reinterpret_cast<f4*>(p)[i] = pv[u];
+                    reinterpret_cast<f4*>(buf)[i] = bv[u];
+                    if (shadow) reinterpret_cast<us4*>(shadow)[i] = o;
+                }
+            }
+        }
+    }
+}
+
 // Second pass of a split-K product: C = epilogue(sum_s partial[s]) with the full fused epilogue (bias, ReLU,
 // dropout keys, bf16 / fp32, accumulate) -- 4 consecutive columns per thread, fixed summation order (deterministic).
 template <bool OUT_BF16>
@@ -1347,7 +1397,19 @@ ODW_EXPORT int odw_sgd_momentum(float* p, const float* g, float* buf, void* shad
     ODW_REQUIRE((((uintptr_t)p) & 15) == 0 && (((uintptr_t)g) & 15) == 0 && (((uintptr_t)buf) & 15) == 0 &&
                     (((uintptr_t)shadow_bf16) & 7) == 0, "sgd_momentum: buffers must be 16-byte aligned");
     size_t blocks = ((size_t)n / 4 + 255) / 256;
-    sgd_kernel<<<(int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks)), 256, 0, (hipStream_t)stream_>>>(
+    static const int mode = getenv("ODW_SGD_MODE") ? atoi(getenv("ODW_SGD_MODE")) : 3;
+    static const int cap = getenv("ODW_SGD_GRID") ? atoi(getenv("ODW_SGD_GRID")) : 65536;
+    const int grid = (int)(blocks < 1 ? 1 : (blocks > (size_t)cap ? (size_t)cap : blocks));
+    if (mode && n % 4 == 0) {
+        hipStream_t st = (hipStream_t)stream_;
+        unsigned short* sh = (unsigned short*)shadow_bf16;
+        if (mode == 1) sgd_kernel_x<1><<<grid, 256, 0, st>>>(p, g, buf, sh, (size_t)n / 4, lr, wd, momentum, grad_scale, first_step);
+        else if (mode == 2) sgd_kernel_x<2><<<grid, 256, 0, st>>>(p, g, buf, sh, (size_t)n / 4, lr, wd, momentum, grad_scale, first_step);
+        else sgd_kernel_x<3><<<grid, 256, 0, st>>>(p, g, buf, sh, (size_t)n / 4, lr, wd, momentum, grad_scale, first_step);
+        ODW_CHECK_LAUNCH("sgd_kernel_x");
+        return ODW_OK;
+    }
+    sgd_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(
         p, g, buf, (unsigned short*)shadow_bf16, (size_t)n, lr, wd, momentum, grad_scale, first_step);
     ODW_CHECK_LAUNCH("sgd_kernel");
     return ODW_OK;

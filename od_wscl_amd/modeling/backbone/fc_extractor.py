@@ -142,7 +142,8 @@ class _RowGather(torch.autograd.Function):
         holder, e0, n = ctx.args
 
         def fold(extra, identity_rows):
-            extra[e0:e0 + n].add_(dx)
+            extra[e0:e0 + n].copy_(dx)       # the entries are this node's alone (zero before): a converting copy, not
+                                             # the mixed-dtype add_ (104 us for 250 rows against ~10)
 
         if holder is None or holder.done:
             raise RuntimeError("_RowGather: the pooling node already ran its backward")
