@@ -64,3 +64,44 @@ def test_two_rank_step_keeps_replicas_identical(tmp_path):
     # early exchange of the head on the side stream == one exchange after backward, up to the run-to-run noise of
     # the atomic accumulations in the ROI pooling backward (~1e-7 absolute after three steps; a flipped near-tie selection moves a parameter by at most lr x |grad|)
     np.testing.assert_allclose(res[True][0]["p"], res[False][0]["p"], rtol=0, atol=1e-4)
+
+
+def _rccl_worker(rank, port, out_dir):
+    """One rank, backend "nccl" (= RCCL): the collectives degenerate to copies, but the process group, the chunked
+    async all-reduce on the side stream and the bench's barrier / MAX reduction run through RCCL's real entry points."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", ODW_NO_TIMER="1")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from od_wscl_amd import engine
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    flat = torch.arange(3_000_000, dtype=torch.float32, device=dev)
+    want = flat.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        engine.all_reduce_flat(flat, 2, chunk_elems=1 << 20)         # world=2 forces the collective path; the group has 1 rank
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(flat, want)
+    cfg = bench.build_cfg(21)
+    step, _ = engine.build_training_step(cfg, dev, dtype="bf16", world=2, seed=cfg.SEED, backend="hip")   # grad_scale 1/2
+    images, targets, rois = bench.synthetic_batch(cfg.SEED, 0, 224, 120, 21, dev)
+    vals = []
+    for it in range(2):
+        l, _ = step(images, targets, rois, DeviceRand(cfg.SEED, first_stream=(1 << 20) + (it << 12), device=dev))
+        vals.append(float(sum(l.values())))
+    dist.barrier()
+    t = torch.tensor([1.5], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rccl.npz"), losses=np.array(vals), t=t.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_step(tmp_path):
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    assert np.isfinite(r["losses"]).all() and float(r["t"][0]) == 1.5
