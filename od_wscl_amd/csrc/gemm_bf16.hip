@@ -709,6 +709,30 @@ __device__ __forceinline__ void dma_tile_conv(const unsigned short* __restrict__
     }
 }
 
+// The same operand DMA when a K step of 64 lies inside ONE tap (C >= 64): the tap decode, its shift and the channel
+// offset are wave-uniform, and a lane's four rows carry a 9-bit "tap in bounds" mask and a byte offset computed once
+// before the K loop -- ~7 VALU instructions per row and step instead of ~30.  Measured: 2-4 % per layer (831 -> 812 us
+// for the 13 forward layers): the arithmetic was not the bound.  One workgroup alone on a CU runs 2.06 TF = one K step
+// (2.1 MFLOP) per ~1 us, i.e. per loaded DMA latency: with 64 KB of operands in flight per CU (2 workgroups x 1 stage)
+// the 128x128 tile is latency-bound, and a third stage only trades a co-resident workgroup for it (the 3-slot ring
+// form measured the same); larger tiles do not fit the 76x76 layers' 184-tile grids.
+__device__ __forceinline__ void dma_tile_conv_uniform(const unsigned short* __restrict__ X, const ConvGeom& g, int k0,
+                                                      uint4* __restrict__ tile, int wave, const unsigned (&voff)[4],
+                                                      const unsigned (&vmask)[4]) {
+    const int tap = __builtin_amdgcn_readfirstlane(k0 >> g.logC);
+    const int ci0 = k0 & (g.C - 1);
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+    const int dh = (ty - 1) * g.dil * g.sign, dw = (tx - 1) * g.dil * g.sign;
+    const int delta = (((dh * g.W + dw) << g.logC) + ci0) * 2;          // bytes, wave-uniform (may be negative)
+    const char* base = reinterpret_cast<const char*>(X) + delta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool ok = (vmask[i] >> tap) & 1u;
+        const void* src = ok ? static_cast<const void*>(base + voff[i]) : static_cast<const void*>(g.zero);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(tile + (wave * 32 + i * 8) * kChunksPerRow), 16, 0, 0);
+    }
+}
+
 template <bool OUT_BF16>
 __global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
     const unsigned short* __restrict__ X, ConvGeom g, const unsigned short* __restrict__ B, int ldb, int M, int N,
@@ -747,6 +771,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
         rw[i] = p - rh[i] * g.W;
     }
 
+    // C >= 64: every K step of 64 stays inside one tap (and K, kbase are multiples of 64)
+    const bool uni = g.logC >= 6 && (K & (BK - 1)) == 0;
+    unsigned voff[4], vmask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        voff[i] = (((unsigned)(rm[i] < 0 ? 0 : rm[i]) << g.logC) + (unsigned)c * 8u) * 2u;
+        unsigned mk = 0;
+        if (rm[i] >= 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int y = rh[i] + (t / 3 - 1) * g.dil * g.sign, x = rw[i] + (t % 3 - 1) * g.dil * g.sign;
+                if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) mk |= 1u << t;
+            }
+        }
+        vmask[i] = mk;
+    }
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -754,7 +797,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     const int nk = (K + BK - 1) / BK;
-    dma_tile_conv(X, g, kbase, lds, wave, lane, rm, rh, rw);
+    if (uni) dma_tile_conv_uniform(X, g, kbase, lds, wave, voff, vmask);
+    else dma_tile_conv(X, g, kbase, lds, wave, lane, rm, rh, rw);
     dma_tile(B, ldb, N, n0, 0, lds + kTileChunks, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -764,7 +808,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
         uint4* sb = sa + kTileChunks;
         if (kt + 1 < nk) {
             uint4* na = lds + (size_t)(stage ^ 1) * 2 * kTileChunks;
-            dma_tile_conv(X, g, kbase + (kt + 1) * BK, na, wave, lane, rm, rh, rw);
+            if (uni) dma_tile_conv_uniform(X, g, kbase + (kt + 1) * BK, na, wave, voff, vmask);
+            else dma_tile_conv(X, g, kbase + (kt + 1) * BK, na, wave, lane, rm, rh, rw);
             dma_tile(B, ldb, N, n0, (kt + 1) * BK, na + kTileChunks, wave, lane);
         }
 #pragma unroll
