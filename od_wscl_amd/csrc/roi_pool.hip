@@ -218,16 +218,24 @@ __device__ __forceinline__ unsigned rp_key(float v, int cell) {
 // inner loop.  (Measured before: a straight per-cell scan, fp32 compare or key max, 2-byte or packed 8-byte stores:
 // 600-710 us for P = 2000 on 76x76x512 -- ~1 G cell visits at 15 % of the LDS read rate; the scan, not the
 // output traffic, bounds ROI pooling.  A thread per (ROI, bin column) walking its 7 bins with the column set-up
-// hoisted: 437 us against 370 -- the rows of a strip diverge more across a wave than single bins do.)
+// hoisted: 437 us against 370 -- the rows of a strip diverge more across a wave than single bins do.
+// Later experiments (ODW_RPS_ROWSTRIP): with the stores suppressed the kernel takes 187 us, table build alone 14 us --
+// the 98-byte output segments of one plane are half of the time; XCD-contiguous planes recover 10 % of it.)
 template <int PW_T>
 __global__ __launch_bounds__(kPlaneThreads) void roi_pool_stack_fwd_plane(
     const float* __restrict__ feat, const int* __restrict__ tab, int C, int H, int W, int R, int PH, int PW_rt,
     const float* __restrict__ keep, const float* __restrict__ keep_sum, unsigned short* __restrict__ X, int ld,
-    unsigned short* __restrict__ argmax) {
+    unsigned short* __restrict__ argmax, int rowstrip) {
     extern __shared__ __attribute__((aligned(16))) unsigned keys[];
     const int PW = PW_T > 0 ? PW_T : PW_rt;
-    const int b = blockIdx.x / C;
-    const int c = blockIdx.x % C;
+    // workgroup i runs on XCD i % 8: give each XCD a CONTIGUOUS range of planes, so that the two 98-byte segments
+    // neighbouring planes write into one 128-byte line of X meet in the same L2 and leave it as one full line
+    // (round-robin planes: every line is written back partially by two L2s; stores were half of this kernel's time)
+    int plane = blockIdx.x;
+    if ((gridDim.x & 7) == 0 && !(rowstrip & 4)) plane = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    rowstrip &= 3;
+    const int b = plane / C;
+    const int c = plane % C;
     const int HW = H * W;
     unsigned* T0 = keys;
     unsigned* T1 = keys + HW;
@@ -249,6 +257,73 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_pool_stack_fwd_plane(
     const int n_lo = (int)((long long)R * blockIdx.y / gridDim.y), n_hi = (int)((long long)R * (blockIdx.y + 1) / gridDim.y);
     const float numel = (float)((double)R * nb);
     const float sum = keep ? *keep_sum : 1.0f;
+    if (PW_T == 7 && rowstrip) {
+        // One thread = one bin ROW (ROI n, ph) = 7 bins that share the row range [hs, he): one pass over the rows with
+        // 14 LDS reads each, the loop and address set-up paid once per 7 bins; trip counts differ across a wave exactly
+        // as in the per-bin form (a column strip, 7 different row ranges in sequence, measured slower: 437 us).
+        const int items = rowstrip == 3 ? 0 : (n_hi - n_lo) * PH;
+        for (int it = threadIdx.x; it < items; it += blockDim.x) {
+            const int n = n_lo + it / PH, ph = it - (it / PH) * PH;
+            const int* t = tab + (size_t)n * ts;
+            if (t[0] != b) continue;
+            const int hs = t[1 + ph], he = t[1 + PH + ph];
+            const unsigned* tb[7];
+            int o0[7], o1[7];
+            bool wide = false;
+#pragma unroll
+            for (int pw = 0; pw < 7; ++pw) {
+                const int ws = t[1 + 2 * PH + pw], we = t[1 + 2 * PH + 7 + pw];
+                const int bw = we - ws;
+                const int lvl = bw >= 8 ? 3 : (bw >= 4 ? 2 : (bw >= 2 ? 1 : 0));
+                tb[pw] = bw > 0 ? keys + lvl * HW : nullptr;
+                o0[pw] = ws;
+                o1[pw] = we - (1 << lvl);
+                wide |= bw > 16;
+            }
+            unsigned best[7] = {0, 0, 0, 0, 0, 0, 0};
+            if (!wide) {
+                for (int h = hs; h < he; ++h) {
+                    const int r = h * W;
+#pragma unroll
+                    for (int pw = 0; pw < 7; ++pw)
+                        if (tb[pw]) {
+                            unsigned m = max(tb[pw][r + o0[pw]], tb[pw][r + o1[pw]]);
+                            // 8 < width <= 16: the two 8-wide windows at the ends cover the bin
+                            best[pw] = max(best[pw], m);
+                        }
+                }
+            } else {
+                for (int h = hs; h < he; ++h) {
+                    const unsigned* row = T3 + h * W;
+#pragma unroll
+                    for (int pw = 0; pw < 7; ++pw)
+                        if (tb[pw]) {
+                            unsigned m = max(tb[pw][h * W + o0[pw]], tb[pw][h * W + o1[pw]]);
+                            for (int w = o0[pw] + 8; w < o1[pw]; w += 8) m = max(m, row[w]);
+                            best[pw] = max(best[pw], m);
+                        }
+                }
+            }
+            const size_t col0 = (size_t)c * 49 + ph * 7;
+            unsigned short* xr = X + (size_t)n * ld + col0;
+            unsigned short* ar = argmax + (size_t)n * C * 49 + col0;
+            const float* kr = keep ? keep + (size_t)n * 49 + ph * 7 : nullptr;
+#pragma unroll
+            for (int pw = 0; pw < 7; ++pw) {
+                unsigned short vbits = 0, a = 0xFFFF;
+                if (best[pw]) {
+                    const unsigned ord = best[pw] >> 16;
+                    vbits = (unsigned short)((ord & 0x8000u) ? (ord & 0x7FFFu) : (~ord & 0xFFFFu));
+                    a = (unsigned short)(0xFFFFu - (best[pw] & 0xFFFFu));
+                }
+                if (rowstrip == 2 && best[pw] != 0xdeadbeefu) continue;
+                xr[pw] = vbits;
+                if (keep) xr[(size_t)R * ld + pw] = rp_f2bf(((rp_bf2f(vbits) * kr[pw]) * numel) / sum);
+                ar[pw] = a;
+            }
+        }
+        return;
+    }
     int n = n_lo + threadIdx.x / nb;
     int bin = threadIdx.x % nb;
     const int dn = blockDim.x / nb, dr = blockDim.x % nb;
@@ -486,12 +561,14 @@ ODW_EXPORT int odw_roi_pool_stack_forward(const float* feat, const float* rois, 
     const dim3 grid((unsigned)groups, (unsigned)chunks);
     if (PW == 7) {
         ODW_CHECK_HIP(allow_lds(roi_pool_stack_fwd_plane<7>, lds), "roi_pool_stack_fwd_plane<7> attr");
+        static const int rowstrip = getenv("ODW_RPS_ROWSTRIP") ? atoi(getenv("ODW_RPS_ROWSTRIP")) : 1;
         roi_pool_stack_fwd_plane<7><<<grid, kPlaneThreads, lds, stream>>>(feat, tab, C, H, W, R, PH, PW, keep, keep_sum,
-                                                                         (unsigned short*)X_bf16, ld, (unsigned short*)argmax_u16);
+                                                                         (unsigned short*)X_bf16, ld, (unsigned short*)argmax_u16,
+                                                                         PH == 7 ? rowstrip : 0);
     } else {
         ODW_CHECK_HIP(allow_lds(roi_pool_stack_fwd_plane<0>, lds), "roi_pool_stack_fwd_plane<0> attr");
         roi_pool_stack_fwd_plane<0><<<grid, kPlaneThreads, lds, stream>>>(feat, tab, C, H, W, R, PH, PW, keep, keep_sum,
-                                                                         (unsigned short*)X_bf16, ld, (unsigned short*)argmax_u16);
+                                                                         (unsigned short*)X_bf16, ld, (unsigned short*)argmax_u16, 0);
     }
     ODW_CHECK_LAUNCH("roi_pool_stack_fwd_plane");
     return ODW_OK;
