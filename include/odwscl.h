@@ -342,6 +342,18 @@ int odw_image_preprocess(const uint8_t* rgb, int in_h, int in_w, int out_h, int 
                          const float* lighting_rgb, const float* mean, const float* std, int to_bgr255, float* out,
                          int Hp, int Wp, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- ResNet-C5 bodies (modeling/backbone/resnet.py:258-406) on NHWC bf16 activations: what is neither a GEMM (the
+ * 1x1 convolutions run on odw_gemm_nt_bf16 with the frozen batch-norm folded into weight and bias) nor the 3x3
+ * implicit GEMM above.  odw_add_relu_bf16: out = relu(a + b), the residual junction (:368-373), n % 8 == 0;
+ * odw_relu_bwd_bf16: g = dout where out > 0.  odw_stem_conv7x7_bn_relu: the 7x7/2 stem on the fp32 NCHW image with
+ * weight (Co,3,7,7) fp32, y = relu(conv * scale[co] + shift[co]) -> NHWC bf16 (B, (H+1)/2.., Co) (:381-403);
+ * odw_maxpool3x3s2_nhwc_bf16: the 3x3/2 pad-1 max pool that follows it (:404). */
+int odw_add_relu_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+int odw_relu_bwd_bf16(const void* dout, const void* out, void* g, int64_t n, void* stream);
+int odw_stem_conv7x7_bn_relu(const float* img_nchw, const float* weight, const float* scale, const float* shift, int B,
+                             int H, int W, int Co, void* out_nhwc_bf16, void* stream);
+int odw_maxpool3x3s2_nhwc_bf16(const void* X, int B, int H, int W, int C, void* Y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

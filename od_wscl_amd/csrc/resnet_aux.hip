@@ -1,0 +1,182 @@
+// resnet_aux.hip -- the pieces of the ResNet-C5 bodies (wetectron/modeling/backbone/resnet.py:258-406) that are not a
+// GEMM or a 3x3 implicit GEMM, on NHWC bf16 activations:
+//   add_relu        out = relu(a + b)                the residual junction of a bottleneck (:368-373)
+//   relu_bwd        g = dout where out > 0           its gradient (the same tensor goes to both branches)
+//   stem_conv7x7    7x7 / stride 2 / pad 3 convolution of the fp32 NCHW image + frozen batch-norm + ReLU (:381-403):
+//                   3 input channels -- 147 MACs per output, direct form; weights + the affine in LDS
+//   maxpool3x3s2    3x3 / stride 2 / pad 1 max pool (:404)
+// The stem and layer1 are frozen in every shipped config (FREEZE_CONV_BODY_AT 2), so the last two are forward-only.
+#include "odw_common.h"
+
+namespace {
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// 8 bf16 per lane (16-byte accesses); BWD: a = dout, b = out
+template <bool BWD>
+__global__ __launch_bounds__(256) void add_relu_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                                                       uint4* __restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 va = a[i], vb = b[i];
+        const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+        unsigned wo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (BWD) {      // keep dout where out > 0 (out is a ReLU output: positive <=> non-zero magnitude, sign clear)
+                const unsigned lo = (wb[q] & 0x7fffu) && !(wb[q] & 0x8000u) ? (wa[q] & 0xffffu) : 0u;
+                const unsigned hi = (wb[q] & 0x7fff0000u) && !(wb[q] & 0x80000000u) ? (wa[q] & 0xffff0000u) : 0u;
+                wo[q] = lo | hi;
+            } else {
+                const float s0 = bf2f((unsigned short)(wa[q] & 0xffff)) + bf2f((unsigned short)(wb[q] & 0xffff));
+                const float s1 = bf2f((unsigned short)(wa[q] >> 16)) + bf2f((unsigned short)(wb[q] >> 16));
+                wo[q] = (unsigned)f2bf(s0 > 0.0f ? s0 : 0.0f) | ((unsigned)f2bf(s1 > 0.0f ? s1 : 0.0f) << 16);
+            }
+        }
+        out[i] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+    }
+}
+
+// One thread = one output pixel x 8 output channels.  w_lds[(ky*7+kx)*3 + ci][co] fp32 (147 x Co), scale/shift (Co).
+__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int B, int H, int W, int Ho, int Wo, int Co,
+                                                           unsigned short* __restrict__ out) {
+    extern __shared__ float w_lds[];                // 147*Co weights, then Co scale, Co shift
+    float* s_scale = w_lds + 147 * Co;
+    float* s_shift = s_scale + Co;
+    for (int i = threadIdx.x; i < 147 * Co; i += blockDim.x) {
+        const int k = i / Co, co = i - k * Co;      // k = (ky*7+kx)*3 + ci ; source layout (Co, 3, 7, 7)
+        const int ci = k % 3, kk = k / 3;
+        w_lds[i] = w[((size_t)co * 3 + ci) * 49 + kk];
+    }
+    for (int i = threadIdx.x; i < Co; i += blockDim.x) { s_scale[i] = scale[i]; s_shift[i] = shift[i]; }
+    __syncthreads();
+    const int groups = Co / 8;
+    const size_t total = (size_t)B * Ho * Wo * groups;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        size_t p = t / groups;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float* base = img + (size_t)b * 3 * H * W;
+        for (int ky = 0; ky < 7; ++ky) {
+            const int y = yo * 2 - 3 + ky;
+            if ((unsigned)y >= (unsigned)H) continue;
+            for (int kx = 0; kx < 7; ++kx) {
+                const int x = xo * 2 - 3 + kx;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const float* wk = w_lds + ((ky * 7 + kx) * 3) * Co + g * 8;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = base[((size_t)ci * H + y) * W + x];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = fmaf(v, wk[ci * Co + q], acc[q]);
+                }
+            }
+        }
+        unsigned wo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float r0 = acc[2 * q] * s_scale[g * 8 + 2 * q] + s_shift[g * 8 + 2 * q];
+            float r1 = acc[2 * q + 1] * s_scale[g * 8 + 2 * q + 1] + s_shift[g * 8 + 2 * q + 1];
+            r0 = r0 > 0.0f ? r0 : 0.0f;
+            r1 = r1 > 0.0f ? r1 : 0.0f;
+            wo[q] = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+        }
+        reinterpret_cast<uint4*>(out)[t] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+    }
+}
+
+// NHWC bf16 3x3 / stride 2 / pad 1 max pool, 8 channels per thread (padding never wins: -inf)
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint4* __restrict__ X, int B, int H, int W, int C8, int Ho,
+                                                           int Wo, uint4* __restrict__ Y) {
+    const size_t total = (size_t)B * Ho * Wo * C8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        size_t q = i / C8;
+        const int xo = (int)(q % Wo); q /= Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        float best[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) best[k] = -__builtin_inff();
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = yo * 2 - 1 + dy;
+            if ((unsigned)y >= (unsigned)H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int x = xo * 2 - 1 + dx;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const uint4 v = X[(((size_t)b * H + y) * W + x) * C8 + c];
+                const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    best[2 * k] = fmaxf(best[2 * k], bf2f((unsigned short)(wv[k] & 0xffff)));
+                    best[2 * k + 1] = fmaxf(best[2 * k + 1], bf2f((unsigned short)(wv[k] >> 16)));
+                }
+            }
+        }
+        Y[i] = make_uint4((unsigned)f2bf(best[0]) | ((unsigned)f2bf(best[1]) << 16),
+                          (unsigned)f2bf(best[2]) | ((unsigned)f2bf(best[3]) << 16),
+                          (unsigned)f2bf(best[4]) | ((unsigned)f2bf(best[5]) << 16),
+                          (unsigned)f2bf(best[6]) | ((unsigned)f2bf(best[7]) << 16));
+    }
+}
+
+int blocks_for(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+ODW_EXPORT int odw_add_relu_bf16(const void* a, const void* b, void* out, int64_t n, void* stream_) {
+    ODW_REQUIRE(n >= 0 && n % 8 == 0, "add_relu: n=%lld must be a multiple of 8", (long long)n);
+    if (n == 0) return ODW_OK;
+    ODW_REQUIRE(a && b && out && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) == 0, "add_relu: pointers");
+    add_relu_kernel<false><<<blocks_for((size_t)n / 8), 256, 0, (hipStream_t)stream_>>>((const uint4*)a, (const uint4*)b,
+                                                                                        (uint4*)out, (size_t)n / 8);
+    ODW_CHECK_LAUNCH("add_relu_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_relu_bwd_bf16(const void* dout, const void* out, void* g, int64_t n, void* stream_) {
+    ODW_REQUIRE(n >= 0 && n % 8 == 0, "relu_bwd: n=%lld must be a multiple of 8", (long long)n);
+    if (n == 0) return ODW_OK;
+    ODW_REQUIRE(dout && out && g && ((((uintptr_t)dout) | ((uintptr_t)out) | ((uintptr_t)g)) & 15) == 0, "relu_bwd: pointers");
+    add_relu_kernel<true><<<blocks_for((size_t)n / 8), 256, 0, (hipStream_t)stream_>>>((const uint4*)dout, (const uint4*)out,
+                                                                                       (uint4*)g, (size_t)n / 8);
+    ODW_CHECK_LAUNCH("add_relu_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_stem_conv7x7_bn_relu(const float* img_nchw, const float* weight, const float* scale, const float* shift,
+                                        int B, int H, int W, int Co, void* out_nhwc_bf16, void* stream_) {
+    ODW_REQUIRE(B > 0 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0 && Co <= 128, "stem_conv7x7: bad dims");
+    ODW_REQUIRE(img_nchw && weight && scale && shift && out_nhwc_bf16 && (((uintptr_t)out_nhwc_bf16) & 15) == 0,
+                "stem_conv7x7: pointers");
+    const int Ho = (H + 2 * 3 - 7) / 2 + 1, Wo = (W + 2 * 3 - 7) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (Co / 8);
+    const size_t lds = (size_t)(147 + 2) * Co * sizeof(float);
+    stem_conv7x7_kernel<<<blocks_for(total) > 2048 ? 2048 : blocks_for(total), 256, lds, (hipStream_t)stream_>>>(
+        img_nchw, weight, scale, shift, B, H, W, Ho, Wo, Co, (unsigned short*)out_nhwc_bf16);
+    ODW_CHECK_LAUNCH("stem_conv7x7_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_maxpool3x3s2_nhwc_bf16(const void* X, int B, int H, int W, int C, void* Y, void* stream_) {
+    ODW_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && X && Y, "maxpool3x3s2: bad arguments");
+    ODW_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 15) == 0, "maxpool3x3s2: 16-byte alignment");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t n = (size_t)B * Ho * Wo * (C / 8);
+    maxpool3x3s2_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream_>>>((const uint4*)X, B, H, W, C / 8, Ho, Wo, (uint4*)Y);
+    ODW_CHECK_LAUNCH("maxpool3x3s2_kernel");
+    return ODW_OK;
+}

@@ -301,6 +301,10 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             from .modeling.backbone.vgg16_hip import VGGBackboneHip
             model.backbone_hip = VGGBackboneHip(model.backbone.body)
             conv_desc = "od_wscl_amd HIP implicit-GEMM conv3x3 (NHWC bf16, MFMA)"
+        elif conv == "hip" and use_autocast and cfg.MODEL.BACKBONE.CONV_BODY.startswith("R-"):
+            from .modeling.backbone.resnet_hip import ResNetBackboneHip
+            model.backbone_hip = ResNetBackboneHip(model.backbone.body)
+            conv_desc = "od_wscl_amd HIP: 1x1 convs on the MFMA GEMM, implicit-GEMM conv3x3, folded frozen BN (NHWC bf16)"
         else:
             model.backbone_autocast = torch.bfloat16 if use_autocast else None
             conv_desc = "torch/MIOpen (%s)" % ("bf16 autocast" if use_autocast else "f32")

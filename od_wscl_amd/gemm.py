@@ -203,12 +203,12 @@ class _FusedLinear(torch.autograd.Function):
         else:
             dzt = torch.empty((N, m8), dtype=torch.bfloat16, device=dy.device)
             ld_t, t_cols = m8, m8
-        if bias is not None:
+        if bias is not None and bias.requires_grad:
             if bias.grad is None:
                 bias.grad = torch.zeros_like(bias)
             db = bias.grad
         else:
-            db = None
+            db = None           # no bias, or a constant one (the folded shift of a frozen batch-norm)
         scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
         if y is not None and y.dtype != torch.bfloat16:
             y = y.to(torch.bfloat16)
@@ -251,8 +251,8 @@ class _FusedLinear(torch.autograd.Function):
             kernel_timer.layer = tag and tag + "_wgrad"
             gemm_nt(dzt, xt, N, K, M, target, accumulate=not fresh)
             kernel_timer.layer = None
-        if bias is not None and not bias.is_leaf:
-            raise RuntimeError("fused_linear: bias must be a leaf parameter or None")
+        if bias is not None and bias.requires_grad and not bias.is_leaf:
+            raise RuntimeError("fused_linear: bias must be a leaf parameter, a constant or None")
         return dx, dw, None, None, None, None, None, None, None, None, None, None
 
 

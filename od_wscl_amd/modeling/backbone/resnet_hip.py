@@ -1,0 +1,221 @@
+"""ResNet-C5 bodies (R-50-C5 / R-101-C5, wetectron/modeling/backbone/resnet.py:84-148,258-406) on the gfx950 kernels.
+
+NHWC bf16 activations (n_pix x C matrices) end to end:
+  * every 1x1 convolution IS a Linear over the pixel rows -> the MFMA GEMM of the head (csrc/gemm_bf16.hip through
+    gemm.fused_linear: forward, input gradient, weight gradient) with bias + ReLU in the epilogue;
+  * the 3x3 convolutions run on the implicit-GEMM kernel of the VGG body (conv3x3_glds_kernel; dgrad = the mirrored
+    kernel, wgrad = transposed im2col + split-K GEMM);
+  * the frozen batch-norms (layers/batch_norm.py:6-31) are folded: y = conv(x, W * s[co]) + t[co] -- scale into the
+    bf16 weight copy, shift as the epilogue bias; the weight gradient flows back through the scale by autograd;
+  * residual junction relu(y3 + identity) and its gradient: csrc/resnet_aux.hip; the stride of the first 1x1 of
+    layer2.0 / layer3.0 (STRIDE_IN_1X1) is a row subsampling of the NHWC matrix shared by conv1 and the projection;
+  * stem (7x7/2 + BN + ReLU, 3x3/2 max pool): csrc/resnet_aux.hip, forward only -- the stem and layer1 are frozen in
+    every shipped config (FREEZE_CONV_BODY_AT 2) and nothing below layer2 receives a gradient.
+The parameters stay the nn.Conv2d weights / FrozenBatchNorm2d buffers of the reference-named modules."""
+import torch
+from torch import nn
+
+from ... import _lib as L
+from ... import gemm
+from ...utils.kernel_timer import kernel_timer
+from .vgg16_hip import _conv3x3, _r64
+
+
+def _fold(bn):
+    """scale, shift of a FrozenBatchNorm2d (batch_norm.py:23-31)."""
+    scale = bn.weight * bn.running_var.rsqrt()
+    return scale.float().contiguous(), (bn.bias - bn.running_mean * scale).float().contiguous()
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """y = relu(conv3x3(x, w) + shift) on (B*H*W, C) bf16 rows; w = the folded fp32 (Co, Ci, 3, 3) weight."""
+
+    @staticmethod
+    def forward(ctx, x, w, shift, geom, zero_page, need_dx):
+        lib, st = L.lib(), L.stream()
+        B, H, W = geom
+        co, ci = w.shape[0], w.shape[1]
+        m = B * H * W
+        wk = torch.empty((co, _r64(9 * ci)), dtype=torch.bfloat16, device=x.device)
+        wd = torch.empty((ci, _r64(9 * co)), dtype=torch.bfloat16, device=x.device) if need_dx else None
+        L.check(lib.odw_conv_weight_prep(L.ptr(w.detach().contiguous()), co, ci, ci, L.ptr(wk), wk.stride(0), L.ptr(wd),
+                                         wd.stride(0) if wd is not None else 0, st), "conv_weight_prep")
+        y = torch.empty((m, co), dtype=torch.bfloat16, device=x.device)
+        _conv3x3(lib, x, m, H, W, ci, 1, 0, wk, co, y, shift, True, None, 0, zero_page, st, 2.0 * m * co * 9 * ci)
+        ctx.save_for_backward(x, y, wd, zero_page)
+        ctx.dims = (B, H, W, co, ci)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, wd, zero_page = ctx.saved_tensors
+        B, H, W, co, ci = ctx.dims
+        lib, st = L.lib(), L.stream()
+        m = B * H * W
+        m64 = _r64(m)
+        dy = dy.contiguous()
+        dz = torch.empty((m, _r64(co)), dtype=torch.bfloat16, device=dy.device)
+        dzt = torch.empty((co, m64), dtype=torch.bfloat16, device=dy.device)
+        L.check(lib.odw_linear_bwd_prep(L.ptr(dy), 1 if dy.dtype == torch.float32 else 0, dy.stride(0), L.ptr(y), y.stride(0),
+                                        m, co, 1.0, L.ptr(dz), dz.stride(0), L.ptr(dzt), m64, None, st), "conv bwd prep")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            colt = torch.empty((9 * ci, m64), dtype=torch.bfloat16, device=dy.device)
+            L.check(lib.odw_im2col_t_bf16(L.ptr(x), m, H, W, ci, 1, L.ptr(colt), m64, st), "im2col_t")
+            dwk = torch.empty((co, 9 * ci), dtype=torch.float32, device=dy.device)
+            gemm.gemm_nt(dzt, colt, co, 9 * ci, m, dwk)
+            dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
+            L.check(lib.odw_conv_wgrad_unpack(L.ptr(dwk), 9 * ci, co, ci, ci, L.ptr(dw), st), "wgrad_unpack")
+        dx = None
+        if ctx.needs_input_grad[0] and wd is not None:
+            dx = torch.empty((m, ci), dtype=torch.bfloat16, device=dy.device)
+            dzc = dz if dz.shape[1] == co else dz[:, :co].contiguous()
+            _conv3x3(lib, dzc, m, H, W, co, 1, 1, wd, ci, dx, None, False, None, 0, zero_page, st, 2.0 * m * co * 9 * ci)
+        return dx, dw, None, None, None, None
+
+
+class _AddReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        L.check(L.lib().odw_add_relu_bf16(L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.stream()), "add_relu")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, = ctx.saved_tensors
+        dout = dout.contiguous()
+        g = torch.empty_like(out)
+        L.check(L.lib().odw_relu_bwd_bf16(L.ptr(dout), L.ptr(out), L.ptr(g), out.numel(), L.stream()), "relu_bwd")
+        return g, g
+
+
+class _ToNCHW(torch.autograd.Function):
+    """(B*H*W, C) bf16 rows -> (B, C, H, W) fp32, the layout the pooling operators take; backward the other way."""
+
+    @staticmethod
+    def forward(ctx, x, geom):
+        B, H, W = geom
+        C = x.shape[1]
+        feat = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        L.check(L.lib().odw_nhwc_bf16_to_nchw_f32(L.ptr(x.contiguous()), B, H * W, C, L.ptr(feat), L.stream()), "nhwc_to_nchw")
+        ctx.geom = geom
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        B, H, W = ctx.geom
+        C = dfeat.shape[1]
+        dx = torch.empty((B * H * W, C), dtype=torch.bfloat16, device=dfeat.device)
+        L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(dfeat.contiguous().float()), B, H * W, C, C, L.ptr(dx), L.stream()),
+                "nchw_to_nhwc")
+        return dx, None
+
+
+class _Folded(object):
+    """Per convolution: the folded batch-norm constants, and for frozen convolutions the bf16 operand copies."""
+    __slots__ = ("scale", "shift", "shadow", "key")
+
+
+class ResNetBackboneHip(nn.Module):
+    """Drop-in for the ResNet body's forward (model.backbone.body): same parameters and buffers, gfx950 kernels."""
+
+    def __init__(self, body):
+        super().__init__()
+        self.base = [body]              # not registered: parameters / buffers stay owned by the reference-named modules
+        self.cache = {}
+        self.zero_page = None
+
+    # ---- constants ------------------------------------------------------------------------------------------
+    def _const(self, conv, bn):
+        key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+               conv.weight._version if not conv.weight.requires_grad else -1)
+        f = self.cache.get(id(conv))
+        if f is None or f.key != key:
+            f = _Folded()
+            with torch.no_grad():
+                f.scale, f.shift = _fold(bn)
+            f.shadow, f.key = None, key
+            self.cache[id(conv)] = f
+        return f
+
+    def _w1x1(self, conv, f):
+        """(Co, Ci) folded weight of a 1x1 convolution and its bf16 operand copies (cached while frozen)."""
+        co, ci = conv.weight.shape[:2]
+        if not conv.weight.requires_grad:
+            if f.shadow is None:
+                with torch.no_grad():
+                    w = (conv.weight.reshape(co, ci) * f.scale[:, None]).contiguous()
+                f.shadow = (w, gemm.Shadow(w))
+            return f.shadow
+        w = conv.weight.reshape(co, ci) * f.scale[:, None]
+        return w, gemm.Shadow(w)
+
+    # ---- layers ---------------------------------------------------------------------------------------------
+    def _conv1x1(self, x, conv, bn, relu):
+        f = self._const(conv, bn)
+        w, sh = self._w1x1(conv, f)
+        return gemm.fused_linear(x, w, f.shift, sh, relu=relu)
+
+    def _conv3x3(self, x, conv, bn, geom, need_dx):
+        f = self._const(conv, bn)
+        assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+        w = conv.weight * f.scale[:, None, None, None]
+        return _Conv3x3Fn.apply(x, w, f.shift, geom, self.zero_page, need_dx)
+
+    @staticmethod
+    def _subsample(x, geom, stride):
+        if stride == 1:
+            return x, geom
+        B, H, W = geom
+        xs = x.reshape(B, H, W, x.shape[1])[:, ::stride, ::stride, :]
+        Hs, Ws = xs.shape[1], xs.shape[2]
+        return xs.reshape(B * Hs * Ws, x.shape[1]), (B, Hs, Ws)
+
+    def _block(self, x, geom, blk, need_dx):
+        stride = blk.conv1.stride[0]
+        xs, g2 = self._subsample(x, geom, stride)
+        a1 = self._conv1x1(xs, blk.conv1, blk.bn1, True)
+        a2 = self._conv3x3(a1, blk.conv2, blk.bn2, g2, True)
+        y3 = self._conv1x1(a2, blk.conv3, blk.bn3, False)
+        if blk.downsample is not None:
+            assert blk.downsample[0].stride[0] == stride
+            idn = self._conv1x1(xs, blk.downsample[0], blk.downsample[1], False)
+        else:
+            idn = x
+        return _AddReLU.apply(y3, idn), g2
+
+    def forward(self, images):
+        L.need_gpu(images)
+        body = self.base[0]
+        lib, st = L.lib(), L.stream()
+        dev = images.device
+        if self.zero_page is None:
+            self.zero_page = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+        images = images.float().contiguous()
+        B, _, H, W = images.shape
+        with torch.no_grad():
+            stem = body.stem
+            f = self._const(stem.conv1, stem.bn1)
+            co = stem.conv1.weight.shape[0]
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            s = torch.empty((B * Ho * Wo, co), dtype=torch.bfloat16, device=dev)
+            L.check(lib.odw_stem_conv7x7_bn_relu(L.ptr(images), L.ptr(stem.conv1.weight.detach().float().contiguous()),
+                                                 L.ptr(f.scale), L.ptr(f.shift), B, H, W, co, L.ptr(s), st), "stem")
+            Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+            x = torch.empty((B * Hp * Wp, co), dtype=torch.bfloat16, device=dev)
+            L.check(lib.odw_maxpool3x3s2_nhwc_bf16(L.ptr(s), B, Ho, Wo, co, L.ptr(x), st), "maxpool3x3s2")
+        geom = (B, Hp, Wp)
+        seen_trainable = False
+        for name in body.stages:
+            for blk in getattr(body, name):
+                trainable = any(p.requires_grad for p in blk.parameters())
+                if trainable and torch.is_grad_enabled():
+                    x, geom = self._block(x, geom, blk, need_dx=seen_trainable)
+                    seen_trainable = True
+                else:
+                    with torch.no_grad():
+                        x, geom = self._block(x, geom, blk, need_dx=False)
+        return [_ToNCHW.apply(x, geom)]

@@ -27,6 +27,9 @@ def build_eval_model(cfg, device, dtype="bf16"):
     if dtype == "bf16" and cfg.MODEL.BACKBONE.CONV_BODY.startswith("VGG16"):
         from od_wscl_amd.modeling.backbone.vgg16_hip import VGGBackboneHip
         model.backbone_hip = VGGBackboneHip(model.backbone.body)
+    elif dtype == "bf16" and cfg.MODEL.BACKBONE.CONV_BODY.startswith("R-"):
+        from od_wscl_amd.modeling.backbone.resnet_hip import ResNetBackboneHip
+        model.backbone_hip = ResNetBackboneHip(model.backbone.body)
     elif dtype == "bf16":
         model.backbone_autocast = torch.bfloat16
     return model
