@@ -402,6 +402,15 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
 // 128 registers, still two waves per SIMD inside the 512-entry file) and the block 256x256: LDS
 // reads per MFMA drop 25 %, L2 -> LDS bytes per FLOP drop 33 %, and one K-step is 2048 MFMA cycles per
 // SIMD -- long enough that a plain double buffer (2 x 64 KB) hides the DMA of the next tile completely.
+// Measured against hipBLASLt (tools/gemm_vs_lib.py, bf16 in/out, no epilogue): stacked fc6 forward 1.09 vs 1.22 PF,
+// fc6 dgrad 0.88 vs 1.05, fc6 wgrad 0.94 vs 1.25, 8192^3 1.26 vs 1.56 -- the library is 12-35 % ahead on the plain
+// product.  Tried for that gap and rejected: the same 256x256 tile as FOUR waves of 128x128 with the 16 accumulators
+// in AGPRs (one wave per SIMD, LDS reads per K step 192 -> 128 KB, two asm statements per K slice, reads ordered by
+// need with counted lgkmcnt waits): bit-correct on the first run, but 1.04-1.08 PF, and 1.30 PF with the operand DMA
+// removed where this 8-wave form reaches 1.55-1.6 (= the MFMA pipe at the ~1.6 GHz it holds under load).  With a
+// single wave per SIMD nothing covers the barrier / fragment waits of a K step; what the library adds instead is
+// operand prefetch through registers (its depth is not bounded by the 160 KB of LDS).  Next: register-staged
+// prefetch of the B tile on top of this form.
 constexpr int GM = 256, GN = 256;
 constexpr int kBigThreads = 512;
 constexpr int kBigStageChunks = (GM + GN) * kChunksPerRow;        // 4096 uint4 = 64 KB
