@@ -61,6 +61,12 @@ int odw_roi_pool_backward(const float* grad_out, const int32_t* argmax, const fl
 int odw_roi_pool_stack_forward(const float* feat, const float* rois, float spatial_scale, int B, int C, int H, int W,
                                int R, int PH, int PW, const float* keep, const float* keep_sum, void* X_bf16, int ld,
                                void* argmax_u16, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same forward (7x7 bins) reading the backbone's NHWC bf16 map (B, H, W, C), C % 64 == 0: one workgroup per
+ * (ROI, 64 channels) = 6272 contiguous output bytes per row, full 16-byte stores. */
+int64_t odw_roi_pool_stack_nhwc_workspace(int R, int B, int C, int H, int W);
+int odw_roi_pool_stack_forward_nhwc(const void* feat_nhwc_bf16, const float* rois, float spatial_scale, int B, int C,
+                                    int H, int W, int R, const float* keep, const float* keep_sum, void* X_bf16, int ld,
+                                    void* argmax_u16, void* workspace, int64_t workspace_bytes, void* stream);
 int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld, const void* argmax_u16, const float* rois,
                                 const float* keep, const float* keep_sum, const float* extra, const int* extra_roi,
                                 int E, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW, float* grad_in,

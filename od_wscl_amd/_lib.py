@@ -44,6 +44,8 @@ SIGNATURES = {
     "odw_unstack_clean_aug_bwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "odw_rows_drop_noise": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_i, c_i, c_p]),
     "odw_roi_pool_stack_forward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p]),
+    "odw_roi_pool_stack_nhwc_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
+    "odw_roi_pool_stack_forward_nhwc": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p]),
     "odw_roi_pool_stack_backward": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                           c_i, c_p, c_p]),
     "odw_rows_drop_noise_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_p]),

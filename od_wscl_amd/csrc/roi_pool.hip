@@ -574,6 +574,128 @@ ODW_EXPORT int odw_roi_pool_stack_forward(const float* feat, const float* rois, 
     return ODW_OK;
 }
 
+// ---- the same pooling from the backbone's NHWC bf16 map, one workgroup per (ROI, 64-channel chunk) -------------
+// The plane-per-workgroup form above owns 98 contiguous output bytes per ROI and array: half of its time goes into
+// those partial-line stores.  Here a workgroup owns 64 channels of ONE ROI = 6272 contiguous bytes of each output
+// row (column = c*49 + bin): a thread scans one bin for 8 channels with 16-byte loads straight from the NHWC map (L2
+// resident, no LDS copy of the plane, no table build), the 49 x 64 results are laid out in LDS in output order and
+// leave as full 16-byte vectors.  The key trick is the same: (order-preserving image of the bf16 bits) << 16 |
+// (0xFFFF - cell), max over the bin = maximum and first position at once.
+// pre-pass: the map in order-preserving form (u16 whose unsigned order is the bf16 order), 16 bytes per thread
+__global__ __launch_bounds__(256) void nhwc_ord_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = in[i];
+        unsigned d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] ^= 0x80008000u | (((d[q] >> 15) & 0x00010001u) * 0x7FFFu);
+        out[i] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+}
+
+__global__ __launch_bounds__(512) void roi_pool_stack_fwd_nhwc(const unsigned short* __restrict__ feat,
+                                                               const int* __restrict__ tab, int C, int H, int W, int R,
+                                                               const float* __restrict__ keep,
+                                                               const float* __restrict__ keep_sum,
+                                                               unsigned short* __restrict__ X, int ld,
+                                                               unsigned short* __restrict__ argmax) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_val[64 * 49], s_arg[64 * 49];
+    __shared__ float s_keep[49];
+    __shared__ int s_tab[29];
+    const int n = blockIdx.x, c0 = blockIdx.y * 64;
+    if (threadIdx.x < 29) s_tab[threadIdx.x] = tab[(size_t)n * 29 + threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 49) s_keep[threadIdx.x - 64] = keep ? keep[(size_t)n * 49 + threadIdx.x - 64] : 0.0f;
+    __syncthreads();
+    const int bin = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    if (bin < 49) {
+        const int ph = bin / 7, pw = bin - ph * 7;
+        const int b = s_tab[0], hs = s_tab[1 + ph], he = s_tab[8 + ph], ws = s_tab[15 + pw], we = s_tab[22 + pw];
+        unsigned best[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned short* base = feat + ((size_t)b * H * W) * C + c0 + cg * 8;
+        for (int h = hs; h < he; ++h) {
+            for (int w = ws; w < we; ++w) {       // (unrolling this loop by 4: 238 -> 265 us)
+                const int cell = h * W + w;
+                const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)cell * C);
+                const unsigned pos = 0xFFFFu - (unsigned)cell;
+                const unsigned d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {        // `feat` is the pre-pass's order-preserving image of the map
+                    best[2 * q] = max(best[2 * q], (d[q] << 16) | pos);
+                    best[2 * q + 1] = max(best[2 * q + 1], (d[q] & 0xFFFF0000u) | pos);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            unsigned short vbits = 0, a = 0xFFFF;
+            if (best[q]) {
+                const unsigned ord = best[q] >> 16;
+                vbits = (unsigned short)((ord & 0x8000u) ? (ord & 0x7FFFu) : (~ord & 0xFFFFu));
+                a = (unsigned short)(0xFFFFu - (best[q] & 0xFFFFu));
+            }
+            s_val[(cg * 8 + q) * 49 + bin] = vbits;
+            s_arg[(cg * 8 + q) * 49 + bin] = a;
+        }
+    }
+    __syncthreads();
+    // 64 channels x 49 bins = 3136 values = 392 vectors of 8, contiguous in the output row
+    if (threadIdx.x < 392) {
+        const int e0 = threadIdx.x * 8;
+        const size_t col = (size_t)c0 * 49 + e0;
+        const uint4 vv = *reinterpret_cast<const uint4*>(s_val + e0);
+        *reinterpret_cast<uint4*>(X + (size_t)n * ld + col) = vv;
+        *reinterpret_cast<uint4*>(argmax + (size_t)n * C * 49 + col) = *reinterpret_cast<const uint4*>(s_arg + e0);
+        if (keep) {
+            const float numel = (float)((double)R * 49), sum = *keep_sum;
+            const unsigned d[4] = {vv.x, vv.y, vv.z, vv.w};
+            unsigned o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ea = e0 + 2 * q, eb = ea + 1;
+                const float ka = s_keep[ea % 49], kb = s_keep[eb % 49];
+                const float ra = ((rp_bf2f(d[q] & 0xFFFFu) * ka) * numel) / sum;
+                const float rb = ((rp_bf2f(d[q] >> 16) * kb) * numel) / sum;
+                o[q] = (unsigned)rp_f2bf(ra) | ((unsigned)rp_f2bf(rb) << 16);
+            }
+            *reinterpret_cast<uint4*>(X + (size_t)(R + n) * ld + col) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+ODW_EXPORT int64_t odw_roi_pool_stack_nhwc_workspace(int R, int B, int C, int H, int W) {
+    return odw_align_up(odw_roi_pool_workspace(R, 7, 7), 256) + (int64_t)B * H * W * C * 2;
+}
+
+ODW_EXPORT int odw_roi_pool_stack_forward_nhwc(const void* feat_nhwc_bf16, const float* rois, float spatial_scale, int B,
+                                               int C, int H, int W, int R, const float* keep, const float* keep_sum,
+                                               void* X_bf16, int ld, void* argmax_u16, void* workspace,
+                                               int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(B >= 1 && C > 0 && C % 64 == 0 && H > 0 && W > 0 && R >= 0, "roi_pool_stack_forward_nhwc: bad dims (C %% 64)");
+    if (R == 0) return ODW_OK;
+    ODW_REQUIRE(feat_nhwc_bf16 && rois && X_bf16 && argmax_u16 && (!keep || keep_sum), "roi_pool_stack_forward_nhwc: null pointer");
+    ODW_REQUIRE((long)H * W < 65535, "roi_pool_stack_forward_nhwc: %dx%d feature map does not fit a 16-bit argmax", H, W);
+    ODW_REQUIRE(ld >= C * 49 && ld % 8 == 0 && (((uintptr_t)X_bf16) & 15) == 0 && (((uintptr_t)argmax_u16) & 15) == 0 &&
+                    (((uintptr_t)feat_nhwc_bf16) & 15) == 0, "roi_pool_stack_forward_nhwc: alignment / ld");
+    const int64_t need = odw_roi_pool_stack_nhwc_workspace(R, B, C, H, W);
+    if (workspace_bytes < need || !workspace) {
+        odw_set_error("roi_pool_stack_forward_nhwc: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        return ODW_EWORKSPACE;
+    }
+    ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "roi_pool_stack_forward_nhwc: workspace alignment");
+    int* tab = (int*)workspace;
+    unsigned short* ordmap = (unsigned short*)((char*)workspace + odw_align_up(odw_roi_pool_workspace(R, 7, 7), 256));
+    roi_bins_kernel<<<(R + 255) / 256, 256, 0, stream>>>(rois, spatial_scale, R, 7, 7, H, W, tab);
+    ODW_CHECK_LAUNCH("roi_bins_kernel");
+    const size_t n16 = (size_t)B * H * W * C / 8;
+    nhwc_ord_kernel<<<(unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096), 256, 0, stream>>>(
+        (const uint4*)feat_nhwc_bf16, (uint4*)ordmap, n16);
+    ODW_CHECK_LAUNCH("nhwc_ord_kernel");
+    roi_pool_stack_fwd_nhwc<<<dim3((unsigned)R, (unsigned)(C / 64)), 512, 0, stream>>>(
+        ordmap, tab, C, H, W, R, keep, keep_sum, (unsigned short*)X_bf16, ld, (unsigned short*)argmax_u16);
+    ODW_CHECK_LAUNCH("roi_pool_stack_fwd_nhwc");
+    return ODW_OK;
+}
+
 ODW_EXPORT int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
                                            const float* rois, const float* keep, const float* keep_sum,
                                            const float* extra, const int* extra_roi, int E, int skip_clean, int B, int C,

@@ -157,7 +157,7 @@ class _PoolStack(torch.autograd.Function):
     both halves plus the parked gradients of the sampled-row views into d(features) (csrc/roi_pool.hip)."""
 
     @staticmethod
-    def forward(ctx, feat, rois5, keep, keep_sum, holder, scale, ph, pw):
+    def forward(ctx, feat, rois5, keep, keep_sum, holder, scale, ph, pw, nhwc=None):
         feat = feat.contiguous()
         rois5 = rois5.contiguous().float()
         B, C, H, W = feat.shape
@@ -167,9 +167,17 @@ class _PoolStack(torch.autograd.Function):
         lib = L.lib()
         ws_bytes = lib.odw_roi_pool_workspace(R, ph, pw)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=feat.device)
-        L.check(lib.odw_roi_pool_stack_forward(L.ptr(feat), L.ptr(rois5), scale, B, C, H, W, R, ph, pw, L.ptr(keep),
-                                               L.ptr(keep_sum), L.ptr(x), x.stride(0), L.ptr(argmax), L.ptr(ws), ws_bytes,
-                                               L.stream()), "roi_pool_stack_forward")
+        if nhwc is not None and ph == 7 and pw == 7 and C % 64 == 0 and nhwc.numel() == feat.numel():
+            # the backbone's own NHWC bf16 map (`feat` is its fp32 NCHW copy): (ROI, 64-channel) workgroups
+            ws_bytes = lib.odw_roi_pool_stack_nhwc_workspace(R, B, C, H, W)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=feat.device)
+            L.check(lib.odw_roi_pool_stack_forward_nhwc(L.ptr(nhwc), L.ptr(rois5), scale, B, C, H, W, R, L.ptr(keep),
+                                                        L.ptr(keep_sum), L.ptr(x), x.stride(0), L.ptr(argmax), L.ptr(ws),
+                                                        ws_bytes, L.stream()), "roi_pool_stack_forward_nhwc")
+        else:
+            L.check(lib.odw_roi_pool_stack_forward(L.ptr(feat), L.ptr(rois5), scale, B, C, H, W, R, ph, pw, L.ptr(keep),
+                                                   L.ptr(keep_sum), L.ptr(x), x.stride(0), L.ptr(argmax), L.ptr(ws),
+                                                   ws_bytes, L.stream()), "roi_pool_stack_forward")
         ctx.save_for_backward(rois5, keep, keep_sum, argmax)
         ctx.dims = (B, C, H, W, R, ph, pw)
         ctx.holder = holder
@@ -199,7 +207,7 @@ class _PoolStack(torch.autograd.Function):
                                                     L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
                                                     L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph, pw,
                                                     L.ptr(dfeat), L.stream()), "roi_pool_stack_backward")
-        return dfeat, None, None, None, None, None, None, None
+        return dfeat, None, None, None, None, None, None, None, None
 
 
 class TwoFCROIFeatureExtractor(nn.Module):
@@ -340,8 +348,9 @@ class TwoFCROIFeatureExtractor(nn.Module):
         if self._grad_holder is not None and self._grad_holder.pending:
             raise RuntimeError("the gradient of the previous step's sampled-row views was never folded")
         self._grad_holder = _GradHolder("extra")
+        nhwc = getattr(feat, "_odw_nhwc", None) if os.environ.get("ODW_POOL_NHWC") != "0" else None
         x = _PoolStack.apply(feat, rois5, block.contiguous(), block.sum(), self._grad_holder,
-                             float(self.pooler.poolers[0].spatial_scale), res[0], res[1])
+                             float(self.pooler.poolers[0].spatial_scale), res[0], res[1], nhwc)
         # The clean half feeds only Sim_Net, and the contrastive loss touches a few hundred of its P rows: the stacked
         # evaluation takes part in backward with its DropBlock half only (grad_rows); the clean rows the loss ends
         # up using are re-evaluated by recompute_clean_rows with their original dropout draws (row_ids).

@@ -218,4 +218,6 @@ class ResNetBackboneHip(nn.Module):
                 else:
                     with torch.no_grad():
                         x, geom = self._block(x, geom, blk, need_dx=False)
-        return [_ToNCHW.apply(x, geom)]
+        feat = _ToNCHW.apply(x, geom)
+        feat._odw_nhwc = x.detach()     # the NHWC bf16 map itself: the fused ROI pooling reads it directly
+        return [feat]

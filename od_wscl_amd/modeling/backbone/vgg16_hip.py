@@ -84,6 +84,7 @@ class _VGGFn(torch.autograd.Function):
         feat = torch.empty((B, net.layers[-1].cout, h, w), dtype=torch.float32, device=dev)
         L.check(lib.odw_nhwc_bf16_to_nchw_f32(L.ptr(x), B, h * w, net.layers[-1].cout, L.ptr(feat), st), "nhwc_to_nchw")
         ctx.net, ctx.saved_acts, ctx.batch = net, saved, B
+        net.last_nhwc = x           # the NHWC bf16 map itself: the fused ROI pooling reads it directly
         return feat
 
     @staticmethod
@@ -144,6 +145,7 @@ class VGGBackboneHip(nn.Module):
         self.base = [vgg_base]            # not registered: the parameters stay owned by VGG_Base
         self.layers = _layers_of(vgg_base.features)
         self.zero_page = None
+        self.last_nhwc = None
         self._frozen_ready = False
 
     def _prep(self):
@@ -169,4 +171,6 @@ class VGGBackboneHip(nn.Module):
         with torch.no_grad():
             self._prep()
         params = [p for l in self.layers for p in (l.conv.weight, l.conv.bias)]
-        return [_VGGFn.apply(images.float(), self, *params)]
+        feat = _VGGFn.apply(images.float(), self, *params)
+        feat._odw_nhwc = self.last_nhwc
+        return [feat]

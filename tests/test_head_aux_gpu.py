@@ -212,3 +212,38 @@ def test_pool_stack_equals_pool_then_stack(monkeypatch):
         assert (ga - gb).abs().max().item() <= 1e-4 * gb.abs().max().item() + 1e-6, (ga - gb).abs().max().item()
     finally:
         ll.set_backend("torch")
+
+
+def test_pool_stack_nhwc_equals_plane_form():
+    """The (ROI, 64-channel) pooling forward on the NHWC bf16 map == the plane-per-workgroup form on its NCHW fp32
+    copy: stacked operand (both halves) and 16-bit argmax, bit for bit (incl. empty and clipped bins)."""
+    from od_wscl_amd import _lib as L, synthetic
+    lib = L.lib()
+    for (C, H, W, P, scale, size) in ((128, 38, 50, 300, 0.125, (304, 400)), (512, 19, 19, 200, 0.0625, (304, 304))):
+        g = torch.Generator(device="cuda").manual_seed(C)
+        nhwc = torch.randn(1, H, W, C, device="cuda", generator=g).bfloat16().contiguous()
+        feat = nhwc.float().permute(0, 3, 1, 2).contiguous()
+        bx = torch.from_numpy(synthetic.make_proposals(5, 0, P, size[0], size[1], min_size=8)).cuda()
+        bx[0] = torch.tensor([-40.0, -30.0, -20.0, -10.0])           # entirely outside: every bin empty
+        bx[1] = torch.tensor([0.0, 0.0, float(size[1]) + 90, float(size[0]) + 70])   # clipped at the far edges
+        rois = torch.cat([torch.zeros(P, 1, device="cuda"), bx], dim=1).contiguous()
+        keep = (torch.rand(P, 49, device="cuda", generator=g) > 0.25).float()
+        ks = keep.sum()
+        wsb = lib.odw_roi_pool_workspace(P, 7, 7)
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        outs = []
+        for form in ("plane", "nhwc"):
+            x = torch.full((2 * P, C * 49), 7.0, dtype=torch.bfloat16, device="cuda")
+            am = torch.full((P, C * 49), 5, dtype=torch.int16, device="cuda")
+            if form == "plane":
+                L.check(lib.odw_roi_pool_stack_forward(L.ptr(feat), L.ptr(rois), scale, 1, C, H, W, P, 7, 7, L.ptr(keep), L.ptr(ks),
+                                                       L.ptr(x), x.stride(0), L.ptr(am), L.ptr(ws), wsb, L.stream()), "plane")
+            else:
+                wsn = lib.odw_roi_pool_stack_nhwc_workspace(P, 1, C, H, W)
+                ws2 = torch.empty(wsn, dtype=torch.uint8, device="cuda")
+                L.check(lib.odw_roi_pool_stack_forward_nhwc(L.ptr(nhwc), L.ptr(rois), scale, 1, C, H, W, P, L.ptr(keep), L.ptr(ks),
+                                                            L.ptr(x), x.stride(0), L.ptr(am), L.ptr(ws2), wsn, L.stream()), "nhwc")
+            outs.append((x, am))
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+        assert (outs[1][1][0] == -1).all() and (outs[1][0][0] == 0).all()

@@ -39,3 +39,9 @@ def bwd_skip():
     L.check(lib.odw_roi_pool_stack_backward(L.ptr(dx), 0, dx.stride(0), L.ptr(am), L.ptr(rois), L.ptr(keep), L.ptr(ks), None, None, 0, 1,
                                             1, C, H, W, P, 7, 7, L.ptr(dfeat), L.stream()), "bwd")
 print("bwd skip_clean %.1f us" % timeit(bwd_skip))
+nhwc = feat.permute(0, 2, 3, 1).contiguous().bfloat16()
+wsn = lib.odw_roi_pool_stack_nhwc_workspace(P, 1, C, H, W); ws2 = torch.empty(wsn, dtype=torch.uint8, device="cuda")
+def fwd_nhwc():
+    L.check(lib.odw_roi_pool_stack_forward_nhwc(L.ptr(nhwc), L.ptr(rois), 0.125, 1, C, H, W, P, L.ptr(keep), L.ptr(ks), L.ptr(x),
+                                                x.stride(0), L.ptr(am), L.ptr(ws2), wsn, L.stream()), "fwd")
+print("fwd nhwc %.1f us" % timeit(fwd_nhwc))
