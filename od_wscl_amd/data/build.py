@@ -17,7 +17,7 @@ from .transforms import build_transforms
 
 
 class DatasetCatalog(object):
-    """The VOC entries of wetectron/config/paths_catalog.py:10-167 (COCO needs pycocotools, absent here)."""
+    """The VOC and COCO entries of wetectron/config/paths_catalog.py:10-167."""
     DATA_DIR = "datasets"
     DATASETS = {
         "voc_2007_train": {"data_dir": "voc/VOC2007", "split": "train"},
@@ -28,10 +28,21 @@ class DatasetCatalog(object):
         "voc_2012_val": {"data_dir": "voc/VOC2012", "split": "val"},
         "voc_2012_trainval": {"data_dir": "voc/VOC2012", "split": "trainval"},
         "voc_2012_test": {"data_dir": "voc/VOC2012", "split": "test"},
+        "coco_2017_train": {"img_dir": "coco/train2017", "ann_file": "coco/annotations/instances_train2017.json"},
+        "coco_2017_val": {"img_dir": "coco/val2017", "ann_file": "coco/annotations/instances_val2017.json"},
+        "coco_2014_train": {"img_dir": "coco/train2014", "ann_file": "coco/annotations/instances_train2014.json"},
+        "coco_2014_val": {"img_dir": "coco/val2014", "ann_file": "coco/annotations/instances_val2014.json"},
+        "coco_2014_minival": {"img_dir": "coco/val2014", "ann_file": "coco/annotations/instances_minival2014.json"},
+        "coco_2014_valminusminival": {"img_dir": "coco/val2014",
+                                      "ann_file": "coco/annotations/instances_valminusminival2014.json"},
     }
 
     @classmethod
     def get(cls, name):
+        if "coco" in name and name in cls.DATASETS:
+            attrs = cls.DATASETS[name]
+            return dict(factory="COCODataset", args=dict(root=os.path.join(cls.DATA_DIR, attrs["img_dir"]),
+                                                         ann_file=os.path.join(cls.DATA_DIR, attrs["ann_file"])))
         if "voc" in name and name in cls.DATASETS:
             attrs = cls.DATASETS[name]
             return dict(factory="PascalVOCDataset",
@@ -50,6 +61,8 @@ def build_dataset(dataset_list, transforms, dataset_catalog, is_train=True, prop
         data = dataset_catalog.get(dataset_name)
         factory = getattr(D, data["factory"])
         args = dict(data["args"])
+        if data["factory"] == "COCODataset":
+            args["remove_images_without_annotations"] = is_train and "unlabeled" not in dataset_name
         if data["factory"] == "PascalVOCDataset":
             args["use_difficult"] = not is_train
         args["transforms"] = transforms

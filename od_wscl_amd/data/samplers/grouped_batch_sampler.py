@@ -64,8 +64,10 @@ class GroupedBatchSampler(BatchSampler):
 
     def class_labels(self):
         if self._class_labels is None:
-            self._class_labels = [list(set(self.dataset.get_groundtruth(d).get_field("labels").tolist()))
-                                  for d in range(len(self.dataset))]
+            def labels_of(d):       # VOC: a BoxList with a `labels` field; COCO: the class tensor itself (coco.py:191-196)
+                gt = self.dataset.get_groundtruth(d)
+                return (gt.get_field("labels") if hasattr(gt, "get_field") else gt).tolist()
+            self._class_labels = [list(set(labels_of(d))) for d in range(len(self.dataset))]
         return self._class_labels
 
     def _prepare_batches(self):

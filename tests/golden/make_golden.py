@@ -564,6 +564,37 @@ def gen_voc_eval(name, spec, out):
     print("wrote", out)
 
 
+def gen_coco(name, spec, out):
+    """The imported reference's COCODataset (pycocotools / torchvision restated as index shims) on a miniature
+    instances file: kept image ids, targets, proposals, get_groundtruth, with and without the annotation filter."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    import voc_fixture
+    refimport.load_reference()
+    from wetectron.data.datasets.coco import COCODataset
+    data, pixels, proposals = voc_fixture.make_coco_case(spec["seed"], spec["n"])
+    rec = {"spec_seed": np.array(spec["seed"]), "spec_n": np.array(spec["n"])}
+    with tempfile.TemporaryDirectory() as root:
+        ann, img_dir, pkl = voc_fixture.write_coco(root, data, pixels, proposals)
+        for tag, remove in (("train", True), ("test", False)):
+            ds = COCODataset(ann, img_dir, remove, transforms=None, proposal_file=pkl)
+            rec[tag + "_ids"] = np.array(ds.ids)
+            for i in range(len(ds)):
+                img, target, rois, idx = ds[i]
+                rec["%s_boxes_%d" % (tag, i)] = target.bbox.numpy()
+                rec["%s_labels_%d" % (tag, i)] = target.get_field("labels").numpy()
+                rec["%s_rois_%d" % (tag, i)] = rois.bbox.numpy()
+                rec["%s_gt_%d" % (tag, i)] = ds.get_groundtruth(i).numpy()
+                info = ds.get_img_info(i)
+                rec["%s_info_%d" % (tag, i)] = np.array([info["height"], info["width"], info["id"]])
+            print("   %s: %d of %d images kept" % (tag, len(ds), spec["n"]))
+        rec["cat_map"] = np.array(sorted(ds.json_category_id_to_contiguous_id.items()))
+    np.savez_compressed(out, **rec)
+    print("wrote", out)
+
+
+COCO_CASES = {"data_coco": dict(seed=17, n=8)}
+
 EVAL_CASES = {"voc_eval": dict(seed=31, n=24)}
 
 SAMPLER_CASES = {"sampler_voc": dict(seed=5, n=14)}
@@ -589,6 +620,9 @@ if __name__ == "__main__":
     for name, spec in INFER_CASES.items():
         if name in which or not sys.argv[1:]:
             gen_infer(name, spec, os.path.join(HERE, name + ".npz"))
+    for name, spec in COCO_CASES.items():
+        if name in which or not sys.argv[1:]:
+            gen_coco(name, spec, os.path.join(HERE, name + ".npz"))
     for name, spec in EVAL_CASES.items():
         if name in which or not sys.argv[1:]:
             gen_voc_eval(name, spec, os.path.join(HERE, name + ".npz"))

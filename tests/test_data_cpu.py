@@ -237,3 +237,33 @@ def test_voc_metric_matches_the_reference(tmp_path):
         assert abs(r["map"] - float(g["map_" + tag])) < 1e-12
     out = do_voc_evaluation(ds, preds, str(tmp_path))
     assert abs(out["map"] - float(g["map_07"])) < 1e-12 and os.path.exists(os.path.join(str(tmp_path), "result.txt"))
+
+
+def test_coco_dataset_matches_the_reference(tmp_path):
+    """COCODataset on the instances json (no pycocotools): kept ids, targets, proposals, class lists, image infos ==
+    the imported reference's class on the same miniature file, with and without the annotation filter."""
+    from od_wscl_amd.data.datasets import COCODataset
+    g = np.load(os.path.join(HERE, "golden", "data_coco.npz"))
+    data, pixels, proposals = voc_fixture.make_coco_case(int(g["spec_seed"]), int(g["spec_n"]))
+    ann, img_dir, pkl = voc_fixture.write_coco(str(tmp_path), data, pixels, proposals)
+    for tag, remove in (("train", True), ("test", False)):
+        ds = COCODataset(ann, img_dir, remove, transforms=None, proposal_file=pkl)
+        assert ds.ids == g[tag + "_ids"].tolist()
+        for i in range(len(ds)):
+            img, target, rois, idx = ds[i]
+            assert idx == i
+            np.testing.assert_array_equal(target.bbox.numpy(), g["%s_boxes_%d" % (tag, i)])
+            np.testing.assert_array_equal(target.get_field("labels").numpy(), g["%s_labels_%d" % (tag, i)])
+            np.testing.assert_array_equal(rois.bbox.numpy(), g["%s_rois_%d" % (tag, i)])
+            np.testing.assert_array_equal(ds.get_groundtruth(i).numpy(), g["%s_gt_%d" % (tag, i)])
+            info = ds.get_img_info(i)
+            assert [info["height"], info["width"], info["id"]] == g["%s_info_%d" % (tag, i)].tolist()
+    assert sorted(ds.json_category_id_to_contiguous_id.items()) == [tuple(r) for r in g["cat_map"].tolist()]
+    # transforms + collation run on COCO samples like on VOC ones
+    from od_wscl_amd.data import BatchCollator, build_transforms
+    from od_wscl_amd.config import make_defaults
+    cfg = make_defaults()
+    cfg.merge_from_list(["INPUT.MIN_SIZE_TRAIN", (48,), "INPUT.MAX_SIZE_TRAIN", 80])
+    ds = COCODataset(ann, img_dir, True, transforms=build_transforms(cfg, True), proposal_file=pkl)
+    pending, targets, rois, idx = BatchCollator(32)([ds[0], ds[1]])
+    assert len(pending) == 2 and all(t.size == im.size for t, im in zip(targets, pending.images))

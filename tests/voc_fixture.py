@@ -95,3 +95,54 @@ def make_detections(seed, images, objects):
         out.append((np.asarray(boxes, np.float32).reshape(-1, 4), np.asarray(scores, np.float32),
                     np.asarray(labels, np.int64)))
     return out
+
+
+def make_coco_case(seed, n):
+    """A miniature COCO instances file: non-contiguous category ids, crowd objects, an image without annotations, one
+    whose only box is degenerate, boxes sticking out of the image; raw int16 proposals per image id."""
+    rng = np.random.RandomState(seed)
+    cat_ids = [1, 2, 4, 7, 9, 16, 18, 44, 62, 90]
+    cats = [{"id": c, "name": "cat%d" % c, "supercategory": "s"} for c in cat_ids]
+    images, pixels, anns, proposals = [], {}, [], {}
+    aid = 1
+    for k in range(n):
+        img_id = 100 + 7 * (n - k)              # descending in file order: the dataset sorts
+        h, w = (40, 56) if k % 2 else (52, 36)
+        images.append({"id": img_id, "file_name": "im%06d.jpg" % img_id, "height": h, "width": w})
+        pixels[img_id] = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        if k == 2:
+            pass                                                    # no annotation at all
+        elif k == 4:
+            anns.append({"id": aid, "image_id": img_id, "category_id": 4, "bbox": [5.0, 6.0, 1.0, 20.0], "iscrowd": 0, "area": 20.0})
+            aid += 1                                                # only a degenerate box
+        else:
+            for j in range(1 + rng.randint(3)):
+                x, y = rng.randint(-4, w - 10), rng.randint(-4, h - 10)
+                bw, bh = rng.randint(4, w), rng.randint(4, h)
+                anns.append({"id": aid, "image_id": img_id, "category_id": int(cat_ids[rng.randint(len(cat_ids))]),
+                             "bbox": [float(x), float(y), float(bw), float(bh)], "iscrowd": int(j == 2), "area": float(bw * bh)})
+                aid += 1
+        m = 30
+        x1, y1 = rng.randint(-3, w - 4, size=m), rng.randint(-3, h - 4, size=m)
+        b = np.stack([x1, y1, x1 + rng.randint(0, w, size=m), y1 + rng.randint(0, h, size=m)], axis=1)
+        b[3] = b[1]
+        proposals[img_id] = b.astype(np.int16)
+    return {"images": images, "annotations": anns, "categories": cats}, pixels, proposals
+
+
+def write_coco(root, data, pixels, proposals):
+    import json
+    import pickle
+    os.makedirs(os.path.join(root, "img"), exist_ok=True)
+    for im in data["images"]:
+        with open(os.path.join(root, "img", im["file_name"]), "wb") as f:
+            Image.fromarray(pixels[im["id"]], "RGB").save(f, format="PNG")
+    ann = os.path.join(root, "instances.json")
+    with open(ann, "w") as f:
+        json.dump(data, f)
+    pkl = os.path.join(root, "props.pkl")
+    ids = sorted(proposals.keys())
+    with open(pkl, "wb") as f:
+        pickle.dump(dict(boxes=[proposals[i] for i in ids], scores=[np.ones(len(proposals[i]), np.float32) for i in ids],
+                         indexes=ids), f, pickle.HIGHEST_PROTOCOL)
+    return ann, os.path.join(root, "img"), pkl
