@@ -359,6 +359,10 @@ int odw_relu_bwd_bf16(const void* dout, const void* out, void* g, int64_t n, voi
 int odw_stem_conv7x7_bn_relu(const float* img_nchw, const float* weight, const float* scale, const float* shift, int B,
                              int H, int W, int Co, void* out_nhwc_bf16, void* stream);
 int odw_maxpool3x3s2_nhwc_bf16(const void* X, int B, int H, int W, int C, void* Y, void* stream);
+/* First layer of the VGG body when it is frozen (modeling/backbone/vgg16.py:58-60, FREEZE_CONV_BODY_AT >= 1): 3x3 / pad 1
+ * convolution of the fp32 NCHW image, weight (Co,3,3,3) fp32, + bias + ReLU -> NHWC bf16 (B*H*W, Co), direct form. */
+int odw_stem_conv3x3_bias_relu(const float* img_nchw, const float* weight, const float* bias, int B, int H, int W, int Co,
+                               void* out_nhwc_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,64 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
     }
 }
 
+
+// 3x3 / stride 1 / pad 1 convolution of the fp32 NCHW image (3 channels) + bias + ReLU -> NHWC bf16: the first layer of
+// the VGG body (modeling/backbone/vgg16.py:58-60).  On the 128x128 MFMA tile that layer is K = 27 padded to 128 and
+// runs at 14 TF (90 us at 608x608, + 11 us for the layout pass of the image); it is 47 MB of output and 0.64 GFLOP.
+// This direct form measures 80 us: issue-bound (27 loads + 216 FMAs + 54 LDS reads per thread), not yet at the 12 us
+// the output traffic would allow -- two pixels per thread would halve the loads per FMA.
+// One thread = one pixel x 8 output channels; weights [tap*3 + ci][co] fp32 and the bias in LDS.
+__global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int B, int H, int W, int Co,
+                                                           unsigned short* __restrict__ out) {
+    extern __shared__ float w_lds[];                // 27*Co weights, then Co bias
+    float* s_bias = w_lds + 27 * Co;
+    for (int i = threadIdx.x; i < 27 * Co; i += blockDim.x) {
+        const int k = i / Co, co = i - k * Co;      // k = tap*3 + ci ; source layout (Co, 3, 3, 3)
+        const int ci = k % 3, tap = k / 3;
+        w_lds[i] = w[((size_t)co * 3 + ci) * 9 + tap];
+    }
+    for (int i = threadIdx.x; i < Co; i += blockDim.x) s_bias[i] = bias ? bias[i] : 0.0f;
+    __syncthreads();
+    const int groups = Co / 8;
+    const size_t total = (size_t)B * H * W * groups;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        size_t p = t / groups;
+        const int x0 = (int)(p % W); p /= W;
+        const int y0 = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = s_bias[g * 8 + q];
+        const float* base = img + (size_t)b * 3 * H * W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int y = y0 - 1 + ky;
+            if ((unsigned)y >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int x = x0 - 1 + kx;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const float* wk = w_lds + ((ky * 3 + kx) * 3) * Co + g * 8;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = base[((size_t)ci * H + y) * W + x];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = fmaf(v, wk[ci * Co + q], acc[q]);
+                }
+            }
+        }
+        unsigned wo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float r0 = acc[2 * q] > 0.0f ? acc[2 * q] : 0.0f, r1 = acc[2 * q + 1] > 0.0f ? acc[2 * q + 1] : 0.0f;
+            wo[q] = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+        }
+        reinterpret_cast<uint4*>(out)[t] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+    }
+}
+
 // NHWC bf16 3x3 / stride 2 / pad 1 max pool, 8 channels per thread (padding never wins: -inf)
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint4* __restrict__ X, int B, int H, int W, int C8, int Ho,
                                                            int Wo, uint4* __restrict__ Y) {
@@ -178,5 +236,18 @@ ODW_EXPORT int odw_maxpool3x3s2_nhwc_bf16(const void* X, int B, int H, int W, in
     const size_t n = (size_t)B * Ho * Wo * (C / 8);
     maxpool3x3s2_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream_>>>((const uint4*)X, B, H, W, C / 8, Ho, Wo, (uint4*)Y);
     ODW_CHECK_LAUNCH("maxpool3x3s2_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_stem_conv3x3_bias_relu(const float* img_nchw, const float* weight, const float* bias, int B, int H, int W,
+                                          int Co, void* out_nhwc_bf16, void* stream_) {
+    ODW_REQUIRE(B > 0 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0 && Co <= 256, "stem_conv3x3: bad dims");
+    ODW_REQUIRE(img_nchw && weight && out_nhwc_bf16 && (((uintptr_t)out_nhwc_bf16) & 15) == 0, "stem_conv3x3: pointers");
+    const size_t total = (size_t)B * H * W * (Co / 8);
+    const size_t lds = (size_t)28 * Co * sizeof(float);
+    const int grid = blocks_for(total) > 4096 ? 4096 : blocks_for(total);
+    stem_conv3x3_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(img_nchw, weight, bias, B, H, W, Co,
+                                                                 (unsigned short*)out_nhwc_bf16);
+    ODW_CHECK_LAUNCH("stem_conv3x3_kernel");
     return ODW_OK;
 }

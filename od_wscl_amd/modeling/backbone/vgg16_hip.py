@@ -7,6 +7,8 @@ The parameters stay the nn.Conv2d weights of `VGG_Base.features` (same names, sa
 checkpoints and the optimiser); packed bf16 copies are refreshed from them at the start of each
 forward.  Frozen layers (FREEZE_CONV_BODY_AT=2 -> conv1_x, conv2_x) run forward only, and no input
 gradient is computed below the first trainable convolution."""
+import os
+
 import torch
 from torch import nn
 
@@ -62,15 +64,25 @@ class _VGGFn(torch.autograd.Function):
         B, C, H, W = images.shape
         dev = images.device
         st = L.stream()
-        x = torch.empty((B * H * W, 8), dtype=torch.bfloat16, device=dev)
-        L.check(lib.odw_nchw_f32_to_nhwc_bf16(L.ptr(images.contiguous()), B, H * W, C, 8, L.ptr(x), st), "nchw_to_nhwc")
+        l0 = net.layers[0]
+        # a frozen 3-channel first layer runs as a direct kernel on the fp32 NCHW image (K = 27 wastes the MFMA tile)
+        direct0 = (not l0.trainable and l0.cin == 3 and l0.dil == 1 and l0.relu and l0.cout % 8 == 0
+                   and os.environ.get("ODW_NO_STEM") != "1")
+        x = None
+        if not direct0:
+            x = torch.empty((B * H * W, 8), dtype=torch.bfloat16, device=dev)
+            L.check(lib.odw_nchw_f32_to_nhwc_bf16(L.ptr(images.contiguous()), B, H * W, C, 8, L.ptr(x), st), "nchw_to_nhwc")
         saved = []          # per layer: (input activation, pre-pool activation or None, H, W)
         h, w = H, W
-        for l in net.layers:
+        for li, l in enumerate(net.layers):
             m = B * h * w
             y = torch.empty((m, l.cout), dtype=torch.bfloat16, device=dev)
-            _conv3x3(lib, x, m, h, w, l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
-                     2.0 * m * l.cout * 9 * l.cin)
+            if li == 0 and direct0:
+                L.check(lib.odw_stem_conv3x3_bias_relu(L.ptr(images.contiguous()), L.ptr(l.conv.weight.detach()),
+                                                       L.ptr(l.conv.bias.detach()), B, H, W, l.cout, L.ptr(y), st), "stem_conv3x3")
+            else:
+                _conv3x3(lib, x, m, h, w, l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
+                         2.0 * m * l.cout * 9 * l.cin)
             pre = None
             if l.pool:
                 pre = y

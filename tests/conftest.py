@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _parity_backend_by_default():
+    """Every test starts with the Linear layers on the parity back end ("torch", fp32): engine.build_training_step
+    switches the process-wide setting to the bf16 MFMA kernels and nothing switches it back."""
+    from od_wscl_amd.layers import linear as ll
+    ll.set_backend("torch")
+    yield
+    ll.set_backend("torch")
+
+
 @pytest.fixture(scope="session")
 def ops_golden():
     return np.load(os.path.join(GOLDEN, "ops_ref.npz"))
