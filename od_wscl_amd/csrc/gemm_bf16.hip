@@ -402,9 +402,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
 // 128 registers, still two waves per SIMD inside the 512-entry file) and the block 256x256: LDS
 // reads per MFMA drop 25 %, L2 -> LDS bytes per FLOP drop 33 %, and one K-step is 2048 MFMA cycles per
 // SIMD -- long enough that a plain double buffer (2 x 64 KB) hides the DMA of the next tile completely.
-// Measured against hipBLASLt (tools/gemm_vs_lib.py, bf16 in/out, no epilogue): stacked fc6 forward 1.09 vs 1.22 PF,
-// fc6 dgrad 0.88 vs 1.05, fc6 wgrad 0.94 vs 1.25, 8192^3 1.26 vs 1.56 -- the library is 12-35 % ahead on the plain
-// product.  Tried for that gap and rejected: the same 256x256 tile as FOUR waves of 128x128 with the 16 accumulators
+// Default since the end of round 1 (X == 7): the spare 32 KB of LDS hold a THIRD B slot, B is fetched two tiles
+// ahead and the closing wait becomes vmcnt(4) -- the critical lookahead grows from 0.75 to 1.0 K step:
+// fc6 forward 1.06 -> 1.12 PF, dgrad 0.88 -> 0.95, wgrad 0.92 -> 1.00, 8192^3 1.27 -> 1.33.
+// Measured against hipBLASLt (tools/gemm_vs_lib.py, bf16 in/out, no epilogue), two-slot form: stacked fc6 forward
+// 1.09 vs 1.22 PF, fc6 dgrad 0.88 vs 1.05, fc6 wgrad 0.94 vs 1.25, 8192^3 1.26 vs 1.56 -- the library is 12-35 % ahead
+// on the plain product.  Tried for that gap and rejected: the same 256x256 tile as FOUR waves of 128x128 with the 16 accumulators
 // in AGPRs (one wave per SIMD, LDS reads per K step 192 -> 128 KB, two asm statements per K slice, reads ordered by
 // need with counted lgkmcnt waits): bit-correct on the first run, but 1.04-1.08 PF, and 1.30 PF with the operand DMA
 // removed where this 8-wave form reaches 1.55-1.6 (= the MFMA pipe at the ~1.6 GHz it holds under load).  With a
@@ -466,7 +469,7 @@ __device__ __forceinline__ void big_slice(f32x16 (&acc)[4][2], const bf16x8 (&ca
 // The same slice with four LDS-DMA pieces of one operand tile (4 KB of this wave's share) issued one per MFMA in
 // its second half, instead of four back-to-back between slices: m0 = LDS destination of the piece, the source is
 // sbase + voff[lane] (SGPR base advancing 128 B per K-step, constant per-lane row/chunk offsets).
-template <bool SYNC>
+template <bool SYNC, int VM = 0>
 __device__ __forceinline__ void big_slice_dma(f32x16 (&acc)[4][2], const bf16x8 (&ca)[4], const bf16x8 (&cb)[2],
                                               bf16x8 (&na)[4], bf16x8 (&nb)[2], unsigned addr_a, unsigned addr_b,
                                               unsigned lds_dst, const unsigned (&voff)[4], unsigned long long sbase) {
@@ -500,7 +503,11 @@ __device__ __forceinline__ void big_slice_dma(f32x16 (&acc)[4][2], const bf16x8 
         : "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(addr_a), "v"(addr_b),      \
           "s"(lds_dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase)                      \
         : "memory", "scc"       /* m0 is rewritten too: hipcc reserves it and reloads it before each use of its own */
-    if (SYNC) {
+    if (SYNC && VM == 4) {      // three-slot B ring: the four newest pieces (B of tile k+2) may stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     "s_waitcnt vmcnt(4)\n\t"
+                     "s_barrier\n\t" ODW_BIG_BODY_DMA ODW_BIG_OPERANDS_DMA);
+    } else if (SYNC) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                      "s_waitcnt vmcnt(0)\n\t"
                      "s_barrier\n\t" ODW_BIG_BODY_DMA ODW_BIG_OPERANDS_DMA);
@@ -620,12 +627,21 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
     uint4* const slot1 = lds + kBigStageChunks;
 
     const int nk = (K + BK - 1) / BK;
+    // X == 7: LDS = [A0 | A1 | B0 | B1 | B2] (5 x 32 KB = the whole 160 KB): B is fetched TWO tiles ahead, so the wait
+    // that closes a K step only concerns pieces issued at least one full step earlier (A: 1.0 step, B: 1.75; the
+    // two-slot form waits for B pieces issued 0.75 step earlier)
+    constexpr unsigned kHalf = (unsigned)(GM * kChunksPerRow * 16);      // 32 KB
+    if (X == 7) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) off_b[kk] += kHalf;                // B region starts at 64 KB
+    }
     // prologue: tile 0 -> slot 0, landed and visible; A half of tile 1 in flight
     dma_rows<32>(A, lda, M, m0, 0, slot0, wave, lane);
-    dma_rows<32>(B, ldb, N, n0, 0, slot0 + GM * kChunksPerRow, wave, lane);
+    dma_rows<32>(B, ldb, N, n0, 0, X == 7 ? lds + 2 * GM * kChunksPerRow : slot0 + GM * kChunksPerRow, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (nk > 1) dma_rows<32>(A, lda, M, m0, BK, slot1, wave, lane);
+    if (nk > 1) dma_rows<32>(A, lda, M, m0, BK, X == 7 ? lds + GM * kChunksPerRow : slot1, wave, lane);
+    if (X == 7 && nk > 1) dma_rows<32>(B, ldb, N, n0, BK, lds + 3 * GM * kChunksPerRow, wave, lane);
     if (X == 1 && nk > 1) dma_rows<32>(B, ldb, N, n0, BK, slot1 + GM * kChunksPerRow, wave, lane);
     bf16x8 f0a[4], f0b[2], f1a[4], f1b[2];
     asm volatile("ds_read_b128 %0, %6\n\t"
@@ -637,7 +653,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
                  : "=&v"(f0a[0]), "=&v"(f0a[1]), "=&v"(f0a[2]), "=&v"(f0a[3]), "=&v"(f0b[0]), "=&v"(f0b[1])
                  : "v"(off_a[0]), "v"(off_b[0])
                  : "memory");
-    if (X == 0 || X == 6) {
+    if (X == 0 || X == 6 || X == 7) {
         // per-lane source offsets of this wave's four pieces of an A / B tile (rows clamped at the matrix edge)
         unsigned voa[4], vob[4];
 #pragma unroll
@@ -651,6 +667,22 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
             vob[i] = (unsigned)gb * (unsigned)ldb * 2u + (unsigned)c * 16u;
         }
         const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t*)lds + (unsigned)wave * 4096u;
+        if (X == 7) {
+            unsigned bs = 0;                                     // B slot of tile kt
+            for (int kt = 0; kt < nk; ++kt) {
+                const unsigned cur_a = (kt & 1) ? kHalf : 0u, nxt_a = kHalf - cur_a;
+                const unsigned b1 = bs == 2 ? 0u : bs + 1u, b2 = b1 == 2 ? 0u : b1 + 1u;
+                const unsigned cur_b = bs * kHalf, nxt_b = b1 * kHalf, dst_b = b2 * kHalf;
+                const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;
+                big_slice_dma<false>(acc, f0a, f0b, f1a, f1b, off_a[1] + cur_a, off_b[1] + cur_b, lds0 + 2 * kHalf + dst_b, vob,
+                                     (unsigned long long)(uintptr_t)B + (unsigned long long)k2 * (BK * 2));
+                big_slice<false>(acc, f1a, f1b, f0a, f0b, off_a[2] + cur_a, off_b[2] + cur_b);
+                big_slice<false>(acc, f0a, f0b, f1a, f1b, off_a[3] + cur_a, off_b[3] + cur_b);
+                big_slice_dma<true, 4>(acc, f1a, f1b, f0a, f0b, off_a[0] + nxt_a, off_b[0] + nxt_b, lds0 + cur_a, voa,
+                                       (unsigned long long)(uintptr_t)A + (unsigned long long)k2 * (BK * 2));
+                bs = b1;
+            }
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned cur = (kt & 1) ? kSlotBytes : 0u, nxt = kSlotBytes - cur;
             // (past the end the pieces re-fetch the last tile into a slot nobody reads: no branches in the loop)
@@ -1273,10 +1305,10 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
         const dim3 grid_r((unsigned)(((M + RM - 1) / RM) * ((N + RN - 1) / RN)), (unsigned)plan.splits);
         const dim3 grid_b((unsigned)(((M + GM - 1) / GM) * ((N + GN - 1) / GN)), (unsigned)plan.splits);
         if (plan.variant == 3) {
-            const size_t big_lds = (size_t)2 * kBigStageChunks * sizeof(uint4);
-            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 0>),
+            const size_t big_lds = (size_t)5 * GM * kChunksPerRow * sizeof(uint4);      // three-slot B ring
+            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr");
-            gemm_nt_bf16_big_kernel<false, 0><<<grid_b, kBigThreads, big_lds, stream>>>(
+            gemm_nt_bf16_big_kernel<false, 7><<<grid_b, kBigThreads, big_lds, stream>>>(
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, workspace, N, pe,
                 (M + GM - 1) / GM, (N + GN - 1) / GN);
         } else {
@@ -1305,6 +1337,23 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
     const int btiles_m = (M + GM - 1) / GM, btiles_n = (N + GN - 1) / GN;
     if (use_big) {
         const size_t big_lds = (size_t)2 * kBigStageChunks * sizeof(uint4);   // 128 KB
+        static const int ring3 = !getenv("ODW_GEMM_EXP") || atoi(getenv("ODW_GEMM_EXP")) == 7;
+        if (ring3) {                      // the default: three-slot B ring, 160 KB of LDS (ODW_GEMM_EXP=0: two slots)
+            const size_t lds7 = (size_t)5 * GM * kChunksPerRow * sizeof(uint4);
+            if (c_is_bf16) {
+                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<true, 7>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7), "big7 attr");
+                gemm_nt_bf16_big_kernel<true, 7><<<btiles_m * btiles_n, kBigThreads, lds7, stream>>>(
+                    (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n);
+            } else {
+                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7), "big7 attr");
+                gemm_nt_bf16_big_kernel<false, 7><<<btiles_m * btiles_n, kBigThreads, lds7, stream>>>(
+                    (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n);
+            }
+            ODW_CHECK_HIP(hipGetLastError(), "gemm_nt_bf16 big7 launch");
+            return 0;
+        }
         if (c_is_bf16) {
             ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr");

@@ -47,7 +47,7 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None     # split-K partials
     split = ws is not None
     sym = "gemm_nt_bf16_%skernel<%s>%s" % (_VARIANT_SYMBOL[var], ("false" if split or not out_bf16 else "true")
-                                           + (", 0" if var == 3 else ""), " split-K+reduce" if split else "")
+                                           + (", 7" if var == 3 else ""), " split-K+reduce" if split else "")
     with kernel_timer.region(sym, flops=2.0 * M * N * K):
         L.check(L.lib().odw_gemm_nt_bf16_ws(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out),
                                             out.stride(0), 1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0,
