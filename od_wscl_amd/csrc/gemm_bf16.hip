@@ -404,7 +404,8 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
 // SIMD -- long enough that a plain double buffer (2 x 64 KB) hides the DMA of the next tile completely.
 // Default since the end of round 1 (X == 7): the spare 32 KB of LDS hold a THIRD B slot, B is fetched two tiles
 // ahead and the closing wait becomes vmcnt(4) -- the critical lookahead grows from 0.75 to 1.0 K step:
-// fc6 forward 1.06 -> 1.12 PF, dgrad 0.88 -> 0.95, wgrad 0.92 -> 1.00, 8192^3 1.27 -> 1.33.
+// fc6 forward 1.06 -> 1.12 PF, dgrad 0.88 -> 0.95, wgrad 0.92 -> 1.00, 8192^3 1.27 -> 1.33.  (Moving the four A pieces of
+// the closing slice from its second half to right behind the barrier, +6 % of a step of lookahead for A: no change.)
 // Measured against hipBLASLt (tools/gemm_vs_lib.py, bf16 in/out, no epilogue), two-slot form: stacked fc6 forward
 // 1.09 vs 1.22 PF, fc6 dgrad 0.88 vs 1.05, fc6 wgrad 0.94 vs 1.25, 8192^3 1.26 vs 1.56 -- the library is 12-35 % ahead
 // on the plain product.  Tried for that gap and rejected: the same 256x256 tile as FOUR waves of 128x128 with the 16 accumulators
