@@ -99,8 +99,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
 // 3x3 / stride 1 / pad 1 convolution of the fp32 NCHW image (3 channels) + bias + ReLU -> NHWC bf16: the first layer of
 // the VGG body (modeling/backbone/vgg16.py:58-60).  On the 128x128 MFMA tile that layer is K = 27 padded to 128 and
 // runs at 14 TF (90 us at 608x608, + 11 us for the layout pass of the image); it is 47 MB of output and 0.64 GFLOP.
-// This direct form measures 80 us: issue-bound (27 loads + 216 FMAs + 54 LDS reads per thread), not yet at the 12 us
-// the output traffic would allow -- two pixels per thread would halve the loads per FMA.
+// (First version, one thread per pixel x 8 channels: 80 us, issue-bound on its 27 loads per 216 FMAs.)
 // One thread = one pixel x 8 output channels; weights [tap*3 + ci][co] fp32 and the bias in LDS.
 __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int B, int H, int W, int Co,
@@ -114,42 +113,43 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
     }
     for (int i = threadIdx.x; i < Co; i += blockDim.x) s_bias[i] = bias ? bias[i] : 0.0f;
     __syncthreads();
-    const int groups = Co / 8;
-    const size_t total = (size_t)B * H * W * groups;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int g = (int)(t % groups);
-        size_t p = t / groups;
-        const int x0 = (int)(p % W); p /= W;
-        const int y0 = (int)(p % H);
-        const int b = (int)(p / H);
-        float acc[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = s_bias[g * 8 + q];
+    // one thread = one pixel, ALL output channels: the 27 inputs are loaded once (zero in the padding) and every weight
+    // is an LDS broadcast -- 27 loads per 27*Co FMAs instead of per 27*8
+    const size_t total = (size_t)B * H * W;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int x0 = (int)(p % W);
+        const int y0 = (int)((p / W) % H);
+        const int b = (int)(p / ((size_t)W * H));
         const float* base = img + (size_t)b * 3 * H * W;
+        float v[27];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int y = y0 - 1 + ky;
-            if ((unsigned)y >= (unsigned)H) continue;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int x = x0 - 1 + kx;
-                if ((unsigned)x >= (unsigned)W) continue;
-                const float* wk = w_lds + ((ky * 3 + kx) * 3) * Co + g * 8;
+                const int y = y0 - 1 + ky, x = x0 - 1 + kx;
+                const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
 #pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const float v = base[((size_t)ci * H + y) * W + x];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] = fmaf(v, wk[ci * Co + q], acc[q]);
-                }
+                for (int ci = 0; ci < 3; ++ci) v[(ky * 3 + kx) * 3 + ci] = ok ? base[((size_t)ci * H + y) * W + x] : 0.0f;
             }
-        }
-        unsigned wo[4];
+        uint4* o = reinterpret_cast<uint4*>(out + p * Co);
+        for (int g = 0; g < Co / 8; ++g) {
+            float acc[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float r0 = acc[2 * q] > 0.0f ? acc[2 * q] : 0.0f, r1 = acc[2 * q + 1] > 0.0f ? acc[2 * q + 1] : 0.0f;
-            wo[q] = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+            for (int q = 0; q < 8; ++q) acc[q] = s_bias[g * 8 + q];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+                const float* wk = w_lds + k * Co + g * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(v[k], wk[q], acc[q]);
+            }
+            unsigned wo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float r0 = acc[2 * q] > 0.0f ? acc[2 * q] : 0.0f, r1 = acc[2 * q + 1] > 0.0f ? acc[2 * q + 1] : 0.0f;
+                wo[q] = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+            }
+            o[g] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
         }
-        reinterpret_cast<uint4*>(out)[t] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
     }
 }
 
@@ -243,7 +243,7 @@ ODW_EXPORT int odw_stem_conv3x3_bias_relu(const float* img_nchw, const float* we
                                           int Co, void* out_nhwc_bf16, void* stream_) {
     ODW_REQUIRE(B > 0 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0 && Co <= 256, "stem_conv3x3: bad dims");
     ODW_REQUIRE(img_nchw && weight && out_nhwc_bf16 && (((uintptr_t)out_nhwc_bf16) & 15) == 0, "stem_conv3x3: pointers");
-    const size_t total = (size_t)B * H * W * (Co / 8);
+    const size_t total = (size_t)B * H * W;
     const size_t lds = (size_t)28 * Co * sizeof(float);
     const int grid = blocks_for(total) > 4096 ? 4096 : blocks_for(total);
     stem_conv3x3_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(img_nchw, weight, bias, B, H, W, Co,
