@@ -1241,6 +1241,27 @@ __host__ Plan pick_plan(int M, int N, int K, int lda, int ldb, const void* C, in
     return best;
 }
 
+// Tail split of a 256x256-tiled product whose tile count leaves a thin last round: T = tiles_m * tiles_n workgroups on
+// 256 CUs run ceil(T / 256) rounds, and e.g. fc6's input gradient (2000 x 25088: 8 x 98 = 784 tiles) spends a whole
+// fourth round on 16 tiles.  When the remainder is a few whole tile COLUMNS, the product is run as two: the first
+// (tiles_n - q) tile columns = a multiple of 256 workgroups, and the last q columns as their own small product, which
+// the planner splits along K over the whole chip.  Returns the width of that tail (0 = no split).  Needs no dropout
+// (its counter index is tied to the full row width).
+int tail_columns(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16, float drop_p,
+                 bool have_workspace) {
+    static const bool off = getenv("ODW_GEMM_NO_TAIL") != nullptr;
+    if (off || drop_p > 0.0f || !have_workspace) return 0;
+    if (pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, true).splits > 1) return 0;
+    if (pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, false).variant != 3) return 0;
+    const long tm = (M + GM - 1) / GM, tn = (N + GN - 1) / GN, T = tm * tn;
+    if (T <= 256) return 0;
+    const long rem = T % 256;
+    if (rem == 0 || rem > 96 || rem % tm != 0) return 0;
+    const long q = rem / tm;
+    if (q >= tn) return 0;
+    return N - (int)(tn - q) * GN;
+}
+
 }  // namespace
 
 ODW_EXPORT int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc,
@@ -1250,6 +1271,12 @@ ODW_EXPORT int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, c
 
 ODW_EXPORT int64_t odw_gemm_nt_bf16_workspace(int M, int N, int K, int lda, int ldb, const void* C, int ldc,
                                               int c_is_bf16, int* variant_out) {
+    const int nt = tail_columns(M, N, K, lda, ldb, C, ldc, c_is_bf16, 0.0f, true);
+    if (nt > 0) {       // the partials of the tail product (the main part runs unsplit)
+        const Plan pt = pick_plan(M, nt, K, lda, ldb, C, ldc, c_is_bf16, true);
+        if (variant_out) *variant_out = 3;
+        return pt.splits > 1 ? (int64_t)pt.splits * M * nt * 4 : 0;
+    }
     const Plan p = pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, true);
     if (variant_out) *variant_out = p.variant;
     return p.splits > 1 ? (int64_t)p.splits * M * N * 4 : 0;
@@ -1282,6 +1309,16 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
                 "gemm_nt_bf16: K=%d rounded up to 8 must fit in lda=%d / ldb=%d (zero padded)", K, lda, ldb);
     ODW_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && nseg >= 0 && nseg <= kMaxSeg, "gemm_nt_bf16: bad dropout args");
     ODW_REQUIRE(!(accumulate && c_is_bf16), "gemm_nt_bf16: accumulate needs an fp32 C");
+    if (const int nt = tail_columns(M, N, K, lda, ldb, C, ldc, c_is_bf16, drop_p, workspace != nullptr)) {
+        const int n1 = N - nt;
+        const int rc = odw_gemm_nt_bf16_ws(A, lda, B, ldb, M, n1, K, C, ldc, c_is_bf16, bias, relu, alpha, 0.0f, 0, nullptr,
+                                           nullptr, nullptr, accumulate, nullptr, 0, stream_);
+        if (rc != ODW_OK) return rc;
+        return odw_gemm_nt_bf16_ws(A, lda, reinterpret_cast<const unsigned short*>(B) + (size_t)n1 * ldb, ldb, M, nt, K,
+                                   reinterpret_cast<char*>(C) + (size_t)n1 * (c_is_bf16 ? 2 : 4), ldc, c_is_bf16,
+                                   bias ? bias + n1 : nullptr, relu, alpha, 0.0f, 0, nullptr, nullptr, nullptr, accumulate,
+                                   workspace, workspace_bytes, stream_);
+    }
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = drop_p; ep.nseg = nseg; ep.accumulate = accumulate; ep.alpha = alpha;
     ep.mask = nullptr; ep.ldmask = 0; ep.kchunk = 0; ep.split_stride = 0; ep.row_ids = row_ids;
