@@ -1147,13 +1147,14 @@ __global__ __launch_bounds__(256) void sgd_kernel_x(float* __restrict__ p, const
 // dropout keys, bf16 / fp32, accumulate) -- 4 consecutive columns per thread, fixed summation order (deterministic).
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long stride_f,
-                                                            int M, int N, void* __restrict__ Cv, int ldc, Epilogue ep) {
-    const int n4 = N / 4;
+                                                            int M, int N, int ldw, void* __restrict__ Cv, int ldc,
+                                                            Epilogue ep) {
+    const int n4 = ldw / 4;             // ldw = row stride of the partials, N rounded up to 4 (N itself may be odd)
     const long long total = (long long)M * n4;
     const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
-        const float* p = ws + (size_t)m * N + n;
+        const float* p = ws + (size_t)m * ldw + n;
         float4 a = *reinterpret_cast<const float4*>(p);
         for (int sidx = 1; sidx < S; ++sidx) {
             const float4 b = *reinterpret_cast<const float4*>(p + (size_t)sidx * stride_f);
@@ -1169,6 +1170,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (n + q >= N) break;
             float x = v[q] * ep.alpha;
             if (ep.bias) x += ep.bias[n + q];
             if (ep.relu) x = fmaxf(x, 0.0f);
@@ -1183,11 +1185,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (OUT_BF16) {
             unsigned short* c = reinterpret_cast<unsigned short*>(Cv) + (size_t)m * ldc + n;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) c[q] = f2bf(v[q]);
+            for (int q = 0; q < 4; ++q) if (n + q < N) c[q] = f2bf(v[q]);
         } else {
             float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) c[q] = ep.accumulate ? c[q] + v[q] : v[q];
+            for (int q = 0; q < 4; ++q) if (n + q < N) c[q] = ep.accumulate ? c[q] + v[q] : v[q];
         }
     }
 }
@@ -1228,7 +1230,7 @@ __host__ Plan pick_plan(int M, int N, int K, int lda, int ldb, const void* C, in
         if (only >= 0 && v.id != only) continue;
         const long tiles = (long)((M + v.tm - 1) / v.tm) * ((N + v.tn - 1) / v.tn);
         for (int sp : kSplits) {
-            if (sp > 1 && (!allow_split || !v.splittable || N % 4 != 0)) break;
+            if (sp > 1 && (!allow_split || !v.splittable)) break;
             if (fsplit && sp != atoi(fsplit) && !(sp == 1 && atoi(fsplit) <= 1)) continue;
             const int kc = ((K + sp - 1) / sp + 63) / 64 * 64;
             if (sp > 1 && (kc < 256 || (long)kc * (sp - 1) >= K)) break;
@@ -1275,11 +1277,11 @@ ODW_EXPORT int64_t odw_gemm_nt_bf16_workspace(int M, int N, int K, int lda, int 
     if (nt > 0) {       // the partials of the tail product (the main part runs unsplit)
         const Plan pt = pick_plan(M, nt, K, lda, ldb, C, ldc, c_is_bf16, true);
         if (variant_out) *variant_out = 3;
-        return pt.splits > 1 ? (int64_t)pt.splits * M * nt * 4 : 0;
+        return pt.splits > 1 ? (int64_t)pt.splits * M * ((nt + 3) / 4 * 4) * 4 : 0;
     }
     const Plan p = pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, true);
     if (variant_out) *variant_out = p.variant;
-    return p.splits > 1 ? (int64_t)p.splits * M * N * 4 : 0;
+    return p.splits > 1 ? (int64_t)p.splits * M * ((N + 3) / 4 * 4) * 4 : 0;
 }
 
 ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
@@ -1332,14 +1334,15 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);   // 64 KB
     Plan plan = pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, workspace != nullptr);
-    if (plan.splits > 1 && workspace_bytes < (int64_t)plan.splits * M * N * 4)
+    const int ldw = (N + 3) / 4 * 4;        // row stride of the fp32 partials
+    if (plan.splits > 1 && workspace_bytes < (int64_t)plan.splits * M * ldw * 4)
         plan = pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, false);
     if (plan.splits > 1) {
         // partial products (plain, fp32) into the workspace, then one reduction pass with the fused epilogue
         ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "gemm_nt_bf16: workspace must be 16-byte aligned");
         Epilogue pe = ep;
         pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.accumulate = 0; pe.alpha = 1.0f; pe.row_ids = nullptr;
-        pe.kchunk = plan.kchunk; pe.split_stride = (long long)M * N * 4;
+        pe.kchunk = plan.kchunk; pe.split_stride = (long long)M * ldw * 4;
         const dim3 grid_r((unsigned)(((M + RM - 1) / RM) * ((N + RN - 1) / RN)), (unsigned)plan.splits);
         const dim3 grid_b((unsigned)(((M + GM - 1) / GM) * ((N + GN - 1) / GN)), (unsigned)plan.splits);
         if (plan.variant == 3) {
@@ -1347,25 +1350,25 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
             ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr");
             gemm_nt_bf16_big_kernel<false, 7><<<grid_b, kBigThreads, big_lds, stream>>>(
-                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, workspace, N, pe,
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, workspace, ldw, pe,
                 (M + GM - 1) / GM, (N + GN - 1) / GN);
         } else {
             const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
             ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "ring attr");
             gemm_nt_bf16_ring_kernel<false><<<grid_r, kRingThreads, ring_lds, stream>>>(
-                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, workspace, N, pe,
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, workspace, ldw, pe,
                 (M + RM - 1) / RM, (N + RN - 1) / RN);
         }
         ODW_CHECK_HIP(hipGetLastError(), "gemm_nt_bf16 split-K launch");
-        const long long quads = (long long)M * (N / 4);
+        const long long quads = (long long)M * (ldw / 4);
         const int rblocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
         if (c_is_bf16)
             splitk_reduce_kernel<true><<<rblocks, 256, 0, stream>>>((const float*)workspace, plan.splits,
-                                                                     (long long)M * N, M, N, C, ldc, ep);
+                                                                     (long long)M * ldw, M, N, ldw, C, ldc, ep);
         else
             splitk_reduce_kernel<false><<<rblocks, 256, 0, stream>>>((const float*)workspace, plan.splits,
-                                                                      (long long)M * N, M, N, C, ldc, ep);
+                                                                      (long long)M * ldw, M, N, ldw, C, ldc, ep);
         ODW_CHECK_LAUNCH("splitk_reduce_kernel");
         return ODW_OK;
     }
@@ -1631,10 +1634,10 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
         const int rblocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
         if (y_is_bf16)
             splitk_reduce_kernel<true><<<rblocks, 256, 0, stream>>>((const float*)workspace, sp, (long long)n_pix * N,
-                                                                     n_pix, N, Y, ldy, ep);
+                                                                     n_pix, N, N, Y, ldy, ep);
         else
             splitk_reduce_kernel<false><<<rblocks, 256, 0, stream>>>((const float*)workspace, sp, (long long)n_pix * N,
-                                                                      n_pix, N, Y, ldy, ep);
+                                                                      n_pix, N, N, Y, ldy, ep);
         ODW_CHECK_LAUNCH("splitk_reduce_kernel");
         return ODW_OK;
     }
