@@ -234,6 +234,11 @@ int odw_linear_bwd_prep_part(const void* dY, int dy_is_f32, int ld_dy, const voi
 int odw_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int odw_sgd_momentum(float* p, const float* g, float* buf, void* shadow_bf16, int64_t n, float lr, float wd,
                      float momentum, float grad_scale, int first_step, void* stream);
+/* The same update on at most `max_workgroups` workgroups (0 = as many as the buffer wants): an optimiser pass that runs
+ * BESIDE other kernels (the head's 600 MB on a side stream during the backbone's backward) is paced so that its 3.4 GB
+ * of HBM traffic spread over that time instead of starving whatever runs next to it. */
+int odw_sgd_momentum_paced(float* p, const float* g, float* buf, void* shadow_bf16, int64_t n, float lr, float wd,
+                           float momentum, float grad_scale, int first_step, int max_workgroups, void* stream);
 
 /* ---- OD-WSCL selection logic on the device ------------------------------------------
  * replaces the Python loops of roi_heads/weak_head/loss.py:281-345 (IoU sampling, object

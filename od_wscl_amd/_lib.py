@@ -62,6 +62,7 @@ SIGNATURES = {
     "odw_transpose_to_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "odw_f32_to_bf16": (c_i, [c_p, c_p, c_l, c_p]),
     "odw_sgd_momentum": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_p]),
+    "odw_sgd_momentum_paced": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_i, c_i, c_p]),
     "odw_discover_iou": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p]),
     "odw_discover_sim": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_i,
                                c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

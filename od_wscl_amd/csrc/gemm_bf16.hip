@@ -1533,8 +1533,18 @@ ODW_EXPORT int odw_linear_bwd_prep_part(const void* dY, int dy_is_f32, int ld_dy
     return ODW_OK;
 }
 
+ODW_EXPORT int odw_sgd_momentum_paced(float* p, const float* g, float* buf, void* shadow_bf16, int64_t n, float lr, float wd,
+                                      float momentum, float grad_scale, int first_step, int max_workgroups,
+                                      void* stream_);
+
 ODW_EXPORT int odw_sgd_momentum(float* p, const float* g, float* buf, void* shadow_bf16, int64_t n, float lr, float wd,
                                 float momentum, float grad_scale, int first_step, void* stream_) {
+    return odw_sgd_momentum_paced(p, g, buf, shadow_bf16, n, lr, wd, momentum, grad_scale, first_step, 0, stream_);
+}
+
+ODW_EXPORT int odw_sgd_momentum_paced(float* p, const float* g, float* buf, void* shadow_bf16, int64_t n, float lr, float wd,
+                                      float momentum, float grad_scale, int first_step, int max_workgroups,
+                                      void* stream_) {
     ODW_REQUIRE(n >= 0, "sgd_momentum: bad n");
     if (n == 0) return ODW_OK;
     ODW_REQUIRE(p && g && buf, "sgd_momentum: null pointer");
@@ -1542,7 +1552,8 @@ ODW_EXPORT int odw_sgd_momentum(float* p, const float* g, float* buf, void* shad
                     (((uintptr_t)shadow_bf16) & 7) == 0, "sgd_momentum: buffers must be 16-byte aligned");
     size_t blocks = ((size_t)n / 4 + 255) / 256;
     static const int mode = getenv("ODW_SGD_MODE") ? atoi(getenv("ODW_SGD_MODE")) : 3;
-    static const int cap = getenv("ODW_SGD_GRID") ? atoi(getenv("ODW_SGD_GRID")) : 65536;
+    static const int env_cap = getenv("ODW_SGD_GRID") ? atoi(getenv("ODW_SGD_GRID")) : 65536;
+    const int cap = max_workgroups > 0 ? max_workgroups : env_cap;
     const int grid = (int)(blocks < 1 ? 1 : (blocks > (size_t)cap ? (size_t)cap : blocks));
     if (mode && n % 4 == 0) {
         hipStream_t st = (hipStream_t)stream_;

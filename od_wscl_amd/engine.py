@@ -226,14 +226,20 @@ class FlatSGD(object):
         self.flat_g[self.n_gemm:].zero_()
         self.early_done = False
 
-    def _sgd_region(self, i):
+    def _sgd_region(self, i, paced=0):
+        """paced = workgroup cap of an update that runs BESIDE other kernels (head_grads_ready): at full width the
+        HBM-bound pass starves whatever shares the GPU with it (the first backbone weight-gradient GEMM took 400 us
+        instead of 43) and the overlap bought nothing; on 192-256 workgroups it stretches over the backbone's backward
+        and mostly disappears behind it (8.10 -> 7.96 ms/step, three alternating runs each on one box; 128 and fewer
+        outlast the backward)."""
         start, n, lr, wd = self.regions[i]
         if n == 0:
             return
         shadow = self.flat_w16 if (i == 0 and self.flat_w16 is not None) else None
-        L.check(L.lib().odw_sgd_momentum(L.ptr(self.flat_p[start:]), L.ptr(self.flat_g[start:]),
-                                         L.ptr(self.flat_m[start:]), L.ptr(shadow), n, lr * self.lr_scale, wd, self.momentum,
-                                         1.0 / self.world, 1 if self.first else 0, L.stream()), "sgd_momentum")
+        L.check(L.lib().odw_sgd_momentum_paced(L.ptr(self.flat_p[start:]), L.ptr(self.flat_g[start:]),
+                                               L.ptr(self.flat_m[start:]), L.ptr(shadow), n, lr * self.lr_scale, wd,
+                                               self.momentum, 1.0 / self.world, 1 if self.first else 0, int(paced),
+                                               L.stream()), "sgd_momentum")
 
     def head_grads_ready(self):
         """Called from backward (tensor hook on the pooled features) once every gradient of region 0 is final:
@@ -246,7 +252,8 @@ class FlatSGD(object):
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
             all_reduce_flat(self.flat_g[:self.n_gemm], self.world)
-            self._sgd_region(0)
+            # (paced only without an exchange in front of it: at N > 1 the all-reduce already takes the window)
+            self._sgd_region(0, paced=int(os.environ.get("ODW_SGD_PACE", "256")) if self.world == 1 else 0)
             self._refresh_shadows()
         self.early_done = True
 
