@@ -136,8 +136,12 @@ def tta(pixels_list, raw_boxes_list, sd, cfg, aug):
             C = sc.shape[1]
     out = []
     for i in range(n_img):
-        bbox = torch.mean(torch.stack(merged_b[i]), dim=0)
-        scores = torch.mean(torch.stack(merged_s[i]), dim=0)
+        if aug.get("heur", "AVG") == "UNION":       # bbox_aug.py:57-59: every pass's (P*C) boxes side by side
+            bbox = torch.cat(merged_b[i])
+            scores = torch.cat(merged_s[i])
+        else:
+            bbox = torch.mean(torch.stack(merged_b[i]), dim=0)
+            scores = torch.mean(torch.stack(merged_s[i]), dim=0)
         out.append(filter_results(bbox.reshape(-1, C * 4), scores.reshape(-1, C), first[i], cfg.get("score_thresh", 0.0),
                                   cfg.get("nms_test", 0.4), cfg.get("max_det", 100)))
     return out

@@ -427,7 +427,7 @@ def gen_tta(name, spec, out):
     from wetectron.engine.bbox_aug import im_detect_bbox_aug
     aug = spec["aug"]
     cfg = refimport.reference_cfg(opts=CFG_OPTS + [
-        "MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "TEST.BBOX_AUG.ENABLED", True, "TEST.BBOX_AUG.HEUR", "AVG",
+        "MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "TEST.BBOX_AUG.ENABLED", True, "TEST.BBOX_AUG.HEUR", spec.get("heur", "AVG"),
         "TEST.BBOX_AUG.H_FLIP", aug["h_flip"], "TEST.BBOX_AUG.SCALES", tuple(aug["scales"]),
         "TEST.BBOX_AUG.MAX_SIZE", aug["max_size"], "TEST.BBOX_AUG.SCALE_H_FLIP", aug["scale_h_flip"],
         "INPUT.MIN_SIZE_TEST", aug["min_test"], "INPUT.MAX_SIZE_TEST", aug["max_test"],
@@ -455,7 +455,9 @@ def gen_tta(name, spec, out):
         rec["aug_" + k] = np.array(v)
     sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
     ocfg = dict(score_thresh=float(rec["score_thresh"]), nms_test=float(rec["nms"]), max_det=int(rec["max_det"]))
-    oaug = dict(aug, mean=rec["pixel_mean"], std=rec["pixel_std"], to_bgr255=bool(rec["to_bgr255"]), size_divisible=32)
+    rec["heur"] = np.array(spec.get("heur", "AVG"))
+    oaug = dict(aug, mean=rec["pixel_mean"], std=rec["pixel_std"], to_bgr255=bool(rec["to_bgr255"]), size_divisible=32,
+                heur=spec.get("heur", "AVG"))
     with torch.no_grad():
         ora = I.tta(pixels, boxes_np, sdt, ocfg, oaug)
     for i, r in enumerate(result):
@@ -601,7 +603,10 @@ SAMPLER_CASES = {"sampler_voc": dict(seed=5, n=14)}
 
 TTA_CASES = {"tta_voc_2img": dict(seed=23, images=[(96, 128, 48), (112, 80, 40)],
                                   aug=dict(min_test=96, max_test=160, h_flip=True, scales=(64, 128), max_size=176,
-                                           scale_h_flip=True))}
+                                           scale_h_flip=True)),
+             "tta_union_2img": dict(seed=29, images=[(96, 128, 40), (112, 80, 36)], heur="UNION",
+                                    aug=dict(min_test=96, max_test=160, h_flip=True, scales=(128,), max_size=176,
+                                             scale_h_flip=False))}
 
 DATA_CASES = {"data_voc": dict(seed=11, shapes=[(60, 80), (75, 50), (64, 64), (48, 96)],
                                ids=["000005", "000007", "000009", "000012"], min_train=(48, 64, 80), max_train=100,

@@ -101,15 +101,17 @@ def test_decode_then_filter_equals_the_fused_tail():
         o += n
 
 
-def test_test_time_augmentation_matches_reference_detections():
+@pytest.mark.parametrize("case", ["tta_voc_2img", "tta_union_2img"])
+def test_test_time_augmentation_matches_reference_detections(case):
     """im_detect_bbox_aug: 6 passes (identity, flip, two scales + flips) of a 2-image batch from uint8 pixels --
-    GPU preprocessing, eval forward, decode, un-flip / resize, AVG merge, filter -- against the imported reference."""
+    GPU preprocessing, eval forward, decode, un-flip / resize, AVG merge (or 3 passes and the UNION merge), filter --
+    against the imported reference."""
     from test_e2e_gpu import build_model
     from oracle import data_ref as D
     from od_wscl_amd import bbox_aug
     from od_wscl_amd.config import make_defaults
     from od_wscl_amd.structures import BoxList
-    g = load_e2e("tta_voc_2img")
+    g = load_e2e(case)
     specs, pixels, boxes, aug = tta_inputs(g)
     model = build_model("ROIPool", weights_for("vgg16"), "fused")
     pp = model.roi_heads.strong_post_processor
@@ -117,7 +119,7 @@ def test_test_time_augmentation_matches_reference_detections():
     model.eval()
     cfg = make_defaults()
     cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.NUM_CLASSES", 21, "MODEL.ROI_HEADS.SCORE_THRESH", float(g["score_thresh"]),
-                         "MODEL.ROI_HEADS.NMS", float(g["nms"]), "TEST.BBOX_AUG.ENABLED", True, "TEST.BBOX_AUG.HEUR", "AVG",
+                         "MODEL.ROI_HEADS.NMS", float(g["nms"]), "TEST.BBOX_AUG.ENABLED", True, "TEST.BBOX_AUG.HEUR", aug["heur"],
                          "TEST.BBOX_AUG.H_FLIP", aug["h_flip"], "TEST.BBOX_AUG.SCALES", aug["scales"],
                          "TEST.BBOX_AUG.MAX_SIZE", aug["max_size"], "TEST.BBOX_AUG.SCALE_H_FLIP", aug["scale_h_flip"],
                          "INPUT.MIN_SIZE_TEST", aug["min_test"], "INPUT.MAX_SIZE_TEST", aug["max_test"],

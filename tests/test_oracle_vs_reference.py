@@ -210,14 +210,16 @@ def tta_inputs(g):
     aug = dict(min_test=int(g["aug_min_test"]), max_test=int(g["aug_max_test"]), h_flip=bool(g["aug_h_flip"]),
                scales=tuple(int(v) for v in g["aug_scales"].tolist()), max_size=int(g["aug_max_size"]),
                scale_h_flip=bool(g["aug_scale_h_flip"]), mean=g["pixel_mean"], std=g["pixel_std"],
-               to_bgr255=bool(g["to_bgr255"]), size_divisible=32)
+               to_bgr255=bool(g["to_bgr255"]), size_divisible=32, heur=str(g["heur"]) if "heur" in g.files else "AVG")
     return specs, pixels, boxes, aug
 
 
-def test_test_time_augmentation_matches_imported_reference(weights_np):
-    """im_detect_bbox_aug (engine/bbox_aug.py) restated: 6 passes over a 2-image batch, AVG merge, filter."""
+@pytest.mark.parametrize("case", ["tta_voc_2img", "tta_union_2img"])
+def test_test_time_augmentation_matches_imported_reference(weights_np, case):
+    """im_detect_bbox_aug (engine/bbox_aug.py) restated: 6 passes over a 2-image batch with the AVG merge, 3 passes
+    with the UNION merge; filter."""
     from oracle import inference_ref as I
-    g = load_e2e("tta_voc_2img")
+    g = load_e2e(case)
     specs, pixels, boxes, aug = tta_inputs(g)
     sd = {k: torch.from_numpy(v) for k, v in weights_np.items()}
     with torch.no_grad():
