@@ -249,7 +249,8 @@ def e2e_inputs_infer(g):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/wetectron"), reason="reference tree not present")
 @pytest.mark.parametrize("yaml_rel,arch", [("configs/voc/voc07_contra_db_b8_lr0.01_mcg.yaml", "vgg16"),
-                                           ("configs/voc/voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml", "r50")])
+                                           ("configs/voc/voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml", "r50"),
+                                           ("configs/voc/voc07_r101_c5_contra_db_b8_lr0.02_ss.yaml", "r101")])
 def test_state_dict_layout_equals_the_reference_model(yaml_rel, arch):
     """Checkpoint compatibility: the imported reference model and ours, built from the same
     yaml, expose the same state-dict keys with the same shapes, so `.pth` files travel both ways."""
