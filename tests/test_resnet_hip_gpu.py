@@ -94,3 +94,31 @@ def test_resnet50_body_matches_torch_fp32():
     with torch.no_grad():
         again = hip(images)[0]
     assert torch.equal(again, got.detach())
+
+
+def test_resnet101_body_forward_matches_torch_fp32():
+    """The same node on the R-101-C5 body (23 blocks in layer3): built from the config, kaiming-initialised convolutions,
+    random frozen batch-norm constants; features against the torch fp32 modules."""
+    from od_wscl_amd.config import make_defaults
+    from od_wscl_amd.modeling.backbone import build_backbone
+    from od_wscl_amd.modeling.backbone.resnet_hip import ResNetBackboneHip
+    cfg = make_defaults()
+    cfg.merge_from_list(["MODEL.BACKBONE.CONV_BODY", "R-101-C5"])
+    torch.manual_seed(3)
+    body = build_backbone(cfg).body.cuda()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    with torch.no_grad():
+        for n, b in body.named_buffers():
+            if n.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, device="cuda", generator=g) * 0.5 + 0.75)
+            elif n.endswith("weight"):
+                b.copy_(torch.rand(b.shape, device="cuda", generator=g) * 0.4 + 0.8)
+            else:
+                b.copy_(torch.randn(b.shape, device="cuda", generator=g) * 0.05)
+    images = torch.randn(1, 3, 128, 160, device="cuda", generator=g) * 40
+    with torch.no_grad():
+        ref = body(images)[0]
+        got = ResNetBackboneHip(body)(images)[0]
+    assert got.shape == ref.shape == (1, 2048, 8, 10)
+    assert _cos(got, ref) > 0.999, _cos(got, ref)
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 5e-2
