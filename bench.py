@@ -49,12 +49,14 @@ def parse():
                          "(configs/voc/voc07_r50_c5_*.yaml), a secondary line")
     ap.add_argument("--time-every", type=int, default=4,
                     help="bracket the GEMM / conv launches of 1 timed step in N with HIP events (roofline object)")
+    ap.add_argument("--pooler", default="ROIPool", choices=["ROIPool", "ROIAlign"],
+                    help="POOLER_METHOD; every shipped config of the reference uses ROIPool (the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proposals", type=int, default=2000)
     return ap.parse_args()
 
 
-def build_cfg(classes, arch="vgg16"):
+def build_cfg(classes, arch="vgg16", pooler="ROIPool"):
     from od_wscl_amd.config import make_defaults
     cfg = make_defaults()
     # == configs/voc/voc07_contra_db_b8_lr0.01_mcg.yaml of the reference (voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml for r50)
@@ -63,7 +65,7 @@ def build_cfg(classes, arch="vgg16"):
             ["MODEL.BACKBONE.CONV_BODY", "R-50-C5", "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.0625,),
              "MODEL.ROI_BOX_HEAD.FEATURE_EXTRACTOR", "ResNet50Conv5ROIFeatureExtractor"])
     cfg.merge_from_list(body + ["MODEL.WSOD_ON", True, "MODEL.FASTER_RCNN", False,
-                         "MODEL.ROI_BOX_HEAD.NUM_CLASSES", classes, "MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool",
+                         "MODEL.ROI_BOX_HEAD.NUM_CLASSES", classes, "MODEL.ROI_BOX_HEAD.POOLER_METHOD", pooler,
                          "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
                          "MODEL.ROI_WEAK_HEAD.REGRESS_ON", True, "DB.METHOD", "dropblock", "SOLVER.CONTRA", True,
                          "SOLVER.BASE_LR", BENCH_LR, "SOLVER.WEIGHT_DECAY", 0.0001, "SOLVER.IMS_PER_BATCH", 8,
@@ -138,7 +140,7 @@ def main():
     from od_wscl_amd import engine
     from od_wscl_amd.utils.device_rand import DeviceRand
 
-    cfg = build_cfg(args.classes, args.arch)
+    cfg = build_cfg(args.classes, args.arch, args.pooler)
     seed = cfg.SEED
     step_fn, info = engine.build_training_step(cfg, device, dtype=args.dtype, world=world, seed=seed,
                                                  backend=args.backend)
@@ -185,9 +187,10 @@ def main():
             "value": round(value, 1), "unit": "proposals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s + %d MCG-like proposals, batch 1/GPU, %dpx (padded %d), ROIPool 7x7, "
+            "config": {"workload": "%s + %d MCG-like proposals, batch 1/GPU, %dpx (padded %d), %s 7x7, "
                                    "OD-WSCL loss (CONTRA), SGD step, %d classes"
-                                   % ("VGG16-OICR" if args.arch == "vgg16" else "R-50-C5", args.proposals, args.size, images.tensors.shape[-1], args.classes),
+                                   % ("VGG16-OICR" if args.arch == "vgg16" else "R-50-C5", args.proposals, args.size, images.tensors.shape[-1],
+                                      args.pooler, args.classes),
                        "global_batch": world, "parallelism": "dp%d" % world, "lr": BENCH_LR, "gemm_backend": info["gemm_backend"],
                        "conv_backend": info["conv_backend"], "optimizer": info["optimizer"]},
             "per_gpu": round(value / world, 1),

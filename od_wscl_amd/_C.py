@@ -70,10 +70,12 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
     if gin.numel() == 0:
         return gin
-    L.check(L.lib().odw_roi_align_backward(L.ptr(grad), L.ptr(rois), float(spatial_scale), batch_size,
-                                           channels, height, width, rois.shape[0], pooled_height,
-                                           pooled_width, int(sampling_ratio), L.ptr(gin), L.stream()),
-            "roi_align_backward")
+    ws_bytes = L.lib().odw_roi_align_backward_workspace(rois.shape[0], pooled_height, pooled_width)
+    ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=grad.device)
+    L.check(L.lib().odw_roi_align_backward_ws(L.ptr(grad), L.ptr(rois), float(spatial_scale), batch_size,
+                                              channels, height, width, rois.shape[0], pooled_height,
+                                              pooled_width, int(sampling_ratio), L.ptr(gin), L.ptr(ws), int(ws_bytes),
+                                              L.stream()), "roi_align_backward")
     return gin
 
 

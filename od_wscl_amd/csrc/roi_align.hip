@@ -11,6 +11,7 @@
 // must be evaluated as separate fp32 mul/add/div, not FMA, to land on the
 // same side of integer boundaries as the reference.
 #include "odw_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -176,6 +177,98 @@ __global__ void roi_align_bwd_direct(const float* __restrict__ grad_out, const f
     }
 }
 
+// ---- separable form of the backward -----------------------------------------------------------------------------
+// The bilinear weight of sample (iy, ix) on a cell is a PRODUCT of a row weight and a column weight, the sample grid of
+// a bin is a product grid, and the validity test (y in [-1,H], x in [-1,W]) is a conjunction: the gradient of bin
+// (ph, pw) on cell (cy, cx) is go / count * wy[ph][cy] * wx[pw][cx] with wy / wx summed over the samples of one axis.
+// A pre-pass builds the 14 axis vectors of every ROI once (they do not depend on the channel); the plane kernel then
+// spends one multiply + one LDS atomic per touched CELL (~(bin+2)^2) instead of re-deriving four taps per SAMPLE
+// (4 * ceil(bin)^2, ~60 instructions each) in every one of the C planes: 16.7 ms -> ~1 ms at P = 2000 on 76x76x512.
+// Only the backward: its summation order is free (atomics); the forward keeps the reference's order.
+constexpr int kAxisLen = 30;                 // cells one bin can touch along an axis (bin extent + 2); longer: fallback
+constexpr int kAxisStride = 2 + kAxisLen;    // [first cell, cell count, weights...]
+
+__global__ void roi_align_axis_kernel(const float* __restrict__ rois, float scale, int R, int PH, int PW, int H, int W,
+                                      int sr, float* __restrict__ tab) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = PH + PW;
+    if (t >= R * per) return;
+    const int n = t / per, k = t - n * per;
+    const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
+    const bool is_y = k < PH;
+    const int p = is_y ? k : k - PH;
+    const int L = is_y ? H : W, grid = is_y ? g.gh : g.gw;
+    const float start = is_y ? g.sh : g.sw, bin = is_y ? g.bin_h : g.bin_w;
+    float w[kAxisLen + 1];
+#pragma unroll
+    for (int i = 0; i <= kAxisLen; ++i) w[i] = 0.0f;
+    int first = -1, last = -1;
+    bool overflow = false;              // a bin wider than the vector (a box far larger than the map): sample form
+    for (int i = 0; i < grid; ++i) {
+        float v = start + (float)p * bin + ((float)i + 0.5f) * bin / (float)grid;      // ROIAlign_cuda.cu:109-112
+        if (v < -1.0f || v > (float)L) continue;
+        if (v <= 0) v = 0;
+        int lo = (int)v, hi;
+        if (lo >= L - 1) { hi = lo = L - 1; v = (float)lo; } else { hi = lo + 1; }
+        const float l = v - (float)lo, hwt = 1.0f - l;
+        if (first < 0) first = lo;
+        const int a = lo - first, b2 = hi - first;
+        if (b2 >= kAxisLen) { overflow = true; break; }
+        w[a] += hwt;
+        w[b2] += l;
+        last = hi;
+    }
+    float* o = tab + (size_t)t * kAxisStride;
+    reinterpret_cast<int*>(o)[0] = first < 0 ? 0 : first;
+    reinterpret_cast<int*>(o)[1] = overflow ? -1 : (first < 0 ? 0 : last - first + 1);
+#pragma unroll
+    for (int i = 0; i < kAxisLen; ++i) o[2 + i] = w[i];
+}
+
+template <int CG>
+__global__ __launch_bounds__(kPlaneThreads) void roi_align_bwd_sep_plane(
+    const float* __restrict__ grad_out, const float* __restrict__ rois, float scale, const float* __restrict__ tab,
+    int C, int H, int W, int R, int PH, int PW, int sr, float* __restrict__ grad_in) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int groups = (C + CG - 1) / CG;
+    const int b = blockIdx.x / groups;
+    const int c0 = (blockIdx.x % groups) * CG;
+    const int nc = min(CG, C - c0);
+    const int HW = H * W;
+    for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) acc[i] = 0.0f;
+    __syncthreads();
+    const int nb = PH * PW, per_roi = nc * nb, per = PH + PW;
+    int n = threadIdx.x / per_roi, r = threadIdx.x % per_roi;
+    const int dn = kPlaneThreads / per_roi, dr = kPlaneThreads % per_roi;
+    for (; n < R; n += dn, r += dr) {
+        if (r >= per_roi) { r -= per_roi; ++n; if (n >= R) break; }
+        const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
+        if (g.b != b) continue;
+        const int cl = r / nb, bin = r - cl * nb;
+        const int ph = bin / PW, pw = bin - ph * PW;
+        const float* ty = tab + ((size_t)n * per + ph) * kAxisStride;
+        const float* tx = tab + ((size_t)n * per + PH + pw) * kAxisStride;
+        const int y0 = reinterpret_cast<const int*>(ty)[0], ny = reinterpret_cast<const int*>(ty)[1];
+        const int x0 = reinterpret_cast<const int*>(tx)[0], nx = reinterpret_cast<const int*>(tx)[1];
+        if (ny == 0 || nx == 0) continue;
+        if (ny < 0 || nx < 0) {         // oversized bin: the sample-by-sample form
+            float* q = acc + cl * HW;
+            align_scatter(g, H, W, ph, pw, grad_out[((size_t)n * C + c0 + cl) * nb + bin],
+                          [q](int pos, float v) { atomicAdd(q + pos, v); });
+            continue;
+        }
+        const float go = grad_out[((size_t)n * C + c0 + cl) * nb + bin] / g.count;
+        float* p = acc + cl * HW + y0 * W + x0;
+        for (int cy = 0; cy < ny; ++cy) {
+            const float gy = go * ty[2 + cy];
+            for (int cx = 0; cx < nx; ++cx) atomicAdd(p + cy * W + cx, gy * tx[2 + cx]);
+        }
+    }
+    __syncthreads();
+    float* dst = grad_in + ((size_t)b * C + c0) * HW;
+    for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) dst[i] = acc[i];
+}
+
 int pick_cg(int B, int C, int HW) {
     const int cands[3] = {4, 2, 1};
     int fit = 0;
@@ -234,9 +327,19 @@ ODW_EXPORT int odw_roi_align_forward(const float* feat, const float* rois, float
     return ODW_OK;
 }
 
+ODW_EXPORT int64_t odw_roi_align_backward_workspace(int R, int PH, int PW) {
+    return R > 0 ? odw_align_up((int64_t)R * (PH + PW) * kAxisStride * 4, 256) : 0;
+}
+
 ODW_EXPORT int odw_roi_align_backward(const float* grad_out, const float* rois, float scale, int B, int C,
                                       int H, int W, int R, int PH, int PW, int sr, float* grad_in,
                                       void* stream_) {
+    return odw_roi_align_backward_ws(grad_out, rois, scale, B, C, H, W, R, PH, PW, sr, grad_in, nullptr, 0, stream_);
+}
+
+ODW_EXPORT int odw_roi_align_backward_ws(const float* grad_out, const float* rois, float scale, int B, int C,
+                                         int H, int W, int R, int PH, int PW, int sr, float* grad_in,
+                                         void* workspace, int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 0,
                 "roi_align_backward: bad dims");
@@ -261,6 +364,30 @@ ODW_EXPORT int odw_roi_align_backward(const float* grad_out, const float* rois, 
     }
     const int grid = B * ((C + cg - 1) / cg);
     const size_t lds = (size_t)cg * HW * 4;
+    // separable form when the caller brought the table space and no bin can outgrow an axis vector
+    if (workspace && workspace_bytes >= odw_roi_align_backward_workspace(R, PH, PW) &&
+        (((uintptr_t)workspace) & 15) == 0 && !getenv("ODW_ROI_ALIGN_SAMPLES")) {
+        float* tab = (float*)workspace;
+        const int items = R * (PH + PW);
+        roi_align_axis_kernel<<<(items + 255) / 256, 256, 0, stream>>>(rois, scale, R, PH, PW, H, W, sr, tab);
+        ODW_CHECK_LAUNCH("roi_align_axis_kernel");
+        switch (cg) {
+            case 4:
+                ODW_CHECK_HIP(allow_lds(roi_align_bwd_sep_plane<4>, lds), "roi_align_bwd_sep_plane attr");
+                roi_align_bwd_sep_plane<4><<<grid, kPlaneThreads, lds, stream>>>(grad_out, rois, scale, tab, C, H, W, R, PH, PW, sr, grad_in);
+                break;
+            case 2:
+                ODW_CHECK_HIP(allow_lds(roi_align_bwd_sep_plane<2>, lds), "roi_align_bwd_sep_plane attr");
+                roi_align_bwd_sep_plane<2><<<grid, kPlaneThreads, lds, stream>>>(grad_out, rois, scale, tab, C, H, W, R, PH, PW, sr, grad_in);
+                break;
+            default:
+                ODW_CHECK_HIP(allow_lds(roi_align_bwd_sep_plane<1>, lds), "roi_align_bwd_sep_plane attr");
+                roi_align_bwd_sep_plane<1><<<grid, kPlaneThreads, lds, stream>>>(grad_out, rois, scale, tab, C, H, W, R, PH, PW, sr, grad_in);
+                break;
+        }
+        ODW_CHECK_LAUNCH("roi_align_bwd_sep_plane");
+        return ODW_OK;
+    }
     switch (cg) {
         case 4:
             ODW_CHECK_HIP(allow_lds(roi_align_bwd_plane<4>, lds), "roi_align_bwd_plane attr");
