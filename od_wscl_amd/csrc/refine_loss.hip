@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kRowThreads) void refine_rows_kernel(
     }
 }
 
-__global__ __launch_bounds__(128) void refine_finish_kernel(const float* __restrict__ part, int nblocks, Heads h,
+__global__ __launch_bounds__(512) void refine_finish_kernel(const float* __restrict__ part, int nblocks, Heads h,
                                                             const int* __restrict__ img_off,
                                                             const float* __restrict__ colstat,
                                                             const float* __restrict__ lab, const int* __restrict__ n_pos,
@@ -297,21 +297,24 @@ __global__ __launch_bounds__(128) void refine_finish_kernel(const float* __restr
     const float* cst = colstat + (size_t)img * 3 * kMaxC;
     const float* lv = lab + (size_t)img * C;
     const float inv_img = 1.0f / (float)n_img;
-    const int c = threadIdx.x;
+    // 4 x 128 threads: group i < 3 sums column c of refinement branch i over the row blocks, group 3 the six loss
+    // partials -- every sum keeps its block order (the same bits as one thread doing all four in sequence, a quarter
+    // of the dependent-load chain)
+    const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
     const size_t stride = 8 + 3 * kMaxC;
-    if (c < C) {
+    if (grp == 0 && c < C) {
         const float s = cst[2 * kMaxC + c];
         const float ph = fminf(fmaxf(s, eps), 1.0f - eps);
         const float lp = fmaxf(logf(ph), -100.0f), lq = fmaxf(logf(1.0f - ph), -100.0f);   // torch BCE clamps logs
         phi[c] = ph;
         bce[c] = -(lv[c] * lp + (1.0f - lv[c]) * lq) / (float)C;
-        for (int i = 0; i < 3; ++i) {
-            float a = 0.0f;
-            for (int b = 0; b < nblocks; ++b) a += part[((size_t)img * nblocks + b) * stride + 8 + i * kMaxC + c];
-            rsum[i][c] = a;
-        }
     }
-    if (c < 6) {
+    if (grp < 3 && c < C) {
+        float a = 0.0f;
+        for (int b = 0; b < nblocks; ++b) a += part[((size_t)img * nblocks + b) * stride + 8 + grp * kMaxC + c];
+        rsum[grp][c] = a;
+    }
+    if (grp == 3 && c < 6) {
         float a = 0.0f;
         for (int b = 0; b < nblocks; ++b) a += part[((size_t)img * nblocks + b) * stride + c];
         ls[c] = a;
@@ -390,7 +393,7 @@ ODW_EXPORT int odw_refine_losses(const float* Y, int ldy, const int* head_offset
                                                                    (const long long*)pseudo, weights, targets, sum_p,
                                                                    n_img, eps, (float*)workspace, dY);
     ODW_CHECK_LAUNCH("refine_rows_kernel");
-    refine_finish_kernel<<<n_img, 128, 0, stream>>>((const float*)workspace, nb, h, img_off, colstat, lab, n_pos, n_img,
+    refine_finish_kernel<<<n_img, 512, 0, stream>>>((const float*)workspace, nb, h, img_off, colstat, lab, n_pos, n_img,
                                                     eps, out);
     ODW_CHECK_LAUNCH("refine_finish_kernel");
     return ODW_OK;
