@@ -322,6 +322,14 @@ int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, int C, int 
 int odw_conv_weight_prep(const float* w, int Co, int Ci, int Cp, void* wk, int ldk, void* wd, int ldd, void* stream);
 int odw_conv_wgrad_unpack(const float* dwk, int ld, int Co, int Ci, int Cp, float* dw, void* stream);
 int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm, void* stream);
+/* column-block form: this call owns `cols` (>= n_pix, zero padded) columns of a wider (9*C x ldm) matrix */
+int odw_im2col_t_bf16_part(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm, int cols,
+                           void* stream);
+/* the same pooling / layout helpers on fp32 NHWC activations (bf16x3 precision mode, see odw_split_rows_bf16) */
+int odw_maxpool2x2_nhwc_f32(const float* X, int B, int H, int W, int C, float* Y, void* stream);
+int odw_maxpool2x2_nhwc_f32_bwd(const float* X, const float* dY, int B, int H, int W, int C, float* dX, void* stream);
+int odw_nchw_f32_to_nhwc_f32(const float* in, int B, int HW, int C, int Cp, float* out, void* stream);
+int odw_nhwc_f32_to_nchw_f32(const float* in, int B, int HW, int C, int Cp, float* out, void* stream);
 int odw_maxpool2x2_nhwc_bf16(const void* X, int B, int H, int W, int C, void* Y, void* stream);
 int odw_maxpool2x2_nhwc_bf16_bwd(const void* X, const void* dY, int B, int H, int W, int C, void* dX, void* stream);
 int odw_nhwc_bf16_to_nchw_f32(const void* in, int B, int HW, int C, float* out, void* stream);
@@ -371,10 +379,40 @@ int odw_relu_bwd_bf16(const void* dout, const void* out, void* g, int64_t n, voi
 int odw_stem_conv7x7_bn_relu(const float* img_nchw, const float* weight, const float* scale, const float* shift, int B,
                              int H, int W, int Co, void* out_nhwc_bf16, void* stream);
 int odw_maxpool3x3s2_nhwc_bf16(const void* X, int B, int H, int W, int C, void* Y, void* stream);
+/* fp32 NHWC forms of the four (split precision modes keep activations in fp32 between kernels) */
+int odw_add_relu_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+int odw_relu_bwd_f32(const float* dout, const float* out, float* g, int64_t n, void* stream);
+int odw_stem_conv7x7_bn_relu_f32(const float* img_nchw, const float* weight, const float* scale, const float* shift, int B,
+                                 int H, int W, int Co, float* out_nhwc, void* stream);
+int odw_maxpool3x3s2_nhwc_f32(const float* X, int B, int H, int W, int C, float* Y, void* stream);
 /* First layer of the VGG body when it is frozen (modeling/backbone/vgg16.py:58-60, FREEZE_CONV_BODY_AT >= 1): 3x3 / pad 1
  * convolution of the fp32 NCHW image, weight (Co,3,3,3) fp32, + bias + ReLU -> NHWC bf16 (B*H*W, Co), direct form. */
 int odw_stem_conv3x3_bias_relu(const float* img_nchw, const float* weight, const float* bias, int B, int H, int W, int Co,
                                void* out_nhwc_bf16, void* stream);
+
+/* ---- fp32-grade products on the bf16 matrix cores: operand splitting ("bf16x3") ---------------
+ * replaces the fp32 cuBLAS / cuDNN arithmetic behind torch.nn.Linear / Conv2d in the reference
+ * (config/defaults.py:559 DTYPE float32; modeling/backbone/vgg16.py:58-83,107-193).
+ * An fp32 value is carried as three bf16 planes hi + mid + lo (24 significand bits) laid out along the
+ * REDUCTION axis of a product; plane code 0/1/2 = hi/mid/lo, 3 = a block of zeros.
+ *   odw_split_rows_bf16: out[r][t*block + c] = plane_{pattern[t]}(in[r][c]), c < Cc <= block (zero padded)
+ *   odw_split_cols_bf16: out[c][t*block + r] = plane_{pattern[t]}(in[r][c]), r < R  <= block (zero padded)
+ * pattern = T <= 8 plane codes (HOST array).  With pattern {0,0,0,1,1,2} on one operand and {0,1,2,0,1,0} on the
+ * other, odw_gemm_nt_bf16 / odw_conv3x3_nhwc_bf16 over K' = T*block accumulate the six plane products of order <= 2.
+ *   odw_linear_bwd_mask_f32: dZ = dY * [Y != 0] * scale (Y nullable: dZ = dY), db[n] += sum_m dZ[m][n]
+ *   (single writer per bias entry, fixed summation order). */
+int odw_split_rows_bf16(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
+                        int64_t ld_out, int block, void* stream);
+int odw_split_cols_bf16(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
+                        int64_t ld_out, int block, void* stream);
+int odw_linear_bwd_mask_f32(const float* dY, int64_t ld_dy, const void* Y, int y_is_bf16, int64_t ld_y, int M, int N,
+                            float scale, float* dZ, int64_t ld_z, float* db, void* stream);
+/* fp32-output forms of the stacked-operand producers (same arithmetic, no bf16 rounding of the result) */
+int odw_stack_clean_aug_f32(const float* pooled, const float* block, const float* block_sum, int P, int C, int S,
+                            float* out, int ld, void* stream);
+int odw_rows_drop_noise_f32(const float* pooled, const int* rows, int row_base, int k, int C, int S, float gamma,
+                            uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1, float* keep_sum, float* out, int ld,
+                            int out_row0, void* stream);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,20 @@ SIGNATURES = {
     "odw_image_preprocess_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "odw_image_preprocess": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_l, c_p]),
     "odw_od_assign_indexed": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
+    "odw_im2col_t_bf16_part": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "odw_maxpool2x2_nhwc_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_maxpool2x2_nhwc_f32_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_nchw_f32_to_nhwc_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_nhwc_f32_to_nchw_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_split_rows_bf16": (c_i, [c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_l, c_i, c_p]),
+    "odw_split_cols_bf16": (c_i, [c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_l, c_i, c_p]),
+    "odw_linear_bwd_mask_f32": (c_i, [c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_f, c_p, c_l, c_p, c_p]),
+    "odw_stack_clean_aug_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "odw_rows_drop_noise_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_i, c_i, c_p]),
+    "odw_add_relu_f32": (c_i, [c_p, c_p, c_p, c_l, c_p]),
+    "odw_relu_bwd_f32": (c_i, [c_p, c_p, c_p, c_l, c_p]),
+    "odw_stem_conv7x7_bn_relu_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_maxpool3x3s2_nhwc_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_od_assign": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
 }
 

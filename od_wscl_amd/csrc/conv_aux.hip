@@ -57,7 +57,7 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ dwk, int ld, int C
 // HBM-bound side-stream optimiser for free, now the weight-gradient GEMMs that follow share HBM with it instead
 // (GPU-busy per step 9.11 -> 8.96 ms on the same box class).
 __global__ __launch_bounds__(256) void im2col_t_kernel(const unsigned short* __restrict__ X, int M, int H, int W,
-                                                       int C, int dil, unsigned short* __restrict__ out, int ldm) {
+                                                       int C, int dil, unsigned short* __restrict__ out, int ldm, int cols) {
     const int t = blockIdx.z;
     const int ty9 = t / 3, tx9 = t - 3 * ty9;
     const int dh = (ty9 - 1) * dil, dw = (tx9 - 1) * dil;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const unsigned short* __r
     const int pg = lane & 15, ch = lane >> 4;                 // pixel group (8 pixels), channel chunk (8 channels)
     const int m0 = (blockIdx.y * 4 + wave) * 128 + pg * 8;    // block = 4 waves x 128 pixels
     const int c0 = blockIdx.x * 32 + ch * 8;
-    if (c0 >= C || m0 >= ldm) return;
+    if (c0 >= C || m0 >= cols) return;
     unsigned int r[8][4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -198,6 +198,91 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+// ---- the same helpers on fp32 NHWC activations (the bf16x3 precision mode keeps activations in fp32 between
+// kernels and splits them into bf16 planes right before each product: csrc/split.hip) -----------------------------
+__global__ void maxpool_f32_fwd_kernel(const float* __restrict__ X, int B, int H, int W, int C, float* __restrict__ Y) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t q = i / C;
+        const int xo = (int)(q % Wo); q /= Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c;
+        const float v0 = X[base], v1 = X[base + C], v2 = X[base + (size_t)W * C], v3 = X[base + (size_t)W * C + C];
+        float best = v0;
+        best = v1 > best ? v1 : best;
+        best = v2 > best ? v2 : best;
+        best = v3 > best ? v3 : best;
+        Y[i] = best;
+    }
+}
+
+__global__ void maxpool_f32_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dY, int B, int H, int W,
+                                       int C, float* __restrict__ dX) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t q = i / C;
+        const int xo = (int)(q % Wo); q /= Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c;
+        const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+        float best = -__builtin_inff();
+        int bi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float f = X[base + off[k]];
+            if (f > best) { best = f; bi = k; }
+        }
+        const float g = best > 0.0f ? dY[i] : 0.0f;        // X = the post-ReLU activation that was pooled
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dX[base + off[k]] = k == bi ? g : 0.0f;
+    }
+}
+
+// out[b][p][c] (c < Cp, zero padded) = in[b][c][p], both fp32; TO_NCHW: the inverse (Cp = C)
+template <bool TO_NCHW>
+__global__ __launch_bounds__(256) void layout_f32_kernel(const float* __restrict__ in, int HW, int C, int Cp,
+                                                         float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (TO_NCHW) {
+        const float* src = in + (size_t)b * HW * Cp;
+        float* dst = out + (size_t)b * HW * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = p0 + ty + 8 * k, c = c0 + tx;
+            tile[ty + 8 * k][tx] = (p < HW && c < C) ? src[(size_t)p * Cp + c] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, p = p0 + tx;
+            if (c < C && p < HW) dst[(size_t)c * HW + p] = tile[tx][ty + 8 * k];
+        }
+    } else {
+        const float* src = in + (size_t)b * HW * C;
+        float* dst = out + (size_t)b * HW * Cp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, p = p0 + tx;
+            tile[ty + 8 * k][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = p0 + ty + 8 * k, c = c0 + tx;
+            if (p < HW && c < Cp) dst[(size_t)p * Cp + c] = tile[tx][ty + 8 * k];
+        }
+    }
+}
+
 int blocks_for(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 
 }  // namespace
@@ -223,13 +308,18 @@ ODW_EXPORT int odw_conv_wgrad_unpack(const float* dwk, int ld, int Co, int Ci, i
 
 ODW_EXPORT int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm,
                                  void* stream_) {
-    ODW_REQUIRE(n_pix > 0 && H > 0 && W > 0 && C > 0 && ldm >= n_pix && n_pix % (H * W) == 0 && X && out,
+    return odw_im2col_t_bf16_part(X, n_pix, H, W, C, dilation, out, ldm, ldm, stream_);
+}
+
+ODW_EXPORT int odw_im2col_t_bf16_part(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm,
+                                      int cols, void* stream_) {
+    ODW_REQUIRE(n_pix > 0 && H > 0 && W > 0 && C > 0 && cols >= n_pix && ldm >= cols && n_pix % (H * W) == 0 && X && out,
                 "im2col_t: bad arguments");
-    ODW_REQUIRE(C % 8 == 0 && ldm % 8 == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
-                "im2col_t: C=%d and ldm=%d must be multiples of 8, pointers 16-byte aligned", C, ldm);
-    dim3 grid((C + 31) / 32, (ldm + 511) / 512, 9);
+    ODW_REQUIRE(C % 8 == 0 && ldm % 8 == 0 && cols % 8 == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
+                "im2col_t: C=%d, ldm=%d and cols=%d must be multiples of 8, pointers 16-byte aligned", C, ldm, cols);
+    dim3 grid((C + 31) / 32, (cols + 511) / 512, 9);
     im2col_t_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X, n_pix, H, W, C, dilation,
-                                                            (unsigned short*)out, ldm);
+                                                            (unsigned short*)out, ldm, cols);
     ODW_CHECK_LAUNCH("im2col_t_kernel");
     return ODW_OK;
 }
@@ -267,5 +357,36 @@ ODW_EXPORT int odw_nchw_f32_to_nhwc_bf16(const float* in, int B, int HW, int C, 
     dim3 grid((HW + 31) / 32, (Cp + 31) / 32, B);
     nchw_to_nhwc_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(in, HW, C, Cp, (unsigned short*)out);
     ODW_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_maxpool2x2_nhwc_f32(const float* X, int B, int H, int W, int C, float* Y, void* stream_) {
+    ODW_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && X && Y, "maxpool2x2_f32: bad arguments");
+    maxpool_f32_fwd_kernel<<<blocks_for((size_t)B * (H / 2) * (W / 2) * C), 256, 0, (hipStream_t)stream_>>>(X, B, H, W, C, Y);
+    ODW_CHECK_LAUNCH("maxpool_f32_fwd_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_maxpool2x2_nhwc_f32_bwd(const float* X, const float* dY, int B, int H, int W, int C, float* dX,
+                                           void* stream_) {
+    ODW_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && X && dY && dX, "maxpool2x2_f32_bwd: bad arguments");
+    maxpool_f32_bwd_kernel<<<blocks_for((size_t)B * (H / 2) * (W / 2) * C), 256, 0, (hipStream_t)stream_>>>(X, dY, B, H, W, C, dX);
+    ODW_CHECK_LAUNCH("maxpool_f32_bwd_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_nchw_f32_to_nhwc_f32(const float* in, int B, int HW, int C, int Cp, float* out, void* stream_) {
+    ODW_REQUIRE(B > 0 && HW > 0 && C > 0 && Cp >= C && in && out, "nchw_to_nhwc_f32: bad arguments");
+    dim3 grid((HW + 31) / 32, (Cp + 31) / 32, B);
+    layout_f32_kernel<false><<<grid, 256, 0, (hipStream_t)stream_>>>(in, HW, C, Cp, out);
+    ODW_CHECK_LAUNCH("layout_f32_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_nhwc_f32_to_nchw_f32(const float* in, int B, int HW, int C, int Cp, float* out, void* stream_) {
+    ODW_REQUIRE(B > 0 && HW > 0 && C > 0 && Cp >= C && in && out, "nhwc_to_nchw_f32: bad arguments");
+    dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+    layout_f32_kernel<true><<<grid, 256, 0, (hipStream_t)stream_>>>(in, HW, C, Cp, out);
+    ODW_CHECK_LAUNCH("layout_f32_kernel");
     return ODW_OK;
 }

@@ -24,16 +24,42 @@ __device__ __forceinline__ float bf2f(unsigned int h) { return __uint_as_float(h
 constexpr int kMaxS = 256;      // spatial cells per ROI held in LDS (7x7 = 49, 14x14 = 196)
 
 // one workgroup per ROI; 4 consecutive elements per thread (row length C*S is a multiple of 4)
+template <bool OUT_F32>
 __global__ __launch_bounds__(256) void stack_clean_aug_kernel(const float* __restrict__ pooled,
                                                               const float* __restrict__ block,
                                                               const float* __restrict__ block_sum, int P, int CS, int S,
-                                                              float numel, unsigned short* __restrict__ out, int ld) {
+                                                              float numel, void* __restrict__ outv, int ld) {
     __shared__ float keep[kMaxS];
     const int p = blockIdx.x;
     for (int s = threadIdx.x; s < S; s += blockDim.x) keep[s] = block[(size_t)p * S + s];
     __syncthreads();
     const float sum = *block_sum;
     const float4* src = reinterpret_cast<const float4*>(pooled + (size_t)p * CS);
+    if (OUT_F32) {          // fp32 operand (the split kernels of csrc/split.hip lay it out for the matrix cores)
+        float* out = reinterpret_cast<float*>(outv);
+        float4* clean = reinterpret_cast<float4*>(out + (size_t)p * ld);
+        float4* aug = reinterpret_cast<float4*>(out + (size_t)(P + p) * ld);
+        for (int q = threadIdx.x; q < CS / 4; q += blockDim.x) {
+            const float4 v = src[q];
+            const int s0 = (q * 4) % S;
+            const float x[4] = {v.x, v.y, v.z, v.w};
+            float a[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int s = s0 + t;
+                s = s >= S ? s - S : s;
+                a[t] = ((x[t] * keep[s]) * numel) / sum;
+            }
+            clean[q] = v;
+            aug[q] = make_float4(a[0], a[1], a[2], a[3]);
+        }
+        for (int k = CS + threadIdx.x; k < ld; k += blockDim.x) {
+            out[(size_t)p * ld + k] = 0.0f;
+            out[(size_t)(P + p) * ld + k] = 0.0f;
+        }
+        return;
+    }
+    unsigned short* out = reinterpret_cast<unsigned short*>(outv);
     uint2* clean = reinterpret_cast<uint2*>(out + (size_t)p * ld);
     uint2* aug = reinterpret_cast<uint2*>(out + (size_t)(P + p) * ld);
     for (int q = threadIdx.x; q < CS / 4; q += blockDim.x) {
@@ -126,7 +152,7 @@ __device__ __forceinline__ void normal_pair(uint32_t p, uint32_t k0, uint32_t k1
 }
 
 // BWD = false: out rows from pooled;  BWD = true: dpooled[rows[r]] += d(drop row) and d(noise row) folded back
-template <bool BWD, bool DX_F32, bool SRC_BF16 = false>
+template <bool BWD, bool DX_F32, bool SRC_BF16 = false, bool OUT_F32 = false>
 __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __restrict__ pooled, const void* __restrict__ dXv,
                                                               const int* __restrict__ rows, int row_base, int k, int CS,
                                                               int S, float gamma, uint32_t kd0, uint32_t kd1,
@@ -155,6 +181,20 @@ __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __res
             } else {
                 const float4 v = *reinterpret_cast<const float4*>(pooled + src_row * CS + q * 4);
                 x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+            }
+            if (OUT_F32) {
+                float df[4], nf[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    int sidx = s0 + t;
+                    sidx = sidx >= S ? sidx - S : sidx;
+                    df[t] = ((x[t] * keep[sidx]) * numel) / sum;
+                    nf[t] = z[t] * x[t] + x[t];
+                }
+                float* of = reinterpret_cast<float*>(out);
+                *reinterpret_cast<float4*>(of + (size_t)(row0 + r) * ld + q * 4) = make_float4(df[0], df[1], df[2], df[3]);
+                *reinterpret_cast<float4*>(of + (size_t)(row0 + k + r) * ld + q * 4) = make_float4(nf[0], nf[1], nf[2], nf[3]);
+                continue;
             }
             unsigned short d[4], n[4];
 #pragma unroll
@@ -196,11 +236,18 @@ __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __res
             *dst = acc;
         }
     }
-    if (!BWD)
+    if (!BWD && OUT_F32) {
+        float* of = reinterpret_cast<float*>(out);
+        for (int c = CS + threadIdx.x; c < ld; c += blockDim.x) {
+            of[(size_t)(row0 + r) * ld + c] = 0.0f;
+            of[(size_t)(row0 + k + r) * ld + c] = 0.0f;
+        }
+    } else if (!BWD) {
         for (int c = CS + threadIdx.x; c < ld; c += blockDim.x) {
             out[(size_t)(row0 + r) * ld + c] = 0;
             out[(size_t)(row0 + k + r) * ld + c] = 0;
         }
+    }
 }
 
 // ---- row-wise L2 normalisation of the 128-d embeddings (Sim_Net.forward, sim_head/sim_net.py:25-26: F.normalize) ------
@@ -249,8 +296,22 @@ ODW_EXPORT int odw_stack_clean_aug(const float* pooled, const float* block, cons
     ODW_REQUIRE(pooled && block && block_sum && out_bf16, "stack_clean_aug: null pointer");
     ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0 && S >= 4, "stack_clean_aug: C*S=%ld must be a multiple of 4 and fit ld=%d", cs, ld);
     ODW_REQUIRE((((uintptr_t)pooled) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0, "stack_clean_aug: alignment");
-    stack_clean_aug_kernel<<<P, 256, 0, stream>>>(pooled, block, block_sum, P, (int)cs, S, (float)((double)P * S),
-                                                  (unsigned short*)out_bf16, ld);
+    stack_clean_aug_kernel<false><<<P, 256, 0, stream>>>(pooled, block, block_sum, P, (int)cs, S, (float)((double)P * S),
+                                                         out_bf16, ld);
+    ODW_CHECK_LAUNCH("stack_clean_aug_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_stack_clean_aug_f32(const float* pooled, const float* block, const float* block_sum, int P, int C,
+                                       int S, float* out, int ld, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(P >= 0 && C > 0 && S > 0 && S <= kMaxS, "stack_clean_aug_f32: bad dims P=%d C=%d S=%d", P, C, S);
+    if (P == 0) return ODW_OK;
+    const long cs = (long)C * S;
+    ODW_REQUIRE(pooled && block && block_sum && out, "stack_clean_aug_f32: null pointer");
+    ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0 && S >= 4, "stack_clean_aug_f32: C*S=%ld must be a multiple of 4 and fit ld=%d", cs, ld);
+    ODW_REQUIRE((((uintptr_t)pooled) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "stack_clean_aug_f32: alignment");
+    stack_clean_aug_kernel<true><<<P, 256, 0, stream>>>(pooled, block, block_sum, P, (int)cs, S, (float)((double)P * S), out, ld);
     ODW_CHECK_LAUNCH("stack_clean_aug_kernel");
     return ODW_OK;
 }
@@ -292,6 +353,25 @@ ODW_EXPORT int odw_rows_drop_noise(const void* pooled, int src_is_bf16, const in
         rows_drop_noise_kernel<false, false><<<k, 256, 0, stream>>>((const float*)pooled, nullptr, rows, row_base, k, (int)cs,
                                                                     S, gamma, kd0, kd1, kn0, kn1, keep_sum,
                                                                     (unsigned short*)out_bf16, ld, out_row0, nullptr);
+    ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_rows_drop_noise_f32(const float* pooled, const int* rows, int row_base, int k, int C, int S, float gamma,
+                                       uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1, float* keep_sum, float* out,
+                                       int ld, int out_row0, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(k >= 0 && C > 0 && S >= 4 && S <= kMaxS && row_base >= 0 && out_row0 >= 0, "rows_drop_noise_f32: bad dims");
+    if (k == 0) return ODW_OK;
+    const long cs = (long)C * S;
+    ODW_REQUIRE(pooled && rows && keep_sum && out, "rows_drop_noise_f32: null pointer");
+    ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0 && (long)k * cs < (1ll << 32), "rows_drop_noise_f32: C*S=%ld, ld=%d", cs, ld);
+    ODW_REQUIRE((((uintptr_t)pooled) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "rows_drop_noise_f32: alignment");
+    rows_keep_sum_kernel<<<1, 256, 0, stream>>>(k * S, gamma, kd0, kd1, keep_sum);
+    rows_drop_noise_kernel<false, false, false, true><<<k, 256, 0, stream>>>(pooled, nullptr, rows, row_base, k, (int)cs, S, gamma,
+                                                                             kd0, kd1, kn0, kn1, keep_sum,
+                                                                             reinterpret_cast<unsigned short*>(out), ld, out_row0,
+                                                                             nullptr);
     ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
     return ODW_OK;
 }

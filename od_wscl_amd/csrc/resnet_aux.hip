@@ -43,10 +43,11 @@ __global__ __launch_bounds__(256) void add_relu_kernel(const uint4* __restrict__
 }
 
 // One thread = one output pixel x 8 output channels.  w_lds[(ky*7+kx)*3 + ci][co] fp32 (147 x Co), scale/shift (Co).
+template <bool OUT_F32>
 __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int B, int H, int W, int Ho, int Wo, int Co,
-                                                           unsigned short* __restrict__ out) {
+                                                           void* __restrict__ out) {
     extern __shared__ float w_lds[];                // 147*Co weights, then Co scale, Co shift
     float* s_scale = w_lds + 147 * Co;
     float* s_shift = s_scale + Co;
@@ -83,15 +84,23 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
             }
         }
         unsigned wo[4];
+        float rf[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float r0 = acc[2 * q] * s_scale[g * 8 + 2 * q] + s_shift[g * 8 + 2 * q];
             float r1 = acc[2 * q + 1] * s_scale[g * 8 + 2 * q + 1] + s_shift[g * 8 + 2 * q + 1];
             r0 = r0 > 0.0f ? r0 : 0.0f;
             r1 = r1 > 0.0f ? r1 : 0.0f;
+            rf[2 * q] = r0; rf[2 * q + 1] = r1;
             wo[q] = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
         }
-        reinterpret_cast<uint4*>(out)[t] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+        if (OUT_F32) {
+            float4* o = reinterpret_cast<float4*>(out) + 2 * t;
+            o[0] = make_float4(rf[0], rf[1], rf[2], rf[3]);
+            o[1] = make_float4(rf[4], rf[5], rf[6], rf[7]);
+        } else {
+            reinterpret_cast<uint4*>(out)[t] = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+        }
     }
 }
 
@@ -188,6 +197,48 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint4* __restri
     }
 }
 
+// ---- fp32 NHWC forms (split precision modes keep activations in fp32 between kernels, csrc/split.hip) ---------
+template <bool BWD>
+__global__ __launch_bounds__(256) void add_relu_f32_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                           float4* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 va = a[i], vb = b[i];
+        float4 o;
+        if (BWD) {      // a = dout, b = out
+            o.x = vb.x > 0.0f ? va.x : 0.0f; o.y = vb.y > 0.0f ? va.y : 0.0f;
+            o.z = vb.z > 0.0f ? va.z : 0.0f; o.w = vb.w > 0.0f ? va.w : 0.0f;
+        } else {
+            const float s0 = va.x + vb.x, s1 = va.y + vb.y, s2 = va.z + vb.z, s3 = va.w + vb.w;
+            o.x = s0 > 0.0f ? s0 : 0.0f; o.y = s1 > 0.0f ? s1 : 0.0f;
+            o.z = s2 > 0.0f ? s2 : 0.0f; o.w = s3 > 0.0f ? s3 : 0.0f;
+        }
+        out[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_f32_kernel(const float* __restrict__ X, int B, int H, int W, int C,
+                                                               int Ho, int Wo, float* __restrict__ Y) {
+    const size_t total = (size_t)B * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t q = i / C;
+        const int xo = (int)(q % Wo); q /= Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        float best = -__builtin_inff();
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = yo * 2 - 1 + dy;
+            if ((unsigned)y >= (unsigned)H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int x = xo * 2 - 1 + dx;
+                if ((unsigned)x >= (unsigned)W) continue;
+                best = fmaxf(best, X[(((size_t)b * H + y) * W + x) * C + c]);
+            }
+        }
+        Y[i] = best;
+    }
+}
+
 int blocks_for(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -223,8 +274,21 @@ ODW_EXPORT int odw_stem_conv7x7_bn_relu(const float* img_nchw, const float* weig
     const int Ho = (H + 2 * 3 - 7) / 2 + 1, Wo = (W + 2 * 3 - 7) / 2 + 1;
     const size_t total = (size_t)B * Ho * Wo * (Co / 8);
     const size_t lds = (size_t)(147 + 2) * Co * sizeof(float);
-    stem_conv7x7_kernel<<<blocks_for(total) > 2048 ? 2048 : blocks_for(total), 256, lds, (hipStream_t)stream_>>>(
-        img_nchw, weight, scale, shift, B, H, W, Ho, Wo, Co, (unsigned short*)out_nhwc_bf16);
+    stem_conv7x7_kernel<false><<<blocks_for(total) > 2048 ? 2048 : blocks_for(total), 256, lds, (hipStream_t)stream_>>>(
+        img_nchw, weight, scale, shift, B, H, W, Ho, Wo, Co, out_nhwc_bf16);
+    ODW_CHECK_LAUNCH("stem_conv7x7_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_stem_conv7x7_bn_relu_f32(const float* img_nchw, const float* weight, const float* scale, const float* shift,
+                                            int B, int H, int W, int Co, float* out_nhwc, void* stream_) {
+    ODW_REQUIRE(B > 0 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0 && Co <= 128, "stem_conv7x7_f32: bad dims");
+    ODW_REQUIRE(img_nchw && weight && scale && shift && out_nhwc && (((uintptr_t)out_nhwc) & 15) == 0, "stem_conv7x7_f32: pointers");
+    const int Ho = (H + 2 * 3 - 7) / 2 + 1, Wo = (W + 2 * 3 - 7) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (Co / 8);
+    const size_t lds = (size_t)(147 + 2) * Co * sizeof(float);
+    stem_conv7x7_kernel<true><<<blocks_for(total) > 2048 ? 2048 : blocks_for(total), 256, lds, (hipStream_t)stream_>>>(
+        img_nchw, weight, scale, shift, B, H, W, Ho, Wo, Co, out_nhwc);
     ODW_CHECK_LAUNCH("stem_conv7x7_kernel");
     return ODW_OK;
 }
@@ -249,5 +313,34 @@ ODW_EXPORT int odw_stem_conv3x3_bias_relu(const float* img_nchw, const float* we
     stem_conv3x3_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(img_nchw, weight, bias, B, H, W, Co,
                                                                  (unsigned short*)out_nhwc_bf16);
     ODW_CHECK_LAUNCH("stem_conv3x3_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_add_relu_f32(const float* a, const float* b, float* out, int64_t n, void* stream_) {
+    ODW_REQUIRE(n >= 0 && n % 4 == 0, "add_relu_f32: n=%lld must be a multiple of 4", (long long)n);
+    if (n == 0) return ODW_OK;
+    ODW_REQUIRE(a && b && out && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) == 0, "add_relu_f32: pointers");
+    add_relu_f32_kernel<false><<<blocks_for((size_t)n / 4), 256, 0, (hipStream_t)stream_>>>((const float4*)a, (const float4*)b,
+                                                                                            (float4*)out, (size_t)n / 4);
+    ODW_CHECK_LAUNCH("add_relu_f32_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_relu_bwd_f32(const float* dout, const float* out, float* g, int64_t n, void* stream_) {
+    ODW_REQUIRE(n >= 0 && n % 4 == 0, "relu_bwd_f32: n=%lld must be a multiple of 4", (long long)n);
+    if (n == 0) return ODW_OK;
+    ODW_REQUIRE(dout && out && g && ((((uintptr_t)dout) | ((uintptr_t)out) | ((uintptr_t)g)) & 15) == 0, "relu_bwd_f32: pointers");
+    add_relu_f32_kernel<true><<<blocks_for((size_t)n / 4), 256, 0, (hipStream_t)stream_>>>((const float4*)dout, (const float4*)out,
+                                                                                           (float4*)g, (size_t)n / 4);
+    ODW_CHECK_LAUNCH("add_relu_f32_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_maxpool3x3s2_nhwc_f32(const float* X, int B, int H, int W, int C, float* Y, void* stream_) {
+    ODW_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && X && Y, "maxpool3x3s2_f32: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t n = (size_t)B * Ho * Wo * C;
+    maxpool3x3s2_f32_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream_>>>(X, B, H, W, C, Ho, Wo, Y);
+    ODW_CHECK_LAUNCH("maxpool3x3s2_f32_kernel");
     return ODW_OK;
 }

@@ -1,0 +1,195 @@
+// split.hip -- fp32-grade products on the bf16 matrix cores by operand splitting ("bf16x3").
+//
+// The reference computes every Linear and convolution in fp32 (config/defaults.py:559 DTYPE float32;
+// modeling/backbone/vgg16.py:107-193).  gfx950's fp32-input MFMA peaks at 157 TFLOP/s, its bf16 MFMA at 2.5 PFLOP/s
+// with exact bf16 x bf16 products and fp32 accumulation -- so an fp32 value is carried as THREE bf16 planes
+//     x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)     (24 significand bits)
+// and a product a.b as the six plane products of total order <= 2
+//     hi.hi + hi.mid + hi.lo + mid.hi + mid.mid + lo.hi                                  (dropped terms <= 2^-24 |a.b|)
+// laid out along the REDUCTION axis: operand A holds the planes [hi hi hi mid mid lo], operand B [hi mid lo hi mid hi],
+// each `block` elements wide, and the unchanged MFMA kernels (gemm_nt_bf16_*, conv3x3_glds_kernel) run over
+// K' = T * block.  417 TFLOP/s-equivalent instead of 157, and the tuned tile pipeline instead of a second one.
+// The two kernels here produce those operands from fp32 tensors:
+//   split_rows : out[r][t*block + c] = plane_{pat[t]}(in[r][c])           (activations, weights: reduction along c)
+//   split_cols : out[c][t*block + r] = plane_{pat[t]}(in[r][c])           (weight gradients: reduction along r)
+// pat[t] in {0,1,2} = hi/mid/lo, 3 = a zero block (the convolution wants a power-of-two channel count: T = 8).
+#include "odw_common.h"
+
+namespace {
+
+constexpr int kMaxTerms = 8;
+
+struct Pattern { int T; int p[kMaxTerms]; };
+
+__device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// the three planes (+ a zero) of one value; both subtractions are exact in fp32
+__device__ __forceinline__ void planes(float x, unsigned short (&p)[4]) {
+    p[0] = f2bf(x);
+    p[1] = p[2] = p[3] = 0;
+    if ((__float_as_uint(x) & 0x7f800000u) == 0x7f800000u) return;      // inf / nan live in the hi plane alone
+    const float r1 = x - bf2f(p[0]);
+    p[1] = f2bf(r1);
+    const float r2 = r1 - bf2f(p[1]);
+    p[2] = f2bf(r2);
+}
+
+// one thread = 8 consecutive columns of one row: T 16-byte stores
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ in, long long ld_in, int R, int Cc,
+                                                         Pattern pat, unsigned short* __restrict__ out,
+                                                         long long ld_out, int block) {
+    const int chunks = block / 8;
+    const long long total = (long long)R * chunks;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / chunks), c0 = (int)(i % chunks) * 8;
+        const float* src = in + (long long)r * ld_in + c0;
+        unsigned short pl[8][4];
+        if (c0 + 8 <= Cc && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+            const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) planes(v[j], pl[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) planes(c0 + j < Cc ? src[j] : 0.0f, pl[j]);
+        }
+        unsigned short* dst = out + (long long)r * ld_out + c0;
+        for (int t = 0; t < pat.T; ++t) {
+            const int p = pat.p[t];
+            uint4 o;
+            o.x = (unsigned)pl[0][p] | ((unsigned)pl[1][p] << 16);
+            o.y = (unsigned)pl[2][p] | ((unsigned)pl[3][p] << 16);
+            o.z = (unsigned)pl[4][p] | ((unsigned)pl[5][p] << 16);
+            o.w = (unsigned)pl[6][p] | ((unsigned)pl[7][p] << 16);
+            *reinterpret_cast<uint4*>(dst + (long long)t * block) = o;
+        }
+    }
+}
+
+// 64 x 64 tile through LDS (fp32, padded rows): coalesced 256-byte reads along c, 16-byte writes along r
+__global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict__ in, long long ld_in, int R, int Cc,
+                                                         Pattern pat, unsigned short* __restrict__ out,
+                                                         long long ld_out, int block) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;         // 64 x 4
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = r0 + ty + 4 * k, c = c0 + tx;
+        tile[ty + 4 * k][tx] = (r < R && c < Cc) ? in[(long long)r * ld_in + c] : 0.0f;
+    }
+    __syncthreads();
+    // 64 output rows (c) x 8 chunks of 8 consecutive r: two items per thread
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = threadIdx.x + it * 256;
+        const int c = item & 63, q = item >> 6;                      // lanes walk c: LDS column stride 65 = conflict-free
+        if (c0 + c >= Cc || r0 + q * 8 >= block) continue;
+        unsigned short pl[8][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) planes(tile[q * 8 + j][c], pl[j]);
+        unsigned short* dst = out + (long long)(c0 + c) * ld_out + r0 + q * 8;
+        for (int t = 0; t < pat.T; ++t) {
+            const int p = pat.p[t];
+            uint4 o;
+            o.x = (unsigned)pl[0][p] | ((unsigned)pl[1][p] << 16);
+            o.y = (unsigned)pl[2][p] | ((unsigned)pl[3][p] << 16);
+            o.z = (unsigned)pl[4][p] | ((unsigned)pl[5][p] << 16);
+            o.w = (unsigned)pl[6][p] | ((unsigned)pl[7][p] << 16);
+            *reinterpret_cast<uint4*>(dst + (long long)t * block) = o;
+        }
+    }
+}
+
+// dZ = dY * [Y != 0] * scale in fp32 and db[n] += sum_m dZ[m][n]: the backward prologue of a Linear whose ReLU /
+// dropout were fused into the forward epilogue (the saved output is zero exactly where either one cut).  One
+// workgroup owns 64 columns: every bias-gradient entry has a single writer and a fixed summation order.
+template <bool Y_BF16>
+__global__ __launch_bounds__(256) void linear_bwd_mask_kernel(const float* __restrict__ dY, long long ld_dy,
+                                                              const void* __restrict__ Yv, long long ld_y, int M, int N,
+                                                              float scale, float* __restrict__ dZ, long long ld_z,
+                                                              float* __restrict__ db) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    float acc = 0.0f;
+    if (n < N) {
+        for (int m = ry; m < M; m += 4) {
+            float v = dY[(long long)m * ld_dy + n];
+            if (Yv) {
+                const bool on = Y_BF16
+                    ? (reinterpret_cast<const unsigned short*>(Yv)[(long long)m * ld_y + n] & 0x7fff) != 0
+                    : reinterpret_cast<const float*>(Yv)[(long long)m * ld_y + n] != 0.0f;
+                v = on ? v * scale : 0.0f;
+            }
+            dZ[(long long)m * ld_z + n] = v;
+            acc += v;
+        }
+    }
+    red[ry][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (db && ry == 0 && n < N) db[n] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+bool pattern_ok(const int* pattern, int T, Pattern& pat) {
+    if (!pattern || T < 1 || T > kMaxTerms) return false;
+    pat.T = T;
+    for (int t = 0; t < kMaxTerms; ++t) pat.p[t] = 3;
+    for (int t = 0; t < T; ++t) {
+        if (pattern[t] < 0 || pattern[t] > 3) return false;
+        pat.p[t] = pattern[t];
+    }
+    return true;
+}
+
+}  // namespace
+
+ODW_EXPORT int odw_split_rows_bf16(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
+                                   int64_t ld_out, int block, void* stream_) {
+    Pattern pat;
+    ODW_REQUIRE(pattern_ok(pattern, T, pat), "split_rows: pattern = up to %d plane codes in 0..3", kMaxTerms);
+    ODW_REQUIRE(R >= 0 && Cc >= 0 && ld_in >= Cc && block >= Cc && block % 8 == 0 && ld_out >= (int64_t)T * block && ld_out % 8 == 0,
+                "split_rows: bad dims R=%d C=%d block=%d", R, Cc, block);
+    if (R == 0 || block == 0) return ODW_OK;
+    ODW_REQUIRE(in && out && (((uintptr_t)out) & 15) == 0, "split_rows: pointers");
+    const long long total = (long long)R * (block / 8);
+    const long long blocks = (total + 255) / 256;
+    split_rows_kernel<<<(int)(blocks > 65536 ? 65536 : blocks), 256, 0, (hipStream_t)stream_>>>(
+        in, ld_in, R, Cc, pat, (unsigned short*)out, ld_out, block);
+    ODW_CHECK_LAUNCH("split_rows_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_split_cols_bf16(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
+                                   int64_t ld_out, int block, void* stream_) {
+    Pattern pat;
+    ODW_REQUIRE(pattern_ok(pattern, T, pat), "split_cols: pattern = up to %d plane codes in 0..3", kMaxTerms);
+    ODW_REQUIRE(R >= 0 && Cc >= 0 && ld_in >= Cc && block >= R && block % 8 == 0 && ld_out >= (int64_t)T * block && ld_out % 8 == 0,
+                "split_cols: bad dims R=%d C=%d block=%d", R, Cc, block);
+    if (Cc == 0 || block == 0) return ODW_OK;
+    ODW_REQUIRE(in && out && (((uintptr_t)out) & 15) == 0, "split_cols: pointers");
+    dim3 grid((Cc + 63) / 64, (block + 63) / 64);
+    split_cols_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(in, ld_in, R, Cc, pat, (unsigned short*)out, ld_out, block);
+    ODW_CHECK_LAUNCH("split_cols_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_linear_bwd_mask_f32(const float* dY, int64_t ld_dy, const void* Y, int y_is_bf16, int64_t ld_y, int M,
+                                       int N, float scale, float* dZ, int64_t ld_z, float* db, void* stream_) {
+    ODW_REQUIRE(M >= 0 && N >= 0 && ld_dy >= N && ld_z >= N && (!Y || ld_y >= N), "linear_bwd_mask: bad dims");
+    if (M == 0 || N == 0) return ODW_OK;
+    ODW_REQUIRE(dY && dZ, "linear_bwd_mask: null pointer");
+    const int grid = (N + 63) / 64;
+    if (y_is_bf16)
+        linear_bwd_mask_kernel<true><<<grid, 256, 0, (hipStream_t)stream_>>>(dY, ld_dy, Y, ld_y, M, N, scale, dZ, ld_z, db);
+    else
+        linear_bwd_mask_kernel<false><<<grid, 256, 0, (hipStream_t)stream_>>>(dY, ld_dy, Y, ld_y, M, N, scale, dZ, ld_z, db);
+    ODW_CHECK_LAUNCH("linear_bwd_mask_kernel");
+    return ODW_OK;
+}

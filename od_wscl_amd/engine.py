@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import precision
 from . import synthetic
 from .layers import linear as linear_layer
 from .modeling.detector import build_detection_model
@@ -40,20 +41,6 @@ def load_formula_weights(model, seed, overrides=None):
             bd = synthetic.init_buffers(bufs, seed)
             for n, b in model.named_buffers():
                 b.copy_(torch.from_numpy(bd[n]))
-
-
-def make_optimizer(cfg, model):
-    """torch.optim.SGD with the reference's parameter groups (solver/build.py:10-24) -- the
-    comparison path; the production path is FlatSGD below."""
-    groups = []
-    for key, value in model.named_parameters():
-        if not value.requires_grad:
-            continue
-        lr, wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
-        if "bias" in key:
-            lr, wd = cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR, cfg.SOLVER.WEIGHT_DECAY_BIAS
-        groups.append({"params": [value], "lr": lr, "weight_decay": wd})
-    return torch.optim.SGD(groups, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
 
 
 def lr_factor(cfg, iteration):
@@ -109,8 +96,7 @@ class FlatSGD(object):
         # (5C+12C) x 4096 matrix and one bias vector -- no torch.cat per step, one weight-gradient launch, one shadow
         pred = getattr(getattr(model, "roi_heads", None), "predictor", None)
         pred_w, pred_b = ([], [])
-        if (linear_layer.get_backend() == "hip_bf16" and hasattr(pred, "set_fused")
-                and os.environ.get("ODW_NO_PRED_FUSE") != "1"):
+        if hasattr(pred, "set_fused") and os.environ.get("ODW_NO_PRED_FUSE") != "1":
             heads = [getattr(pred, h) for h in pred.head_names]
             if all(h.weight.requires_grad and h.bias.requires_grad and h.weight.numel() % 4 == 0 for h in heads):
                 pred_w, pred_b = [h.weight for h in heads], [h.bias for h in heads]
@@ -159,18 +145,24 @@ class FlatSGD(object):
         if gemm_w:
             from . import gemm
 
+            split = precision.split_mode()
+
             def managed_shadow(weight, o):
                 sh = gemm.Shadow(weight)
-                sh.w = self.flat_w16[o:o + weight.numel()].view(weight.shape)
-                sh.wt = torch.empty((weight.shape[1], (weight.shape[0] + 63) // 64 * 64), dtype=torch.bfloat16, device=dev)
-                sh.managed = True
+                if not split:       # bf16: W is a slice of the flat shadow the SGD kernel rewrites, W^T refreshed in place
+                    sh.w = self.flat_w16[o:o + weight.numel()].view(weight.shape)
+                    sh.wt = torch.empty((weight.shape[1], (weight.shape[0] + 63) // 64 * 64), dtype=torch.bfloat16, device=dev)
+                    sh.managed = True
+                    sh.mode = "bf16"
+                # (split precision: the plane layouts are rebuilt from the fp32 master after each step, Shadow.refresh)
                 # Linears whose gradient is large enough for its read-modify-write to matter get ONE weight-gradient
                 # GEMM per step over all their evaluations (gemm.WgradBatch)
                 sh.batch = gemm.WgradBatch() if (weight.numel() >= (8 << 20) and os.environ.get("ODW_NO_WGRAD_BATCH") != "1") else None
                 self.shadows.append(sh)
                 return sh
 
-            self.flat_w16 = torch.empty(n_gemm, dtype=torch.bfloat16, device=dev)
+            if not split:
+                self.flat_w16 = torch.empty(n_gemm, dtype=torch.bfloat16, device=dev)
             for n, p in gemm_w:
                 if id(p) in pred_ids:
                     continue
@@ -188,6 +180,11 @@ class FlatSGD(object):
 
     def _refresh_shadows(self, initial=False):
         from . import gemm
+        if self.flat_w16 is None:           # split precision: invalidate, the next forward re-splits the fp32 master
+            for sh in self.shadows:
+                sh.version = -1
+                sh.w = sh.wt = None
+            return
         if initial:
             L.check(L.lib().odw_f32_to_bf16(L.ptr(self.flat_p), L.ptr(self.flat_w16), self.n_gemm, L.stream()),
                     "f32_to_bf16")
@@ -197,7 +194,7 @@ class FlatSGD(object):
 
     @staticmethod
     def _is_gemm_weight(model, name, p):
-        if linear_layer.get_backend() != "hip_bf16" or p.dim() != 2:
+        if p.dim() != 2:
             return False
         mod = model.get_submodule(name.rsplit(".", 1)[0])
         return isinstance(mod, linear_layer.Linear)
@@ -205,7 +202,7 @@ class FlatSGD(object):
     def sync_from_params(self):
         """After weights were loaded into the model (utils/checkpoint.load_checkpoint copies into the flat views):
         rebuild the bf16 shadows the matrix cores read."""
-        if self.flat_w16 is not None:
+        if self.shadows:
             self._refresh_shadows(initial=True)
 
     def set_iteration(self, iteration):
@@ -282,10 +279,14 @@ class FlatSGD(object):
 
 
 def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="hip"):
-    """backend "hip": Linear layers on the hand-written MFMA GEMM (bf16), fused SGD, flat buffers.
-    backend "torch": F.linear / torch.optim.SGD (fp32 or bf16 autocast) -- comparison only."""
-    hip = backend == "hip"
-    linear_layer.set_backend("hip_bf16" if hip else "torch")
+    """One training step on the gfx950 kernels: MFMA GEMMs / implicit-GEMM convolutions, fused flat SGD, flat-buffer
+    RCCL all-reduce.  dtype = arithmetic precision of the products (od_wscl_amd.precision): "bf16" (throughput) |
+    "bf16x3" (fp32-grade, the reference's DTYPE float32 on the bf16 matrix cores; "fp32" is an alias) | "bf16x2".
+    (The hipBLASLt / MIOpen / torch.optim comparison step lives in tools/torch_baseline.py, outside the product.)"""
+    if backend != "hip":
+        raise ValueError("od_wscl_amd.engine has one back end (the HIP kernels); the library comparison path is "
+                         "tools/torch_baseline.py")
+    precision.set_precision({"fp32": "bf16x3", "f32": "bf16x3"}.get(dtype, dtype))
     model = build_detection_model(cfg).to(device)
     load_formula_weights(model, 1)
     model.train()
@@ -301,67 +302,35 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             torch.cuda.synchronize()
             print("[odw] ok", tag, flush=True)
 
-    use_autocast = dtype == "bf16"
-    if hip:
-        conv = os.environ.get("ODW_CONV", "hip")
-        if conv == "hip" and use_autocast and cfg.MODEL.BACKBONE.CONV_BODY.startswith("VGG16"):
-            from .modeling.backbone.vgg16_hip import VGGBackboneHip
-            model.backbone_hip = VGGBackboneHip(model.backbone.body)
-            conv_desc = "od_wscl_amd HIP implicit-GEMM conv3x3 (NHWC bf16, MFMA)"
-        elif conv == "hip" and use_autocast and cfg.MODEL.BACKBONE.CONV_BODY.startswith("R-"):
-            from .modeling.backbone.resnet_hip import ResNetBackboneHip
-            model.backbone_hip = ResNetBackboneHip(model.backbone.body)
-            conv_desc = "od_wscl_amd HIP: 1x1 convs on the MFMA GEMM, implicit-GEMM conv3x3, folded frozen BN (NHWC bf16)"
-        else:
-            model.backbone_autocast = torch.bfloat16 if use_autocast else None
-            conv_desc = "torch/MIOpen (%s)" % ("bf16 autocast" if use_autocast else "f32")
-        model.roi_heads.loss_evaluator.amp = False
-        opt = FlatSGD(cfg, model, world)
-        model.roi_heads.head_grads_ready = opt.head_grads_ready
+    model.hip_body()
+    if cfg.MODEL.BACKBONE.CONV_BODY.startswith("VGG16"):
+        conv_desc = "od_wscl_amd HIP implicit-GEMM conv3x3 (NHWC, MFMA)"
+    else:
+        conv_desc = "od_wscl_amd HIP: 1x1 convs on the MFMA GEMM, implicit-GEMM conv3x3, folded frozen BN (NHWC)"
+    model.roi_heads.loss_evaluator.amp = False
+    opt = FlatSGD(cfg, model, world)
+    model.roi_heads.head_grads_ready = opt.head_grads_ready
 
-        def step(images, targets, rois, rand, iteration=None):
-            if iteration is not None:           # WarmupMultiStepLR + update_momentum (solver/lr_scheduler.py, trainer.py:38-51)
-                opt.set_iteration(iteration)
-            opt.begin_step()
-            losses, accs = model(images, targets, rois, rand=rand)
-            mark("forward")
-            loss = getattr(losses, "total", None)
-            if loss is None:
-                loss = sum(losses.values())
-            loss.backward()
-            mark("backward")
-            opt.all_reduce()
-            opt.step()
-            mark("optimizer")
-            if "loss" in debug:
-                print("[odw] losses", {k: round(float(v), 5) for k, v in losses.items()}, flush=True)
-            return losses, accs
-
-        info = {"gemm_backend": "od_wscl_amd HIP MFMA gemm_nt_bf16 (bf16 in, fp32 acc)",
-                "conv_backend": conv_desc, "optimizer": "od_wscl_amd fused flat SGD"}
-        return step, info
-
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], broadcast_buffers=False,
-                                                        bucket_cap_mb=128, gradient_as_bucket_view=True)
-    opt = make_optimizer(cfg, model)
-    model.roi_heads.loss_evaluator.amp = use_autocast
-
-    def step(images, targets, rois, rand):
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_autocast):
-            losses, accs = net(images, targets, rois, rand=rand)
+    def step(images, targets, rois, rand, iteration=None):
+        if iteration is not None:           # WarmupMultiStepLR + update_momentum (solver/lr_scheduler.py, trainer.py:38-51)
+            opt.set_iteration(iteration)
+        opt.begin_step()
+        losses, accs = model(images, targets, rois, rand=rand)
         mark("forward")
-        loss = sum(losses.values())
-        opt.zero_grad(set_to_none=True)
+        loss = getattr(losses, "total", None)
+        if loss is None:
+            loss = sum(losses.values())
         loss.backward()
         mark("backward")
+        opt.all_reduce()
         opt.step()
         mark("optimizer")
         if "loss" in debug:
             print("[odw] losses", {k: round(float(v), 5) for k, v in losses.items()}, flush=True)
         return losses, accs
 
-    info = {"gemm_backend": "torch/hipBLASLt (%s)" % dtype, "conv_backend": "torch/MIOpen (%s)" % dtype,
-            "optimizer": "torch.optim.SGD"}
+    step.model, step.optimizer = model, opt
+    mode = precision.get_precision()
+    info = {"gemm_backend": "od_wscl_amd HIP MFMA gemm_nt_bf16 (%s operands, fp32 acc)" % mode,
+            "conv_backend": conv_desc + " " + mode, "optimizer": "od_wscl_amd fused flat SGD", "precision": mode}
     return step, info

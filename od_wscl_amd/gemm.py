@@ -10,6 +10,7 @@ import ctypes
 import torch
 
 from . import _lib as L
+from . import precision as P
 from .utils.kernel_timer import kernel_timer
 
 
@@ -78,26 +79,38 @@ def transpose_bf16(x, rows, cols, out=None):
 
 
 class Shadow(object):
-    """bf16 copies of one fp32 weight: w (N x K) and wt (K x r64(N))."""
+    """bf16 copies of one fp32 weight the matrix cores read: w (N x K) and wt (K x r64(N)); in a split precision
+    mode (precision.py) the same two matrices as bf16 planes along the reduction axis: w (N x T*r64(K)),
+    wt (K x T*r64(N))."""
 
     def __init__(self, weight):
         self.weight = weight
         self.version = -1
+        self.mode = None
         self.w = None
         self.wt = None
-        self.managed = False      # True: the optimiser refreshes w / wt itself (engine.FlatSGD)
+        self.managed = False      # True: the optimiser refreshes w / wt itself (engine.FlatSGD, bf16 mode)
         self.batch = None         # gemm.WgradBatch: one weight-gradient GEMM per step over all evaluations
 
     def refresh(self):
         w = self.weight
-        if self.managed or (self.version == w._version and self.w is not None):
+        mode = P.get_precision()
+        if self.mode == mode and (self.managed or (self.version == w._version and self.w is not None)):
             return self
         n, k = w.shape
         assert k % 8 == 0, "in_features must be a multiple of 8"
         with torch.no_grad():
-            self.w = to_bf16(w.detach())
-            self.wt = transpose_bf16(w.detach(), n, k)
+            if P.split_mode():
+                wd = w.detach()
+                wd = wd if wd.stride(1) == 1 else wd.contiguous()
+                pb = P.patterns("gemm")[1]
+                self.w = P.split_rows(wd, pb, _r64(k))
+                self.wt = P.split_cols(wd, pb, _r64(n))
+            elif not self.managed or self.w is None:
+                self.w = to_bf16(w.detach())
+                self.wt = transpose_bf16(w.detach(), n, k)
         self.version = w._version
+        self.mode = mode
         return self
 
 
@@ -112,7 +125,8 @@ class WgradBatch(object):
         self.rows, self.filled, self.dzt, self.xt, self.kpad = [], 0, None, None, 0
 
     def register(self, m):
-        self.rows.append(_r64(m))
+        """Reserve the column block of an evaluation over m rows (split precision: one block per plane product)."""
+        self.rows.append(_r64(m) * (len(P.patterns("gemm")[0]) if P.split_mode() else 1))
         return len(self.rows) - 1
 
     def offset(self, slot):
@@ -256,7 +270,114 @@ class _FusedLinear(torch.autograd.Function):
         return dx, dw, None, None, None, None, None, None, None, None, None, None
 
 
+class _SplitLinear(torch.autograd.Function):
+    """The same fused Linear in a split precision mode (precision.py: "bf16x3" = fp32-grade): x, y and every gradient
+    are fp32 tensors; right before each of the three products (forward, input gradient, weight gradient) the two
+    operands are laid out as bf16 planes along the reduction axis (csrc/split.hip) and the unchanged MFMA GEMM runs
+    over K' = T * K with the same fused epilogue (bias, ReLU, counter-based dropout, accumulate)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, shadow, relu, drop_p, segs, timer_tag, grad_rows, row_ids, grad_mode):
+        sh = shadow.refresh()
+        pa, pb = P.patterns("gemm")
+        T = len(pa)
+        M, K = x.shape
+        N = weight.shape[0]
+        x32 = x if x.dtype == torch.float32 else x.float()
+        x32 = x32 if x32.stride(1) == 1 else x32.contiguous()
+        kp = _r64(K)
+        xs = P.split_rows(x32, pa, kp)
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        kernel_timer.layer = timer_tag and timer_tag + "_fwd"
+        gemm_nt(xs, sh.w, M, N, T * kp, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs, row_ids=row_ids)
+        kernel_timer.layer = None
+        del xs
+        ctx.save_for_backward(x32, y if (relu or drop_p > 0) else None, weight, bias)
+        slot = None
+        batch = getattr(sh, "batch", None)
+        if batch is not None and weight.is_leaf and weight.requires_grad and grad_mode:
+            slot = batch.register((grad_rows[1] - grad_rows[0]) if grad_rows is not None else M)
+        ctx.cfg = (sh, relu, drop_p, x.dtype, timer_tag, grad_rows, slot)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x32, y, weight, bias = ctx.saved_tensors
+        sh, relu, drop_p, x_dtype, tag, grad_rows, slot = ctx.cfg
+        pa, pb = P.patterns("gemm")
+        T = len(pa)
+        M_all, K = x32.shape
+        N = weight.shape[0]
+        dy = dy if dy.dtype == torch.float32 else dy.float()
+        dy = dy if dy.stride(1) == 1 else dy.contiguous()
+        if grad_rows is not None:
+            ra, rb = grad_rows[0], grad_rows[1]
+            dy, x32 = dy[ra:rb], x32[ra:rb]
+            y = y[ra:rb] if y is not None else None
+        M = x32.shape[0]
+        np_, m64 = _r64(N), _r64(M)
+        if bias is not None and bias.requires_grad:
+            if not bias.is_leaf:
+                raise RuntimeError("fused_linear: bias must be a leaf parameter, a constant or None")
+            if bias.grad is None:
+                bias.grad = torch.zeros_like(bias)
+            db = bias.grad
+        else:
+            db = None
+        scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+        dz = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+        L.check(L.lib().odw_linear_bwd_mask_f32(L.ptr(dy), dy.stride(0), L.ptr(y), 0, y.stride(0) if y is not None else 0,
+                                                M, N, scale, L.ptr(dz), N, L.ptr(db), L.stream()), "linear_bwd_mask_f32")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx_all = torch.empty((M_all, K), dtype=torch.float32, device=dy.device)
+            dx = dx_all
+            if grad_rows is not None:
+                if len(grad_rows) < 3 or grad_rows[2]:
+                    dx_all[:ra].zero_()
+                    dx_all[rb:].zero_()
+                dx = dx_all[ra:rb]
+            dzs = P.split_rows(dz, pa, np_)
+            kernel_timer.layer = tag and tag + "_dgrad"
+            gemm_nt(dzs, sh.wt, M, K, T * np_, dx)
+            kernel_timer.layer = None
+            del dzs
+            dx = dx_all if x_dtype == torch.float32 else dx_all.to(x_dtype)
+        dw = None
+        batch = sh.batch if slot is not None else None
+        if weight.requires_grad and batch is not None:
+            dzt_all, xt_all = batch.buffers(N, K, dy.device)
+            off = batch.offset(slot)
+            P.split_cols(dz, pa, m64, out=dzt_all[:, off:])
+            P.split_cols(x32, pb, m64, out=xt_all[:, off:])
+            batch.done[slot] = True
+            batch.filled += 1
+            if batch.filled == len(batch.rows):
+                batch.flush(weight, tag)
+        elif weight.requires_grad:
+            dzt = P.split_cols(dz, pa, m64)
+            xt = P.split_cols(x32, pb, m64)
+            if weight.is_leaf:
+                fresh = weight.grad is None or getattr(weight, "_odw_fresh", False)
+                if weight.grad is None:
+                    weight.grad = torch.empty_like(weight)
+                weight._odw_fresh = False
+                target = weight.grad
+            else:
+                fresh = True
+                target = dw = torch.empty_like(weight)
+            kernel_timer.layer = tag and tag + "_wgrad"
+            gemm_nt(dzt, xt, N, K, T * m64, target, accumulate=not fresh)
+            kernel_timer.layer = None
+        return dx, dw, None, None, None, None, None, None, None, None, None
+
+
 def fused_linear(x, weight, bias, shadow, relu=False, drop_p=0.0, segs=None, out_f32=False, tag=None, grad_rows=None,
                  row_ids=None):
+    """dropout(relu(x W^T + b)) on the matrix cores.  bf16 mode: bf16 operands, bf16 (or, out_f32, fp32) result;
+    split precision modes: fp32 in, fp32 out (precision.py)."""
+    if P.split_mode():
+        return _SplitLinear.apply(x, weight, bias, shadow, relu, drop_p, segs, tag, grad_rows, row_ids,
+                                  torch.is_grad_enabled())
     return _FusedLinear.apply(x, weight, bias, shadow, relu, drop_p, segs, out_f32, tag, grad_rows, row_ids,
                               torch.is_grad_enabled())      # (grad mode is always off INSIDE Function.forward)

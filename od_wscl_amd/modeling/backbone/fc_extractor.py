@@ -13,22 +13,24 @@ import torch.nn.functional as F
 from ..dropblock import DropBlock2D
 from ..poolers import Pooler
 from ... import _lib as L
-from ...layers import linear as linear_layer
+from ... import precision
 from ...layers.linear import Linear
 
 
 class _StackCleanAug(torch.autograd.Function):
-    """pooled (P,C,h,w) fp32 + DropBlock keep mask -> the bf16 (2P x C*h*w) operand of the first GEMM (rows 0..P-1 the
-    clean features, rows P..2P-1 the DropBlock view), one pass each way (csrc/head_aux.hip)."""
+    """pooled (P,C,h,w) fp32 + DropBlock keep mask -> the (2P x C*h*w) operand of the first GEMM (rows 0..P-1 the
+    clean features, rows P..2P-1 the DropBlock view), one pass each way (csrc/head_aux.hip); bf16, or fp32 in a
+    split precision mode (the GEMM front end lays it out as bf16 planes)."""
 
     @staticmethod
     def forward(ctx, pooled, block, block_sum, holder):
         P, C, h, w = pooled.shape
         S = h * w
         pooled = pooled.contiguous()
-        out = torch.empty((2 * P, C * S), dtype=torch.bfloat16, device=pooled.device)
-        L.check(L.lib().odw_stack_clean_aug(L.ptr(pooled), L.ptr(block), L.ptr(block_sum), P, C, S, L.ptr(out),
-                                            out.stride(0), L.stream()), "stack_clean_aug")
+        out = torch.empty((2 * P, C * S), dtype=precision.act_dtype(), device=pooled.device)
+        fn = L.lib().odw_stack_clean_aug_f32 if out.dtype == torch.float32 else L.lib().odw_stack_clean_aug
+        L.check(fn(L.ptr(pooled), L.ptr(block), L.ptr(block_sum), P, C, S, L.ptr(out), out.stride(0), L.stream()),
+                "stack_clean_aug")
         ctx.save_for_backward(block, block_sum)
         ctx.shape = (P, C, h, w)
         ctx.holder = holder
@@ -87,13 +89,20 @@ class _RowViews(torch.autograd.Function):
         CS = src.shape[1] if from_bf16 else src.shape[1] * src.shape[2] * src.shape[3]
         C = CS // S
         total = sum(g[2] for g in groups)
-        out = torch.empty((2 * total, CS), dtype=torch.bfloat16, device=src.device)
+        out = torch.empty((2 * total, CS), dtype=precision.act_dtype(), device=src.device)
         sums = torch.empty(len(groups), dtype=torch.float32, device=src.device)
         lib, st, row0 = L.lib(), L.stream(), 0
+        if out.dtype == torch.float32 and from_bf16:
+            raise RuntimeError("_RowViews: a split precision mode reads the fp32 pooled tensor, not a bf16 operand")
         for gi, (base, rows, k, kd, kn) in enumerate(groups):
-            L.check(lib.odw_rows_drop_noise(L.ptr(src), 1 if from_bf16 else 0, L.ptr(rows), base, k, C, S, gamma, kd[0],
-                                            kd[1], kn[0], kn[1], L.ptr(sums[gi:]), L.ptr(out), out.stride(0), row0, st),
-                    "rows_drop_noise")
+            if out.dtype == torch.float32:
+                L.check(lib.odw_rows_drop_noise_f32(L.ptr(src), L.ptr(rows), base, k, C, S, gamma, kd[0], kd[1], kn[0],
+                                                    kn[1], L.ptr(sums[gi:]), L.ptr(out), out.stride(0), row0, st),
+                        "rows_drop_noise_f32")
+            else:
+                L.check(lib.odw_rows_drop_noise(L.ptr(src), 1 if from_bf16 else 0, L.ptr(rows), base, k, C, S, gamma,
+                                                kd[0], kd[1], kn[0], kn[1], L.ptr(sums[gi:]), L.ptr(out), out.stride(0),
+                                                row0, st), "rows_drop_noise")
             row0 += 2 * k
         ctx.args = (groups, holder, gamma, tuple(src.shape), sums, C, S, from_bf16)
         return out
@@ -247,13 +256,11 @@ class TwoFCROIFeatureExtractor(nn.Module):
         the two dropouts are fused into the GEMM epilogues; `segs*` carry per-pass keys when
         several passes are stacked along the row dimension."""
         fc6, fc7 = self.fc6, self.fc7
-        if not self.training:
-            if linear_layer.get_backend() == "hip_bf16" and x.is_cuda:      # inference: MFMA GEMMs, ReLU in the epilogue
-                return fc7.fused(fc6.fused(x, relu=True), relu=True)
-            return torch.relu(fc7(torch.relu(fc6(x))))
-        if self.rand is None:
-            x = F.dropout(torch.relu(fc6(x)), 0.5, True)
-            return F.dropout(torch.relu(fc7(x)), 0.5, True)
+        if not self.training:                   # inference: ReLU in the GEMM epilogue
+            return fc7.fused(fc6.fused(x, relu=True), relu=True)
+        if self.rand is None:                   # torch's generator instead of the counter-based streams
+            x = F.dropout(fc6.fused(x, relu=True), 0.5, True)
+            return F.dropout(fc7.fused(x, relu=True), 0.5, True)
         if segs6 is None:
             k6, k7 = self.rand.key(), self.rand.key()
             segs6, segs7 = [(0, k6[0], k6[1])], [(0, k7[0], k7[1])]
@@ -266,7 +273,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
         order (clean fc6, clean fc7, DropBlock centres, aug fc6, aug fc7)."""
         P = pooled.shape[0]
         k1, k2 = self.rand.key(), self.rand.key()
-        fused = (linear_layer.get_backend() == "hip_bf16" and hasattr(self, "dropblock") and pooled.is_cuda
+        fused = (hasattr(self, "dropblock") and pooled.is_cuda and os.environ.get("ODW_NO_STACK_FUSE") != "1"
                  and pooled.dtype == torch.float32 and (pooled.shape[1] * pooled.shape[2] * pooled.shape[3]) % 64 == 0)
         if fused:
             # production path: the DropBlock view is never materialised in fp32 -- one kernel writes the stacked
@@ -298,7 +305,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
         stacked = pooled.dim() == 2 and pooled.dtype == torch.bfloat16
         res = self.pooler.output_size
         S = res[0] * res[1]
-        if not (linear_layer.get_backend() == "hip_bf16" and self.rand is not None and pooled.is_cuda
+        if not (self.rand is not None and pooled.is_cuda
                 and (stacked or pooled.dtype == torch.float32) and self.sim_drop.block_size == 1 and S >= 4
                 and (pooled[0].numel() % 64 == 0) and hasattr(self.rand, "key")):
             if stacked:
@@ -322,8 +329,9 @@ class TwoFCROIFeatureExtractor(nn.Module):
         return x, segs6, segs7
 
     def can_pool_stack(self, features):
-        """ROI pooling may write the stacked bf16 operand directly (csrc/roi_pool.hip: roi_pool_stack_*)."""
-        if not (linear_layer.get_backend() == "hip_bf16" and self.rand is not None and hasattr(self, "dropblock")
+        """ROI pooling may write the stacked bf16 operand directly (csrc/roi_pool.hip: roi_pool_stack_*; its 32-bit
+        (value, position) keys hold bf16 values: a split precision mode pools in fp32 with the operator form)."""
+        if not (not precision.split_mode() and self.rand is not None and hasattr(self, "dropblock")
                 and self.training and len(features) == 1 and os.environ.get("ODW_NO_POOL_STACK") != "1"):
             return False
         f = features[0]

@@ -17,6 +17,7 @@ from torch import nn
 
 from ... import _lib as L
 from ... import gemm
+from ... import precision as P
 from ...utils.kernel_timer import kernel_timer
 from .vgg16_hip import _conv3x3, _r64
 
@@ -74,21 +75,80 @@ class _Conv3x3Fn(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+class _SplitConv3x3Fn(torch.autograd.Function):
+    """The same layer in a split precision mode: fp32 rows in and out; the input (and, backward, dZ) are laid out as
+    bf16 planes along the channel axis, the weights along their (tap, channel) axis (csrc/split.hip), and the unchanged
+    implicit-GEMM kernel runs over T*C channels with an fp32 epilogue (see vgg16_hip._VGGSplitFn)."""
+
+    @staticmethod
+    def forward(ctx, x, w, shift, geom, zero_page, need_dx):
+        lib, st = L.lib(), L.stream()
+        B, H, W = geom
+        co, ci = w.shape[0], w.shape[1]
+        m = B * H * W
+        pa, pb = P.patterns("conv")
+        T = len(pa)
+        wd32 = w.detach()
+        wk = P.split_rows(wd32.permute(0, 2, 3, 1).reshape(co * 9, ci).contiguous(), pb, ci).view(co, -1)
+        wd = P.split_rows(wd32.permute(1, 2, 3, 0).reshape(ci * 9, co).contiguous(), pb, co).view(ci, -1) if need_dx else None
+        x = x.contiguous()
+        xs = P.split_rows(x, pa, ci)
+        y = torch.empty((m, co), dtype=torch.float32, device=x.device)
+        _conv3x3(lib, xs, m, H, W, T * ci, 1, 0, wk, co, y, shift, True, None, 0, zero_page, st, 2.0 * m * co * 9 * ci * T)
+        ctx.save_for_backward(x, y, wd, zero_page)
+        ctx.dims = (B, H, W, co, ci)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, wd, zero_page = ctx.saved_tensors
+        B, H, W, co, ci = ctx.dims
+        lib, st = L.lib(), L.stream()
+        m = B * H * W
+        m64 = _r64(m)
+        pa, _ = P.patterns("conv")
+        ga, gb = P.patterns("gemm")
+        T, Tg = len(pa), len(ga)
+        dy = dy.contiguous().float()
+        dz = torch.empty((m, co), dtype=torch.float32, device=dy.device)
+        L.check(lib.odw_linear_bwd_mask_f32(L.ptr(dy), co, L.ptr(y), 0, co, m, co, 1.0, L.ptr(dz), co, None, st), "conv bwd mask")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dzt = P.split_cols(dz, ga, m64)
+            planes = [P.split_rows(x, (p,), ci) for p in (0, 1, 2)]
+            colt = torch.empty((9 * ci, Tg * m64), dtype=torch.bfloat16, device=dy.device)
+            for t, pl in enumerate(gb):
+                L.check(lib.odw_im2col_t_bf16_part(L.ptr(planes[pl]), m, H, W, ci, 1, L.ptr(colt[:, t * m64:]), Tg * m64, m64, st),
+                        "im2col_t")
+            dwk = torch.empty((co, 9 * ci), dtype=torch.float32, device=dy.device)
+            gemm.gemm_nt(dzt, colt, co, 9 * ci, Tg * m64, dwk)
+            dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
+            L.check(lib.odw_conv_wgrad_unpack(L.ptr(dwk), 9 * ci, co, ci, ci, L.ptr(dw), st), "wgrad_unpack")
+        dx = None
+        if ctx.needs_input_grad[0] and wd is not None:
+            dx = torch.empty((m, ci), dtype=torch.float32, device=dy.device)
+            dzs = P.split_rows(dz, pa, co)
+            _conv3x3(lib, dzs, m, H, W, T * co, 1, 1, wd, ci, dx, None, False, None, 0, zero_page, st, 2.0 * m * co * 9 * ci * T)
+        return dx, dw, None, None, None, None
+
+
 class _AddReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
         out = torch.empty_like(a)
-        L.check(L.lib().odw_add_relu_bf16(L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.stream()), "add_relu")
+        fn = L.lib().odw_add_relu_f32 if a.dtype == torch.float32 else L.lib().odw_add_relu_bf16
+        L.check(fn(L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.stream()), "add_relu")
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         out, = ctx.saved_tensors
-        dout = dout.contiguous()
+        dout = dout.contiguous().to(out.dtype)
         g = torch.empty_like(out)
-        L.check(L.lib().odw_relu_bwd_bf16(L.ptr(dout), L.ptr(out), L.ptr(g), out.numel(), L.stream()), "relu_bwd")
+        fn = L.lib().odw_relu_bwd_f32 if out.dtype == torch.float32 else L.lib().odw_relu_bwd_bf16
+        L.check(fn(L.ptr(dout), L.ptr(out), L.ptr(g), out.numel(), L.stream()), "relu_bwd")
         return g, g
 
 
@@ -100,14 +160,23 @@ class _ToNCHW(torch.autograd.Function):
         B, H, W = geom
         C = x.shape[1]
         feat = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
-        L.check(L.lib().odw_nhwc_bf16_to_nchw_f32(L.ptr(x.contiguous()), B, H * W, C, L.ptr(feat), L.stream()), "nhwc_to_nchw")
+        if x.dtype == torch.float32:
+            L.check(L.lib().odw_nhwc_f32_to_nchw_f32(L.ptr(x.contiguous()), B, H * W, C, C, L.ptr(feat), L.stream()), "nhwc_to_nchw")
+        else:
+            L.check(L.lib().odw_nhwc_bf16_to_nchw_f32(L.ptr(x.contiguous()), B, H * W, C, L.ptr(feat), L.stream()), "nhwc_to_nchw")
         ctx.geom = geom
+        ctx.f32 = x.dtype == torch.float32
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         B, H, W = ctx.geom
         C = dfeat.shape[1]
+        if ctx.f32:
+            dx = torch.empty((B * H * W, C), dtype=torch.float32, device=dfeat.device)
+            L.check(L.lib().odw_nchw_f32_to_nhwc_f32(L.ptr(dfeat.contiguous().float()), B, H * W, C, C, L.ptr(dx), L.stream()),
+                    "nchw_to_nhwc")
+            return dx, None
         dx = torch.empty((B * H * W, C), dtype=torch.bfloat16, device=dfeat.device)
         L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(dfeat.contiguous().float()), B, H * W, C, C, L.ptr(dx), L.stream()),
                 "nchw_to_nhwc")
@@ -163,7 +232,8 @@ class ResNetBackboneHip(nn.Module):
         f = self._const(conv, bn)
         assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
         w = conv.weight * f.scale[:, None, None, None]
-        return _Conv3x3Fn.apply(x, w, f.shift, geom, self.zero_page, need_dx)
+        fn = _SplitConv3x3Fn if P.split_mode() else _Conv3x3Fn
+        return fn.apply(x, w, f.shift, geom, self.zero_page, need_dx)
 
     @staticmethod
     def _subsample(x, geom, stride):
@@ -201,12 +271,16 @@ class ResNetBackboneHip(nn.Module):
             f = self._const(stem.conv1, stem.bn1)
             co = stem.conv1.weight.shape[0]
             Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-            s = torch.empty((B * Ho * Wo, co), dtype=torch.bfloat16, device=dev)
-            L.check(lib.odw_stem_conv7x7_bn_relu(L.ptr(images), L.ptr(stem.conv1.weight.detach().float().contiguous()),
-                                                 L.ptr(f.scale), L.ptr(f.shift), B, H, W, co, L.ptr(s), st), "stem")
+            act = P.act_dtype()
+            f32 = act == torch.float32
+            s = torch.empty((B * Ho * Wo, co), dtype=act, device=dev)
+            stem_fn = lib.odw_stem_conv7x7_bn_relu_f32 if f32 else lib.odw_stem_conv7x7_bn_relu
+            L.check(stem_fn(L.ptr(images), L.ptr(stem.conv1.weight.detach().float().contiguous()),
+                            L.ptr(f.scale), L.ptr(f.shift), B, H, W, co, L.ptr(s), st), "stem")
             Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
-            x = torch.empty((B * Hp * Wp, co), dtype=torch.bfloat16, device=dev)
-            L.check(lib.odw_maxpool3x3s2_nhwc_bf16(L.ptr(s), B, Ho, Wo, co, L.ptr(x), st), "maxpool3x3s2")
+            x = torch.empty((B * Hp * Wp, co), dtype=act, device=dev)
+            pool_fn = lib.odw_maxpool3x3s2_nhwc_f32 if f32 else lib.odw_maxpool3x3s2_nhwc_bf16
+            L.check(pool_fn(L.ptr(s), B, Ho, Wo, co, L.ptr(x), st), "maxpool3x3s2")
         geom = (B, Hp, Wp)
         seen_trainable = False
         for name in body.stages:
@@ -219,5 +293,5 @@ class ResNetBackboneHip(nn.Module):
                     with torch.no_grad():
                         x, geom = self._block(x, geom, blk, need_dx=False)
         feat = _ToNCHW.apply(x, geom)
-        feat._odw_nhwc = x.detach()     # the NHWC bf16 map itself: the fused ROI pooling reads it directly
+        feat._odw_nhwc = x.detach() if x.dtype == torch.bfloat16 else None     # the NHWC bf16 map: the fused ROI pooling reads it
         return [feat]

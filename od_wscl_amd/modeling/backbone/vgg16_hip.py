@@ -14,6 +14,7 @@ from torch import nn
 
 from ... import _lib as L
 from ... import gemm
+from ... import precision as P
 from ...utils.kernel_timer import kernel_timer
 
 
@@ -22,7 +23,7 @@ def _r64(n):
 
 
 class _Layer(object):
-    __slots__ = ("conv", "cin", "cp", "cout", "dil", "relu", "pool", "trainable", "wk", "wd")
+    __slots__ = ("conv", "cin", "cp", "cout", "dil", "relu", "pool", "trainable", "wk", "wd", "mode")
 
 
 def _layers_of(features):
@@ -40,21 +41,23 @@ def _layers_of(features):
             j = i + (2 if l.relu else 1)
             l.pool = j < len(mods) and isinstance(mods[j], nn.MaxPool2d)
             l.trainable = m.weight.requires_grad
-            l.wk = l.wd = None
+            l.wk = l.wd = l.mode = None
             out.append(l)
         i += 1
     return out
 
 
 def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask, zero_page, st, flops):
-    """One implicit-GEMM convolution; the launcher's split-K workspace (deep layers) comes from torch's allocator."""
+    """One implicit-GEMM convolution (y bf16 or fp32); the launcher's split-K workspace (deep layers) comes from
+    torch's allocator."""
     ws_bytes = lib.odw_conv3x3_workspace(m, c, n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=y.device) if ws_bytes else None
-    sym = "conv3x3_glds_kernel<false> split-K+reduce" if ws_bytes else "conv3x3_glds_kernel<true>"
+    out_bf16 = y.dtype == torch.bfloat16
+    sym = "conv3x3_glds_kernel<false> split-K+reduce" if ws_bytes else ("conv3x3_glds_kernel<%s>" % ("true" if out_bf16 else "false"))
     with kernel_timer.region(sym, flops=flops):
-        L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, w, c, dil, mirror, L.ptr(wk), wk.stride(0), n, L.ptr(y), n, 1,
-                                             L.ptr(bias), 1 if relu else 0, L.ptr(mask), ldmask, L.ptr(zero_page),
-                                             L.ptr(ws), ws_bytes, st), "conv3x3")
+        L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, w, c, dil, mirror, L.ptr(wk), wk.stride(0), n, L.ptr(y), n,
+                                             1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0, L.ptr(mask), ldmask,
+                                             L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv3x3")
 
 
 class _VGGFn(torch.autograd.Function):
@@ -149,6 +152,104 @@ class _VGGFn(torch.autograd.Function):
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+class _VGGSplitFn(torch.autograd.Function):
+    """The same backbone node in a split precision mode (precision.py, "bf16x3" = fp32-grade): activations are fp32
+    NHWC between kernels; each convolution's input is laid out as bf16 planes along the channel axis
+    (csrc/split.hip: [hi hi hi mid mid lo 0 0] x Cp channels against weights packed [hi mid lo hi mid hi 0 0]) and
+    the unchanged implicit-GEMM kernel runs over 8*Cp channels with an fp32 epilogue.  Weight gradient: the planes
+    of dZ^T and of the transposed im2col as column blocks of the split-K GEMM's operands."""
+
+    @staticmethod
+    def forward(ctx, images, net, *params):
+        lib = L.lib()
+        B, C, H, W = images.shape
+        dev = images.device
+        st = L.stream()
+        pa, _ = P.patterns("conv")
+        T = len(pa)
+        x = torch.empty((B * H * W, 8), dtype=torch.float32, device=dev)
+        L.check(lib.odw_nchw_f32_to_nhwc_f32(L.ptr(images.contiguous()), B, H * W, C, 8, L.ptr(x), st), "nchw_to_nhwc_f32")
+        saved = []
+        h, w = H, W
+        for l in net.layers:
+            m = B * h * w
+            xs = P.split_rows(x, pa, l.cp)
+            y = torch.empty((m, l.cout), dtype=torch.float32, device=dev)
+            _conv3x3(lib, xs, m, h, w, T * l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
+                     2.0 * m * l.cout * 9 * l.cin * T)
+            del xs
+            pre = None
+            if l.pool:
+                pre = y
+                p = torch.empty((B * (h // 2) * (w // 2), l.cout), dtype=torch.float32, device=dev)
+                L.check(lib.odw_maxpool2x2_nhwc_f32(L.ptr(y), B, h, w, l.cout, L.ptr(p), st), "maxpool_f32")
+                y = p
+            saved.append((x if l.trainable else None, pre if l.trainable else None, h, w))
+            if l.pool:
+                h, w = h // 2, w // 2
+            x = y
+        cl = net.layers[-1].cout
+        feat = torch.empty((B, cl, h, w), dtype=torch.float32, device=dev)
+        L.check(lib.odw_nhwc_f32_to_nchw_f32(L.ptr(x), B, h * w, cl, cl, L.ptr(feat), st), "nhwc_to_nchw_f32")
+        ctx.net, ctx.saved_acts, ctx.batch = net, saved, B
+        net.last_nhwc = None
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        lib = L.lib()
+        net, saved, B = ctx.net, ctx.saved_acts, ctx.batch
+        st = L.stream()
+        dev = dfeat.device
+        pa, _ = P.patterns("conv")
+        ga, gb = P.patterns("gemm")
+        T, Tg = len(pa), len(ga)
+        _, C, h, w = dfeat.shape
+        dz = torch.empty((B * h * w, C), dtype=torch.float32, device=dev)
+        L.check(lib.odw_nchw_f32_to_nhwc_f32(L.ptr(dfeat.contiguous().float()), B, h * w, C, C, L.ptr(dz), st), "nchw_to_nhwc_f32")
+        first = min(i for i, l in enumerate(net.layers) if l.trainable)
+        for li in range(len(net.layers) - 1, first - 1, -1):
+            l = net.layers[li]
+            x_in, pre, h, w = saved[li]
+            if l.pool:
+                d_pre = torch.empty((B * h * w, l.cout), dtype=torch.float32, device=dev)
+                L.check(lib.odw_maxpool2x2_nhwc_f32_bwd(L.ptr(pre), L.ptr(dz), B, h, w, l.cout, L.ptr(d_pre), st), "maxpool_f32_bwd")
+                dz = d_pre
+            m = B * h * w
+            m64 = _r64(m)
+            if getattr(net, "debug", None) is not None:
+                net.debug[li] = dz.reshape(B, h, w, l.cout).permute(0, 3, 1, 2).clone()
+            conv = l.conv
+            if conv.bias.grad is None:
+                conv.bias.grad = torch.zeros_like(conv.bias)
+            if conv.weight.grad is None:
+                conv.weight.grad = torch.empty_like(conv.weight)
+            # bias gradient = column sums of dZ (single writer per entry; dZ passes through unchanged)
+            L.check(lib.odw_linear_bwd_mask_f32(L.ptr(dz), l.cout, None, 0, 0, m, l.cout, 1.0, L.ptr(dz), l.cout,
+                                                L.ptr(conv.bias.grad), st), "conv bias grad")
+            # weight gradient: dWk[co][tap*Cp+ci] = sum over pixels and plane products
+            dzt = P.split_cols(dz, ga, m64)                                   # (Cout, Tg*m64)
+            planes = [P.split_rows(x_in, (p,), l.cp) for p in (0, 1, 2)]      # hi / mid / lo of the layer input, NHWC bf16
+            colt = torch.empty((9 * l.cp, Tg * m64), dtype=torch.bfloat16, device=dev)
+            for t, pl in enumerate(gb):
+                L.check(lib.odw_im2col_t_bf16_part(L.ptr(planes[pl]), m, h, w, l.cp, l.dil, L.ptr(colt[:, t * m64:]),
+                                                   Tg * m64, m64, st), "im2col_t")
+            dwk = torch.empty((l.cout, 9 * l.cp), dtype=torch.float32, device=dev)
+            gemm.gemm_nt(dzt, colt, l.cout, 9 * l.cp, Tg * m64, dwk)
+            L.check(lib.odw_conv_wgrad_unpack(L.ptr(dwk), 9 * l.cp, l.cout, l.cin, l.cp, L.ptr(conv.weight.grad), st),
+                    "wgrad_unpack")
+            del dzt, colt
+            if li > first:
+                prev = net.layers[li - 1]
+                dzs = P.split_rows(dz, pa, l.cout)
+                dx = torch.empty((m, l.cin), dtype=torch.float32, device=dev)
+                mask = planes[0] if (prev.relu and not prev.pool) else None     # hi plane: zero exactly where x_in is
+                _conv3x3(lib, dzs, m, h, w, T * l.cout, l.dil, 1, l.wd, l.cin, dx, None, False, mask,
+                         l.cp if mask is not None else 0, net.zero_page, st, 2.0 * m * l.cout * 9 * l.cin * T)
+                dz = dx
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
 class VGGBackboneHip(nn.Module):
     """Drop-in for VGG_Base.forward: same parameters, gfx950 kernels."""
 
@@ -166,16 +267,31 @@ class VGGBackboneHip(nn.Module):
         if self.zero_page is None:
             self.zero_page = torch.zeros(64, dtype=torch.bfloat16, device=dev)
         first = min(i for i, l in enumerate(self.layers) if l.trainable) if any(l.trainable for l in self.layers) else 99
+        mode = P.get_precision()
         for i, l in enumerate(self.layers):
-            if not l.trainable and self._frozen_ready:
+            if not l.trainable and self._frozen_ready and l.mode == mode:
                 continue
-            if l.wk is None:
+            if P.split_mode():
+                # packed weights as bf16 planes: rows (co, tap) x [T blocks of Cp] and rows (ci, tap) x [T blocks of Cout]
+                _, pb = P.patterns("conv")
+                wt = l.conv.weight.detach()
+                wr = torch.zeros((l.cout, 9, l.cp), dtype=torch.float32, device=dev)
+                wr[:, :, :l.cin] = wt.permute(0, 2, 3, 1).reshape(l.cout, 9, l.cin)
+                l.wk = P.split_rows(wr.view(l.cout * 9, l.cp), pb, l.cp).view(l.cout, -1)
+                l.wd = None
+                if l.trainable and i > first:
+                    wr2 = wt.permute(1, 2, 3, 0).reshape(l.cin * 9, l.cout).contiguous()
+                    l.wd = P.split_rows(wr2, pb, l.cout).view(l.cin, -1)
+                l.mode = mode
+                continue
+            if l.wk is None or l.mode != mode:
                 l.wk = torch.empty((l.cout, _r64(9 * l.cp)), dtype=torch.bfloat16, device=dev)
                 if l.trainable and i > first:
                     l.wd = torch.empty((l.cin, _r64(9 * l.cout)), dtype=torch.bfloat16, device=dev)
             L.check(lib.odw_conv_weight_prep(L.ptr(l.conv.weight.detach()), l.cout, l.cin, l.cp, L.ptr(l.wk), l.wk.stride(0),
                                              L.ptr(l.wd), l.wd.stride(0) if l.wd is not None else 0, L.stream()),
                     "conv_weight_prep")
+            l.mode = mode
         self._frozen_ready = True
 
     def forward(self, images):
@@ -183,6 +299,7 @@ class VGGBackboneHip(nn.Module):
         with torch.no_grad():
             self._prep()
         params = [p for l in self.layers for p in (l.conv.weight, l.conv.bias)]
-        feat = _VGGFn.apply(images.float(), self, *params)
+        fn = _VGGSplitFn if P.split_mode() else _VGGFn
+        feat = fn.apply(images.float(), self, *params)
         feat._odw_nhwc = self.last_nhwc
         return [feat]

@@ -15,6 +15,20 @@ class GeneralizedRCNN(nn.Module):
         self.backbone = build_backbone(cfg)
         self.roi_heads = build_roi_weak_head(cfg, self.backbone.out_channels)
 
+    def hip_body(self):
+        """The HIP rendition of self.backbone.body (created on first use: it allocates device constants)."""
+        hip = getattr(self, "backbone_hip", None)
+        if hip is None:
+            body = self.backbone.body
+            if type(body).__name__ == "VGG_Base":
+                from ..backbone.vgg16_hip import VGGBackboneHip
+                hip = VGGBackboneHip(body)
+            else:
+                from ..backbone.resnet_hip import ResNetBackboneHip
+                hip = ResNetBackboneHip(body)
+            self.backbone_hip = hip
+        return hip
+
     def forward(self, images, targets=None, rois=None, model_cdb=None, iteration=None, rand=None):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
@@ -22,15 +36,9 @@ class GeneralizedRCNN(nn.Module):
             raise ValueError("precomputed proposals (rois) are required")
         if rand is not None:
             self.roi_heads.set_rand(rand)
-        hip = getattr(self, "backbone_hip", None)
-        amp = getattr(self, "backbone_autocast", None)
-        if hip is not None:                  # NHWC bf16 implicit-GEMM convolutions (modeling/backbone/vgg16_hip.py)
-            features = hip(images.tensors)
-        elif amp is not None:
-            with torch.autocast("cuda", dtype=amp):
-                features = [f.float() for f in self.backbone(images.tensors)]
-        else:
-            features = self.backbone(images.tensors)
+        # the body runs on the gfx950 kernels (NHWC implicit-GEMM convolutions, modeling/backbone/vgg16_hip.py /
+        # resnet_hip.py); `self.backbone` only owns the reference-named parameters -- there is no library path
+        features = self.hip_body()(images.tensors)
         x, result, losses, accuracy = self.roi_heads(features, rois, targets, model_cdb, iteration)
         if self.training:
             return (losses if isinstance(losses, dict) else dict(losses)), accuracy

@@ -3,10 +3,9 @@ L2-normalised rows.  On the gfx950 back end both Linears run on the MFMA GEMM (R
 the first epilogue, fp32 output from the second so the normalisation sees full precision)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .... import _lib as L
-from ....layers.linear import Linear, get_backend
+from ....layers.linear import Linear
 
 
 class _L2NormRows(torch.autograd.Function):
@@ -43,10 +42,6 @@ class Sim_Net(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, roi_feat):
-        if get_backend() == "hip_bf16":
-            h = self.mlp[0].fused(roi_feat, relu=True)
-            e = self.mlp[2].fused(h, out_f32=True)
-            if e.is_cuda and e.dtype == torch.float32:
-                return _L2NormRows.apply(e, 1e-12)
-            return F.normalize(e, dim=1)
-        return F.normalize(self.mlp(roi_feat), dim=1)
+        h = self.mlp[0].fused(roi_feat, relu=True)
+        e = self.mlp[2].fused(h, out_f32=True)
+        return _L2NormRows.apply(e, 1e-12)

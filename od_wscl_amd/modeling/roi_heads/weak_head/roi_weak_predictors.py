@@ -9,7 +9,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import registry
-from ....layers.linear import get_backend
+from .... import gemm
 
 _HEADS = ("cls_score", "det_score", "ref1", "bbox_pred1", "ref2", "bbox_pred2", "ref3", "bbox_pred3")
 
@@ -38,19 +38,15 @@ class MISTPredictor(nn.Module):
     def forward(self, x, proposals):
         assert x.dim() == 2
         heads = [getattr(self, n) for n in _HEADS]
-        if self._fused is not None and self.training and get_backend() == "hip_bf16" and x.is_cuda:
-            from .... import gemm
+        if not x.is_cuda:
+            raise RuntimeError("MISTPredictor: tensor is not on the GPU -- the hot path has no CPU implementation")
+        if self._fused is not None and self.training:
             w_cat, b_cat, shadow = self._fused
             out = gemm.fused_linear(x, w_cat, b_cat, shadow, out_f32=True, tag="predictor")
-        elif get_backend() == "hip_bf16" and x.is_cuda:
-            from .... import gemm
-            w = torch.cat([h.weight for h in heads], dim=0)
-            b = torch.cat([h.bias for h in heads], dim=0)
-            out = gemm.fused_linear(x, w, None, gemm.Shadow(w), out_f32=True, tag="predictor") + b
         else:
             w = torch.cat([h.weight for h in heads], dim=0)
             b = torch.cat([h.bias for h in heads], dim=0)
-            out = F.linear(x, w, b)
+            out = gemm.fused_linear(x, w, None, gemm.Shadow(w), out_f32=True, tag="predictor") + b
         out = out.split([h.out_features for h in heads], dim=1)
         cls, det, r1, b1, r2, b2, r3, b3 = out
         if not self.training:       # roi_weak_predictors.py:167-181

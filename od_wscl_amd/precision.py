@@ -1,0 +1,99 @@
+"""Arithmetic precision of the MFMA products (Linear layers and convolutions) of the hot path.
+
+  "bf16"   : operands rounded to bf16 once, fp32 accumulation -- the throughput mode (BASELINE.json north_star:
+             "backbone convs and the ROI-head FC use MFMA bf16 tiles").
+  "bf16x3" : fp32-grade.  Every operand is carried as three bf16 planes hi + mid + lo laid out along the reduction
+             axis and the SAME MFMA kernels accumulate the six plane products of order <= 2 (csrc/split.hip) --
+             the reference's arithmetic (config/defaults.py:559 DTYPE float32) to ~2^-24 per product, on the bf16
+             matrix cores (2.5 PF / 6 = 417 TF-equivalent against 157 TF for the fp32-input MFMA).  Activations
+             stay fp32 between kernels.  This is the mode in which the 1e-3 loss / bit-exact selection parity with
+             the reference's goldens is asserted (tests/test_e2e_gpu.py).
+  "bf16x2" : two planes, three products (hi.hi + hi.mid + mid.hi): ~2^-16 per product at half the cost of bf16x3.
+
+One process-wide setting: every kernel of a step must agree on the activation dtype between kernels."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+_MODE = "bf16"
+
+# plane codes along the reduction axis: 0 = hi, 1 = mid, 2 = lo, 3 = zeros.  The t-th block of operand A meets the
+# t-th block of operand B, so (A[t], B[t]) enumerates the plane products that are summed.
+_PATTERNS = {
+    # GEMM operands: any number of blocks
+    ("bf16x3", "gemm"): ((0, 0, 0, 1, 1, 2), (0, 1, 2, 0, 1, 0)),
+    ("bf16x2", "gemm"): ((0, 0, 1), (0, 1, 0)),
+    # convolution operands: the implicit-GEMM kernel wants a power-of-two channel count -> pad with zero blocks
+    ("bf16x3", "conv"): ((0, 0, 0, 1, 1, 2, 3, 3), (0, 1, 2, 0, 1, 0, 3, 3)),
+    ("bf16x2", "conv"): ((0, 0, 1, 1), (0, 1, 0, 1)),
+}
+
+
+def set_precision(name):
+    global _MODE
+    if name not in ("bf16", "bf16x3", "bf16x2"):
+        raise ValueError("precision %r (bf16 | bf16x3 | bf16x2)" % (name,))
+    _MODE = name
+
+
+def get_precision():
+    return _MODE
+
+
+def split_mode():
+    """True when operands are split into bf16 planes (activations are fp32 between kernels)."""
+    return _MODE != "bf16"
+
+
+def act_dtype():
+    return torch.float32 if split_mode() else torch.bfloat16
+
+
+def patterns(kind="gemm"):
+    """(pattern of operand A, pattern of operand B) for the current mode."""
+    return _PATTERNS[(_MODE, kind)]
+
+
+def r64(n):
+    return (n + 63) // 64 * 64
+
+
+_PAT_C = {}
+
+
+def _c_pattern(pat):
+    a = _PAT_C.get(pat)
+    if a is None:
+        a = _PAT_C[pat] = (ctypes.c_int * len(pat))(*pat)
+    return a
+
+
+def split_rows(x, pat, block=None, out=None):
+    """x (R, C) fp32 -> (R, T*block) bf16: block t holds plane pat[t] of x, zero padded from C to `block`
+    (default: C rounded up to 64).  Reduction along the columns of x."""
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    R, C = x.shape
+    block = r64(C) if block is None else block
+    T = len(pat)
+    if out is None:
+        out = torch.empty((R, T * block), dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().odw_split_rows_bf16(L.ptr(x), x.stride(0), R, C, ctypes.cast(_c_pattern(pat), ctypes.c_void_p), T,
+                                        L.ptr(out), out.stride(0), block, L.stream()), "split_rows_bf16")
+    return out
+
+
+def split_cols(x, pat, block=None, out=None):
+    """x (R, C) fp32 -> (C, T*block) bf16: out[c][t*block + r] = plane pat[t] of x[r][c], zero padded from R to
+    `block` (default: R rounded up to 64).  Reduction along the rows of x.  `out` may be a column-block view of a
+    wider matrix (weight-gradient batches)."""
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    R, C = x.shape
+    block = r64(R) if block is None else block
+    T = len(pat)
+    if out is None:
+        out = torch.empty((C, T * block), dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().odw_split_cols_bf16(L.ptr(x), x.stride(0), R, C, ctypes.cast(_c_pattern(pat), ctypes.c_void_p), T,
+                                        L.ptr(out), out.stride(0), block, L.stream()), "split_cols_bf16")
+    return out

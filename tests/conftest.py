@@ -17,12 +17,12 @@ def pytest_configure(config):
 
 @pytest.fixture(autouse=True)
 def _parity_backend_by_default():
-    """Every test starts with the Linear layers on the parity back end ("torch", fp32): engine.build_training_step
-    switches the process-wide setting to the bf16 MFMA kernels and nothing switches it back."""
-    from od_wscl_amd.layers import linear as ll
-    ll.set_backend("torch")
+    """Every test starts in the fp32-grade precision mode ("bf16x3": the mode the reference goldens are asserted in);
+    engine.build_training_step switches the process-wide setting to its dtype argument and nothing switches it back."""
+    from od_wscl_amd import precision as ll
+    ll.set_precision("bf16x3")
     yield
-    ll.set_backend("torch")
+    ll.set_precision("bf16x3")
 
 
 @pytest.fixture(scope="session")

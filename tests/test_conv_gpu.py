@@ -9,6 +9,15 @@ from od_wscl_amd.utils import rng
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _bf16_precision():
+    """These tests pin the bf16 kernels against fp32 references on bf16-rounded operands (the fp32-grade split mode
+    has its own file, test_split_gpu.py)."""
+    from od_wscl_amd import precision
+    precision.set_precision("bf16")
+    yield
+
+
 def rnd(seed, shape, scale=1.0):
     n = int(np.prod(shape))
     return torch.from_numpy((rng.normal(seed, 1, n) * scale).reshape(shape)).cuda()

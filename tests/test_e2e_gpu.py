@@ -142,13 +142,13 @@ def test_bf16_mfma_backend_tracks_the_reference(name, weights_np):
     selection); the image-level and first-branch losses must stay within a few per cent of the reference."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from od_wscl_amd.layers import linear as ll
+    from od_wscl_amd import precision as ll
     from od_wscl_amd.modeling.backbone.vgg16_hip import VGGBackboneHip
     from od_wscl_amd.structures import BoxList, to_image_list
     from od_wscl_amd.utils.device_rand import DeviceRand
     g = load_e2e(name)
     seed, batch, boxes, labels, cfg = e2e_inputs(g)
-    ll.set_backend("hip_bf16")
+    ll.set_precision("bf16")
     try:
         model = build_model(cfg["pooler"], weights_np, "fused")
         model.backbone_hip = VGGBackboneHip(model.backbone.body)
@@ -172,7 +172,7 @@ def test_bf16_mfma_backend_tracks_the_reference(name, weights_np):
         ref = float(g["gradnorm/roi_heads.feature_extractor.classifier.1.weight"])
         assert abs(gn - ref) <= 0.15 * ref, (gn, ref)
     finally:
-        ll.set_backend("torch")
+        ll.set_precision("bf16x3")
 
 
 def test_engine_step_fused_predictor_equals_unfused(monkeypatch):

@@ -1,5 +1,7 @@
 """csrc/head_aux.hip: the stacked clean + DropBlock GEMM operand and its gradient against the straight PyTorch
 rendition of the reference's DropBlock2D.forward (modeling/dropblock/drop_block.py:45-50) + flatten + cat + cast."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -46,14 +48,14 @@ def test_stacked_path_equals_unfused_path():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from od_wscl_amd.config import make_defaults
-    from od_wscl_amd.layers import linear as ll
+    from od_wscl_amd import precision as ll
     from od_wscl_amd.modeling.backbone import fc_extractor as fx
     from od_wscl_amd.modeling.backbone.vgg16 import VGG16FC67ROIFeatureExtractor
     from od_wscl_amd.utils.device_rand import DeviceRand
     cfg = make_defaults()
     cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
                          "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,), "DB.METHOD", "dropblock"])
-    ll.set_backend("hip_bf16")
+    ll.set_precision("bf16")
     try:
         torch.manual_seed(0)
         fe = VGG16FC67ROIFeatureExtractor(cfg, 512).cuda().train()
@@ -62,13 +64,11 @@ def test_stacked_path_equals_unfused_path():
         for fused in (True, False):
             fe.rand = DeviceRand(77)
             p = pooled.clone().requires_grad_(True)
-            real = fx.linear_layer.get_backend
-            if not fused:
-                fx.linear_layer.get_backend = lambda: "no-fusion"      # only steers the branch in forward_clean_and_aug
+            os.environ["ODW_NO_STACK_FUSE"] = "0" if fused else "1"      # only steers the branch in forward_clean_and_aug
             try:
                 c, a = fe.forward_clean_and_aug(p)
             finally:
-                fx.linear_layer.get_backend = real
+                os.environ.pop("ODW_NO_STACK_FUSE", None)
             (c.float().square().sum() + a.float().sum()).backward()
             res.append((c.float(), a.float(), p.grad.clone(), fe.rand.s.next))
         assert res[0][3] == res[1][3]                                  # same number of random draws
@@ -77,7 +77,7 @@ def test_stacked_path_equals_unfused_path():
         d = (res[0][2] - res[1][2]).abs().max().item()
         assert d <= 1e-2 * res[1][2].abs().max().item(), d
     finally:
-        ll.set_backend("torch")
+        ll.set_precision("bf16x3")
 
 
 def test_sampled_row_views_equal_the_unfused_ops():
@@ -87,13 +87,13 @@ def test_sampled_row_views_equal_the_unfused_ops():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from od_wscl_amd.config import make_defaults
-    from od_wscl_amd.layers import linear as ll
+    from od_wscl_amd import precision as ll
     from od_wscl_amd.modeling.backbone.vgg16 import VGG16FC67ROIFeatureExtractor
     from od_wscl_amd.utils.device_rand import DeviceRand
     cfg = make_defaults()
     cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
                          "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,), "DB.METHOD", "dropblock"])
-    ll.set_backend("hip_bf16")
+    ll.set_precision("bf16")
     try:
         torch.manual_seed(1)
         fe = VGG16FC67ROIFeatureExtractor(cfg, 512).cuda().train()
@@ -133,7 +133,7 @@ def test_sampled_row_views_equal_the_unfused_ops():
         sel = torch.tensor([3, 17, 18, 33, 40], device="cuda")
         assert (p1.grad[sel] - p2.grad[sel]).abs().max().item() <= 2e-2 * p2.grad[sel].abs().max().item()
     finally:
-        ll.set_backend("torch")
+        ll.set_precision("bf16x3")
 
 
 def test_l2norm_rows_kernels():
@@ -164,7 +164,7 @@ def test_pool_stack_equals_pool_then_stack(monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from od_wscl_amd.config import make_defaults
-    from od_wscl_amd.layers import linear as ll
+    from od_wscl_amd import precision as ll
     from od_wscl_amd.modeling.backbone.vgg16 import VGG16FC67ROIFeatureExtractor
     from od_wscl_amd.structures import BoxList
     from od_wscl_amd.utils.device_rand import DeviceRand
@@ -172,7 +172,7 @@ def test_pool_stack_equals_pool_then_stack(monkeypatch):
     cfg = make_defaults()
     cfg.merge_from_list(["MODEL.ROI_BOX_HEAD.POOLER_METHOD", "ROIPool", "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
                          "MODEL.ROI_BOX_HEAD.POOLER_SCALES", (0.125,), "DB.METHOD", "dropblock"])
-    ll.set_backend("hip_bf16")
+    ll.set_precision("bf16")
     monkeypatch.setenv("ODW_NO_SPARSE", "1")      # this test differentiates the clean features themselves
     try:
         torch.manual_seed(2)
@@ -211,7 +211,7 @@ def test_pool_stack_equals_pool_then_stack(monkeypatch):
         ga, gb = out[True][3], out[False][3]
         assert (ga - gb).abs().max().item() <= 1e-4 * gb.abs().max().item() + 1e-6, (ga - gb).abs().max().item()
     finally:
-        ll.set_backend("torch")
+        ll.set_precision("bf16x3")
 
 
 def test_pool_stack_nhwc_equals_plane_form():

@@ -10,6 +10,15 @@ from conftest import weights_for
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _bf16_precision():
+    """These tests pin the bf16 kernels against fp32 references on bf16-rounded operands (the fp32-grade split mode
+    has its own file, test_split_gpu.py)."""
+    from od_wscl_amd import precision
+    precision.set_precision("bf16")
+    yield
+
+
 def _cos(a, b):
     a, b = a.flatten().double(), b.flatten().double()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
@@ -50,7 +59,7 @@ def test_aux_kernels_match_torch():
 
 def test_resnet50_body_matches_torch_fp32():
     from test_e2e_gpu import build_model
-    from od_wscl_amd.layers import linear as ll
+    from od_wscl_amd import precision as ll
     from od_wscl_amd.modeling.backbone.resnet_hip import ResNetBackboneHip
     model = build_model("ROIPool", weights_for("r50"), "fused", "r50")
     body = model.backbone.body

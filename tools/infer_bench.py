@@ -3,13 +3,13 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from od_wscl_amd import engine
-from od_wscl_amd.layers import linear as ll
+from od_wscl_amd import precision as ll
 from od_wscl_amd.modeling.backbone.vgg16_hip import VGGBackboneHip
 from od_wscl_amd.modeling.detector import build_detection_model
 dev = torch.device("cuda", 0)
 cfg = bench.build_cfg(21)
 cfg.merge_from_list(["MODEL.ROI_HEADS.SCORE_THRESH", 0.0, "MODEL.ROI_HEADS.NMS", 0.4])
-ll.set_backend("hip_bf16")
+ll.set_precision("bf16")
 model = build_detection_model(cfg).to(dev)
 engine.load_formula_weights(model, 1)
 model.eval()
