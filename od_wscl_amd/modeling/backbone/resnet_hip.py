@@ -89,8 +89,8 @@ class _SplitConv3x3Fn(torch.autograd.Function):
         pa, pb = P.patterns("conv")
         T = len(pa)
         wd32 = w.detach()
-        wk = P.split_rows(wd32.permute(0, 2, 3, 1).reshape(co * 9, ci).contiguous(), pb, ci).view(co, -1)
-        wd = P.split_rows(wd32.permute(1, 2, 3, 0).reshape(ci * 9, co).contiguous(), pb, co).view(ci, -1) if need_dx else None
+        wk = P.pack_conv_weight(wd32.permute(0, 2, 3, 1).reshape(co * 9, ci).contiguous(), pb, ci, co)
+        wd = P.pack_conv_weight(wd32.permute(1, 2, 3, 0).reshape(ci * 9, co).contiguous(), pb, co, ci) if need_dx else None
         x = x.contiguous()
         xs = P.split_rows(x, pa, ci)
         y = torch.empty((m, co), dtype=torch.float32, device=x.device)

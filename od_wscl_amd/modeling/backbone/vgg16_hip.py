@@ -167,8 +167,9 @@ class _VGGSplitFn(torch.autograd.Function):
         st = L.stream()
         pa, _ = P.patterns("conv")
         T = len(pa)
-        x = torch.empty((B * H * W, 8), dtype=torch.float32, device=dev)
-        L.check(lib.odw_nchw_f32_to_nhwc_f32(L.ptr(images.contiguous()), B, H * W, C, 8, L.ptr(x), st), "nchw_to_nhwc_f32")
+        cp0 = net.layers[0].cp
+        x = torch.empty((B * H * W, cp0), dtype=torch.float32, device=dev)
+        L.check(lib.odw_nchw_f32_to_nhwc_f32(L.ptr(images.contiguous()), B, H * W, C, cp0, L.ptr(x), st), "nchw_to_nhwc_f32")
         saved = []
         h, w = H, W
         for l in net.layers:
@@ -277,11 +278,11 @@ class VGGBackboneHip(nn.Module):
                 wt = l.conv.weight.detach()
                 wr = torch.zeros((l.cout, 9, l.cp), dtype=torch.float32, device=dev)
                 wr[:, :, :l.cin] = wt.permute(0, 2, 3, 1).reshape(l.cout, 9, l.cin)
-                l.wk = P.split_rows(wr.view(l.cout * 9, l.cp), pb, l.cp).view(l.cout, -1)
+                l.wk = P.pack_conv_weight(wr.view(l.cout * 9, l.cp), pb, l.cp, l.cout)
                 l.wd = None
                 if l.trainable and i > first:
                     wr2 = wt.permute(1, 2, 3, 0).reshape(l.cin * 9, l.cout).contiguous()
-                    l.wd = P.split_rows(wr2, pb, l.cout).view(l.cin, -1)
+                    l.wd = P.pack_conv_weight(wr2, pb, l.cout, l.cin)
                 l.mode = mode
                 continue
             if l.wk is None or l.mode != mode:

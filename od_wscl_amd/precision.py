@@ -97,3 +97,14 @@ def split_cols(x, pat, block=None, out=None):
     L.check(L.lib().odw_split_cols_bf16(L.ptr(x), x.stride(0), R, C, ctypes.cast(_c_pattern(pat), ctypes.c_void_p), T,
                                         L.ptr(out), out.stride(0), block, L.stream()), "split_cols_bf16")
     return out
+
+
+def pack_conv_weight(rows, pat, block, n_out):
+    """rows (n_out*9, C) fp32 = a 3x3 weight laid out (output, tap, channel) -> the implicit-GEMM operand
+    (n_out, r64(9 * T * block)) bf16: per tap the T plane blocks of the channel axis, rows zero padded to a multiple
+    of 64 (the kernel reads whole 64-element K tiles)."""
+    w = split_rows(rows, pat, block).view(n_out, -1)
+    k = w.shape[1]
+    if k % 64:
+        w = torch.nn.functional.pad(w, (0, r64(k) - k))
+    return w.contiguous()

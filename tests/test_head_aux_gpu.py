@@ -11,6 +11,14 @@ from od_wscl_amd.utils import rng
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _bf16_precision():
+    """The stacked-operand kernels are pinned in their bf16 form here (bit-exact against the PyTorch rendition)."""
+    from od_wscl_amd import precision
+    precision.set_precision("bf16")
+    yield
+
+
 def _inputs(P, C, h, w, seed):
     x = torch.from_numpy(rng.normal(seed, 1, P * C * h * w).reshape(P, C, h, w)).cuda()
     keep = torch.from_numpy((rng.uniform(seed, 2, P * h * w) > 0.2).astype(np.float32).reshape(P, h, w)).cuda()

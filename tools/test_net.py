@@ -17,21 +17,13 @@ sys.path.insert(0, ROOT)
 
 
 def build_eval_model(cfg, device, dtype="bf16"):
-    """Eval-mode detector on the gfx950 kernels (bf16 MFMA linears + NHWC implicit-GEMM VGG16 body)."""
-    from od_wscl_amd.layers import linear as ll
+    """Eval-mode detector on the gfx950 kernels; dtype = od_wscl_amd.precision mode ("bf16" | "bf16x3" | "bf16x2")."""
+    from od_wscl_amd import precision
     from od_wscl_amd.modeling.detector import build_detection_model
-    if dtype == "bf16":
-        ll.set_backend("hip_bf16")
+    precision.set_precision({"fp32": "bf16x3", "f32": "bf16x3"}.get(dtype, dtype))
     model = build_detection_model(cfg).to(device)
     model.eval()
-    if dtype == "bf16" and cfg.MODEL.BACKBONE.CONV_BODY.startswith("VGG16"):
-        from od_wscl_amd.modeling.backbone.vgg16_hip import VGGBackboneHip
-        model.backbone_hip = VGGBackboneHip(model.backbone.body)
-    elif dtype == "bf16" and cfg.MODEL.BACKBONE.CONV_BODY.startswith("R-"):
-        from od_wscl_amd.modeling.backbone.resnet_hip import ResNetBackboneHip
-        model.backbone_hip = ResNetBackboneHip(model.backbone.body)
-    elif dtype == "bf16":
-        model.backbone_autocast = torch.bfloat16
+    model.hip_body()
     return model
 
 
@@ -40,7 +32,7 @@ def main():
     ap.add_argument("--config-file", default="", metavar="FILE")
     ap.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))
     ap.add_argument("--data-dir", default="")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x3", "bf16x2", "f32"])
     ap.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--data-dir", default="", help="root of the dataset catalog (default: ./datasets)")
     ap.add_argument("--size", type=int, default=600)
     ap.add_argument("--proposals", type=int, default=2000)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x3", "bf16x2", "f32"])
     ap.add_argument("--log-period", type=int, default=20)
     ap.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     args = ap.parse_args()
