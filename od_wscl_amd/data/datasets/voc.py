@@ -1,7 +1,7 @@
-"""PascalVOCDataset (wetectron/data/datasets/voc.py:13-203): VOC devkit layout (JPEGImages / Annotations /
-ImageSets/Main), image-level labels from the XML objects, proposals from a ProposalFile.  A sample is
-(image, target, rois, index); with transforms the image is a `DeferredImage` (decoded pixels + pixel plan) that the
-GPU turns into the normalised tensor at collation time."""
+"""PascalVOCDataset on a VOC devkit directory (JPEGImages / Annotations / ImageSets/Main) -- the dataset interface the
+reference's loader, evaluator and proposal preparation expect (wetectron/data/datasets/voc.py:13-203): image-level
+labels from the XML objects, proposals from a ProposalFile.  A sample is (image, target, rois, index); with transforms
+the image is a `DeferredImage` (decoded pixels + pixel plan) the GPU turns into the normalised tensor at collation."""
 import os
 import xml.etree.ElementTree as ET
 
@@ -12,86 +12,90 @@ from PIL import Image
 from ...structures.bounding_box import BoxList
 from .proposals import ProposalFile, prepare_proposals
 
-
-class PascalVOCDataset(torch.utils.data.Dataset):
-    CLASSES = ("__background__ ", "aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair",
+VOC_CLASSES = ("__background__ ", "aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair",
                "cow", "diningtable", "dog", "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train",
                "tvmonitor")
+_BOX_TAGS = ("xmin", "ymin", "xmax", "ymax")
+
+
+def read_annotation(xml_path, class_index, keep_difficult):
+    """One VOC XML -> (boxes (n,4) fp32 0-based xyxy, labels (n,), difficult (n,) bool, (height, width)).
+    VOC pixel coordinates are 1-based (voc.py:164-172); objects flagged difficult are dropped unless asked for."""
+    root = ET.parse(xml_path).getroot()
+    rows = []
+    for obj in root.iter("object"):
+        hard = obj.find("difficult").text.strip() == "1"
+        if hard and not keep_difficult:
+            continue
+        corner = obj.find("bndbox")
+        rows.append(([int(corner.find(t).text) - 1 for t in _BOX_TAGS],
+                     class_index[obj.find("name").text.lower().strip()], hard))
+    dims = root.find("size")
+    hw = (int(dims.find("height").text), int(dims.find("width").text))
+    boxes = torch.tensor([r[0] for r in rows], dtype=torch.float32).reshape(-1, 4)
+    return boxes, torch.tensor([r[1] for r in rows]), torch.tensor([r[2] for r in rows]), hw
+
+
+class PascalVOCDataset(torch.utils.data.Dataset):
+    CLASSES = VOC_CLASSES
 
     def __init__(self, data_dir, split, use_difficult=False, transforms=None, proposal_file=None, min_size=None):
-        self.root = data_dir
-        self.image_set = split
-        self.keep_difficult = use_difficult
-        self.transforms = transforms
-        self._annopath = os.path.join(self.root, "Annotations", "%s.xml")
-        self._imgpath = os.path.join(self.root, "JPEGImages", "%s.jpg")
-        self._imgsetpath = os.path.join(self.root, "ImageSets", "Main", "%s.txt")
-        with open(self._imgsetpath % self.image_set) as f:
-            self.ids = [x.strip("\n") for x in f.readlines()]
-        self.id_to_img_map = {k: v for k, v in enumerate(self.ids)}
-        cls = PascalVOCDataset.CLASSES
-        self.class_to_ind = dict(zip(cls, range(len(cls))))
-        self.categories = dict(zip(range(len(cls)), cls))
-        self.min_size = min_size
-        self.proposals = ProposalFile(proposal_file) if proposal_file is not None else None
+        self.root, self.image_set = data_dir, split
+        self.keep_difficult, self.transforms, self.min_size = use_difficult, transforms, min_size
+        index_file = os.path.join(data_dir, "ImageSets", "Main", split + ".txt")
+        with open(index_file) as fh:
+            self.ids = [line.rstrip("\n") for line in fh]
+        self.id_to_img_map = dict(enumerate(self.ids))
+        self.class_to_ind = {name: k for k, name in enumerate(VOC_CLASSES)}
+        self.categories = dict(enumerate(VOC_CLASSES))
         self.proposal_file = proposal_file
+        self.proposals = None if proposal_file is None else ProposalFile(proposal_file)
         self.top_k = 2000
+
+    # ---- paths
+    def _xml(self, img_id):
+        return os.path.join(self.root, "Annotations", img_id + ".xml")
+
+    def _jpg(self, img_id):
+        return os.path.join(self.root, "JPEGImages", img_id + ".jpg")
+
+    # ---- the interface of the loader / evaluator
+    def __len__(self):
+        return len(self.ids)
 
     def get_origin_id(self, index):
         return self.ids[index]
 
+    def map_class_id_to_class_name(self, class_id):
+        return VOC_CLASSES[class_id]
+
+    def get_groundtruth(self, index):
+        boxes, labels, hard, (height, width) = read_annotation(self._xml(self.ids[index]), self.class_to_ind,
+                                                               self.keep_difficult)
+        target = BoxList(boxes, (width, height), mode="xyxy")
+        target.add_field("labels", labels)
+        target.add_field("difficult", hard)
+        return target
+
+    def get_img_info(self, index):
+        img_id = self.ids[index]
+        info = {"file_name": "JPEGImages/%s.jpg" % img_id}
+        if os.path.exists(self._xml(img_id)):
+            dims = ET.parse(self._xml(img_id)).getroot().find("size")
+            info["height"], info["width"] = int(dims.find("height").text), int(dims.find("width").text)
+        else:                                   # a test split without annotations: ask the image itself
+            info["width"], info["height"] = Image.open(self._jpg(img_id)).size
+        return info
+
     def __getitem__(self, index):
         img_id = self.ids[index]
-        img = Image.open(self._imgpath % img_id).convert("RGB")
-        if not os.path.exists(self._annopath % img_id):
-            target = None
-        else:
+        img = Image.open(self._jpg(img_id)).convert("RGB")
+        target = None
+        if os.path.exists(self._xml(img_id)):
             target = self.get_groundtruth(index).clip_to_image(remove_empty=True)
         rois = None
-        if self.proposals is not None:
-            # every split keeps boxes with both sides >= 20 px (voc.py:106-109)
+        if self.proposals is not None:          # every split keeps boxes with both sides >= 20 px (voc.py:106-109)
             rois = prepare_proposals(self.proposals.boxes(int(img_id)), img.size, min_size=20)
         if self.transforms is not None:
             img, target, rois = self.transforms(img, target, rois)
         return img, target, rois, index
-
-    def __len__(self):
-        return len(self.ids)
-
-    def get_groundtruth(self, index):
-        anno = self._preprocess_annotation(ET.parse(self._annopath % self.ids[index]).getroot())
-        height, width = anno["im_info"]
-        target = BoxList(anno["boxes"], (width, height), mode="xyxy")
-        target.add_field("labels", anno["labels"])
-        target.add_field("difficult", anno["difficult"])
-        return target
-
-    def _preprocess_annotation(self, target):
-        boxes, gt_classes, difficult_boxes = [], [], []
-        for obj in target.iter("object"):
-            difficult = int(obj.find("difficult").text) == 1
-            if not self.keep_difficult and difficult:
-                continue
-            name = obj.find("name").text.lower().strip()
-            bb = obj.find("bndbox")
-            # VOC pixel indexes are 1-based (voc.py:164-172)
-            boxes.append(tuple(int(bb.find(k).text) - 1 for k in ("xmin", "ymin", "xmax", "ymax")))
-            gt_classes.append(self.class_to_ind[name])
-            difficult_boxes.append(difficult)
-        size = target.find("size")
-        return {"boxes": torch.tensor(boxes, dtype=torch.float32).reshape(-1, 4), "labels": torch.tensor(gt_classes),
-                "difficult": torch.tensor(difficult_boxes),
-                "im_info": (int(size.find("height").text), int(size.find("width").text))}
-
-    def get_img_info(self, index):
-        img_id = self.ids[index]
-        file_name = "JPEGImages/%s.jpg" % img_id
-        if os.path.exists(self._annopath % img_id):
-            size = ET.parse(self._annopath % img_id).getroot().find("size")
-            return {"height": int(size.find("height").text), "width": int(size.find("width").text),
-                    "file_name": file_name}
-        img = Image.open(os.path.join(self.root, file_name)).convert("RGB")
-        return {"height": img.size[1], "width": img.size[0], "file_name": file_name}
-
-    def map_class_id_to_class_name(self, class_id):
-        return PascalVOCDataset.CLASSES[class_id]

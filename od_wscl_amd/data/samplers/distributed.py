@@ -1,34 +1,52 @@
-"""DistributedSampler (wetectron/data/samplers/distributed.py:10-66): rank r of N sees every N-th slice of an
-epoch-seeded permutation padded to a multiple of N -- the data path needs no collective (images are the sharded
-unit)."""
-import math
-
+"""Rank sharding of the image list (the reference's wetectron/data/samplers/distributed.py:42-60 semantics, pinned by
+tests/golden/sampler_voc.npz): images are the data-parallel unit, so the data path needs no
+collective -- every rank derives the same epoch order from the epoch number and takes its own CONTIGUOUS block.
+(torch.utils.data.DistributedSampler strides instead of blocking, i.e. it would hand different images to a rank.)"""
 import torch
 import torch.distributed as dist
 from torch.utils.data.sampler import Sampler
 
 
+def epoch_order(n, epoch, shuffle):
+    """The order all ranks agree on for one epoch: a permutation seeded by the epoch number, or 0..n-1."""
+    if not shuffle:
+        return list(range(n))
+    gen = torch.Generator()
+    gen.manual_seed(epoch)
+    return torch.randperm(n, generator=gen).tolist()
+
+
+def rank_block(order, world, rank):
+    """Block `rank` of `world` equal blocks; the list wraps around so that every rank gets ceil(n / world) items."""
+    per_rank = -(-len(order) // world)
+    wrapped = order + order[:per_rank * world - len(order)]
+    return wrapped[rank * per_rank:(rank + 1) * per_rank]
+
+
+def _dist_default(value, getter, fallback):
+    if value is not None:
+        return value
+    return getter() if dist.is_available() and dist.is_initialized() else fallback
+
+
 class DistributedSampler(Sampler):
     def __init__(self, dataset, num_replicas=None, rank=None, shuffle=True):
-        if num_replicas is None:
-            num_replicas = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if rank is None:
-            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-        self.dataset, self.num_replicas, self.rank, self.shuffle = dataset, num_replicas, rank, shuffle
+        self.dataset = dataset
+        self.num_replicas = _dist_default(num_replicas, dist.get_world_size, 1)
+        self.rank = _dist_default(rank, dist.get_rank, 0)
+        self.shuffle = shuffle
         self.epoch = 0
-        self.num_samples = int(math.ceil(len(self.dataset) * 1.0 / self.num_replicas))
-        self.total_size = self.num_samples * self.num_replicas
+
+    @property
+    def num_samples(self):
+        return -(-len(self.dataset) // self.num_replicas)
+
+    @property
+    def total_size(self):
+        return self.num_samples * self.num_replicas
 
     def __iter__(self):
-        if self.shuffle:
-            g = torch.Generator()
-            g.manual_seed(self.epoch)
-            indices = torch.randperm(len(self.dataset), generator=g).tolist()
-        else:
-            indices = torch.arange(len(self.dataset)).tolist()
-        indices += indices[: (self.total_size - len(indices))]
-        offset = self.num_samples * self.rank
-        return iter(indices[offset: offset + self.num_samples])
+        return iter(rank_block(epoch_order(len(self.dataset), self.epoch, self.shuffle), self.num_replicas, self.rank))
 
     def __len__(self):
         return self.num_samples

@@ -87,25 +87,18 @@ class Resize(object):
         self.max_size = max_size
 
     def get_size(self, image_size):
-        """(h, w) with the short side = a drawn min_size unless the long side would pass max_size
-        (transforms.py:41-61; integer truncation of the long side, `random.choice` consumed once)."""
+        """(h, w) after resizing: the short side becomes a drawn min_size, lowered when the long side would pass
+        max_size; the long side is truncated to an integer (the reference's rule, transforms.py:41-61, with
+        `random.choice` consumed exactly once)."""
         w, h = image_size
-        size = random.choice(self.min_size)
-        max_size = self.max_size
-        if max_size is not None:
-            min_original_size = float(min((w, h)))
-            max_original_size = float(max((w, h)))
-            if max_original_size / min_original_size * size > max_size:
-                size = int(round(max_size * min_original_size / max_original_size))
-        if (w <= h and w == size) or (h <= w and h == size):
+        short, long_ = (w, h) if w <= h else (h, w)
+        target = random.choice(self.min_size)
+        if self.max_size is not None and float(long_) / float(short) * target > self.max_size:
+            target = int(round(self.max_size * float(short) / float(long_)))
+        if short == target:
             return (h, w)
-        if w < h:
-            ow = size
-            oh = int(size * h / w)
-        else:
-            oh = size
-            ow = int(size * w / h)
-        return (oh, ow)
+        other = int(target * long_ / short)
+        return (other, target) if w < h else (target, other)
 
     def __call__(self, image, target=None, rois=None):
         image = defer(image)

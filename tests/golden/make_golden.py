@@ -40,6 +40,9 @@ E2E_CASES = {
     # config 5 of SURVEY.md s8: R-50-C5 body (stride 16) + ResNet50Conv5ROIFeatureExtractor
     "e2e_r50_2img": dict(seed=27, images=[(256, 320, 48), (224, 288, 40)], labels=[[7], [12]], pooler="ROIPool",
                          arch="r50", min_size=32, yaml="configs/voc/voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml"),
+    # config 4 of SURVEY.md s8: the COCO14 shape -- 81 classes (predictor N = 1377), labels up to 80
+    "e2e_coco_2img": dict(seed=41, images=[(96, 128, 56), (112, 96, 48)], labels=[[17, 63], [80]], pooler="ROIPool",
+                          classes=81, yaml="configs/coco/coco14_contra_db_b8_lr0.01_mcg.yaml"),
 }
 # predictor / Sim_Net scales that give well separated scores (the reference's N(0,0.001)
 # predictor init makes every score nearly tied, which no fp32 re-ordering survives)
@@ -204,7 +207,8 @@ def gen_e2e(name, spec, out):
     model.train()
     seed = spec["seed"]
     shapes = [(n, tuple(p.shape)) for n, p in model.named_parameters()]
-    assert shapes == H.param_shapes(21, arch), "parameter naming drifted"
+    ncls = spec.get("classes", 21)
+    assert shapes == H.param_shapes(ncls, arch), "parameter naming drifted"
     sd = synthetic.init_state_dict(shapes, WEIGHT_SEED, overrides=OVERRIDES)
     with torch.no_grad():
         for n, p in model.named_parameters():
@@ -276,6 +280,7 @@ def gen_e2e(name, spec, out):
     rec["spec_pooler"] = np.array(spec["pooler"])
     rec["spec_arch"] = np.array(arch)
     rec["spec_min_size"] = np.array(spec.get("min_size", 12))
+    rec["spec_classes"] = np.array(ncls)
     rec["spec_labels_flat"] = np.array([l for ls in spec["labels"] for l in ls])
     rec["spec_labels_count"] = np.array([len(ls) for ls in spec["labels"]])
     rec["streams_used"] = np.array(rand.s.next)
