@@ -215,6 +215,58 @@ class FlatSGD(object):
                 self.flat_m.mul_(corr)
             self.lr_scale = f
 
+    # ---- optimizer / scheduler state in the reference's checkpoint layout (utils/checkpoint.py:41-63 saves
+    # optimizer.state_dict() of torch.optim.SGD with one parameter per group, solver/build.py:10-24, and the
+    # scheduler's state_dict) ------------------------------------------------------------------------------------
+    def _param_order(self, model):
+        return [n for n, p in model.named_parameters() if p.requires_grad and n in self.slices]
+
+    def state_dict(self, model):
+        """torch.optim.SGD.state_dict() layout: group i / state i = the i-th trainable parameter of
+        model.named_parameters(); momentum buffers are views of the flat momentum copied out."""
+        s = self.cfg.SOLVER
+        groups, state = [], {}
+        for i, n in enumerate(self._param_order(model)):
+            off, numel = self.slices[n]
+            bias = "bias" in n
+            groups.append({"lr": (s.BASE_LR * s.BIAS_LR_FACTOR if bias else s.BASE_LR) * self.lr_scale,
+                           "weight_decay": s.WEIGHT_DECAY_BIAS if bias else s.WEIGHT_DECAY, "momentum": self.momentum,
+                           "dampening": 0, "nesterov": False, "params": [i]})
+            if not self.first:
+                shape = dict(model.named_parameters())[n].shape
+                state[i] = {"momentum_buffer": self.flat_m[off:off + numel].view(shape).clone()}
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, model, sd):
+        """Momentum buffers of a checkpoint written by state_dict() above or by the reference's torch.optim.SGD."""
+        order = self._param_order(model)
+        state = sd.get("state", {})
+        if len(sd.get("param_groups", order)) != len(order):
+            raise ValueError("optimizer state has %d parameter groups, the model %d trainable parameters"
+                             % (len(sd["param_groups"]), len(order)))
+        loaded = 0
+        for i, n in enumerate(order):
+            entry = state.get(i, state.get(str(i)))
+            if entry is None or entry.get("momentum_buffer") is None:
+                continue
+            off, numel = self.slices[n]
+            self.flat_m[off:off + numel].copy_(entry["momentum_buffer"].reshape(-1).to(self.flat_m.device))
+            loaded += 1
+        if loaded:
+            self.first = False
+        return loaded
+
+    def scheduler_state(self, iteration):
+        """WarmupMultiStepLR.state_dict() fields that matter on resume (solver/lr_scheduler.py:14-56)."""
+        s = self.cfg.SOLVER
+        return {"last_epoch": int(iteration), "milestones": tuple(s.STEPS), "gamma": s.GAMMA, "warmup_factor": s.WARMUP_FACTOR,
+                "warmup_iters": s.WARMUP_ITERS, "warmup_method": s.WARMUP_METHOD}
+
+    def resume(self, iteration):
+        """Learning-rate factor of a run that has completed `iteration` steps (no momentum rescale: the buffers were
+        saved under that factor)."""
+        self.lr_scale = lr_factor(self.cfg, iteration) if iteration > 0 else 1.0
+
     def begin_step(self):
         """Gradient buffer state for a new step: GEMM weights are overwritten by their first wgrad
         launch; everything autograd accumulates into (convs, predictor heads, biases) is zeroed."""

@@ -65,6 +65,17 @@ class PostProcessor(nn.Module):
             return results
         if self.nms <= 0:
             raise ValueError("MODEL.ROI_HEADS.NMS must be > 0")
+        if max_p > self.FUSED_MAX_P:
+            # more proposals than one workgroup of the fused kernel sorts in LDS (the reference has no cap at test
+            # time: top_k is -1 for COCO): decode on the device, then the reference's own per-class loop on odw_nms
+            decoded = torch.empty((offs[-1], C, 4), dtype=torch.float32, device=dev)
+            L.check(L.lib().odw_detect_decode(L.ptr(reg), reg.shape[1] if reg is not None else 0,
+                                              1 if self.cls_agnostic_bbox_reg else 0, L.ptr(concat), L.ptr(img_off),
+                                              L.ptr(img_wh), n_img, offs[-1], C, float(w[0]), float(w[1]), float(w[2]),
+                                              float(w[3]), float(self.box_coder.bbox_xform_clip), L.ptr(decoded),
+                                              L.stream()), "detect_decode")
+            return [self._per_class(prob[offs[i]:offs[i + 1]], decoded[offs[i]:offs[i + 1]], b.size, C)
+                    for i, b in enumerate(boxes)]
         out = self._outputs(n_img, C, max_p, dev)
         L.check(L.lib().odw_detect_postprocess(L.ptr(prob), C, L.ptr(reg), reg.shape[1] if reg is not None else 0,
                                                1 if self.cls_agnostic_bbox_reg else 0, L.ptr(concat), L.ptr(img_off),
@@ -73,6 +84,28 @@ class PostProcessor(nn.Module):
                                                max_p, L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]),
                                                L.stream()), "detect_postprocess")
         return self._collect(out, [b.size for b in boxes], C)
+
+    FUSED_MAX_P = 4096          # boxes per (image, class) the fused kernels hold in LDS (csrc/detect.hip)
+
+    def _per_class(self, prob, boxes_pc, size, C):
+        """inference.py:216-258 class by class for box counts beyond the fused kernel: score > thresh, odw_nms with
+        torchvision semantics, labels; then the same best-`detections_per_img` cut.  One host synchronisation per
+        class, like the reference."""
+        from .... import _C
+        dev = prob.device
+        bx, sc, lab, idx = [], [], [], []
+        for j in range(1, C):
+            inds = torch.nonzero(prob[:, j] > self.score_thresh, as_tuple=False).squeeze(1)
+            if inds.numel() == 0:
+                continue
+            if inds.numel() > 8192:
+                raise NotImplementedError("PostProcessor: %d boxes of one class pass the score threshold; odw_nms sorts "
+                                          "at most 8192 (ODW_NMS_MAX_N)" % inds.numel())
+            b_j, s_j = boxes_pc[inds, j].contiguous(), prob[inds, j].contiguous()
+            keep = _C.nms_torchvision(b_j, s_j, self.nms)
+            bx.append(b_j[keep]); sc.append(s_j[keep]); idx.append(inds[keep].int())
+            lab.append(torch.full((keep.numel(),), j, dtype=torch.int64, device=dev))
+        return self._finish(bx, sc, lab, idx, size, dev)
 
     @staticmethod
     def _outputs(n_img, C, max_p, dev):
@@ -90,9 +123,8 @@ class PostProcessor(nn.Module):
         if self.nms <= 0:
             raise ValueError("MODEL.ROI_HEADS.NMS must be > 0")
         P = boxes_pc.shape[0]
-        if P > 4096:
-            raise NotImplementedError("filter_results: %d boxes per class exceed the kernel's 4096 (the UNION heuristic "
-                                      "of TEST.BBOX_AUG concatenates every pass; the shipped configs use AVG)" % P)
+        if P > self.FUSED_MAX_P:        # e.g. the UNION heuristic of TEST.BBOX_AUG concatenates every pass
+            return self._per_class(prob, boxes_pc, boxlist.size, num_classes)
         dev = prob.device
         img_off = torch.tensor([0, P], dtype=torch.int32, device=dev)
         out = self._outputs(1, num_classes, P, dev)
@@ -115,22 +147,26 @@ class PostProcessor(nn.Module):
                     sc.append(out_scores[i, j - 1, :k])
                     idx.append(out_index[i, j - 1, :k])
                     lab.append(torch.full((k,), j, dtype=torch.int64, device=dev))
-            if bx:
-                bx, sc, lab, idx = torch.cat(bx), torch.cat(sc), torch.cat(lab), torch.cat(idx)
-            else:
-                bx, sc = torch.zeros((0, 4), device=dev), torch.zeros((0,), device=dev)
-                lab, idx = torch.zeros((0,), dtype=torch.int64, device=dev), torch.zeros((0,), dtype=torch.int32, device=dev)
-            n = int(sc.numel())
-            if n > self.detections_per_img > 0:                        # inference.py:246-255: ties at the cut are kept
-                thresh, _ = torch.kthvalue(sc.cpu(), n - self.detections_per_img + 1)
-                keep = torch.nonzero(sc >= thresh.item(), as_tuple=False).squeeze(1)
-                bx, sc, lab, idx = bx[keep], sc[keep], lab[keep], idx[keep]
-            r = BoxList(bx, size, mode="xyxy")
-            r.add_field("scores", sc)
-            r.add_field("labels", lab)
-            r.add_field("proposal_index", idx.long())
-            results.append(r)
+            results.append(self._finish(bx, sc, lab, idx, size, dev))
         return results
+
+    def _finish(self, bx, sc, lab, idx, size, dev):
+        """Per-class survivors -> one BoxList, cut to the best `detections_per_img` (inference.py:246-255: ties kept)."""
+        if bx:
+            bx, sc, lab, idx = torch.cat(bx), torch.cat(sc), torch.cat(lab), torch.cat(idx)
+        else:
+            bx, sc = torch.zeros((0, 4), device=dev), torch.zeros((0,), device=dev)
+            lab, idx = torch.zeros((0,), dtype=torch.int64, device=dev), torch.zeros((0,), dtype=torch.int32, device=dev)
+        n = int(sc.numel())
+        if n > self.detections_per_img > 0:
+            thresh, _ = torch.kthvalue(sc.cpu(), n - self.detections_per_img + 1)
+            keep = torch.nonzero(sc >= thresh.item(), as_tuple=False).squeeze(1)
+            bx, sc, lab, idx = bx[keep], sc[keep], lab[keep], idx[keep]
+        r = BoxList(bx, size, mode="xyxy")
+        r.add_field("scores", sc)
+        r.add_field("labels", lab)
+        r.add_field("proposal_index", idx.long())
+        return r
 
 
 def make_roi_box_post_processor(cfg, regression=True):

@@ -163,6 +163,9 @@ class RoIRegLossFused(RoIRegLossComputation):
         for t in targets:
             lab = t.get_field("labels_host") if t.has_field("labels_host") else t.get_field("labels").tolist()
             pos_host.append(sorted(set(int(v) - 1 for v in lab if int(v) > 0)))
+        if not any(pos_host):
+            raise ValueError("RoIRegLossFused: no image of the batch has a foreground label -- the trainer skips such "
+                             "batches (engine/trainer.py:81-84, tools/train_net.py)")
         maxpos = max(1, max(len(p) for p in pos_host))
         lab_key = ("lab", tuple(tuple(pc) for pc in pos_host), C, str(device))
         lab_vecs = _CONST_CACHE.get(lab_key)

@@ -50,8 +50,47 @@ def load_checkpoint(model, path, map_location="cpu"):
     return loaded
 
 
-def save_checkpoint(model, path, **extra):
-    """Checkpointer.save (checkpoint.py:41-63): the reference's layout, loadable by wetectron."""
+def save_checkpoint(model, path, optimizer=None, iteration=None, **extra):
+    """Checkpointer.save (checkpoint.py:41-63): {"model", "optimizer", "scheduler", "iteration"} in the reference's
+    layout, loadable by wetectron.  `optimizer` = engine.FlatSGD (its momenta are written as a torch.optim.SGD
+    state_dict, one group per trainable parameter)."""
     data = {"model": model.state_dict()}
+    if optimizer is not None:
+        data["optimizer"] = optimizer.state_dict(model)
+        data["scheduler"] = optimizer.scheduler_state(iteration or 0)
+    if iteration is not None:
+        data["iteration"] = int(iteration)
     data.update(extra)
     torch.save(data, path)
+
+
+def last_checkpoint(output_dir):
+    """Checkpointer.has_checkpoint / get_checkpoint_file (checkpoint.py:106-123): the path recorded in
+    OUTPUT_DIR/last_checkpoint, or None."""
+    import os
+    tag = os.path.join(output_dir, "last_checkpoint") if output_dir else ""
+    if not tag or not os.path.exists(tag):
+        return None
+    with open(tag) as f:
+        path = f.read().strip()
+    return path if path and os.path.exists(path) else None
+
+
+def tag_last_checkpoint(output_dir, path):
+    import os
+    with open(os.path.join(output_dir, "last_checkpoint"), "w") as f:
+        f.write(path)
+
+
+def restore_training_state(optimizer, model, rest):
+    """Apply what load_checkpoint returned to an engine.FlatSGD: momenta, schedule position; returns the iteration
+    to continue from.  Without this a resumed run silently restarts with zero momentum."""
+    iteration = int(rest.get("iteration", 0) or 0)
+    if rest.get("optimizer") is not None:
+        optimizer.load_state_dict(model, rest["optimizer"])
+    sched = rest.get("scheduler")
+    if sched is not None and "last_epoch" in sched:
+        iteration = max(iteration, int(sched["last_epoch"]))
+    optimizer.sync_from_params()
+    optimizer.resume(iteration)
+    return iteration

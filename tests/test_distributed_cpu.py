@@ -131,3 +131,53 @@ def test_checkpoint_layout_and_suffix_matching(tmp_path):
     assert (c.backbone.body.conv1.weight == 2).all() and (c.backbone.body.layer1[0].weight == 3).all()
     torch.save({"w": 1}, str(tmp_path / "bare.pth"))            # a bare state-dict is wrapped as {"model": ...}
     assert ck.load_checkpoint(Net(), str(tmp_path / "bare.pth")) == {}
+
+
+def test_optimizer_state_round_trips_in_the_reference_layout(tmp_path):
+    """FlatSGD's momenta are saved as a torch.optim.SGD state_dict (one group per trainable parameter, the layout
+    the reference's Checkpointer writes, utils/checkpoint.py:41-63 + solver/build.py:10-24): torch's own optimizer
+    loads it, and a resumed FlatSGD continues with the same momenta, `first` cleared and the schedule position."""
+    from od_wscl_amd import engine
+    from od_wscl_amd.config import make_defaults
+    from od_wscl_amd.utils import checkpoint as ck
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(3, 4, 3)
+            self.frozen = torch.nn.Conv2d(4, 4, 1)
+            self.out = torch.nn.Conv2d(4, 2, 1)
+            for p in self.frozen.parameters():
+                p.requires_grad_(False)
+
+    cfg = make_defaults()
+    cfg.merge_from_list(["SOLVER.BASE_LR", 0.01, "SOLVER.STEPS", (5, 8), "SOLVER.WARMUP_ITERS", 2])
+    torch.manual_seed(0)
+    a = Net()
+    oa = engine.FlatSGD(cfg, a, world=1)
+    oa.flat_m.copy_(torch.randn_like(oa.flat_m))
+    oa.first = False
+    oa.lr_scale = engine.lr_factor(cfg, 6)
+    path = str(tmp_path / "model_0000006.pth")
+    ck.save_checkpoint(a, path, optimizer=oa, iteration=6)
+    ck.tag_last_checkpoint(str(tmp_path), path)
+    assert ck.last_checkpoint(str(tmp_path)) == path and ck.last_checkpoint(str(tmp_path / "nope")) is None
+    saved = torch.load(path)
+    assert set(saved) == {"model", "optimizer", "scheduler", "iteration"} and saved["scheduler"]["last_epoch"] == 6
+    # torch.optim.SGD with the reference's grouping accepts it
+    trainable = [(n, p) for n, p in Net().named_parameters() if p.requires_grad]
+    ref_opt = torch.optim.SGD([{"params": [p], "lr": 0.01} for n, p in trainable], 0.01, momentum=0.9)
+    ref_opt.load_state_dict(saved["optimizer"])
+    assert len(ref_opt.state_dict()["state"]) == len(trainable)
+    assert abs(saved["optimizer"]["param_groups"][1]["lr"] - 0.01 * 2 * 0.1) < 1e-12      # bias: lr x2, after one decay step
+    # resume into a fresh model + optimizer
+    b = Net()
+    ob = engine.FlatSGD(cfg, b, world=1)
+    assert ob.first and float(ob.flat_m.abs().sum()) == 0.0
+    rest = ck.load_checkpoint(b, path)
+    assert ck.restore_training_state(ob, b, rest) == 6
+    assert not ob.first and ob.lr_scale == oa.lr_scale
+    for n, (off, k) in oa.slices.items():
+        o2, _ = ob.slices[n]
+        assert torch.equal(oa.flat_m[off:off + k], ob.flat_m[o2:o2 + k]), n
+        assert torch.equal(oa.flat_p[off:off + k], ob.flat_p[o2:o2 + k]), n

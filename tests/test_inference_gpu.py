@@ -133,3 +133,38 @@ def test_test_time_augmentation_matches_reference_detections(case):
         np.testing.assert_array_equal(r.get_field("labels").cpu().numpy(), g["det_labels_%d" % i])
         np.testing.assert_allclose(r.get_field("scores").cpu().numpy(), g["det_scores_%d" % i], rtol=1e-4, atol=1e-7)
         np.testing.assert_allclose(r.bbox.cpu().numpy(), g["det_boxes_%d" % i], rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("regress", [True, False])
+def test_per_class_fallback_equals_the_fused_kernel(regress):
+    """More proposals per image than the fused kernel holds in LDS (4096; the reference has no cap at test time) take
+    the decode + per-class odw_nms path: forced here at P = 600 by lowering the switch, it must return exactly what the
+    fused kernel returns -- and a real P = 5000 image must run."""
+    from od_wscl_amd import synthetic
+    from od_wscl_amd.modeling.box_coder import BoxCoder
+    from od_wscl_amd.modeling.roi_heads.box_head.inference import PostProcessor
+    from od_wscl_amd.structures import BoxList
+    from od_wscl_amd.utils import rng
+    W, H, C = 320, 240, 21
+    for P in (600, 5000):
+        sizes = [P - P // 3, P // 3] if P == 600 else [P]
+        boxes = [torch.from_numpy(synthetic.make_proposals(9, k, n, H, W, min_size=4)) for k, n in enumerate(sizes)]
+        prob = torch.softmax(torch.from_numpy(rng.normal(9, 3, P * C).reshape(P, C)) * 2, dim=1).cuda()
+        reg = (torch.from_numpy(rng.normal(9, 4, P * 4 * C).reshape(P, 4 * C)) * 0.5).cuda()
+        bl = [BoxList(b.cuda(), (W, H), "xyxy") for b in boxes]
+        pp = PostProcessor(0.01, 0.4, 100, BoxCoder((10.0, 10.0, 5.0, 5.0)), False, False, regression=regress)
+        x = (prob, reg) if regress else prob
+        kw = dict(softmax_on=False) if regress else {}
+        if P == 600:
+            want = pp(x, bl, **kw)
+            pp.FUSED_MAX_P = 100
+        got = pp(x, bl, **kw)
+        if P == 600:
+            for a, b in zip(got, want):
+                np.testing.assert_array_equal(a.get_field("labels").cpu().numpy(), b.get_field("labels").cpu().numpy())
+                np.testing.assert_array_equal(a.get_field("scores").cpu().numpy(), b.get_field("scores").cpu().numpy())
+                np.testing.assert_array_equal(a.bbox.cpu().numpy(), b.bbox.cpu().numpy())
+                np.testing.assert_array_equal(a.get_field("proposal_index").cpu().numpy(),
+                                              b.get_field("proposal_index").cpu().numpy())
+        else:
+            assert len(got) == 1 and 0 < len(got[0]) <= 120 and bool(torch.isfinite(got[0].bbox).all())

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--config-file", default="", metavar="FILE")
     ap.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))
     ap.add_argument("--data-dir", default="")
+    ap.add_argument("--allow-random-init", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x3", "bf16x2", "f32"])
     ap.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     args = ap.parse_args()
@@ -56,8 +57,17 @@ def main():
     if args.data_dir:
         DatasetCatalog.DATA_DIR = args.data_dir
     model = build_eval_model(cfg, device, args.dtype)
-    if cfg.MODEL.WEIGHT and os.path.isfile(cfg.MODEL.WEIGHT):
-        ck.load_checkpoint(model, cfg.MODEL.WEIGHT)
+    weight = ck.last_checkpoint(cfg.OUTPUT_DIR) if not (cfg.MODEL.WEIGHT and os.path.isfile(cfg.MODEL.WEIGHT)) else cfg.MODEL.WEIGHT
+    if weight and os.path.isfile(weight):
+        ck.load_checkpoint(model, weight)
+    elif not args.allow_random_init:
+        raise SystemExit("MODEL.WEIGHT %r is not a local file and OUTPUT_DIR holds no checkpoint: an evaluation of "
+                         "randomly initialised weights is meaningless (pass --allow-random-init to run it anyway)"
+                         % cfg.MODEL.WEIGHT)
+    for name in cfg.DATASETS.TEST:
+        if "coco" in name:
+            raise SystemExit("dataset %r: the COCO bbox metric (pycocotools' COCOeval) is outside this build -- only the "
+                             "VOC07 metric is implemented (od_wscl_amd/data/evaluation.py)" % name)
     loaders = make_data_loader(cfg, is_train=False, is_distributed=world > 1)
     for name, loader in zip(cfg.DATASETS.TEST, loaders):
         out = os.path.join(cfg.OUTPUT_DIR, "inference", name) if cfg.OUTPUT_DIR else None

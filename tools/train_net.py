@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x3", "bf16x2", "f32"])
     ap.add_argument("--log-period", type=int, default=20)
+    ap.add_argument("--allow-random-init", action="store_true",
+                    help="train from the formula initialisation when MODEL.WEIGHT cannot be resolved locally")
     ap.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     args = ap.parse_args()
 
@@ -89,17 +91,24 @@ def main():
     if not args.synthetic and not cfg.DATASETS.TRAIN:
         raise SystemExit("DATASETS.TRAIN is empty: pass a config that names a dataset, or --synthetic")
 
-    step, info = engine.build_training_step(cfg, device, dtype=args.dtype, world=world, seed=cfg.SEED, backend="hip")
-    opt = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, engine.FlatSGD)][0]
-    model = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, torch.nn.Module)][0]
+    step, info = engine.build_training_step(cfg, device, dtype=args.dtype, world=world, seed=cfg.SEED)
+    opt, model = step.optimizer, step.model
     start_iter = 0
-    weight = cfg.MODEL.WEIGHT
+    # resume order of the reference (utils/checkpoint.py:65-84): OUTPUT_DIR/last_checkpoint first, then MODEL.WEIGHT
+    resume_from = ck.last_checkpoint(cfg.OUTPUT_DIR)
+    weight = resume_from or cfg.MODEL.WEIGHT
     if weight and os.path.isfile(weight):           # catalog:// and http:// sources need the network: not here
         rest = ck.load_checkpoint(model, weight)
-        opt.sync_from_params()
-        start_iter = int(rest.get("iteration", 0))
+        if resume_from:                             # our own run: momenta, schedule position, iteration
+            start_iter = ck.restore_training_state(opt, model, rest)
+        else:                                       # pretrained weights: a fresh schedule (trainer.py / train_net.py:75-77)
+            opt.sync_from_params()
         if rank == 0:
-            print("loaded %s (iteration %d)" % (weight, start_iter), flush=True)
+            print("loaded %s (%s, iteration %d)" % (weight, "resume" if resume_from else "weights only", start_iter), flush=True)
+    elif weight and not (args.synthetic or args.allow_random_init):
+        raise SystemExit("MODEL.WEIGHT %r is not a local file (catalog:// and http:// sources need the network).  Pass the "
+                         "path of a pretrained .pth (VGG16: keys features.N / classifier.{1,4}, matched by suffix), or "
+                         "--allow-random-init to train from the formula initialisation" % weight)
     elif weight and rank == 0:
         print("MODEL.WEIGHT %r is not a local file: training from the formula initialisation" % weight, flush=True)
 
@@ -115,6 +124,15 @@ def main():
         iteration += 1                                             # engine/trainer.py:94
         if iteration > max_iter:
             break
+        # engine/trainer.py:81-84 skips a batch that holds an image without labels (VOC images whose objects are all
+        # "difficult"); every rank must take the same decision or the gradient all-reduce would hang
+        empty = int(any(len(t) < 1 for t in targets))
+        if world > 1:
+            flag = torch.tensor([empty], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            empty = int(flag.item())
+        if empty:
+            continue
         rand = DeviceRand(cfg.SEED + rank, first_stream=(1 << 20) + (iteration << 12), device=device)
         losses, accs = step(images, targets, rois, rand, iteration=iteration)
         seen += sum(len(r) for r in rois)
@@ -127,9 +145,8 @@ def main():
             t0, seen = time.time(), 0
         if rank == 0 and out_dir and period and (iteration % period == 0 or iteration == max_iter):
             path = os.path.join(out_dir, "model_%07d.pth" % iteration if iteration != max_iter else "model_final.pth")
-            ck.save_checkpoint(model, path, iteration=iteration)
-            with open(os.path.join(out_dir, "last_checkpoint"), "w") as f:      # utils/checkpoint.py:120-123
-                f.write(path)
+            ck.save_checkpoint(model, path, optimizer=opt, iteration=iteration)
+            ck.tag_last_checkpoint(out_dir, path)                               # utils/checkpoint.py:120-123
     if world > 1:
         dist.destroy_process_group()
 
