@@ -207,7 +207,8 @@ constexpr int kStackThreads = 512;
 // LDS read + one v_max_u32 per cell -- max value AND first row-major position of it -- instead of read, compare,
 // two selects and a branch.  0 = "no cell" (every real key is >= 0x00800000).
 __device__ __forceinline__ unsigned rp_key(float v, int cell) {
-    const unsigned b = __float_as_uint(v) >> 16;
+    unsigned b = __float_as_uint(v) >> 16;
+    b = b == 0x8000u ? 0u : b;          // -0.0 == +0.0 in the reference's scan (first cell wins)
     const unsigned ord = (b & 0x8000u) ? (~b & 0xFFFFu) : (b | 0x8000u);
     return (ord << 16) | (0xFFFFu - (unsigned)cell);
 }
@@ -587,7 +588,13 @@ __global__ __launch_bounds__(256) void nhwc_ord_kernel(const uint4* __restrict__
         const uint4 v = in[i];
         unsigned d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] ^= 0x80008000u | (((d[q] >> 15) & 0x00010001u) * 0x7FFFu);
+        for (int q = 0; q < 4; ++q) {
+            // -0.0 compares EQUAL to +0.0 in the reference's `>` scan (first cell wins): fold it onto +0.0 before the
+            // order-preserving map, or a bin whose maximum is zero would prefer the +0.0 cell
+            if ((d[q] & 0xFFFFu) == 0x8000u) d[q] &= 0xFFFF0000u;
+            if ((d[q] >> 16) == 0x8000u) d[q] &= 0x0000FFFFu;
+            d[q] ^= 0x80008000u | (((d[q] >> 15) & 0x00010001u) * 0x7FFFu);
+        }
         out[i] = make_uint4(d[0], d[1], d[2], d[3]);
     }
 }

@@ -33,24 +33,29 @@ def ops_golden():
 _WEIGHTS = {}
 
 
-def weights_for(arch):
-    """The one formula-generated weight set every e2e golden of `arch` was produced with (WEIGHT_SEED=1);
+def weights_for(arch, classes=21):
+    """The one formula-generated weight set every e2e golden of (`arch`, `classes`) was produced with (WEIGHT_SEED=1);
     for the ResNets the frozen batch-norm buffers come with it."""
-    if arch not in _WEIGHTS:
+    key = arch if classes == 21 else (arch, classes)
+    if key not in _WEIGHTS:
         from od_wscl_amd import synthetic
         from oracle import hotpath_ref as H
-        sd = synthetic.init_state_dict(H.param_shapes(21, arch), 1,
+        sd = synthetic.init_state_dict(H.param_shapes(classes, arch), 1,
                                        overrides={"predictor": 0.002, "model_sim.mlp.2": 0.05})
         if arch != "vgg16":
             sd.update(synthetic.init_buffers(H.resnet_buffer_shapes(arch), 1))
         _WEIGHTS.clear()                       # one set resident at a time (0.6-1 GB each)
-        _WEIGHTS[arch] = sd
-    return _WEIGHTS[arch]
+        _WEIGHTS[key] = sd
+    return _WEIGHTS[key]
 
 
 @pytest.fixture(scope="session")
 def weights_np():
     return weights_for("vgg16")
+
+
+def e2e_classes(g):
+    return int(g["spec_classes"]) if "spec_classes" in g.files else 21
 
 
 def e2e_arch(g):

@@ -41,7 +41,9 @@ E2E_CASES = {
     "e2e_r50_2img": dict(seed=27, images=[(256, 320, 48), (224, 288, 40)], labels=[[7], [12]], pooler="ROIPool",
                          arch="r50", min_size=32, yaml="configs/voc/voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml"),
     # config 4 of SURVEY.md s8: the COCO14 shape -- 81 classes (predictor N = 1377), labels up to 80
-    "e2e_coco_2img": dict(seed=41, images=[(96, 128, 56), (112, 96, 48)], labels=[[17, 63], [80]], pooler="ROIPool",
+    # (one label per image: with 80 foreground classes and this weight set the same proposal tops both classes of a
+    # two-label image in most seeds, which is quirk Q3's rounding-dependent `1.0 >= |e|^2` -- excluded by construction)
+    "e2e_coco_2img": dict(seed=204, images=[(96, 128, 44), (80, 112, 36)], labels=[[17], [63]], pooler="ROIPool",
                           classes=81, yaml="configs/coco/coco14_contra_db_b8_lr0.01_mcg.yaml"),
 }
 # predictor / Sim_Net scales that give well separated scores (the reference's N(0,0.001)

@@ -9,11 +9,12 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import e2e_arch, e2e_inputs, load_e2e, weights_for
+from conftest import e2e_arch, e2e_classes, e2e_inputs, load_e2e, weights_for
 
 pytestmark = pytest.mark.gpu
 
 E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img", "e2e_r50_2img"]
+E2E_ALL = E2E + ["e2e_coco_2img"]          # the COCO14 shape: 81 classes, predictor N = 1377
 LOSS_RTOL = 1e-3
 
 
@@ -26,12 +27,12 @@ ARCH_OPTS = {
 }
 
 
-def build_model(pooler, weights_np, loss_impl="fused", arch="vgg16"):
+def build_model(pooler, weights_np, loss_impl="fused", arch="vgg16", classes=21):
     from od_wscl_amd.config import make_defaults
     from od_wscl_amd.modeling.detector import build_detection_model
     cfg = make_defaults()
     cfg.merge_from_list(["MODEL.WSOD_ON", True, "MODEL.FASTER_RCNN", False,
-                         "MODEL.ROI_BOX_HEAD.NUM_CLASSES", 21, "MODEL.ROI_BOX_HEAD.POOLER_METHOD", pooler,
+                         "MODEL.ROI_BOX_HEAD.NUM_CLASSES", classes, "MODEL.ROI_BOX_HEAD.POOLER_METHOD", pooler,
                          "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
                          "MODEL.ROI_WEAK_HEAD.REGRESS_ON", True, "DB.METHOD", "dropblock", "SOLVER.CONTRA", True,
                          "nms", 0.1, "lmda", 0.03, "temp", 0.2, "ODW.LOSS_IMPL", loss_impl] + ARCH_OPTS[arch])
@@ -44,7 +45,7 @@ def build_model(pooler, weights_np, loss_impl="fused", arch="vgg16"):
 
 
 @pytest.mark.parametrize("loss_impl", ["fused", "loops"])
-@pytest.mark.parametrize("name", E2E)
+@pytest.mark.parametrize("name", E2E_ALL)
 def test_model_matches_reference_golden(name, loss_impl):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -52,7 +53,7 @@ def test_model_matches_reference_golden(name, loss_impl):
     from od_wscl_amd.utils.device_rand import DeviceRand
     g = load_e2e(name)
     seed, batch, boxes, labels, cfg = e2e_inputs(g)
-    model = build_model(cfg["pooler"], weights_for(e2e_arch(g)), loss_impl, e2e_arch(g))
+    model = build_model(cfg["pooler"], weights_for(e2e_arch(g), e2e_classes(g)), loss_impl, e2e_arch(g), e2e_classes(g))
     specs = g["spec_images"]
     rois, targets = [], []
     for k, (h, w, p) in enumerate(specs):
@@ -68,7 +69,7 @@ def test_model_matches_reference_golden(name, loss_impl):
     assert rand.s.next == int(g["streams_used"])
     for k, v in losses.items():
         ref = float(g["loss/" + k])
-        assert abs(float(v) - ref) <= LOSS_RTOL * max(abs(ref), 1e-6), (k, float(v), ref)
+        assert abs(float(v.detach()) - ref) <= LOSS_RTOL * max(abs(ref), 1e-6), (k, float(v.detach()), ref)
     for k, v in accs.items():
         assert abs(float(v) - float(g["acc/" + k])) < 1e-6, k
     for k in g.files:
@@ -144,7 +145,7 @@ def _run_golden(name, mode):
     g = load_e2e(name)
     seed, batch, boxes, labels, cfg = e2e_inputs(g)
     precision.set_precision(mode)
-    model = build_model(cfg["pooler"], weights_for(e2e_arch(g)), "fused", e2e_arch(g))
+    model = build_model(cfg["pooler"], weights_for(e2e_arch(g), e2e_classes(g)), "fused", e2e_arch(g), e2e_classes(g))
     rois, targets = [], []
     for k, (h, w, p) in enumerate(g["spec_images"]):
         rois.append(BoxList(boxes[k].cuda(), (int(w), int(h)), "xyxy"))
@@ -158,7 +159,7 @@ def _run_golden(name, mode):
     return losses, trace, model, g
 
 
-@pytest.mark.parametrize("name", E2E)
+@pytest.mark.parametrize("name", E2E_ALL)
 def test_bf16x2_mode_meets_the_loss_and_selection_bars(name):
     """Two bf16 planes per operand, three plane products (half the MFMA work of bf16x3): on all four goldens the losses
     stay within the 1e-3 bar and every selected index set is the reference's (observed: losses <= 9e-5, profiles/r02/
@@ -180,13 +181,13 @@ def test_bf16x2_mode_meets_the_loss_and_selection_bars(name):
 
 
 # observed deviation of the single-plane bf16 mode from the reference (profiles/r02/precision_deviation.json):
-# worst loss 17 % / 4.4 % / 1.0 % / 4.1 %, worst gradient norm 19 % / 5.8 % / 2.5 % / 4.3 %, selection sets that
-# differ 4 of 15 / 0 / 2 of 9 / 0 -- bounds below = those with ~1.5x head-room
+# worst loss 17 % / 4.4 % / 1.0 % / 4.1 % / 1.8 %, worst gradient norm 19 % / 5.8 % / 2.5 % / 4.3 % / 2.7 %, selection
+# sets that differ 4 of 15 / 0 / 2 of 9 / 0 / 2 of 12 -- bounds below = those with ~1.5x head-room
 BF16_BOUNDS = {"e2e_voc_2img": (0.26, 0.30, 6), "e2e_voc_1img": (0.07, 0.09, 1), "e2e_align_1img": (0.02, 0.04, 3),
-               "e2e_r50_2img": (0.07, 0.07, 1)}
+               "e2e_r50_2img": (0.07, 0.07, 1), "e2e_coco_2img": (0.03, 0.04, 3)}
 
 
-@pytest.mark.parametrize("name", E2E)
+@pytest.mark.parametrize("name", E2E_ALL)
 def test_bf16_mode_tracks_the_reference(name):
     """The throughput mode (one bf16 plane per operand: what bench.py times) on all four goldens.  bf16 operands cannot
     meet the 1e-3 bar and may legitimately flip a near-threshold selection (which moves that branch's loss pair); the

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import e2e_arch, e2e_inputs, load_e2e, weights_for
+from conftest import e2e_arch, e2e_classes, e2e_inputs, load_e2e, weights_for
 from oracle import hotpath_ref as H
 from oracle import native
 
@@ -124,7 +124,7 @@ def test_roi_pool_known_answers():
     assert gin[0, 0, 1, 3] == 6 + 1 and gin[0, 0, 1, 1] == 1 and gin.sum() == 6 + 6 + 6
 
 
-E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img", "e2e_r50_2img"]
+E2E = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img", "e2e_r50_2img", "e2e_coco_2img"]
 
 
 @pytest.mark.parametrize("name", E2E)
@@ -134,9 +134,9 @@ def test_end_to_end_matches_imported_reference(name):
     seed, batch, boxes, labels, cfg = e2e_inputs(g)
     arch = e2e_arch(g)
     frozen = H.FROZEN if arch == "vgg16" else H.FROZEN_RESNET
-    param_names = set(n for n, _ in H.param_shapes(21, arch))
+    param_names = set(n for n, _ in H.param_shapes(e2e_classes(g), arch))
     sd = {}
-    for k, v in weights_for(arch).items():
+    for k, v in weights_for(arch, e2e_classes(g)).items():
         t = torch.from_numpy(v.copy())
         if k in param_names and not k.startswith(frozen):
             t.requires_grad_(True)

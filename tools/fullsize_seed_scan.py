@@ -1,0 +1,58 @@
+"""Pick seeds for the full-size parity tests (tests/test_fullsize_gpu.py): run the CPU oracle's forward at the C1 / C2 /
+C4 shapes of BASELINE.json on formula-generated inputs and print the decision margins of each seed -- how far every
+data-dependent selection (argmax, similarity threshold, NMS order, quirk Q3) was from flipping.  A seed is usable
+when all margins are far above fp32 re-association noise, so that "bit-exact selection" tests the algorithm and not
+the summation order of a K = 25088 dot product.
+
+    python tools/fullsize_seed_scan.py c2 300 310
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CASES = {  # name: (size, proposals, classes, labels)
+    "c1": (300, 500, 21, [4, 11]),
+    "c2": (600, 2000, 21, [3, 9]),
+    "c4": (800, 4000, 81, [17]),
+}
+FLOORS = {"argmax_rel": 1e-3, "sim_thresh_abs": 1e-4, "q3_abs": 1e-4, "nms_order_rel": 1e-3}
+
+
+def inputs(name, seed):
+    from od_wscl_amd import synthetic
+    size, p, classes, labels = CASES[name]
+    pad = synthetic.pad_to(size)
+    batch = torch.zeros(1, 3, pad, pad)
+    batch[0, :, :size, :size] = torch.from_numpy(synthetic.make_image(seed, 0, size, size)[:, :size, :size].copy())
+    boxes = [torch.from_numpy(synthetic.make_proposals(seed, 0, p, size, size))]
+    return batch, boxes, [torch.tensor(labels, dtype=torch.int64)], classes
+
+
+def main():
+    from conftest import weights_for
+    from oracle import hotpath_ref as H
+    name, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    torch.set_num_threads(8)
+    classes = CASES[name][2]
+    sd = {k: torch.from_numpy(v) for k, v in weights_for("vgg16", classes).items()}
+    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", sampling_ratio=0, arch="vgg16", scale=0.125)
+    for seed in range(lo, hi):
+        batch, boxes, labels, _ = inputs(name, seed)
+        tr = {}
+        t0 = time.time()
+        with torch.no_grad():
+            losses, _ = H.forward(batch, boxes, labels, sd, H.Rand(seed), cfg, tr)
+        m = {k[7:]: float(v) for k, v in tr.items() if k.startswith("margin/")}
+        ok = all(m[k] > FLOORS[k] for k in m)
+        print("%s seed %d  %s  %s  supcon_n %d  (%.1f s)" % (name, seed, "OK " if ok else "-- ",
+              " ".join("%s=%.2e" % kv for kv in sorted(m.items())), int(tr["supcon_n"]), time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    main()

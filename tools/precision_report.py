@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def run(name, mode):
-    from conftest import e2e_arch, e2e_inputs, load_e2e, weights_for
+    from conftest import e2e_arch, e2e_classes, e2e_inputs, load_e2e, weights_for
     from test_e2e_gpu import build_model
     from od_wscl_amd import precision
     from od_wscl_amd.structures import BoxList, to_image_list
@@ -25,7 +25,7 @@ def run(name, mode):
     precision.set_precision(mode)
     g = load_e2e(name)
     seed, batch, boxes, labels, cfg = e2e_inputs(g)
-    model = build_model(cfg["pooler"], weights_for(e2e_arch(g)), "fused", e2e_arch(g))
+    model = build_model(cfg["pooler"], weights_for(e2e_arch(g), e2e_classes(g)), "fused", e2e_arch(g), e2e_classes(g))
     rois, targets = [], []
     for k, (h, w, p) in enumerate(g["spec_images"]):
         rois.append(BoxList(boxes[k].cuda(), (int(w), int(h)), "xyxy"))
@@ -58,7 +58,7 @@ def run(name, mode):
 
 
 def main():
-    names = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img", "e2e_r50_2img"]
+    names = ["e2e_voc_2img", "e2e_voc_1img", "e2e_align_1img", "e2e_r50_2img", "e2e_coco_2img"]
     report = {}
     for mode in ("bf16x3", "bf16x2", "bf16"):
         for name in names:
