@@ -118,6 +118,11 @@ int odw_box_iou(const float* a, int N, const float* b, int M, float* iou, void* 
  * replaces `torch.mm(sim_feature, sim_feature.T)` of
  * roi_heads/weak_head/loss.py:319.  E (P,D) fp32, D % 4 == 0 -> S (P,P) fp32. */
 int odw_pairwise_sim(const float* E, int P, int D, float* S, void* stream);
+/* Workspace form (D = 128): E is split once into three bf16 planes (csrc/split.hip arithmetic) and the products run
+ * on the bf16 matrix cores, six plane products per fp32-grade product -- the kernel is then bound by the 4 P^2-byte
+ * write of S.  odw_pairwise_sim_workspace(P, D) bytes; NULL / too small = the exact-fp32 MFMA chain of the plain entry. */
+int64_t odw_pairwise_sim_workspace(int P, int D);
+int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- SupConLossV2 ------------------------------------------------------------
  * replaces roi_heads/sim_head/sim_loss.py:49-80 forward + its autograd

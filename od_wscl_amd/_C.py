@@ -130,7 +130,9 @@ def pairwise_sim(E):
     P, D = E.shape
     S = torch.empty((P, P), dtype=torch.float32, device=E.device)
     if P:
-        L.check(L.lib().odw_pairwise_sim(L.ptr(E), P, D, L.ptr(S), L.stream()), "pairwise_sim")
+        ws_bytes = L.lib().odw_pairwise_sim_workspace(P, D)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=E.device) if ws_bytes else None
+        L.check(L.lib().odw_pairwise_sim_ws(L.ptr(E), P, D, L.ptr(S), L.ptr(ws), ws_bytes, L.stream()), "pairwise_sim")
     return S
 
 
