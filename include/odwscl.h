@@ -51,6 +51,12 @@ int odw_roi_pool_forward(const float* feat, const float* rois, float spatial_sca
 int odw_roi_pool_backward(const float* grad_out, const int32_t* argmax, const float* rois,
                           int B, int C, int H, int W, int R, int PH, int PW,
                           float* grad_in, void* stream);
+/* Deterministic form of the backward: fixed-point accumulation (one power-of-two scale per launch from an atomicMax
+ * pre-pass, 64-bit integer LDS atomics) -- bit-identical from run to run, where the reference's float atomicAdd
+ * (ROIPool_cuda.cu:101) is not.  workspace: >= 4 bytes of device memory. */
+int odw_roi_pool_backward_det(const float* grad_out, const int32_t* argmax, const float* rois,
+                              int B, int C, int H, int W, int R, int PH, int PW,
+                              float* grad_in, void* workspace, int64_t workspace_bytes, void* stream);
 /* ROIPool fused with the operand staging of the first head GEMM (same pooling semantics as odw_roi_pool_forward:
  * csrc/cuda/ROIPool_cuda.cu:17-108): X (2R x ld) bf16, row n = pooled features of ROI n flattened (C, PH, PW), row
  * R+n = ((x * keep[n][bin]) * R*PH*PW) / *keep_sum (DropBlock2D.forward, drop_block.py:45-50; keep = NULL: only

@@ -3,6 +3,8 @@ pybind11 (csrc/vision.cpp:9-25), same names, argument order and return values,
 backed by libodwscl.so.  `wetectron/layers/*.py` works unchanged with
 `from od_wscl_amd import _C`.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -39,9 +41,15 @@ def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, p
     gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
     if gin.numel() == 0:
         return gin
-    L.check(L.lib().odw_roi_pool_backward(L.ptr(grad), L.ptr(argmax), L.ptr(rois), batch_size, channels,
-                                          height, width, rois.shape[0], pooled_height, pooled_width,
-                                          L.ptr(gin), L.stream()), "roi_pool_backward")
+    if os.environ.get("ODW_POOL_BWD_ATOMIC") == "1":       # float LDS atomics: order-dependent rounding (comparison)
+        L.check(L.lib().odw_roi_pool_backward(L.ptr(grad), L.ptr(argmax), L.ptr(rois), batch_size, channels,
+                                              height, width, rois.shape[0], pooled_height, pooled_width,
+                                              L.ptr(gin), L.stream()), "roi_pool_backward")
+        return gin
+    ws = torch.empty(64, dtype=torch.uint8, device=grad.device)
+    L.check(L.lib().odw_roi_pool_backward_det(L.ptr(grad), L.ptr(argmax), L.ptr(rois), batch_size, channels,
+                                              height, width, rois.shape[0], pooled_height, pooled_width,
+                                              L.ptr(gin), L.ptr(ws), 64, L.stream()), "roi_pool_backward_det")
     return gin
 
 

@@ -28,6 +28,7 @@ SIGNATURES = {
     "odw_roi_pool_workspace": (c_l, [c_i, c_i, c_i]),
     "odw_roi_pool_forward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_p]),
     "odw_roi_pool_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_roi_pool_backward_det": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "odw_roi_align_forward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_roi_align_backward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_roi_align_backward_workspace": (c_l, [c_i, c_i, c_i]),

@@ -170,6 +170,67 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_pool_bwd_plane(
     for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) dst[i] = acc[i];
 }
 
+// ---- deterministic backward --------------------------------------------------------------------------------
+// ROIPool's backward is a pure scatter-add of grad_out through argmax (csrc/cuda/ROIPool_cuda.cu:80-108 does it with
+// float atomicAdd: the summation order, hence the rounding, changes from run to run).  Integer addition is
+// associative: every gradient is converted to fixed point with ONE power-of-two scale for the launch (2^40 / the
+// power of two above max|grad_out|, found by an order-independent atomicMax pre-pass), accumulated with 64-bit LDS
+// integer atomics (at most R*PH*PW < 2^18 terms of magnitude <= 2^40 per cell: no overflow), and converted back.
+// The result is bit-identical from run to run and is the correctly rounded sum to ~2^-40 of the largest gradient.
+__global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ x, size_t n4, const float* __restrict__ tail,
+                                                     int ntail, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        m = max(m, __float_as_uint(fabsf(v.x)));        // non-negative floats order like their bit patterns (NaN on top)
+        m = max(m, __float_as_uint(fabsf(v.y)));
+        m = max(m, __float_as_uint(fabsf(v.z)));
+        m = max(m, __float_as_uint(fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) m = max(m, __float_as_uint(fabsf(tail[threadIdx.x])));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+__global__ __launch_bounds__(kPlaneThreads) void roi_pool_bwd_plane_det(
+    const float* __restrict__ grad_out, const int* __restrict__ argmax, const float* __restrict__ rois,
+    const unsigned* __restrict__ absmax_bits, int C, int H, int W, int R, int nb, int cells_per_pass,
+    float* __restrict__ grad_in) {
+    extern __shared__ __attribute__((aligned(16))) long long iacc[];
+    const int b = blockIdx.x / C;
+    const int c = blockIdx.x % C;
+    const int HW = H * W;
+    float* dst = grad_in + ((size_t)b * C + c) * HW;
+    const float amax = __uint_as_float(*absmax_bits);
+    if (!(amax > 0.0f) || !(amax < __builtin_inff())) {      // all-zero gradient (or inf / nan: propagate it like a sum would)
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) dst[i] = amax > 0.0f ? amax : 0.0f;
+        if (!(amax > 0.0f)) return;
+    }
+    int e;
+    frexpf(amax, &e);                                        // amax < 2^e
+    const float scale = ldexpf(1.0f, 40 - e), inv = ldexpf(1.0f, e - 40);
+    for (int lo = 0; lo < HW; lo += cells_per_pass) {
+        const int hi = min(HW, lo + cells_per_pass);
+        for (int i = threadIdx.x; i < hi - lo; i += blockDim.x) iacc[i] = 0;
+        __syncthreads();
+        int n = threadIdx.x / nb, r = threadIdx.x % nb;
+        const int dn = kPlaneThreads / nb, dr = kPlaneThreads % nb;
+        for (; n < R; n += dn, r += dr) {
+            if (r >= nb) { r -= nb; ++n; if (n >= R) break; }
+            if ((int)rois[(size_t)n * 5] != b) continue;
+            const size_t o = ((size_t)n * C + c) * nb + r;
+            const int a = argmax[o];
+            if (a >= lo && a < hi)
+                atomicAdd(reinterpret_cast<unsigned long long*>(&iacc[a - lo]),
+                          (unsigned long long)__float2ll_rn(grad_out[o] * scale));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < hi - lo; i += blockDim.x) dst[lo + i] = (float)iacc[i] * inv;
+        __syncthreads();
+    }
+}
+
 __global__ void roi_pool_bwd_direct(const float* __restrict__ grad_out, const int* __restrict__ argmax,
                                     const float* __restrict__ rois, int C, int H, int W, int R, int nb,
                                     float* __restrict__ grad_in) {
@@ -532,6 +593,37 @@ ODW_EXPORT int odw_roi_pool_backward(const float* grad_out, const int32_t* argma
             break;
     }
     ODW_CHECK_LAUNCH("roi_pool_bwd_plane");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_roi_pool_backward_det(const float* grad_out, const int32_t* argmax, const float* rois, int B, int C,
+                                         int H, int W, int R, int PH, int PW, float* grad_in, void* workspace,
+                                         int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 0, "roi_pool_backward_det: bad dims");
+    if (B == 0) return ODW_OK;
+    ODW_REQUIRE(grad_in, "roi_pool_backward_det: null grad_in");
+    const size_t in_bytes = (size_t)B * C * H * W * 4;
+    if (R == 0) {
+        ODW_CHECK_HIP(hipMemsetAsync(grad_in, 0, in_bytes, stream), "roi_pool_backward_det memset");
+        return ODW_OK;
+    }
+    ODW_REQUIRE(grad_out && argmax && rois, "roi_pool_backward_det: null pointer");
+    ODW_REQUIRE(workspace && workspace_bytes >= 4 && (((uintptr_t)workspace) & 3) == 0, "roi_pool_backward_det: workspace of 4 bytes");
+    ODW_REQUIRE(PH * PW <= kPlaneThreads, "roi_pool_backward_det: pooled size too large");
+    ODW_REQUIRE((((uintptr_t)grad_out) & 15) == 0, "roi_pool_backward_det: grad_out must be 16-byte aligned");
+    unsigned* mx = (unsigned*)workspace;
+    ODW_CHECK_HIP(hipMemsetAsync(mx, 0, 4, stream), "roi_pool_backward_det memset");
+    const size_t n = (size_t)R * C * PH * PW;
+    absmax_kernel<<<2048, 256, 0, stream>>>((const float4*)grad_out, n / 4, grad_out + (n / 4) * 4, (int)(n % 4), mx);
+    ODW_CHECK_LAUNCH("absmax_kernel");
+    const int HW = H * W;
+    const int cap = (ODW_LDS_BYTES - 1024) / 8;                    // 64-bit cells one workgroup holds
+    const int cpp = HW < cap ? HW : cap;
+    const size_t lds = (size_t)cpp * 8;
+    ODW_CHECK_HIP(allow_lds(roi_pool_bwd_plane_det, lds), "roi_pool_bwd_plane_det attr");
+    roi_pool_bwd_plane_det<<<B * C, kPlaneThreads, lds, stream>>>(grad_out, argmax, rois, mx, C, H, W, R, PH * PW, cpp, grad_in);
+    ODW_CHECK_LAUNCH("roi_pool_bwd_plane_det");
     return ODW_OK;
 }
 

@@ -61,6 +61,24 @@ def test_roi_pool_forward_backward(C, B, Cc, H, W, n, scale, ph, pw):
     rg = native.roi_pool_bwd(g, ra, rois, feat.shape, ph, pw)
     # the reference sums with atomicAdd (order undefined): fp32 re-association tolerance
     np.testing.assert_allclose(gin.cpu().numpy(), rg, rtol=1e-5, atol=1e-5)
+    # ours is the fixed-point (order-independent) form: bit-identical from run to run, and the exact sum to 2^-40 of
+    # the largest gradient -- closer to the double-precision sum than any fp32 summation order
+    gin2 = C.roi_pool_backward(dev(g), None, dev(rois), arg, scale, ph, pw, B, Cc, H, W)
+    assert torch.equal(gin, gin2)
+    # a heavy-collision case: every ROI is the full image, so each bin's arg-max cell receives n contributions
+    full = np.tile(np.array([[0, 0, 0, W / scale - 1, H / scale - 1]], np.float32), (200, 1))
+    o2, a2 = C.roi_pool_forward(dev(feat), dev(full), scale, ph, pw)
+    g2 = rng.normal(24, 1, o2.numel()).reshape(tuple(o2.shape)) * np.exp(rng.normal(25, 1, o2.numel()).reshape(tuple(o2.shape)) * 4)
+    runs = [C.roi_pool_backward(dev(g2), None, dev(full), a2, scale, ph, pw, B, Cc, H, W) for _ in range(3)]
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    want = np.zeros((B * Cc * H * W,), np.float64)
+    idx = a2.cpu().numpy().reshape(200, Cc, -1)
+    flat = g2.astype(np.float64).reshape(200, Cc, -1)
+    for c in range(Cc):
+        ok = idx[:, c] >= 0
+        np.add.at(want, c * H * W + idx[:, c][ok], flat[:, c][ok])
+    got = runs[0].cpu().numpy().reshape(-1).astype(np.float64)
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max() + 2.0 ** -38 * np.abs(g2).max()
 
 
 def test_roi_pool_empty_and_known_answers(C):
