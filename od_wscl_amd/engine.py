@@ -85,6 +85,23 @@ def all_reduce_flat(flat, world, chunk_elems=64 * 1024 * 1024, group=None):
         w.wait()
 
 
+def reduce_loss_dict(loss_dict, world=None, dst=0, group=None):
+    """Logging reduce of the reference's trainer (engine/trainer.py:14-36): the per-rank loss values summed onto rank
+    `dst` in ONE small collective (the dictionary's values stacked in sorted-key order) and divided by the world size
+    there; other ranks get the un-normalised partial sums back, like the reference.  world < 2: the input itself."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world < 2:
+        return loss_dict
+    with torch.no_grad():
+        names = sorted(loss_dict.keys())
+        stacked = torch.stack([loss_dict[k].detach().float().reshape(()) for k in names], dim=0)
+        dist.reduce(stacked, dst=dst, group=group)
+        if dist.get_rank() == dst:
+            stacked /= world
+        return {k: v for k, v in zip(names, stacked)}
+
+
 class FlatSGD(object):
     """Parameters, gradients and momenta as three flat fp32 buffers + the fused SGD kernel."""
 

@@ -44,7 +44,9 @@ def _worker(rank, world, port, out_dir):
     d = g * (1.0 / world) + wd * p
     buf = d.clone()
     p_new = p - lr * buf
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), boxes=rois[0].bbox.numpy(), labels=targets[0].get_field("labels").numpy(),
+    # 4) the logging reduce of the reference's trainer (engine/trainer.py:14-36)
+    red = engine.reduce_loss_dict({"loss_b": torch.tensor(float(rank + 1)), "loss_a": torch.tensor(10.0 * (rank + 1))}, world)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), red_a=float(red["loss_a"]), red_b=float(red["loss_b"]), boxes=rois[0].bbox.numpy(), labels=targets[0].get_field("labels").numpy(),
              img_sum=float(images.tensors.sum()), w=w, g=g.numpy(), local=local.numpy(), p_new=p_new.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -61,6 +63,7 @@ def test_two_rank_gloo_allreduce_and_sharding(tmp_path):
     np.testing.assert_array_equal(r0["g"], r1["g"])                                         # all-reduced
     np.testing.assert_allclose(r0["g"], r0["local"] + r1["local"], rtol=1e-6, atol=1e-6)   # = sum over ranks
     np.testing.assert_array_equal(r0["p_new"], r1["p_new"])                                 # replicas stay in sync
+    assert float(r0["red_a"]) == 15.0 and float(r0["red_b"]) == 1.5                          # rank 0: mean over the ranks
 
 
 def test_world_one_is_a_noop():
@@ -68,6 +71,8 @@ def test_world_one_is_a_noop():
     g = torch.ones(10)
     engine.all_reduce_flat(g, 1)
     assert torch.equal(g, torch.ones(10))
+    d = {"loss": torch.tensor(2.0)}
+    assert engine.reduce_loss_dict(d, 1) is d
 
 
 def test_lr_schedule_and_momentum_correction():

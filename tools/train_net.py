@@ -136,7 +136,10 @@ def main():
         rand = DeviceRand(cfg.SEED + rank, first_stream=(1 << 20) + (iteration << 12), device=device)
         losses, accs = step(images, targets, rois, rand, iteration=iteration)
         seen += sum(len(r) for r in rois)
-        if rank == 0 and (iteration % args.log_period == 0 or iteration == max_iter):
+        log_now = iteration % args.log_period == 0 or iteration == max_iter
+        if log_now and world > 1:                                  # trainer.py:108-111: rank 0 logs the mean over ranks
+            losses = engine.reduce_loss_dict(dict(losses), world)
+        if rank == 0 and log_now:
             torch.cuda.synchronize()
             dt = time.time() - t0
             txt = "  ".join("%s: %.4f" % (k, float(v.detach())) for k, v in losses.items())
