@@ -77,6 +77,12 @@ int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld, const voi
                                 const float* keep, const float* keep_sum, const float* extra, const int* extra_roi,
                                 int E, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW, float* grad_in,
                                 void* stream);
+/* Workspace form (>= 4 bytes): fixed-point accumulation -- deterministic, and 64-bit integer LDS atomics run at 10x
+ * the rate of ds_add_f32 on gfx950 (csrc/odw_fixed.h).  NULL workspace = the float-atomic form above. */
+int odw_roi_pool_stack_backward_ws(const void* dX, int dx_is_f32, int ld, const void* argmax_u16, const float* rois,
+                                   const float* keep, const float* keep_sum, const float* extra, const int* extra_roi,
+                                   int E, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW,
+                                   float* grad_in, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- ROIAlign -------------------------------------------------------------
  * replaces _C.roi_align_forward / roi_align_backward
@@ -93,6 +99,12 @@ int odw_roi_align_backward(const float* grad_out, const float* rois, float spati
  * per ROI 14 axis weight vectors are built once and every plane spends one LDS atomic per touched cell instead of four
  * taps per sample (16.7 -> ~1 ms at P = 2000 on 76x76x512).  NULL / too small a workspace = the sample form above. */
 int64_t odw_roi_align_backward_workspace(int R, int PH, int PW);
+/* The forward in the same separable form (workspace of odw_roi_align_backward_workspace bytes: the per-ROI axis
+ * vectors; they are staged in LDS chunk by chunk): (bin+2)^2 cell reads per bin instead of 4 taps per sample.  The
+ * sample coordinates are the reference's, the order of the fp32 additions is not (1e-6 against ROIAlign_cpu.cpp). */
+int odw_roi_align_forward_ws(const float* feat, const float* rois, float spatial_scale, int B, int C, int H, int W,
+                             int R, int PH, int PW, int sampling_ratio, float* out, void* workspace,
+                             int64_t workspace_bytes, void* stream);
 int odw_roi_align_backward_ws(const float* grad_out, const float* rois, float spatial_scale, int B, int C, int H, int W,
                               int R, int PH, int PW, int sampling_ratio, float* grad_in, void* workspace,
                               int64_t workspace_bytes, void* stream);

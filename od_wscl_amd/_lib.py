@@ -30,6 +30,7 @@ SIGNATURES = {
     "odw_roi_pool_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_roi_pool_backward_det": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "odw_roi_align_forward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_roi_align_forward_ws": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "odw_roi_align_backward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_roi_align_backward_workspace": (c_l, [c_i, c_i, c_i]),
     "odw_roi_align_backward_ws": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "odw_roi_pool_stack_forward_nhwc": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p]),
     "odw_roi_pool_stack_backward": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                           c_i, c_p, c_p]),
+    "odw_roi_pool_stack_backward_ws": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                             c_i, c_i, c_p, c_p, c_l, c_p]),
     "odw_rows_drop_noise_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_p]),
     "odw_l2norm_rows": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
     "odw_l2norm_rows_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),

@@ -11,7 +11,9 @@
 // must be evaluated as separate fp32 mul/add/div, not FMA, to land on the
 // same side of integer boundaries as the reference.
 #include "odw_common.h"
+#include "odw_fixed.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -185,8 +187,9 @@ __global__ void roi_align_bwd_direct(const float* __restrict__ grad_out, const f
 // spends one multiply + one LDS atomic per touched CELL (~(bin+2)^2) instead of re-deriving four taps per SAMPLE
 // (4 * ceil(bin)^2, ~60 instructions each) in every one of the C planes: 16.7 ms -> ~1 ms at P = 2000 on 76x76x512.
 // Only the backward: its summation order is free (atomics); the forward keeps the reference's order.
-constexpr int kAxisLen = 30;                 // cells one bin can touch along an axis (bin extent + 2); longer: fallback
-constexpr int kAxisStride = 2 + kAxisLen;    // [first cell, cell count, weights...]
+constexpr int kAxisLen = 34;                 // cells one bin can touch along an axis (bin extent + 2); longer: fallback
+constexpr int kAxisStride = 2 + kAxisLen;    // [first cell, cell count, weights...]; 36 floats: the 7 vectors of an axis
+                                             // start in 7 different LDS banks (a 32-float pitch put them in 2)
 
 __global__ void roi_align_axis_kernel(const float* __restrict__ rois, float scale, int R, int PH, int PW, int H, int W,
                                       int sr, float* __restrict__ tab) {
@@ -269,6 +272,146 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_bwd_sep_plane(
     for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) dst[i] = acc[i];
 }
 
+// ---- separable forward + backward with the axis vectors staged in LDS ------------------------------------------
+// The forward is the same sum regrouped: out = (1/count) sum_cy sum_cx wy[cy] wx[cx] F[y0+cy][x0+cx] -- (bin+2)^2
+// cell reads instead of 4 taps and ~60 coordinate instructions per SAMPLE, with the sample coordinates themselves
+// still evaluated by roi_align_axis_kernel in the reference's fp32 operation order (which cell a sample lands in is
+// what must not move; the order in which fp32 terms are added may: 1e-6 against the reference's own CPU kernel).
+// A workgroup owns CG planes in LDS and walks the ROIs in chunks of kChunk: the chunk's axis vectors are copied to
+// LDS once (the first version read them from global memory inside the cell loop: 5.8 ms backward at P = 2000, all of
+// it load latency), one thread = one (ROI, bin) for ALL CG planes, so the weights are formed once per cell.
+constexpr int kChunk = 16;
+
+template <int CG, bool BWD>
+__global__ __launch_bounds__(kPlaneThreads) void roi_align_sep_plane(
+    const float* __restrict__ src, const float* __restrict__ rois, float scale, const float* __restrict__ tab,
+    const unsigned* __restrict__ absmax_bits, int C, int H, int W, int R, int PH, int PW, int sr, float* __restrict__ dst) {
+    // FWD: src = feat (B,C,H,W), dst = out (R,C,PH,PW), planes fp32;
+    // BWD: src = grad_out, dst = grad_in, planes 64-bit fixed point (odw_fixed.h: deterministic, and the integer LDS
+    //      atomic runs at 10x the rate of ds_add_f32)
+    typedef typename std::conditional<BWD, long long, float>::type cell_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int groups = (C + CG - 1) / CG;
+    const int b = blockIdx.x / groups;
+    const int c0 = (blockIdx.x % groups) * CG;
+    const int nc = min(CG, C - c0);
+    const int HW = H * W;
+    cell_t* plane = reinterpret_cast<cell_t*>(smem_raw);                                  // CG * HW
+    const int per = PH + PW, nb = PH * PW;
+    const int tab_chunk = kChunk * per * kAxisStride;                                      // floats; a multiple of 4
+    float* stab = reinterpret_cast<float*>(smem_raw + (((size_t)CG * HW * sizeof(cell_t) + 15) & ~(size_t)15));   // 2 buffers
+    odwfx::Scale sc = {0.0f, 0.0f, 1};
+    if (BWD) {
+        sc = odwfx::scale_of(*absmax_bits);
+        if (sc.state != 1) {
+            const float fill = sc.state == 0 ? 0.0f : __uint_as_float(0x7fc00000u);
+            float* d = dst + ((size_t)b * C + c0) * HW;
+            for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) d[i] = fill;
+            return;
+        }
+        for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) plane[i] = 0;
+    } else {
+        const float* f = src + ((size_t)b * C + c0) * HW;
+        for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) plane[i] = (cell_t)f[i];
+    }
+    // the axis vectors of chunk k+1 travel global -> registers while chunk k is processed, registers -> LDS after it
+    const int n_chunks = (R + kChunk - 1) / kChunk;
+    float4 pre[2];
+    auto fetch = [&](int k) {
+        const int nr = min(kChunk, R - k * kChunk);
+        const float4* t4 = reinterpret_cast<const float4*>(tab + (size_t)k * tab_chunk);
+        const int n4 = nr * per * kAxisStride / 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = threadIdx.x + q * kPlaneThreads;
+            pre[q] = i < n4 ? t4[i] : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto stash = [&](int k) {
+        float4* s4 = reinterpret_cast<float4*>(stab + (k & 1) * tab_chunk);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = threadIdx.x + q * kPlaneThreads;
+            if (i < tab_chunk / 4) s4[i] = pre[q];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int k = 0; k < n_chunks; ++k) {
+        const int n0 = k * kChunk;
+        const int nr = min(kChunk, R - n0);
+        if (k + 1 < n_chunks) fetch(k + 1);
+        const float* cur = stab + (k & 1) * tab_chunk;
+        for (int item = threadIdx.x; item < nr * nb; item += blockDim.x) {
+            const int nl = item / nb, bin = item - nl * nb;
+            const int n = n0 + nl;
+            const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
+            if (g.b != b) continue;
+            const int ph = bin / PW, pw = bin - ph * PW;
+            const float* ty = cur + (nl * per + ph) * kAxisStride;
+            const float* tx = cur + (nl * per + PH + pw) * kAxisStride;
+            const int y0 = reinterpret_cast<const int*>(ty)[0], ny = reinterpret_cast<const int*>(ty)[1];
+            const int x0 = reinterpret_cast<const int*>(tx)[0], nx = reinterpret_cast<const int*>(tx)[1];
+            const size_t o = ((size_t)n * C + c0) * nb + bin;
+            if (ny < 0 || nx < 0) {                    // a bin wider than an axis vector: the sample-by-sample form
+                for (int cl = 0; cl < nc; ++cl) {
+                    cell_t* q = plane + cl * HW;
+                    if constexpr (BWD) {
+                        const float tf = sc.to_fixed;
+                        align_scatter(g, H, W, ph, pw, src[o + (size_t)cl * nb], [q, tf](int pos, float v) { odwfx::add(q + pos, v, tf); });
+                    } else {
+                        dst[o + (size_t)cl * nb] = align_one(q, g, H, W, ph, pw);
+                    }
+                }
+                continue;
+            }
+            float v[CG];
+#pragma unroll
+            for (int cl = 0; cl < CG; ++cl) v[cl] = BWD ? (cl < nc ? src[o + (size_t)cl * nb] / g.count : 0.0f) : 0.0f;
+            cell_t* p = plane + y0 * W + x0;
+            for (int cy = 0; cy < ny; ++cy) {
+                const float wy = ty[2 + cy];
+                for (int cx = 0; cx < nx; ++cx) {
+                    const float w = wy * tx[2 + cx];
+#pragma unroll
+                    for (int cl = 0; cl < CG; ++cl) {
+                        if (cl < nc) {
+                            if constexpr (BWD) odwfx::add(p + cl * HW + cy * W + cx, v[cl] * w, sc.to_fixed);
+                            else v[cl] += w * p[cl * HW + cy * W + cx];
+                        }
+                    }
+                }
+            }
+            if (!BWD) {
+#pragma unroll
+                for (int cl = 0; cl < CG; ++cl)
+                    if (cl < nc) dst[o + (size_t)cl * nb] = (ny == 0 || nx == 0) ? 0.0f : v[cl] / g.count;
+            }
+        }
+        if (k + 1 < n_chunks) stash(k + 1);
+        __syncthreads();
+    }
+    if (BWD) {
+        float* d = dst + ((size_t)b * C + c0) * HW;
+        for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) d[i] = (float)plane[i] * sc.to_float;
+    }
+}
+
+// channel planes per workgroup for the chunk-staged kernels: the planes + one chunk of axis vectors must fit in LDS
+int pick_cg_sep(int B, int C, int HW, int per, int cell_bytes) {
+    const int cands[3] = {4, 2, 1};
+    const int64_t tab_bytes = (int64_t)2 * kChunk * per * kAxisStride * 4 + 16;
+    int fit = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int cg = cands[k];
+        if ((int64_t)cg * HW * cell_bytes + tab_bytes > ODW_LDS_BYTES) continue;
+        if (!fit) fit = cg;
+        if ((int64_t)B * ((C + cg - 1) / cg) >= ODW_NUM_CU) return cg;
+    }
+    return fit ? 1 : 0;
+}
+
 int pick_cg(int B, int C, int HW) {
     const int cands[3] = {4, 2, 1};
     int fit = 0;
@@ -327,8 +470,61 @@ ODW_EXPORT int odw_roi_align_forward(const float* feat, const float* rois, float
     return ODW_OK;
 }
 
+namespace {
+template <bool BWD>
+int launch_sep(const float* src, const float* rois, float scale, float* tab, int B, int C, int H, int W, int R, int PH,
+               int PW, int sr, float* dst, int cg, hipStream_t stream) {
+    static_assert((kChunk * kAxisStride) % 4 == 0, "axis-vector chunks are copied as float4");
+    ODW_REQUIRE(kChunk * (PH + PW) * kAxisStride <= 8 * kPlaneThreads, "roi_align: pooled size too large for the staged form");
+    const int items = R * (PH + PW);
+    roi_align_axis_kernel<<<(items + 255) / 256, 256, 0, stream>>>(rois, scale, R, PH, PW, H, W, sr, tab);
+    ODW_CHECK_LAUNCH("roi_align_axis_kernel");
+    // the launch's fixed-point scale lives right behind the axis vectors (backward only)
+    unsigned* mx = reinterpret_cast<unsigned*>(tab + (size_t)R * (PH + PW) * kAxisStride);
+    if (BWD) {
+        ODW_CHECK_HIP(hipMemsetAsync(mx, 0, 4, stream), "roi_align memset");
+        odwfx::absmax_kernel<false><<<1024, 256, 0, stream>>>(src, (size_t)R * C * PH * PW, mx);
+        ODW_CHECK_LAUNCH("absmax_kernel");
+    }
+    const int grid = B * ((C + cg - 1) / cg);
+    const size_t lds = (((size_t)cg * H * W * (BWD ? 8 : 4) + 15) & ~(size_t)15) + (size_t)2 * kChunk * (PH + PW) * kAxisStride * 4;
+    switch (cg) {
+        case 4:
+            ODW_CHECK_HIP(allow_lds(roi_align_sep_plane<4, BWD>, lds), "roi_align_sep_plane attr");
+            roi_align_sep_plane<4, BWD><<<grid, kPlaneThreads, lds, stream>>>(src, rois, scale, tab, mx, C, H, W, R, PH, PW, sr, dst);
+            break;
+        case 2:
+            ODW_CHECK_HIP(allow_lds(roi_align_sep_plane<2, BWD>, lds), "roi_align_sep_plane attr");
+            roi_align_sep_plane<2, BWD><<<grid, kPlaneThreads, lds, stream>>>(src, rois, scale, tab, mx, C, H, W, R, PH, PW, sr, dst);
+            break;
+        default:
+            ODW_CHECK_HIP(allow_lds(roi_align_sep_plane<1, BWD>, lds), "roi_align_sep_plane attr");
+            roi_align_sep_plane<1, BWD><<<grid, kPlaneThreads, lds, stream>>>(src, rois, scale, tab, mx, C, H, W, R, PH, PW, sr, dst);
+            break;
+    }
+    ODW_CHECK_LAUNCH("roi_align_sep_plane");
+    return ODW_OK;
+}
+}  // namespace
+
+ODW_EXPORT int64_t odw_roi_align_backward_workspace(int R, int PH, int PW);
+
+ODW_EXPORT int odw_roi_align_forward_ws(const float* feat, const float* rois, float scale, int B, int C, int H, int W,
+                                        int R, int PH, int PW, int sr, float* out, void* workspace,
+                                        int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 0, "roi_align_forward: bad dims");
+    if (R == 0 || B == 0) return ODW_OK;
+    ODW_REQUIRE(feat && rois && out, "roi_align_forward: null pointer");
+    const int cg = pick_cg_sep(B, C, H * W, PH + PW, 4);
+    if (cg == 0 || !workspace || workspace_bytes < odw_roi_align_backward_workspace(R, PH, PW) ||
+        (((uintptr_t)workspace) & 15) != 0 || PH * PW > kPlaneThreads || getenv("ODW_ROI_ALIGN_SAMPLES"))
+        return odw_roi_align_forward(feat, rois, scale, B, C, H, W, R, PH, PW, sr, out, stream_);
+    return launch_sep<false>(feat, rois, scale, (float*)workspace, B, C, H, W, R, PH, PW, sr, out, cg, stream);
+}
+
 ODW_EXPORT int64_t odw_roi_align_backward_workspace(int R, int PH, int PW) {
-    return R > 0 ? odw_align_up((int64_t)R * (PH + PW) * kAxisStride * 4, 256) : 0;
+    return R > 0 ? odw_align_up((int64_t)R * (PH + PW) * kAxisStride * 4 + 16, 256) : 0;      // axis vectors + the scale word
 }
 
 ODW_EXPORT int odw_roi_align_backward(const float* grad_out, const float* rois, float scale, int B, int C,
@@ -368,6 +564,10 @@ ODW_EXPORT int odw_roi_align_backward_ws(const float* grad_out, const float* roi
     if (workspace && workspace_bytes >= odw_roi_align_backward_workspace(R, PH, PW) &&
         (((uintptr_t)workspace) & 15) == 0 && !getenv("ODW_ROI_ALIGN_SAMPLES")) {
         float* tab = (float*)workspace;
+        const int cgs = pick_cg_sep(B, C, HW, PH + PW, 8);
+        ODW_REQUIRE((((uintptr_t)grad_out) & 15) == 0, "roi_align_backward: grad_out must be 16-byte aligned");
+        if (cgs > 0 && !getenv("ODW_ROI_ALIGN_GLOBAL_TAB"))
+            return launch_sep<true>(grad_out, rois, scale, tab, B, C, H, W, R, PH, PW, sr, grad_in, cgs, stream);
         const int items = R * (PH + PW);
         roi_align_axis_kernel<<<(items + 255) / 256, 256, 0, stream>>>(rois, scale, R, PH, PW, H, W, sr, tab);
         ODW_CHECK_LAUNCH("roi_align_axis_kernel");

@@ -212,10 +212,11 @@ class _PoolStack(torch.autograd.Function):
             holder.done = True
         dfeat = torch.empty((B, C, H, W), dtype=torch.float32, device=dx.device)
         skip_clean = 1 if (holder is not None and holder.clean_rows == 0) else 0      # sparse backward: clean half unset
-        L.check(L.lib().odw_roi_pool_stack_backward(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
-                                                    L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
-                                                    L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph, pw,
-                                                    L.ptr(dfeat), L.stream()), "roi_pool_stack_backward")
+        ws = torch.empty(64, dtype=torch.uint8, device=dx.device)       # the launch's fixed-point scale (odw_fixed.h)
+        L.check(L.lib().odw_roi_pool_stack_backward_ws(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
+                                                       L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
+                                                       L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph, pw,
+                                                       L.ptr(dfeat), L.ptr(ws), 64, L.stream()), "roi_pool_stack_backward")
         return dfeat, None, None, None, None, None, None, None, None
 
 

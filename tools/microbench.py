@@ -66,6 +66,8 @@ def main():
         rec("roi_align_fwd_sr2", ms, out_b + feat.numel() * 4, P=P, HW=H)
         ms = timeit(lambda: _C.roi_align_backward(g, rois, 0.125, 7, 7, 1, 512, H, W, 2), iters=5)
         rec("roi_align_bwd_sr2", ms, out_b + feat.numel() * 4, P=P, HW=H)
+        ms = timeit(lambda: _C.roi_align_backward(g, rois, 0.125, 7, 7, 1, 512, H, W, 0), iters=5)
+        rec("roi_align_bwd_sr0", ms, out_b + feat.numel() * 4, P=P, HW=H)
         sc = torch.rand(P, device="cuda")
         bxd = rois[:, 1:].contiguous()
         ms = timeit(lambda: _C.nms_torchvision(bxd, sc, 0.1), iters=5)
