@@ -423,13 +423,15 @@ int odw_stem_conv3x3_bias_relu(const float* img_nchw, const float* weight, const
  * pattern = T <= 8 plane codes (HOST array).  With pattern {0,0,0,1,1,2} on one operand and {0,1,2,0,1,0} on the
  * other, odw_gemm_nt_bf16 / odw_conv3x3_nhwc_bf16 over K' = T*block accumulate the six plane products of order <= 2.
  *   odw_linear_bwd_mask_f32: dZ = dY * [Y != 0] * scale (Y nullable: dZ = dY), db[n] += sum_m dZ[m][n]
- *   (single writer per bias entry, fixed summation order). */
+ *   (two fixed-order stages: single writer per bias entry, deterministic; db = NULL skips it and needs no workspace). */
 int odw_split_rows_bf16(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
                         int64_t ld_out, int block, void* stream);
 int odw_split_cols_bf16(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
                         int64_t ld_out, int block, void* stream);
+int64_t odw_linear_bwd_mask_workspace(int M, int N);     /* bytes the bias gradient's two-stage reduction wants */
 int odw_linear_bwd_mask_f32(const float* dY, int64_t ld_dy, const void* Y, int y_is_bf16, int64_t ld_y, int M, int N,
-                            float scale, float* dZ, int64_t ld_z, float* db, void* stream);
+                            float scale, float* dZ, int64_t ld_z, float* db, void* workspace, int64_t workspace_bytes,
+                            void* stream);
 /* fp32-output forms of the stacked-operand producers (same arithmetic, no bf16 rounding of the result) */
 int odw_stack_clean_aug_f32(const float* pooled, const float* block, const float* block_sum, int P, int C, int S,
                             float* out, int ld, void* stream);

@@ -108,7 +108,8 @@ SIGNATURES = {
     "odw_nhwc_f32_to_nchw_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_split_rows_bf16": (c_i, [c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_l, c_i, c_p]),
     "odw_split_cols_bf16": (c_i, [c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_l, c_i, c_p]),
-    "odw_linear_bwd_mask_f32": (c_i, [c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_f, c_p, c_l, c_p, c_p]),
+    "odw_linear_bwd_mask_workspace": (c_l, [c_i, c_i]),
+    "odw_linear_bwd_mask_f32": (c_i, [c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_f, c_p, c_l, c_p, c_p, c_l, c_p]),
     "odw_stack_clean_aug_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "odw_rows_drop_noise_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_i, c_i, c_p]),
     "odw_add_relu_f32": (c_i, [c_p, c_p, c_p, c_l, c_p]),

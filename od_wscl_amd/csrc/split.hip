@@ -108,19 +108,23 @@ __global__ __launch_bounds__(256) void split_cols_kernel(const float* __restrict
 }
 
 // dZ = dY * [Y != 0] * scale in fp32 and db[n] += sum_m dZ[m][n]: the backward prologue of a Linear whose ReLU /
-// dropout were fused into the forward epilogue (the saved output is zero exactly where either one cut).  One
-// workgroup owns 64 columns: every bias-gradient entry has a single writer and a fixed summation order.
+// dropout were fused into the forward epilogue (the saved output is zero exactly where either one cut).  A workgroup
+// owns 64 columns x one chunk of rows; the bias gradient is reduced in two fixed-order stages (column sums of each
+// row chunk, then the chunks in order), so every entry has one writer and one summation order: deterministic.
+constexpr int kMaskRows = 256;          // rows per workgroup
+
 template <bool Y_BF16>
 __global__ __launch_bounds__(256) void linear_bwd_mask_kernel(const float* __restrict__ dY, long long ld_dy,
                                                               const void* __restrict__ Yv, long long ld_y, int M, int N,
                                                               float scale, float* __restrict__ dZ, long long ld_z,
-                                                              float* __restrict__ db) {
+                                                              float* __restrict__ part) {
     __shared__ float red[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ry = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * kMaskRows, m1 = min(M, m0 + kMaskRows);
     float acc = 0.0f;
     if (n < N) {
-        for (int m = ry; m < M; m += 4) {
+        for (int m = m0 + ry; m < m1; m += 4) {
             float v = dY[(long long)m * ld_dy + n];
             if (Yv) {
                 const bool on = Y_BF16
@@ -134,7 +138,17 @@ __global__ __launch_bounds__(256) void linear_bwd_mask_kernel(const float* __res
     }
     red[ry][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (db && ry == 0 && n < N) db[n] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (part && ry == 0 && n < N)
+        part[(long long)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void bias_grad_finish_kernel(const float* __restrict__ part, int chunks, int N,
+                                                               float* __restrict__ db) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.0f;
+    for (int c = 0; c < chunks; ++c) acc += part[(long long)c * N + n];
+    db[n] += acc;
 }
 
 bool pattern_ok(const int* pattern, int T, Pattern& pat) {
@@ -180,16 +194,30 @@ ODW_EXPORT int odw_split_cols_bf16(const float* in, int64_t ld_in, int R, int Cc
     return ODW_OK;
 }
 
+ODW_EXPORT int64_t odw_linear_bwd_mask_workspace(int M, int N) {
+    return M > 0 && N > 0 ? (int64_t)((M + kMaskRows - 1) / kMaskRows) * N * 4 : 0;
+}
+
 ODW_EXPORT int odw_linear_bwd_mask_f32(const float* dY, int64_t ld_dy, const void* Y, int y_is_bf16, int64_t ld_y, int M,
-                                       int N, float scale, float* dZ, int64_t ld_z, float* db, void* stream_) {
+                                       int N, float scale, float* dZ, int64_t ld_z, float* db, void* workspace,
+                                       int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(M >= 0 && N >= 0 && ld_dy >= N && ld_z >= N && (!Y || ld_y >= N), "linear_bwd_mask: bad dims");
     if (M == 0 || N == 0) return ODW_OK;
     ODW_REQUIRE(dY && dZ, "linear_bwd_mask: null pointer");
-    const int grid = (N + 63) / 64;
+    ODW_REQUIRE(!db || (workspace && workspace_bytes >= odw_linear_bwd_mask_workspace(M, N)),
+                "linear_bwd_mask: the bias gradient needs odw_linear_bwd_mask_workspace(M, N) bytes");
+    const int chunks = (M + kMaskRows - 1) / kMaskRows;
+    const dim3 grid((N + 63) / 64, chunks);
+    float* part = db ? (float*)workspace : nullptr;
     if (y_is_bf16)
-        linear_bwd_mask_kernel<true><<<grid, 256, 0, (hipStream_t)stream_>>>(dY, ld_dy, Y, ld_y, M, N, scale, dZ, ld_z, db);
+        linear_bwd_mask_kernel<true><<<grid, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, dZ, ld_z, part);
     else
-        linear_bwd_mask_kernel<false><<<grid, 256, 0, (hipStream_t)stream_>>>(dY, ld_dy, Y, ld_y, M, N, scale, dZ, ld_z, db);
+        linear_bwd_mask_kernel<false><<<grid, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, dZ, ld_z, part);
     ODW_CHECK_LAUNCH("linear_bwd_mask_kernel");
+    if (db) {
+        bias_grad_finish_kernel<<<(N + 255) / 256, 256, 0, stream>>>(part, chunks, N, db);
+        ODW_CHECK_LAUNCH("bias_grad_finish_kernel");
+    }
     return ODW_OK;
 }

@@ -325,9 +325,7 @@ class _SplitLinear(torch.autograd.Function):
         else:
             db = None
         scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
-        dz = torch.empty((M, N), dtype=torch.float32, device=dy.device)
-        L.check(L.lib().odw_linear_bwd_mask_f32(L.ptr(dy), dy.stride(0), L.ptr(y), 0, y.stride(0) if y is not None else 0,
-                                                M, N, scale, L.ptr(dz), N, L.ptr(db), L.stream()), "linear_bwd_mask_f32")
+        dz = P.bwd_mask(dy, y, scale, db)
         dx = None
         if ctx.needs_input_grad[0]:
             dx_all = torch.empty((M_all, K), dtype=torch.float32, device=dy.device)

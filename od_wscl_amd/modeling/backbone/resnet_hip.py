@@ -110,8 +110,7 @@ class _SplitConv3x3Fn(torch.autograd.Function):
         ga, gb = P.patterns("gemm")
         T, Tg = len(pa), len(ga)
         dy = dy.contiguous().float()
-        dz = torch.empty((m, co), dtype=torch.float32, device=dy.device)
-        L.check(lib.odw_linear_bwd_mask_f32(L.ptr(dy), co, L.ptr(y), 0, co, m, co, 1.0, L.ptr(dz), co, None, st), "conv bwd mask")
+        dz = P.bwd_mask(dy, y, 1.0)
         dw = None
         if ctx.needs_input_grad[1]:
             dzt = P.split_cols(dz, ga, m64)

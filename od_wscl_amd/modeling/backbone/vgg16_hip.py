@@ -226,8 +226,7 @@ class _VGGSplitFn(torch.autograd.Function):
             if conv.weight.grad is None:
                 conv.weight.grad = torch.empty_like(conv.weight)
             # bias gradient = column sums of dZ (single writer per entry; dZ passes through unchanged)
-            L.check(lib.odw_linear_bwd_mask_f32(L.ptr(dz), l.cout, None, 0, 0, m, l.cout, 1.0, L.ptr(dz), l.cout,
-                                                L.ptr(conv.bias.grad), st), "conv bias grad")
+            P.bwd_mask(dz, None, 1.0, conv.bias.grad, out=dz)
             # weight gradient: dWk[co][tap*Cp+ci] = sum over pixels and plane products
             dzt = P.split_cols(dz, ga, m64)                                   # (Cout, Tg*m64)
             planes = [P.split_rows(x_in, (p,), l.cp) for p in (0, 1, 2)]      # hi / mid / lo of the layer input, NHWC bf16

@@ -48,20 +48,28 @@ class _Staging(object):
     non-blocking in-stream memcpy per stage."""
 
     def __init__(self, device, slots=8, width=1 << 16):
-        self.host = torch.zeros((slots, width), dtype=torch.int32).pin_memory()
+        self.device, self.slot, self.slots = device, 0, slots
+        self._allocate(width)
+
+    def _allocate(self, width):
+        self.host = torch.zeros((self.slots, width), dtype=torch.int32).pin_memory()
         self.host_np = self.host.numpy()
-        self.dev = torch.zeros((slots, width), dtype=torch.int32, device=device)
-        self.slot, self.slots, self.width = 0, slots, width
+        self.dev = torch.zeros((self.slots, width), dtype=torch.int32, device=self.device)
+        self.width = width
 
     def upload(self, arrays):
         """arrays: list of 1-D integer numpy arrays / lists -> list of int32 device views (one H2D copy)."""
+        need = sum(len(a) for a in arrays)
+        if need > self.width:
+            # a larger batch (the reference's IMS_PER_BATCH 8 on one GPU stages ~70 k indices): grow once.  Copies still
+            # in flight out of the old pinned ring keep it alive through the stream's references; a sync keeps it simple.
+            torch.cuda.current_stream().synchronize()
+            self._allocate(1 << (need - 1).bit_length())
         k = self.slot
         self.slot = (self.slot + 1) % self.slots
         pos, views = 0, []
         for a in arrays:
             n = len(a)
-            if pos + n > self.width:
-                raise RuntimeError("fused loss: index staging buffer too small (%d > %d)" % (pos + n, self.width))
             self.host_np[k, pos:pos + n] = a
             views.append((pos, n))
             pos += n

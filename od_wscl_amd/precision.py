@@ -108,3 +108,16 @@ def pack_conv_weight(rows, pat, block, n_out):
     if k % 64:
         w = torch.nn.functional.pad(w, (0, r64(k) - k))
     return w.contiguous()
+
+
+def bwd_mask(dy, y, scale, db=None, out=None):
+    """dZ = dY * [Y != 0] * scale (Y None: dZ = dY) in fp32 and db += column sums of dZ (deterministic two-stage
+    reduction); `out` may alias dy.  dy (M, N) fp32 with unit column stride."""
+    M, N = dy.shape
+    dz = torch.empty((M, N), dtype=torch.float32, device=dy.device) if out is None else out
+    ws_bytes = L.lib().odw_linear_bwd_mask_workspace(M, N) if db is not None else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device) if ws_bytes else None
+    L.check(L.lib().odw_linear_bwd_mask_f32(L.ptr(dy), dy.stride(0), L.ptr(y), 0, y.stride(0) if y is not None else 0, M, N,
+                                            float(scale), L.ptr(dz), dz.stride(0), L.ptr(db), L.ptr(ws), ws_bytes, L.stream()),
+            "linear_bwd_mask_f32")
+    return dz

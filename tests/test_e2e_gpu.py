@@ -311,3 +311,29 @@ def test_engine_steps_over_changing_shapes(monkeypatch):
         assert all(np.isfinite(v) for v in vals), (it, losses)
     torch.cuda.synchronize()
     assert torch.isfinite(opt.flat_p).all() and not torch.equal(opt.flat_p, p0)
+
+
+def test_engine_step_with_several_images_per_rank(monkeypatch):
+    """The reference trains IMS_PER_BATCH images per process (8 on its single-GPU setup, README.md:99-100): a 3-image
+    batch through the engine, with the index staging ring starting far too small so that it has to grow."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from od_wscl_amd import engine
+    from od_wscl_amd.modeling.roi_heads.weak_head import loss_fused
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("ODW_NO_TIMER", "1")
+    real_init = loss_fused._Staging.__init__
+    monkeypatch.setattr(loss_fused._Staging, "__init__", lambda self, device, slots=8, width=64: real_init(self, device, slots, 64))
+    cfg = bench.build_cfg(21)
+    step, _ = engine.build_training_step(cfg, dev, dtype="bf16", world=1, seed=cfg.SEED)
+    images, targets, rois = bench.synthetic_batch(cfg.SEED, 0, 224, 120, 21, dev, n_images=3)
+    assert len(rois) == 3 and images.tensors.shape[0] == 3
+    p0 = step.optimizer.flat_p.clone()
+    for it in range(2):
+        losses, accs = step(images, targets, rois, DeviceRand(cfg.SEED, first_stream=(1 << 20) + (it << 12), device=dev))
+        assert all(np.isfinite(float(v.detach())) for v in losses.values()), losses
+    torch.cuda.synchronize()
+    assert step.model.roi_heads.loss_evaluator._staging.width > 64
+    assert torch.isfinite(step.optimizer.flat_p).all() and not torch.equal(step.optimizer.flat_p, p0)

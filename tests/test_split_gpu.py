@@ -123,16 +123,14 @@ def test_split_conv_matches_fp64(cin, cout, dil, H, W):
 
 
 def test_bwd_mask_kernel_bias_gradient_is_deterministic():
-    from od_wscl_amd import _lib as L
+    from od_wscl_amd import precision as P
     g = torch.Generator(device="cuda").manual_seed(3)
     dy = torch.randn(777, 130, device="cuda", generator=g)
     y = torch.randn(777, 130, device="cuda", generator=g).clamp_min(0)
     outs = []
     for _ in range(3):
-        dz = torch.empty_like(dy)
         db = torch.zeros(130, device="cuda")
-        L.check(L.lib().odw_linear_bwd_mask_f32(L.ptr(dy), 130, L.ptr(y), 0, 130, 777, 130, 2.0, L.ptr(dz), 130, L.ptr(db),
-                                                L.stream()), "mask")
+        dz = P.bwd_mask(dy, y, 2.0, db)
         outs.append((dz.clone(), db.clone()))
     exp = dy * (y != 0) * 2.0
     assert torch.equal(outs[0][0], exp)
