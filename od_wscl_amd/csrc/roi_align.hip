@@ -277,10 +277,12 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_bwd_sep_plane(
 // cell reads instead of 4 taps and ~60 coordinate instructions per SAMPLE, with the sample coordinates themselves
 // still evaluated by roi_align_axis_kernel in the reference's fp32 operation order (which cell a sample lands in is
 // what must not move; the order in which fp32 terms are added may: 1e-6 against the reference's own CPU kernel).
-// A workgroup owns CG planes in LDS and walks the ROIs in chunks of kChunk: the chunk's axis vectors are copied to
-// LDS once (the first version read them from global memory inside the cell loop: 5.8 ms backward at P = 2000, all of
-// it load latency), one thread = one (ROI, bin) for ALL CG planes, so the weights are formed once per cell.
-constexpr int kChunk = 16;
+// A workgroup owns CG planes in LDS; each of its 16 WAVES takes one ROI at a time from a shared counter (ROI sizes
+// span 2.5 .. 75 cells: in lock-step chunks the whole workgroup waited for the largest box of every chunk), keeps the
+// ROI's 14 axis vectors in a wave-private LDS slot (the next ROI's vectors travel global -> registers meanwhile; the
+// first version read them from global memory inside the cell loop: 5.8 ms backward at P = 2000), and a lane = one bin
+// forms each cell weight once for all CG planes.  No workgroup barrier between the plane load and the final store.
+constexpr int kSepWaves = kPlaneThreads / 64;
 
 template <int CG, bool BWD>
 __global__ __launch_bounds__(kPlaneThreads) void roi_align_sep_plane(
@@ -298,8 +300,9 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_sep_plane(
     const int HW = H * W;
     cell_t* plane = reinterpret_cast<cell_t*>(smem_raw);                                  // CG * HW
     const int per = PH + PW, nb = PH * PW;
-    const int tab_chunk = kChunk * per * kAxisStride;                                      // floats; a multiple of 4
-    float* stab = reinterpret_cast<float*>(smem_raw + (((size_t)CG * HW * sizeof(cell_t) + 15) & ~(size_t)15));   // 2 buffers
+    const int tab_roi = per * kAxisStride;                                                 // floats per ROI; a multiple of 4
+    float* stab = reinterpret_cast<float*>(smem_raw + (((size_t)CG * HW * sizeof(cell_t) + 15) & ~(size_t)15));
+    int* next_roi = reinterpret_cast<int*>(stab + (size_t)kSepWaves * 2 * tab_roi);
     odwfx::Scale sc = {0.0f, 0.0f, 1};
     if (BWD) {
         sc = odwfx::scale_of(*absmax_bits);
@@ -314,85 +317,95 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_sep_plane(
         const float* f = src + ((size_t)b * C + c0) * HW;
         for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) plane[i] = (cell_t)f[i];
     }
-    // the axis vectors of chunk k+1 travel global -> registers while chunk k is processed, registers -> LDS after it
-    const int n_chunks = (R + kChunk - 1) / kChunk;
+    if (threadIdx.x == 0) *next_roi = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* wt = stab + (size_t)wave * 2 * tab_roi;
+    const int n4 = tab_roi / 4;                       // <= 128 float4: two per lane
+    auto grab = [&]() {
+        int n = 0;
+        if (lane == 0) n = atomicAdd(next_roi, 1);
+        return __builtin_amdgcn_readfirstlane(n);
+    };
     float4 pre[2];
-    auto fetch = [&](int k) {
-        const int nr = min(kChunk, R - k * kChunk);
-        const float4* t4 = reinterpret_cast<const float4*>(tab + (size_t)k * tab_chunk);
-        const int n4 = nr * per * kAxisStride / 4;
+    auto fetch = [&](int n) {
+        const float4* t4 = reinterpret_cast<const float4*>(tab + (size_t)n * tab_roi);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int i = threadIdx.x + q * kPlaneThreads;
+            const int i = lane + q * 64;
             pre[q] = i < n4 ? t4[i] : make_float4(0, 0, 0, 0);
         }
     };
-    auto stash = [&](int k) {
-        float4* s4 = reinterpret_cast<float4*>(stab + (k & 1) * tab_chunk);
+    auto stash = [&](int buf) {
+        float4* s4 = reinterpret_cast<float4*>(wt + buf * tab_roi);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int i = threadIdx.x + q * kPlaneThreads;
-            if (i < tab_chunk / 4) s4[i] = pre[q];
+            const int i = lane + q * 64;
+            if (i < n4) s4[i] = pre[q];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the wave's own LDS writes, visible to its lanes
+        __builtin_amdgcn_wave_barrier();
     };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int k = 0; k < n_chunks; ++k) {
-        const int n0 = k * kChunk;
-        const int nr = min(kChunk, R - n0);
-        if (k + 1 < n_chunks) fetch(k + 1);
-        const float* cur = stab + (k & 1) * tab_chunk;
-        for (int item = threadIdx.x; item < nr * nb; item += blockDim.x) {
-            const int nl = item / nb, bin = item - nl * nb;
-            const int n = n0 + nl;
-            const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
-            if (g.b != b) continue;
-            const int ph = bin / PW, pw = bin - ph * PW;
-            const float* ty = cur + (nl * per + ph) * kAxisStride;
-            const float* tx = cur + (nl * per + PH + pw) * kAxisStride;
-            const int y0 = reinterpret_cast<const int*>(ty)[0], ny = reinterpret_cast<const int*>(ty)[1];
-            const int x0 = reinterpret_cast<const int*>(tx)[0], nx = reinterpret_cast<const int*>(tx)[1];
-            const size_t o = ((size_t)n * C + c0) * nb + bin;
-            if (ny < 0 || nx < 0) {                    // a bin wider than an axis vector: the sample-by-sample form
-                for (int cl = 0; cl < nc; ++cl) {
-                    cell_t* q = plane + cl * HW;
-                    if constexpr (BWD) {
-                        const float tf = sc.to_fixed;
-                        align_scatter(g, H, W, ph, pw, src[o + (size_t)cl * nb], [q, tf](int pos, float v) { odwfx::add(q + pos, v, tf); });
-                    } else {
-                        dst[o + (size_t)cl * nb] = align_one(q, g, H, W, ph, pw);
+    int n = grab(), buf = 0;
+    if (n < R) { fetch(n); stash(0); }
+    while (n < R) {
+        const int nn = grab();
+        if (nn < R) fetch(nn);                         // in flight while this ROI is processed
+        const float* cur = wt + buf * tab_roi;
+        const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
+        if (g.b == b) {
+            for (int bin = lane; bin < nb; bin += 64) {
+                const int ph = bin / PW, pw = bin - ph * PW;
+                const float* ty = cur + ph * kAxisStride;
+                const float* tx = cur + (PH + pw) * kAxisStride;
+                const int y0 = reinterpret_cast<const int*>(ty)[0], ny = reinterpret_cast<const int*>(ty)[1];
+                const int x0 = reinterpret_cast<const int*>(tx)[0], nx = reinterpret_cast<const int*>(tx)[1];
+                const size_t o = ((size_t)n * C + c0) * nb + bin;
+                if (ny < 0 || nx < 0) {                // a bin wider than an axis vector: the sample-by-sample form
+                    for (int cl = 0; cl < nc; ++cl) {
+                        cell_t* q = plane + cl * HW;
+                        if constexpr (BWD) {
+                            const float tf = sc.to_fixed;
+                            align_scatter(g, H, W, ph, pw, src[o + (size_t)cl * nb], [q, tf](int pos, float v) { odwfx::add(q + pos, v, tf); });
+                        } else {
+                            dst[o + (size_t)cl * nb] = align_one(q, g, H, W, ph, pw);
+                        }
                     }
+                    continue;
                 }
-                continue;
-            }
-            float v[CG];
+                float v[CG];
 #pragma unroll
-            for (int cl = 0; cl < CG; ++cl) v[cl] = BWD ? (cl < nc ? src[o + (size_t)cl * nb] / g.count : 0.0f) : 0.0f;
-            cell_t* p = plane + y0 * W + x0;
-            for (int cy = 0; cy < ny; ++cy) {
-                const float wy = ty[2 + cy];
-                for (int cx = 0; cx < nx; ++cx) {
-                    const float w = wy * tx[2 + cx];
+                for (int cl = 0; cl < CG; ++cl) v[cl] = BWD ? (cl < nc ? src[o + (size_t)cl * nb] / g.count : 0.0f) : 0.0f;
+                cell_t* p = plane + y0 * W + x0;
+                for (int cy = 0; cy < ny; ++cy) {
+                    const float wy = ty[2 + cy];
+                    for (int cx = 0; cx < nx; ++cx) {
+                        const float w = wy * tx[2 + cx];
 #pragma unroll
-                    for (int cl = 0; cl < CG; ++cl) {
-                        if (cl < nc) {
-                            if constexpr (BWD) odwfx::add(p + cl * HW + cy * W + cx, v[cl] * w, sc.to_fixed);
-                            else v[cl] += w * p[cl * HW + cy * W + cx];
+                        for (int cl = 0; cl < CG; ++cl) {
+                            if (cl < nc) {
+                                if constexpr (BWD) odwfx::add(p + cl * HW + cy * W + cx, v[cl] * w, sc.to_fixed);
+                                else v[cl] += w * p[cl * HW + cy * W + cx];
+                            }
                         }
                     }
                 }
-            }
-            if (!BWD) {
+                if (!BWD) {
 #pragma unroll
-                for (int cl = 0; cl < CG; ++cl)
-                    if (cl < nc) dst[o + (size_t)cl * nb] = (ny == 0 || nx == 0) ? 0.0f : v[cl] / g.count;
+                    for (int cl = 0; cl < CG; ++cl)
+                        if (cl < nc) dst[o + (size_t)cl * nb] = (ny == 0 || nx == 0) ? 0.0f : v[cl] / g.count;
+                }
             }
         }
-        if (k + 1 < n_chunks) stash(k + 1);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();               // every lane is done with slot buf ^ 1's previous content
+        if (nn < R) stash(buf ^ 1);
+        buf ^= 1;
+        n = nn;
     }
     if (BWD) {
+        __syncthreads();
         float* d = dst + ((size_t)b * C + c0) * HW;
         for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) d[i] = (float)plane[i] * sc.to_float;
     }
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_sep_plane(
 // channel planes per workgroup for the chunk-staged kernels: the planes + one chunk of axis vectors must fit in LDS
 int pick_cg_sep(int B, int C, int HW, int per, int cell_bytes) {
     const int cands[3] = {4, 2, 1};
-    const int64_t tab_bytes = (int64_t)2 * kChunk * per * kAxisStride * 4 + 16;
+    const int64_t tab_bytes = (int64_t)2 * kSepWaves * per * kAxisStride * 4 + 32;
     int fit = 0;
     for (int k = 0; k < 3; ++k) {
         const int cg = cands[k];
@@ -474,8 +487,8 @@ namespace {
 template <bool BWD>
 int launch_sep(const float* src, const float* rois, float scale, float* tab, int B, int C, int H, int W, int R, int PH,
                int PW, int sr, float* dst, int cg, hipStream_t stream) {
-    static_assert((kChunk * kAxisStride) % 4 == 0, "axis-vector chunks are copied as float4");
-    ODW_REQUIRE(kChunk * (PH + PW) * kAxisStride <= 8 * kPlaneThreads, "roi_align: pooled size too large for the staged form");
+    static_assert(kAxisStride % 4 == 0, "axis vectors are copied as float4");
+    ODW_REQUIRE((PH + PW) * kAxisStride <= 512, "roi_align: pooled size too large for the staged form");
     const int items = R * (PH + PW);
     roi_align_axis_kernel<<<(items + 255) / 256, 256, 0, stream>>>(rois, scale, R, PH, PW, H, W, sr, tab);
     ODW_CHECK_LAUNCH("roi_align_axis_kernel");
@@ -487,7 +500,7 @@ int launch_sep(const float* src, const float* rois, float scale, float* tab, int
         ODW_CHECK_LAUNCH("absmax_kernel");
     }
     const int grid = B * ((C + cg - 1) / cg);
-    const size_t lds = (((size_t)cg * H * W * (BWD ? 8 : 4) + 15) & ~(size_t)15) + (size_t)2 * kChunk * (PH + PW) * kAxisStride * 4;
+    const size_t lds = (((size_t)cg * H * W * (BWD ? 8 : 4) + 15) & ~(size_t)15) + (size_t)2 * kSepWaves * (PH + PW) * kAxisStride * 4 + 16;
     switch (cg) {
         case 4:
             ODW_CHECK_HIP(allow_lds(roi_align_sep_plane<4, BWD>, lds), "roi_align_sep_plane attr");
