@@ -1208,7 +1208,11 @@ __host__ Plan pick_plan(int M, int N, int K, int lda, int ldb, const void* C, in
     const int k64 = (K + 63) / 64 * 64;
     const bool dma_ok = lda >= k64 && ldb >= k64 && K > 0;
     const int c_el = c_is_bf16 ? 2 : 4;
-    const bool big_ok = dma_ok && N % 8 == 0 && ((size_t)ldc * c_el) % 16 == 0 && (((uintptr_t)C) & 15) == 0;
+    // the 256x256 kernel forms its per-lane operand offsets in 32 bits (row * ld * 2 bytes): operands past 4 GiB -- the
+    // R-50 head's fc6 in the bf16x3 mode is 4000 x 602112 bf16 -- go to the ring kernel, which addresses in 64 bits
+    const bool fits32 = (unsigned long long)M * (unsigned long long)lda * 2ull < (1ull << 32) &&
+                        (unsigned long long)N * (unsigned long long)ldb * 2ull < (1ull << 32);
+    const bool big_ok = dma_ok && fits32 && N % 8 == 0 && ((size_t)ldc * c_el) % 16 == 0 && (((uintptr_t)C) & 15) == 0;
     const char* force = getenv("ODW_GEMM_VARIANT");
     const char* fsplit = getenv("ODW_GEMM_SPLITK");
     int only = -1;

@@ -2,7 +2,7 @@
 
   * one training step of the product (fp32-grade mode "bf16x3", HIP body, fused loss) against the CPU oracle
     (oracle/hotpath_ref.py) on the same formula-generated inputs at P = 500 @ 300 px, P = 2000 @ 600 px (608^2) and
-    P = 4000 / 81 classes @ 800 px;
+    P = 4000 / 81 classes @ 800 px, and the R-50-C5 body at P = 2000 @ 600 px (config 5);
   * the fused pooling kernel of the training step (roi_pool_stack_fwd_nhwc: stacked operand + 16-bit argmax written
     straight from the backbone's NHWC map) bit-exact against the C oracle's ROIPool at the C2 shape.
 
@@ -26,7 +26,7 @@ from conftest import weights_for  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = {"c1": 303, "c2": 301, "c4": 305}
+SEEDS = {"c1": 303, "c2": 301, "c4": 305, "c5": 300}
 
 
 def _sets_close(a, b, allow_frac=0.02, allow_abs=2):
@@ -35,7 +35,7 @@ def _sets_close(a, b, allow_frac=0.02, allow_abs=2):
     return diff <= max(allow_abs, int(allow_frac * max(len(a), len(b)))), diff, len(a), len(b)
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c4"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c5"])
 def test_full_size_step_matches_the_oracle(name):
     import fullsize_seed_scan as S
     from oracle import hotpath_ref as H
@@ -44,19 +44,22 @@ def test_full_size_step_matches_the_oracle(name):
     from od_wscl_amd.structures import BoxList, to_image_list
     from od_wscl_amd.utils.device_rand import DeviceRand
     seed = SEEDS[name]
-    size, p, classes, labels = S.CASES[name]
+    size, p, classes, labels = S.CASES[name][:4]
+    arch = S.arch_of(name)
     batch, boxes, lab, _ = S.inputs(name, seed)
-    w_np = weights_for("vgg16", classes)
+    w_np = weights_for(arch, classes)
     # ---- oracle (CPU, fp32): forward with its selection trace, backward for the gradient norms (not at C4: time)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    frozen = H.FROZEN
+    frozen = H.FROZEN if arch == "vgg16" else H.FROZEN_RESNET
+    param_names = set(n for n, _ in H.param_shapes(classes, arch))
     sd = {}
     for k, v in w_np.items():
         t = torch.from_numpy(v.copy())
-        if not k.startswith(frozen) and name != "c4":
+        if k in param_names and not k.startswith(frozen) and name != "c4":
             t.requires_grad_(True)
         sd[k] = t
-    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", sampling_ratio=0, arch="vgg16", scale=0.125)
+    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", sampling_ratio=0, arch=arch,
+               scale=0.125 if arch == "vgg16" else 0.0625)
     tr = {}
     ctx = torch.no_grad() if name == "c4" else torch.enable_grad()
     with ctx:
@@ -65,7 +68,7 @@ def test_full_size_step_matches_the_oracle(name):
             sum(ref_losses.values()).backward()
     # ---- product
     precision.set_precision("bf16x3")
-    model = build_model("ROIPool", w_np, "fused", "vgg16", classes)
+    model = build_model("ROIPool", w_np, "fused", arch, classes)
     rois = [BoxList(boxes[0].cuda(), (size, size), "xyxy")]
     t = BoxList(torch.zeros((len(labels), 4)).cuda(), (size, size), "xyxy")
     t.add_field("labels", lab[0].cuda())
@@ -93,7 +96,7 @@ def test_full_size_step_matches_the_oracle(name):
         assert abs(float(accs[k]) - float(ref_accs[k])) < 1e-6, k
     if name != "c4":
         for n, p_ in model.named_parameters():
-            if sd[n].grad is not None:
+            if n in sd and sd[n].grad is not None:
                 ref = sd[n].grad.double().norm().item()
                 got = p_.grad.double().norm().item()
                 assert abs(got - ref) <= 2e-2 * ref + 1e-6, (n, got, ref)

@@ -16,21 +16,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-CASES = {  # name: (size, proposals, classes, labels)
+CASES = {  # name: (size, proposals, classes, labels[, arch])
     "c1": (300, 500, 21, [4, 11]),
     "c2": (600, 2000, 21, [3, 9]),
     "c4": (800, 4000, 81, [17]),
+    "c5": (600, 2000, 21, [7, 12], "r50"),       # R-50-C5 body (configs/voc/voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml)
 }
+
+
+def arch_of(name):
+    return CASES[name][4] if len(CASES[name]) > 4 else "vgg16"
 FLOORS = {"argmax_rel": 1e-3, "sim_thresh_abs": 1e-4, "q3_abs": 1e-4, "nms_order_rel": 1e-3}
 
 
 def inputs(name, seed):
     from od_wscl_amd import synthetic
-    size, p, classes, labels = CASES[name]
+    size, p, classes, labels = CASES[name][:4]
     pad = synthetic.pad_to(size)
     batch = torch.zeros(1, 3, pad, pad)
     batch[0, :, :size, :size] = torch.from_numpy(synthetic.make_image(seed, 0, size, size)[:, :size, :size].copy())
-    boxes = [torch.from_numpy(synthetic.make_proposals(seed, 0, p, size, size))]
+    boxes = [torch.from_numpy(synthetic.make_proposals(seed, 0, p, size, size, min_size=32 if arch_of(name) != "vgg16" else 20))]
     return batch, boxes, [torch.tensor(labels, dtype=torch.int64)], classes
 
 
@@ -40,8 +45,10 @@ def main():
     name, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     torch.set_num_threads(8)
     classes = CASES[name][2]
-    sd = {k: torch.from_numpy(v) for k, v in weights_for("vgg16", classes).items()}
-    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", sampling_ratio=0, arch="vgg16", scale=0.125)
+    arch = arch_of(name)
+    sd = {k: torch.from_numpy(v) for k, v in weights_for(arch, classes).items()}
+    cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", sampling_ratio=0, arch=arch,
+               scale=0.125 if arch == "vgg16" else 0.0625)
     for seed in range(lo, hi):
         batch, boxes, labels, _ = inputs(name, seed)
         tr = {}
