@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from od_wscl_amd.utils import rng as _rng
+from oracle import rng_ref as _rng          # the oracle's own restatement of the generator (not the product's)
 from . import native
 
 # modeling/backbone/vgg16.py:86-93 'VGG16-OICR': conv channels, 'M' maxpool, 'I' identity

@@ -271,3 +271,17 @@ def test_state_dict_layout_equals_the_reference_model(yaml_rel, arch):
     assert len(matched) == len(a)
     for (k, v) in ours.state_dict().items():
         assert torch.equal(v, ref.state_dict()[k]), k
+
+
+def test_oracle_generator_is_independent_of_and_identical_to_the_product_generator():
+    """oracle/rng_ref.py restates the counter-based generator without importing the product's host twin; the two must
+    produce the same bits (the device kernel is pinned against the product's in tests/test_e2e_gpu.py)."""
+    import inspect
+    from oracle import rng_ref
+    from od_wscl_amd.utils import rng
+    assert "od_wscl_amd" not in inspect.getsource(rng_ref).split('"""', 2)[2]
+    for seed, stream, n, off in [(0, 0, 17, 0), (58, 3, 1000, 5), (2 ** 31 + 7, 2 ** 20 + 9, 4097, 123457), (1234, 77, 64, 2 ** 32 - 10)]:
+        np.testing.assert_array_equal(rng_ref.bits(seed, stream, n, off), rng.bits(seed, stream, n, off))
+        np.testing.assert_array_equal(rng_ref.uniform(seed, stream, n, off), rng.uniform(seed, stream, n, off))
+        np.testing.assert_array_equal(rng_ref.normal(seed, stream, n, off), rng.normal(seed, stream, n, off))
+    assert rng_ref.stream_key(58, 3) == rng.stream_key(58, 3)
