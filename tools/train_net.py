@@ -22,12 +22,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def synthetic_loader(cfg, rank, device, size, proposals, max_iter):
+def synthetic_loader(cfg, rank, device, size, proposals, max_iter, start_iter=0):
     from od_wscl_amd import synthetic
     from od_wscl_amd.structures import BoxList, to_image_list
     classes = cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES
     div = cfg.DATALOADER.SIZE_DIVISIBILITY or 32
-    for it in range(max_iter):
+    for it in range(start_iter, max_iter):           # a resumed run continues the sequence where it stopped
         key = it * 1000 + rank                       # a different image per (iteration, rank)
         img = torch.from_numpy(synthetic.make_image(cfg.SEED, key, size, size))[:, :size, :size]
         boxes = torch.from_numpy(synthetic.make_proposals(cfg.SEED, key, proposals, size, size))
@@ -117,7 +117,7 @@ def main():
     out_dir = cfg.OUTPUT_DIR
     if rank == 0 and out_dir:
         os.makedirs(out_dir, exist_ok=True)
-    loader = synthetic_loader(cfg, rank, device, args.size, args.proposals, max_iter) if args.synthetic else \
+    loader = synthetic_loader(cfg, rank, device, args.size, args.proposals, max_iter, start_iter) if args.synthetic else \
         dataset_loader(cfg, device, world, start_iter, args.data_dir)
     t0, seen = time.time(), 0
     for iteration, (images, targets, rois) in enumerate(loader, start_iter):
