@@ -138,3 +138,58 @@ def test_pool_stack_nhwc_is_bit_exact_against_the_oracle(P, C, H, W):
     numel = np.float32(float(P) * 49)
     want_aug = (torch.from_numpy(out).reshape(P, C, 49) * keep.cpu()[:, None, :] * numel / ksum.cpu()).bfloat16().float()
     np.testing.assert_array_equal(x[P:].float().cpu().numpy().reshape(P, C, 49), want_aug.numpy())
+
+
+@pytest.mark.parametrize("dx_f32,skip_clean", [(False, False), (False, True), (True, False)])
+def test_pool_stack_backward_matches_the_oracle_scatter(dx_f32, skip_clean):
+    """roi_pool_stack_backward_ws (the pooling backward the training step runs: both halves of the stacked operand's
+    gradient + parked extra rows, fixed-point accumulation) directly against the oracle: a float64 scatter-add of
+    dX_clean + ((dX_aug * keep) * numel) / sum through the oracle's own arg-max -- and bit-identical from run to run."""
+    from oracle import native
+    from od_wscl_amd import _lib as L
+    from od_wscl_amd import synthetic
+    from od_wscl_amd.utils import rng
+    P, C, H, W, E = 700, 128, 38, 50, 40
+    feat = torch.from_numpy(rng.normal(31, 1, C * H * W).reshape(1, C, H, W)).bfloat16().float()
+    boxes = synthetic.make_proposals(31, 0, P, H * 8, W * 8, min_size=4)
+    rois = np.concatenate([np.zeros((P, 1), np.float32), boxes], 1)
+    _, amax = native.roi_pool_fwd(feat.numpy(), rois, 0.125, 7, 7)                     # (P, C, 7, 7), -1 = empty bin
+    arg16 = torch.from_numpy(np.where(amax < 0, 0xFFFF, amax).astype(np.uint16).view(np.int16).reshape(P, C * 49)).cuda()
+    keep = (torch.from_numpy(rng.uniform(31, 3, P * 49).reshape(P, 49)) > 0.3).float().cuda()
+    ksum = keep.sum()
+    dx = torch.from_numpy(rng.normal(31, 4, 2 * P * C * 49).reshape(2 * P, C * 49)) * 1e-3
+    dx = dx.cuda() if dx_f32 else dx.cuda().bfloat16()
+    if skip_clean:
+        dx[:P] = float("nan")                                                          # rows [0, P) are unset in the step
+    extra = (torch.from_numpy(rng.normal(31, 5, E * C * 49).reshape(E, C * 49)) * 1e-3).cuda()
+    extra_roi = torch.from_numpy((np.arange(E) * 17 % P).astype(np.int32)).cuda()
+    r = torch.from_numpy(rois).cuda()
+    lib = L.lib()
+    outs = []
+    for _ in range(2):
+        gin = torch.empty((1, C, H, W), device="cuda")
+        ws = torch.empty(64, dtype=torch.uint8, device="cuda")
+        L.check(lib.odw_roi_pool_stack_backward_ws(L.ptr(dx), 1 if dx_f32 else 0, dx.stride(0), L.ptr(arg16), L.ptr(r), L.ptr(keep),
+                                                   L.ptr(ksum), L.ptr(extra), L.ptr(extra_roi), E, 1 if skip_clean else 0, 1, C,
+                                                   H, W, P, 7, 7, L.ptr(gin), L.ptr(ws), 64, L.stream()), "stack_bwd")
+        outs.append(gin.clone())
+    assert torch.equal(outs[0], outs[1])                                               # order-independent accumulation
+    d = dx.float().cpu().double().numpy().reshape(2, P, C, 49)
+    kp = keep.cpu().double().numpy()
+    numel, ssum = np.float32(P * 49), float(ksum)
+    g = (0.0 if skip_clean else d[0]) + d[1] * kp[:, None, :] * float(numel) / ssum
+    if skip_clean:
+        g = np.where(kp[:, None, :] == 0, 0.0, g)
+    want = np.zeros((C, H * W))
+    a = amax.reshape(P, C, 49)
+    for c in range(C):
+        ok = a[:, c] >= 0
+        np.add.at(want[c], a[:, c][ok], g[:, c][ok])
+    ex = extra.cpu().double().numpy().reshape(E, C, 49)
+    er = extra_roi.cpu().numpy()
+    for e in range(E):
+        for c in range(C):
+            ok = a[er[e], c] >= 0
+            np.add.at(want[c], a[er[e], c][ok], ex[e, c][ok])
+    got = outs[0].cpu().double().numpy().reshape(C, H * W)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max() + 1e-12
