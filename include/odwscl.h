@@ -338,6 +338,10 @@ int odw_conv3x3_nhwc_bf16(const void* X, int n_pix, int H, int W, int C, int dil
 /* Workspace form: for the deep layers (few output tiles, K = 9*C long) the launcher splits K over the grid and
  * reduces fp32 partials with the same fused epilogue.  odw_conv3x3_workspace = bytes wanted (0 = no split). */
 int64_t odw_conv3x3_workspace(int n_pix, int C, int N);
+/* The same for a known geometry: covers the halo-tile kernel (conv3x3_halo_kernel: a 16x16 spatial tile of pixels x 128
+ * output channels per workgroup, the input patch staged in LDS once per 64-channel block and shared by the nine taps),
+ * which serves every layer with C % 64 == 0 and dilation 1 or 2 and slices the channel blocks of small maps. */
+int64_t odw_conv3x3_workspace_hw(int n_pix, int H, int W, int C, int N, int dilation);
 int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, int C, int dilation, int mirror, const void* Wk,
                              int ldw, int N, void* Y, int ldy, int y_is_bf16, const float* bias, int relu,
                              const void* mask, int ldmask, const void* zero_page, void* workspace,

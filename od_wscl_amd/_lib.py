@@ -75,6 +75,7 @@ SIGNATURES = {
     "odw_discover_sim": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_i,
                                c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "odw_conv3x3_workspace": (c_l, [c_i, c_i, c_i]),
+    "odw_conv3x3_workspace_hw": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "odw_conv3x3_nhwc_bf16_ws": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p,
                                        c_p, c_l, c_p]),
     "odw_conv3x3_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_p]),

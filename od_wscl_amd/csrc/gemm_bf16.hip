@@ -71,6 +71,15 @@ __device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-
 }
 
 
+// two floats -> packed bf16 (round-to-nearest-even) in ONE instruction (v_cvt_pk_bf16_f32, gfx950); the integer form
+// above is ~8 VALU instructions per element, and the staged epilogues convert 128 elements per lane
+typedef __bf16 odw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float odw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+    const odw_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, odw_bf16x2));
+}
+
 // staging: thread t moves 16-byte chunks t, t+256, t+512, t+768 of each operand tile
 __device__ __forceinline__ void load_tile(const unsigned short* __restrict__ A, int lda,
                                           const unsigned short* __restrict__ B, int ldb, int M, int N, int K,
@@ -303,6 +312,173 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_glds_kernel(
     store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
 }
 
+// Bias and mask operands of the staged epilogues (band_store), fetched as BATCHES of independent loads.
+// Left per element -- "if (ep.bias && n < N) x += ep.bias[n]" -- hipcc emits one conditional global_load + s_waitcnt
+// vmcnt(0) per output element: 128 serialised L2 round trips (~12-25 us) at the end of every workgroup, which was half
+// of the convolution kernels on the wide maps and 15-20 % of the mid-sized head products.  A lane's columns inside the
+// wave's 64 are cw(j, g) = 32 j + 8 g + 4 (lane >> 5) + {0..3}, the same for every row band: the bias goes through LDS
+// once per wave (band_store), the mask comes as one 8-byte load per column group and band.
+// mask words of one row for the lane's 8 column groups: bit test "(bf16 & 0x7fff) != 0" per element.  vec = rows and
+// columns of the mask allow one 8-byte load per group (ldmask % 4 == 0, 8-byte aligned base, N % 4 == 0).
+__device__ __forceinline__ void epi_load_mask(const Epilogue& ep, bool vec, long long m, int nw, int N, int half,
+                                              uint2 (&mk)[2][4]) {
+    const unsigned short* row = ep.mask + (size_t)(m > 0 ? m : 0) * ep.ldmask;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nw + j * 32 + 8 * g + 4 * half;
+            if (vec) {
+                mk[j][g] = *reinterpret_cast<const uint2*>(row + (n < N ? n : 0));
+            } else {
+                unsigned short e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = row[n + q < N ? n + q : 0];
+                mk[j][g] = make_uint2((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16));
+            }
+        }
+}
+__device__ __forceinline__ bool epi_mask_zero(const uint2& w, int q) {
+    const uint32_t d = q < 2 ? w.x : w.y;
+    return (((q & 1) ? (d >> 16) : d) & 0x7fffu) == 0;
+}
+
+// Staged epilogue of a wave's (NI x 32) x 64 block of C held as TRANSPOSED accumulators (the kernels run their MFMAs
+// with the operands swapped: lane & 31 = row, each group of 4 registers = 4 consecutive columns,
+// col = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  rowmap(r) = row of C for row r of the wave's block, or -1 = not stored
+// (rows past M; pixels past the image edge in the halo-tile convolution, whose rows are not consecutive in C).
+// Per 32-row band the wave applies the fused epilogue (alpha, bias, ReLU, ReLU-backward mask, counter-based dropout),
+// parks the band in its private LDS region as 8-byte (bf16) / 16-byte (fp32) pieces (padded rows, conflict-free) and
+// streams it out with one 16-byte store per lane: full 128-byte (bf16) / 256-byte (fp32) row segments instead of
+// 2-byte scatters.  Rows of C must be 16-byte aligned and ldc >= N rounded up to the 16-byte chunk.
+template <bool OUT_BF16, int NI, class RowMap>
+__device__ __forceinline__ void band_store(const f32x16 (&acc)[NI][2], void* __restrict__ Cv, int ldc, int N, int nw,
+                                           int wave, int lane, const Epilogue& ep, char* lds, RowMap rowmap) {
+    constexpr int kEl = OUT_BF16 ? 2 : 4;
+    constexpr int kRowBytes = 64 * kEl + (OUT_BF16 ? 8 : 16);       // padded: conflict-free b64 / b128 writes
+    char* region = lds + wave * (32 * kRowBytes);
+    const int half = lane >> 5, l31 = lane & 31;
+    const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+    // the wave's 64 bias values: one load per lane, parked in LDS behind the staging regions (32 registers held
+    // across the bands made the 256x256 kernel spill); each column group reads its 4 back with one ds_read_b128
+    float* const bias_s = reinterpret_cast<float*>(lds + 8 * 32 * (64 * 4 + 16)) + wave * 64;
+    {
+        const int n = nw + lane;
+        bias_s[lane] = ep.bias ? ep.bias[n < N ? n : N - 1] : 0.0f;       // columns >= N are never stored
+    }
+    const bool mask_vec = ep.mask && ep.ldmask % 4 == 0 && N % 4 == 0 && (((uintptr_t)ep.mask) & 7) == 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const long long m = rowmap(i * 32 + l31);
+        uint2 mk[2][4];
+        if (ep.mask) epi_load_mask(ep, mask_vec, m, nw, N, half, mk);
+        int srow = ep.seg_row[0];
+        uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
+        uint32_t lrow = 0;
+        if (ep.drop_p > 0.0f) {
+            if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
+            if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
+            if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+            lrow = (ep.row_ids && m >= 0) ? (uint32_t)ep.row_ids[m] : (uint32_t)((int)m - srow);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cw = j * 32 + 8 * g + 4 * half;            // column inside the wave's 64
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_s + cw);
+                const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = acc[i][j][4 * g + q] * ep.alpha + bq[q];
+                    if (ep.relu) x = fmaxf(x, 0.0f);
+                    if (ep.mask && epi_mask_zero(mk[j][g], q)) x = 0.0f;
+                    if (ep.drop_p > 0.0f) {
+                        const uint32_t idx = lrow * (uint32_t)N + (uint32_t)(nw + cw + q);
+                        x = odw_uniform(idx, k0, k1) >= ep.drop_p ? x * keep_scale : 0.0f;
+                    }
+                    v[q] = x;
+                }
+                if (OUT_BF16) {
+                    uint2 pk;
+                    pk.x = f2bf_pk(v[0], v[1]);
+                    pk.y = f2bf_pk(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(region + l31 * kRowBytes + cw * 2) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(region + l31 * kRowBytes + cw * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        // the wave's own LDS traffic is ordered: read the band back row-major, 16 bytes per lane
+        constexpr int kLanesPerRow = 64 * kEl / 16;                  // 8 (bf16) or 16 (fp32)
+        constexpr int kRowsPerPass = 64 / kLanesPerRow;
+#pragma unroll
+        for (int t = 0; t < 32 / kRowsPerPass; ++t) {
+            const int r = t * kRowsPerPass + lane / kLanesPerRow, cchunk = lane % kLanesPerRow;
+            const uint4 d = *reinterpret_cast<const uint4*>(region + r * kRowBytes + cchunk * 16);
+            const long long gm = rowmap(i * 32 + r);
+            const int gn = nw + cchunk * (16 / kEl);
+            if (gm < 0 || gn >= N) continue;
+            char* dst = reinterpret_cast<char*>(Cv) + ((size_t)gm * ldc + gn) * kEl;
+            if (!OUT_BF16 && ep.accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(dst);
+                const float4 a = __builtin_bit_cast(float4, d);
+                *reinterpret_cast<float4*>(dst) = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+            } else {
+                *reinterpret_cast<uint4*>(dst) = d;
+            }
+        }
+    }
+}
+
+// The same block without the 16-byte-alignment conditions (any N, any ldc): element stores straight from the
+// transposed accumulators.  Only odd-shaped outputs take it (the 357-column predictor written in place).
+template <bool OUT_BF16, int NI, class RowMap>
+__device__ __forceinline__ void band_store_scalar(const f32x16 (&acc)[NI][2], void* __restrict__ Cv, int ldc, int N, int nw,
+                                                  int lane, const Epilogue& ep, RowMap rowmap) {
+    const int half = lane >> 5, l31 = lane & 31;
+    const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const long long m = rowmap(i * 32 + l31);
+        if (m < 0) continue;
+        int srow = ep.seg_row[0];
+        uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
+        uint32_t lrow = 0;
+        if (ep.drop_p > 0.0f) {
+            if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
+            if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
+            if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+            lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)((int)m - srow);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nw + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n >= N) continue;
+                float x = acc[i][j][r] * ep.alpha + (ep.bias ? ep.bias[n] : 0.0f);
+                if (ep.relu) x = fmaxf(x, 0.0f);
+                if (ep.mask && (ep.mask[(size_t)m * ep.ldmask + n] & 0x7fff) == 0) x = 0.0f;
+                if (ep.drop_p > 0.0f)
+                    x = odw_uniform(lrow * (uint32_t)N + (uint32_t)n, k0, k1) >= ep.drop_p ? x * keep_scale : 0.0f;
+                if (OUT_BF16) {
+                    reinterpret_cast<unsigned short*>(Cv)[(size_t)m * ldc + n] = f2bf(x);
+                } else {
+                    float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
+                    *c = ep.accumulate ? *c + x : x;
+                }
+            }
+    }
+}
+
+// rows of C reachable with 16-byte vector stores for every 16-byte column chunk that starts below N
+__device__ __forceinline__ bool band_store_ok(const void* Cv, int ldc, int N, int el) {
+    const int chunk = 16 / el;
+    return (((uintptr_t)Cv) & 15) == 0 && ((size_t)ldc * el) % 16 == 0 && ldc >= (N + chunk - 1) / chunk * chunk;
+}
+
 // ---- 256x128 tile, 3-stage LDS ring, counted vmcnt -------------------------------------------------
 // The 128x128 kernel above is LATENCY bound: a tile's DMA is issued one K-step (~0.35 us of MFMA)
 // before it is needed, HBM/L2 latency under load is 1-2 us, so every K-step ends in a vmcnt(0) stall.
@@ -388,11 +564,19 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)       // operands swapped: transposed accumulators for band_store
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     }
-    store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
+    const int mw = m0 + wm * 64;
+    auto rowmap = [&](int r) -> long long { return mw + r < M ? (long long)(mw + r) : -1ll; };
+    if (band_store_ok(Cv, ldc, N, OUT_BF16 ? 2 : 4)) {           // workgroup-uniform
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // every wave is done with the operand tiles
+        band_store<OUT_BF16, 2>(acc, Cv, ldc, N, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds), rowmap);
+    } else {
+        band_store_scalar<OUT_BF16, 2>(acc, Cv, ldc, N, n0 + wn * 64, lane, ep, rowmap);
+    }
 }
 
 // ---- 256x256 tile, 8 waves of 128x64 ---------------------------------------------------------
@@ -519,81 +703,6 @@ __device__ __forceinline__ void big_slice_dma(f32x16 (&acc)[4][2], const bf16x8 
 #undef ODW_BIG_OPERANDS_DMA
 }
 
-// Epilogue of the 256x256 kernel.  The slices run the MFMAs with the operands swapped, so an accumulator holds a
-// TRANSPOSED 32x32 tile: lane & 31 = row of C, and each group of 4 registers = 4 consecutive columns
-// (col = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Per 32-row band the wave applies the fused epilogue, parks the
-// band in its private LDS region as 8-byte (bf16) / 16-byte (fp32) pieces, and streams it out again with one
-// 16-byte store per lane: full 128-byte (bf16) / 256-byte (fp32) row segments instead of 2-byte scatters.
-template <bool OUT_BF16>
-__device__ __forceinline__ void big_store(const f32x16 (&acc)[4][2], void* __restrict__ Cv, int ldc, int M, int N,
-                                          int mw, int nw, int wave, int lane, const Epilogue& ep, char* lds) {
-    constexpr int kEl = OUT_BF16 ? 2 : 4;
-    constexpr int kRowBytes = 64 * kEl + (OUT_BF16 ? 8 : 16);       // padded: conflict-free b64 / b128 writes
-    char* region = lds + wave * (32 * kRowBytes);
-    const int half = lane >> 5, l31 = lane & 31;
-    const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = mw + i * 32 + l31;
-        int srow = ep.seg_row[0];
-        uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
-        if (ep.drop_p > 0.0f) {
-            if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
-            if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
-            if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
-        }
-        const uint32_t lrow = (ep.row_ids && m < M) ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cw = j * 32 + 8 * g + 4 * half;            // column inside the wave's 64
-                const int n = nw + cw;
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float x = acc[i][j][4 * g + q] * ep.alpha;
-                    if (ep.bias && n + q < N) x += ep.bias[n + q];
-                    if (ep.relu) x = fmaxf(x, 0.0f);
-                    if (ep.mask && m < M && n + q < N && (ep.mask[(size_t)m * ep.ldmask + n + q] & 0x7fff) == 0) x = 0.0f;
-                    if (ep.drop_p > 0.0f) {
-                        const uint32_t idx = lrow * (uint32_t)N + (uint32_t)(n + q);
-                        x = odw_uniform(idx, k0, k1) >= ep.drop_p ? x * keep_scale : 0.0f;
-                    }
-                    v[q] = x;
-                }
-                if (OUT_BF16) {
-                    uint2 pk;
-                    pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                    pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(region + l31 * kRowBytes + cw * 2) = pk;
-                } else {
-                    *reinterpret_cast<float4*>(region + l31 * kRowBytes + cw * 4) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-        // the wave's own LDS traffic is ordered: read the band back row-major, 16 bytes per lane
-        constexpr int kLanesPerRow = 64 * kEl / 16;                  // 8 (bf16) or 16 (fp32)
-        constexpr int kRowsPerPass = 64 / kLanesPerRow;
-#pragma unroll
-        for (int t = 0; t < 32 / kRowsPerPass; ++t) {
-            const int r = t * kRowsPerPass + lane / kLanesPerRow, cchunk = lane % kLanesPerRow;
-            const uint4 d = *reinterpret_cast<const uint4*>(region + r * kRowBytes + cchunk * 16);
-            const int gm = mw + i * 32 + r, gn = nw + cchunk * (16 / kEl);
-            if (gm < M && gn < N) {
-                char* dst = reinterpret_cast<char*>(Cv) + ((size_t)gm * ldc + gn) * kEl;
-                if (!OUT_BF16 && ep.accumulate) {
-                    const float4 o = *reinterpret_cast<const float4*>(dst);
-                    const float4 a = __builtin_bit_cast(float4, d);
-                    *reinterpret_cast<float4*>(dst) = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
-                } else {
-                    *reinterpret_cast<uint4*>(dst) = d;
-                }
-            }
-        }
-    }
-}
-
 template <bool OUT_BF16, int X = 0>
 __global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
@@ -716,7 +825,9 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last (unused) prefetch must not outlive its registers
     __builtin_amdgcn_s_barrier();                           // every wave is done with the operand tiles
-    big_store<OUT_BF16>(acc, Cv, ldc, M, N, m0 + wm * 128, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds));
+    const int mw = m0 + wm * 128;
+    band_store<OUT_BF16, 4>(acc, Cv, ldc, N, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds),
+                            [&](int r) -> long long { return mw + r < M ? (long long)(mw + r) : -1ll; });
 }
 
 // ---- implicit-GEMM 3x3 convolution on the same tile ------------------------------------------
@@ -872,6 +983,186 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_glds_kernel(
         __syncthreads();
     }
     store_tile_out<OUT_BF16>(acc, Cv, ldc, M, N, m0, n0, wm, wn, half, l31, ep);
+}
+
+// ---- halo-tile implicit GEMM: the activation patch is fetched ONCE per channel block, not once per tap ---------------
+// What bounds conv3x3_glds_kernel (profiles/r02/pmc_conv_*.txt: MFMA busy 19.5 %, no LDS conflicts, L2 hits 86-92 %) is
+// the L2 -> LDS byte rate a CU sustains (~40 GB/s per CU in every DMA kernel of this file), and an implicit GEMM whose
+// K walks (tap, channel) pulls each activation row through it nine times -- once per tap -- next to the weights.
+// Here a workgroup owns a 16 x 16 SPATIAL tile of output pixels x 128 output channels.  Per 64-channel block it stages
+// the (16 + 2 dil)^2 halo patch of the input in LDS once (41 / 51 KB, double buffered, padding and out-of-image pixels
+// read a zero page), and the nine taps of that block are nine K steps whose A fragments are ds_read_b128 of the SAME
+// patch at a wave-uniform row shift (dy * pitch + dx); only the 128 x 64 weight tile of each (block, tap) streams,
+// through a three-slot ring with counted vmcnt (the ring GEMM's pipeline).  Bytes per K step of 256 x 128 x 64:
+// 16 KB of weights + 1/9 of the patch = 20.6 KB against 48 KB (256x128 ring) / 64 KB (two 128x128 tiles).
+// LDS rows are one pixel's 64 channels (128 B); chunk c of halo row r lives in slot c ^ ((r >> 1) & 7), so the 16 lanes
+// of a ds_read_b128 group -- 16 horizontally adjacent pixels = 16 consecutive halo rows at ANY shift -- hit 16
+// different 16-byte bank groups.  C (the channel count of X) must be a multiple of 64.
+constexpr int HT = 16;                                        // tile side (pixels)
+constexpr int kHaloThreads = 512;
+constexpr int kHaloBStage = RN * kChunksPerRow;               // 1024 uint4 = 16 KB: one (block, tap) weight tile
+
+template <int DIL>
+struct Halo {
+    static constexpr int HWp = HT + 2 * DIL;                  // patch pitch (pixels)
+    static constexpr int kRows = HWp * HWp;                   // 324 / 400 halo rows of 128 B
+    static constexpr int NA = (kRows + 63) / 64;              // DMA instructions per wave per patch (8 rows each, 8 waves)
+    static constexpr int kBufChunks = NA * 64 * kChunksPerRow;
+    static constexpr size_t kLdsBytes = ((size_t)2 * kBufChunks + 3 * kHaloBStage) * sizeof(uint4);   // 144 / 160 KB
+};
+
+template <bool OUT_BF16, int DIL, int DBG = 0>
+__global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
+    const unsigned short* __restrict__ X, ConvGeom g, const unsigned short* __restrict__ B, int ldb, int n_img, int N,
+    void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_y, int tiles_x, int tiles_n, int splits, int cb_per_split) {
+    using HC = Halo<DIL>;
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];     // [patch 0 | patch 1 | weight ring of 3]
+    uint4* const bring = lds + 2 * HC::kBufChunks;
+    // workgroup -> (spatial tile, channel tile, K slice).  Workgroup b runs on XCD b % 8 and each XCD owns a contiguous
+    // chunk of the order below, in which the spatial tiles of ONE (channel tile, slice) are consecutive: the workgroups
+    // resident on an XCD stream the same weight tiles through its L2 together.
+    const int nsp = n_img * tiles_y * tiles_x;
+    const int nblk = nsp * tiles_n * splits;
+    int t;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int combo = t / nsp, sp = t - combo * nsp;
+    const int tn = combo % tiles_n, split = combo / tiles_n;
+    const int img = sp / (tiles_y * tiles_x), rem = sp - img * (tiles_y * tiles_x);
+    const int y0 = (rem / tiles_x) * HT, x0 = (rem % tiles_x) * HT, n0 = tn * RN;
+    const int cb0 = split * cb_per_split;
+    const int ncb_all = g.C >> 6;
+    const int cb1 = cb0 + cb_per_split < ncb_all ? cb0 + cb_per_split : ncb_all;
+    if (splits > 1) Cv = reinterpret_cast<char*>(Cv) + (long long)split * ep.split_stride;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;            // 4 x 2 waves: 4 tile rows (64 pixels) x 64 channels each
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // this lane's share of a patch: byte offset of (pixel, 16-byte chunk) in X for channel block 0; ~0 = zero page
+    unsigned voff[HC::NA];
+#pragma unroll
+    for (int i = 0; i < HC::NA; ++i) {
+        const int hr = (i * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((hr >> 1) & 7);
+        const int hy = hr / HC::HWp, hx = hr - hy * HC::HWp;
+        const int y = y0 - DIL + hy, x = x0 - DIL + hx;
+        const bool ok = hr < HC::kRows && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+        voff[i] = ok ? ((unsigned)((img * g.H + y) * g.W + x) << g.logC) * 2u + (unsigned)c * 16u : 0xffffffffu;
+    }
+    auto dma_patch = [&](int cb, uint4* buf) {
+        const char* base = reinterpret_cast<const char*>(X) + (size_t)cb * 128;
+#pragma unroll
+        for (int i = 0; i < HC::NA; ++i) {
+            const void* src = voff[i] != 0xffffffffu ? static_cast<const void*>(base + voff[i])
+                                                     : static_cast<const void*>(g.zero);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(buf + (i * 8 + wave) * 64), 16, 0, 0);
+        }
+    };
+    // halo row of this lane's two fragment rows at the centre tap
+    int hrb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int prow = wm * 64 + i * 32 + l31;
+        hrb[i] = ((prow >> 4) + DIL) * HC::HWp + (prow & 15) + DIL;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int nsteps = (cb1 - cb0) * 9;
+    // prologue: patch of the first block, weight tiles of steps 0 and 1
+    dma_patch(cb0, lds);
+    dma_rows<16>(B, ldb, N, n0, cb0 * 64, bring, wave, lane);
+    if (nsteps > 1) dma_rows<16>(B, ldb, N, n0, g.C + cb0 * 64, bring + kHaloBStage, wave, lane);
+    int tap = 0, cb = cb0, slot = 0;                     // step t
+    int tap2 = 2, cb2 = cb0;                             // step t + 2 (the weight tile issued during step t)
+    for (int st = 0; st < nsteps; ++st) {
+        // Issue order of a step: weight tile t+2 (2 pieces per wave), then -- at tap 0 -- the next block's patch (NA
+        // pieces).  Tile t has landed when at most the pieces issued after it are outstanding.
+        if (st + 2 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if ((tap == 1 || tap == 2) && cb + 1 < cb1) {
+            if (HC::NA == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (DBG != 1 && DBG != 5 && st + 2 < nsteps) {
+            const int s2 = slot + 2 >= 3 ? slot - 1 : slot + 2;
+            dma_rows<16>(B, ldb, N, n0, tap2 * g.C + cb2 * 64, bring + s2 * kHaloBStage, wave, lane);
+        }
+        if (DBG != 1 && DBG != 6 && tap == 0 && cb + 1 < cb1) dma_patch(cb + 1, lds + (((cb - cb0) + 1) & 1) * HC::kBufChunks);
+        const uint4* sa = lds + ((cb - cb0) & 1) * HC::kBufChunks;
+        const uint4* sb = bring + slot * kHaloBStage;
+        const int ty_ = (tap * 11) >> 5, tx_ = tap - 3 * ty_;
+        const int delta = ((ty_ - 1) * HC::HWp + (tx_ - 1)) * DIL * g.sign;
+        int arow[2], asw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hr = hrb[i] + delta;
+            arow[i] = hr * kChunksPerRow;
+            asw[i] = (hr >> 1) & 7;
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int c = kk * 2 + half;
+            bf16x8 fa[2], fb[2];
+            if (DBG == 2) {             // timing experiment: no LDS reads
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, make_uint4(arow[i], c, asw[i], st));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, make_uint4(j, c, lane, st));
+            } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[arow[i] + (c ^ asw[i])]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
+            }
+            if (DBG == 3) {             // timing experiment: no MFMAs (the fragments are still consumed)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint4 ua = __builtin_bit_cast(uint4, fa[i]), ub = __builtin_bit_cast(uint4, fb[j]);
+                        acc[i][j][0] += __uint_as_float((ua.x ^ ub.y) & 0x3fffffffu);
+                        acc[i][j][1] += __uint_as_float((ua.z ^ ub.w) & 0x3fffffffu);
+                    }
+            } else {
+            // operands swapped: the accumulator holds the TRANSPOSED 32x32 tile (lane & 31 = pixel, 4 consecutive
+            // registers = 4 consecutive channels), which is what the staged epilogue wants
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+        if (++tap == 9) { tap = 0; ++cb; }
+        if (++tap2 == 9) { tap2 = 0; ++cb2; }
+    }
+
+    // ---- epilogue: rows of the tile are pixels (ty, tx); the ones past the image edge are not stored.
+    // Measured (ODW_HALO_DBG=4, profiles/r02/conv_halo_experiments.txt): with 2-byte stores straight from the
+    // accumulators the epilogue was HALF of the kernel on the wide maps (conv1_2: 133 us with, 60 us without); it now
+    // goes through LDS in 32-pixel bands and leaves as 16-byte vectors (band_store).
+    if (DBG == 4 && acc[0][0][0] != 12345.0f) return;        // timing experiment: no stores
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // every wave is done with the operand tiles
+    const int hw = g.H * g.W;
+    band_store<OUT_BF16, 2>(acc, Cv, ldc, N, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds),
+                            [&](int r) -> long long {
+                                const int prow = wm * 64 + r;
+                                const int y = y0 + (prow >> 4), x = x0 + (prow & 15);
+                                if (DBG == 7) return (y < g.H && x < g.W) ? (long long)(prow + 256 * (blockIdx.x & 15)) : -1ll;
+                                return (y < g.H && x < g.W) ? (long long)img * hw + (long long)y * g.W + x : -1ll;
+                            });
 }
 
 // ---- layout helpers ---------------------------------------------------------------------
@@ -1596,6 +1887,41 @@ ODW_EXPORT int64_t odw_conv3x3_workspace(int n_pix, int C, int N) {
     return sp > 1 ? (int64_t)sp * n_pix * N * 4 : 0;
 }
 
+namespace {
+// The halo-tile kernel serves every layer whose channel count is a multiple of 64 (all of VGG16 past the stem, the 3x3
+// convolutions of the ResNet bodies, every layer of the split-precision modes).  K slices: its grid is (images x 16x16
+// tiles) x (N / 128); the 76x76 layers make 25 x 4 = 100 workgroups, so two slices of the channel blocks fill 200 CUs.
+struct HaloPlan { bool use; int tiles_y, tiles_x, tiles_n, splits, cb_per_split; };
+HaloPlan halo_plan(int n_pix, int H, int W, int C, int N, int dilation) {
+    HaloPlan p = {false, 0, 0, 0, 1, 0};
+    const char* he = getenv("ODW_CONV_HALO");              // ODW_CONV_HALO=0: the 128x128 kernel (comparison runs)
+    if ((he && atoi(he) == 0) || C < 64 || C % 64 != 0 || (dilation != 1 && dilation != 2)) return p;
+    if ((unsigned long long)n_pix * (unsigned long long)C * 2ull >= (1ull << 32)) return p;
+    p.use = true;
+    p.tiles_y = (H + HT - 1) / HT; p.tiles_x = (W + HT - 1) / HT; p.tiles_n = (N + RN - 1) / RN;
+    const int ncb = C / 64;
+    const long tiles = (long)(n_pix / (H * W)) * p.tiles_y * p.tiles_x * p.tiles_n;
+    int sp = (int)(256 / (tiles > 0 ? tiles : 1));
+    if (sp > 4) sp = 4;
+    if (sp > ncb) sp = ncb;
+    if (sp < 1 || N % 4 != 0) sp = 1;
+    const char* f = getenv("ODW_CONV_SPLITK");
+    if (f && N % 4 == 0) { sp = atoi(f); if (sp > ncb) sp = ncb; if (sp < 1) sp = 1; }
+    p.cb_per_split = (ncb + sp - 1) / sp;
+    p.splits = (ncb + p.cb_per_split - 1) / p.cb_per_split;
+    return p;
+}
+}  // namespace
+
+// Workspace of the convolution launcher for a given geometry (bytes; 0 = none needed).  Covers whichever kernel the
+// launcher will pick (halo-tile or 128x128), so a caller that passes this many bytes never falls back.
+ODW_EXPORT int64_t odw_conv3x3_workspace_hw(int n_pix, int H, int W, int C, int N, int dilation) {
+    if (H <= 0 || W <= 0 || n_pix <= 0) return 0;
+    const HaloPlan hp = halo_plan(n_pix, H, W, C, N, dilation);
+    if (hp.use) return hp.splits > 1 ? (int64_t)hp.splits * n_pix * N * 4 : 0;
+    return odw_conv3x3_workspace(n_pix, C, N);
+}
+
 ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, int C, int dilation, int mirror,
                                         const void* Wk, int ldw, int N, void* Y, int ldy, int y_is_bf16,
                                         const float* bias, int relu, const void* mask, int ldmask,
@@ -1631,6 +1957,67 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
     ep.bias = bias; ep.relu = relu; ep.drop_p = 0.0f; ep.nseg = 0; ep.accumulate = 0; ep.alpha = 1.0f;
     ep.mask = (const unsigned short*)mask; ep.ldmask = ldmask; ep.pm = 0; ep.kchunk = 0; ep.split_stride = 0; ep.row_ids = nullptr;
     for (int i = 0; i < kMaxSeg; ++i) { ep.seg_row[i] = 0; ep.seg_k0[i] = 0; ep.seg_k1[i] = 0; }
+    HaloPlan hp = halo_plan(n_pix, H, W, C, N, dilation);
+    // its epilogue stores 16-byte vectors: rows of Y must be 16-byte aligned (every layer of the bodies is)
+    if (hp.use && ((((uintptr_t)Y) & 15) != 0 || ((size_t)ldy * (y_is_bf16 ? 2 : 4)) % 16 != 0 || N % 8 != 0)) hp.use = false;
+    if (hp.use) {
+        if (hp.splits > 1 && (!workspace || workspace_bytes < (int64_t)hp.splits * n_pix * N * 4)) {
+            hp.splits = 1; hp.cb_per_split = C / 64;           // no room for partials: one slice
+        }
+        const int n_img = n_pix / (H * W);
+        const unsigned grid = (unsigned)(n_img * hp.tiles_y * hp.tiles_x * hp.tiles_n * hp.splits);
+        Epilogue pe = ep;
+        void* out = Y;
+        int ldo = ldy;
+        bool out_bf16 = y_is_bf16 != 0;
+        if (hp.splits > 1) {
+            ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "conv3x3: workspace must be 16-byte aligned");
+            pe.bias = nullptr; pe.relu = 0; pe.mask = nullptr; pe.ldmask = 0;
+            pe.split_stride = (long long)n_pix * N * 4;
+            out = workspace; ldo = N; out_bf16 = false;
+        }
+#define ODW_LAUNCH_HALO(OUTBF, D)                                                                                  \
+        do {                                                                                                       \
+            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<OUTBF, D>),        \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Halo<D>::kLdsBytes), \
+                          "halo attr");                                                                            \
+            conv3x3_halo_kernel<OUTBF, D><<<grid, kHaloThreads, Halo<D>::kLdsBytes, stream>>>(                      \
+                (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y,    \
+                hp.tiles_x, hp.tiles_n, hp.splits, hp.cb_per_split);                                               \
+        } while (0)
+        const char* de = getenv("ODW_HALO_DBG");      // timing experiments (wrong results): 1 no DMA, 2 no LDS reads,
+        const int dbg = de ? atoi(de) : 0;            // 3 no MFMA, 4 no stores, 5 no weight DMA, 6 no patch DMA
+        if (dbg > 0 && out_bf16 && dilation == 1) {
+#define ODW_LAUNCH_HALO_DBG(X_)                                                                                    \
+            do {                                                                                                   \
+                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<true, 1, X_>), \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Halo<1>::kLdsBytes), \
+                              "halo attr");                                                                        \
+                conv3x3_halo_kernel<true, 1, X_><<<grid, kHaloThreads, Halo<1>::kLdsBytes, stream>>>(              \
+                    (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y, \
+                    hp.tiles_x, hp.tiles_n, hp.splits, hp.cb_per_split);                                           \
+            } while (0)
+            if (dbg == 1) ODW_LAUNCH_HALO_DBG(1); else if (dbg == 2) ODW_LAUNCH_HALO_DBG(2); else if (dbg == 3) ODW_LAUNCH_HALO_DBG(3);
+            else if (dbg == 4) ODW_LAUNCH_HALO_DBG(4); else if (dbg == 5) ODW_LAUNCH_HALO_DBG(5); else if (dbg == 6) ODW_LAUNCH_HALO_DBG(6); else ODW_LAUNCH_HALO_DBG(7);
+#undef ODW_LAUNCH_HALO_DBG
+        } else
+        if (dilation == 1) { if (out_bf16) ODW_LAUNCH_HALO(true, 1); else ODW_LAUNCH_HALO(false, 1); }
+        else { if (out_bf16) ODW_LAUNCH_HALO(true, 2); else ODW_LAUNCH_HALO(false, 2); }
+#undef ODW_LAUNCH_HALO
+        ODW_CHECK_HIP(hipGetLastError(), "conv3x3 halo launch");
+        if (hp.splits > 1) {
+            const long long quads = (long long)n_pix * (N / 4);
+            const int rblocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+            if (y_is_bf16)
+                splitk_reduce_kernel<true><<<rblocks, 256, 0, stream>>>((const float*)workspace, hp.splits,
+                                                                         (long long)n_pix * N, n_pix, N, N, Y, ldy, ep);
+            else
+                splitk_reduce_kernel<false><<<rblocks, 256, 0, stream>>>((const float*)workspace, hp.splits,
+                                                                          (long long)n_pix * N, n_pix, N, N, Y, ldy, ep);
+        }
+        ODW_CHECK_LAUNCH("conv3x3_halo_kernel");
+        return ODW_OK;
+    }
     const int sp = workspace ? conv_splits(n_pix, N, C) : 1;
     if (sp > 1 && workspace_bytes >= (int64_t)sp * n_pix * N * 4) {
         ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "conv3x3: workspace must be 16-byte aligned");

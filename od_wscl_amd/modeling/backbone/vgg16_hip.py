@@ -50,10 +50,10 @@ def _layers_of(features):
 def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask, zero_page, st, flops):
     """One implicit-GEMM convolution (y bf16 or fp32); the launcher's split-K workspace (deep layers) comes from
     torch's allocator."""
-    ws_bytes = lib.odw_conv3x3_workspace(m, c, n)
+    ws_bytes = lib.odw_conv3x3_workspace_hw(m, h, w, c, n, dil)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=y.device) if ws_bytes else None
     out_bf16 = y.dtype == torch.bfloat16
-    sym = "conv3x3_glds_kernel<false> split-K+reduce" if ws_bytes else ("conv3x3_glds_kernel<%s>" % ("true" if out_bf16 else "false"))
+    sym = "conv3x3 split-K+reduce" if ws_bytes else ("conv3x3<%s>" % ("bf16" if out_bf16 else "f32"))
     with kernel_timer.region(sym, flops=flops):
         L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, w, c, dil, mirror, L.ptr(wk), wk.stride(0), n, L.ptr(y), n,
                                              1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0, L.ptr(mask), ldmask,

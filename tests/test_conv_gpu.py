@@ -107,6 +107,52 @@ def test_conv3x3_split_k_ring(lib, B, Cin, Cout, H, W, dil, forced, monkeypatch)
         assert (y.float() - y0.float()).abs().max().item() <= tol * scale
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,dil,mirror,splits", [
+    (2, 64, 64, 37, 45, 1, 0, 1), (1, 128, 192, 33, 16, 2, 0, 2), (1, 256, 64, 17, 50, 2, 1, 4), (3, 64, 128, 16, 16, 1, 1, 1),
+    (1, 512, 512, 76, 76, 1, 0, 0), (1, 512, 256, 40, 30, 2, 1, 0), (1, 256, 136, 21, 19, 1, 0, 3)])
+def test_conv3x3_halo_tile_kernel(lib, B, Cin, Cout, H, W, dil, mirror, splits, monkeypatch):
+    """conv3x3_halo_kernel (16x16 spatial tiles, the input patch staged once per 64-channel block) against PyTorch and
+    against the 128x128 kernel on the same operands: ragged image edges, several images, both dilations, mirrored taps
+    (input gradient), channel-block slices + reduction pass, N not a multiple of the tile."""
+    L = lib
+    if splits:
+        monkeypatch.setenv("ODW_CONV_SPLITK", str(splits))
+    m = B * H * W
+    x = rnd(21, (B, Cin, H, W)).bfloat16().float()
+    w = rnd(22, (Cout, Cin, 3, 3), 0.03).bfloat16().float()
+    b = rnd(23, (Cout,), 0.1)
+    zero = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
+    xn = torch.empty((m, Cin), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().odw_nchw_f32_to_nhwc_bf16(L.ptr(x), B, H * W, Cin, Cin, L.ptr(xn), L.stream()), "to nhwc")
+    # the packed [n][tap*C + c] weights; for the mirrored run the same array plays the [ci][tap*Cout + co] copy
+    wk = torch.zeros((Cout, r64(9 * Cin)), dtype=torch.bfloat16, device="cuda")
+    wk[:, :9 * Cin] = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).bfloat16()
+    mask = (rnd(24, (m, Cout)) > -0.5).to(torch.bfloat16)
+    if mirror:      # taps flipped: correlation with the 180-degree rotated kernel
+        ref = F.conv2d(x, torch.flip(w, dims=(2, 3)), b, padding=dil, dilation=dil)
+    else:
+        ref = F.conv2d(x, w, b, padding=dil, dilation=dil)
+    ref = torch.relu(ref).permute(0, 2, 3, 1).reshape(m, Cout) * mask.float()
+    ws_bytes = L.lib().odw_conv3x3_workspace_hw(m, H, W, Cin, Cout, dil)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
+    outs = {}
+    for halo in ("1", "0"):
+        monkeypatch.setenv("ODW_CONV_HALO", halo)
+        for dt in (torch.float32, torch.bfloat16):
+            y = torch.full((m, Cout), float("nan"), dtype=dt, device="cuda")
+            L.check(L.lib().odw_conv3x3_nhwc_bf16_ws(L.ptr(xn), m, H, W, Cin, dil, mirror, L.ptr(wk), wk.stride(0), Cout, L.ptr(y),
+                                                     Cout, 1 if dt == torch.bfloat16 else 0, L.ptr(b), 1, L.ptr(mask), Cout,
+                                                     L.ptr(zero), L.ptr(ws) if ws_bytes else None, ws_bytes, L.stream()), "conv")
+            outs[(halo, dt)] = y.float()
+    scale = max(1.0, ref.abs().max().item())
+    for (halo, dt), y in outs.items():
+        tol = 2e-3 if dt == torch.float32 else 1e-2
+        assert torch.isfinite(y).all(), (halo, dt)
+        assert (y - ref).abs().max().item() <= tol * scale, (halo, dt)
+    # same products, same fp32 accumulation up to the order of the K walk
+    assert (outs[("1", torch.float32)] - outs[("0", torch.float32)]).abs().max().item() <= 2e-4 * scale
+
+
 def test_maxpool_and_layout_kernels(lib):
     L = lib
     B, C, H, W = 2, 16, 8, 12

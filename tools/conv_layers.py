@@ -17,7 +17,7 @@ for li, (cin, cout, dil, h) in enumerate(layers):
     wk = torch.randn(cout, _r64(9 * cp), device="cuda").bfloat16()
     y = torch.empty(m, cout, device="cuda", dtype=torch.bfloat16)
     bias = torch.zeros(cout, device="cuda")
-    wsb = lib.odw_conv3x3_workspace(m, cp, cout)
+    wsb = lib.odw_conv3x3_workspace_hw(m, h, h, cp, cout, dil)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
     def run():
         L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, h, cp, dil, 0, L.ptr(wk), wk.stride(0), cout, L.ptr(y), cout, 1,

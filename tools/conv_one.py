@@ -14,7 +14,7 @@ x = torch.randn(m, cin, device="cuda").bfloat16()
 wk = (torch.randn(cout, _r64(9 * cin), device="cuda") * 0.05).bfloat16()
 y = torch.empty(m, cout, device="cuda", dtype=torch.bfloat16)
 bias = torch.zeros(cout, device="cuda")
-wsb = lib.odw_conv3x3_workspace(m, cin, cout)
+wsb = lib.odw_conv3x3_workspace_hw(m, h, h, cin, cout, dil)
 ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
 for _ in range(8):
     L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, h, cin, dil, mirror, L.ptr(wk), wk.stride(0), cout, L.ptr(y), cout, 1,
