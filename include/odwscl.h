@@ -186,6 +186,11 @@ int odw_od_assign(const float* boxes, int P, const float* gt_boxes, const int64_
 int odw_od_assign_indexed(const float* boxes, int P, const int* gt_index, const int* gt_classes,
                           const float* gt_scores, int G, float fg_thresh, float wx, float wy, float ww, float wh,
                           int64_t* labels, float* weights, float* targets, void* stream);
+/* the same with the pseudo-GT count read from device memory (written by odw_discover_sim): no host read in front of it;
+ * g_cap = capacity of the index / class / score lists */
+int odw_od_assign_indexed_dev(const float* boxes, int P, const int* gt_index, const int* gt_classes,
+                              const float* gt_scores, const int* n_gt_dev, int g_cap, float fg_thresh, float wx, float wy,
+                              float ww, float wh, int64_t* labels, float* weights, float* targets, void* stream);
 
 /* ---- ROI-head GEMM on the bf16 matrix cores ---------------------------------------
  * C[M,N] (+)= epilogue( alpha * sum_k A[M,K] B[N,K] )   both operands bf16, K contiguous.

@@ -102,6 +102,7 @@ SIGNATURES = {
     "odw_image_preprocess_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "odw_image_preprocess": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_l, c_p]),
     "odw_od_assign_indexed": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
+    "odw_od_assign_indexed_dev": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
     "odw_im2col_t_bf16_part": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "odw_maxpool2x2_nhwc_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_maxpool2x2_nhwc_f32_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),

@@ -19,8 +19,13 @@ __global__ __launch_bounds__(256) void od_assign_kernel(const float* __restrict_
                                                         float fg_thresh, float wx, float wy, float ww, float wh,
                                                         long long* __restrict__ labels,
                                                         float* __restrict__ weights,
-                                                        float* __restrict__ targets) {
+                                                        float* __restrict__ targets,
+                                                        const int* __restrict__ g_dev = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // G x 5: box + area
+    if (g_dev) {                    // the count lives on the device (written by the discovery kernels): G = its capacity
+        const int g = *g_dev;
+        G = g < 1 ? 1 : (g < G ? g : G);
+    }
     for (int j = threadIdx.x; j < G; j += blockDim.x) {
         const float4 q = INDEXED ? reinterpret_cast<const float4*>(boxes)[reinterpret_cast<const int*>(gt_boxes)[j]]
                                  : reinterpret_cast<const float4*>(gt_boxes)[j];
@@ -89,6 +94,26 @@ ODW_EXPORT int odw_od_assign_indexed(const float* boxes, int P, const int* gt_in
                 "od_assign_indexed: boxes/targets must be 16-byte aligned");
     od_assign_kernel<true><<<(P + 255) / 256, 256, (size_t)G * 5 * 4, (hipStream_t)stream_>>>(
         boxes, P, gt_index, gt_classes, gt_scores, G, fg_thresh, wx, wy, ww, wh, (long long*)labels, weights, targets);
+    ODW_CHECK_LAUNCH("od_assign_kernel");
+    return ODW_OK;
+}
+
+// The same with the number of pseudo-GT boxes read from device memory (n_gt_dev, written by odw_discover_sim) so that
+// the launch does not wait for a host read of the discovery result; g_cap = capacity of the three lists (<= 2048).
+ODW_EXPORT int odw_od_assign_indexed_dev(const float* boxes, int P, const int* gt_index, const int* gt_classes,
+                                         const float* gt_scores, const int* n_gt_dev, int g_cap, float fg_thresh,
+                                         float wx, float wy, float ww, float wh, int64_t* labels, float* weights,
+                                         float* targets, void* stream_) {
+    ODW_REQUIRE(P >= 0 && g_cap >= 1, "od_assign_indexed_dev: P=%d capacity=%d", P, g_cap);
+    if (P == 0) return ODW_OK;
+    if (g_cap > kMaxGT) g_cap = kMaxGT;
+    ODW_REQUIRE(boxes && gt_index && gt_classes && gt_scores && n_gt_dev && labels && weights && targets,
+                "od_assign_indexed_dev: null pointer");
+    ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)targets) & 15) == 0,
+                "od_assign_indexed_dev: boxes/targets must be 16-byte aligned");
+    od_assign_kernel<true><<<(P + 255) / 256, 256, (size_t)g_cap * 5 * 4, (hipStream_t)stream_>>>(
+        boxes, P, gt_index, gt_classes, gt_scores, g_cap, fg_thresh, wx, wy, ww, wh, (long long*)labels, weights, targets,
+        n_gt_dev);
     ODW_CHECK_LAUNCH("od_assign_kernel");
     return ODW_OK;
 }

@@ -73,7 +73,10 @@ class RoIRegLossComputation(object):
     def __call__(self, class_score, det_score, ref_scores, ref_bbox_preds, sim_feature, clean_pooled_feats,
                  feature_extractor, model_sim, proposals, targets, epsilon=1e-8):
         # selection logic and loss arithmetic always run in fp32 (the reference's DTYPE, defaults.py:559)
-        f32 = lambda t: t.float()
+        def f32(t):
+            if callable(t):             # a deferred evaluation (weak_head: Sim_Net on the clean pass): stays deferred
+                return lambda: t().float()
+            return t.float()
         with torch.autocast("cuda", enabled=False):
             return self._call([f32(t) for t in class_score], [f32(t) for t in det_score],
                               [f32(t) for t in ref_scores], [f32(t) for t in ref_bbox_preds], f32(sim_feature),
@@ -85,6 +88,8 @@ class RoIRegLossComputation(object):
 
     def _call(self, class_score, det_score, ref_scores, ref_bbox_preds, sim_feature, clean_pooled_feats,
               feature_extractor, model_sim, proposals, targets, epsilon=1e-8):
+        if callable(sim_feature):
+            sim_feature = sim_feature()
         sizes = [len(p) for p in proposals]
         n_img = len(sizes)
         class_score = F.softmax(torch.cat(class_score, dim=0), dim=1)

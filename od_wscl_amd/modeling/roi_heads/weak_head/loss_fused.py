@@ -77,6 +77,41 @@ class _Staging(object):
         return [self.dev[k, o:o + n] for o, n in views]
 
 
+class _AsyncRead(object):
+    """A device -> host read that does not drain the launch stream: the copy runs on a side stream behind an event
+    recorded where the data is final, into a pinned ring; the caller keeps launching independent work and calls
+    wait() when it needs the numbers.  (tensor.cpu() synchronises the whole stream: whatever was queued behind the
+    producer would have to finish first, and nothing could be queued while the host assembles its index lists.)"""
+    _state = {}
+
+    def __init__(self, src):
+        dev = src.device
+        st = _AsyncRead._state.get(dev)
+        if st is None:
+            st = _AsyncRead._state[dev] = {"stream": torch.cuda.Stream(device=dev), "bufs": [None] * 4, "k": 0}
+        n = src.numel()
+        k = st["k"]
+        st["k"] = (k + 1) % len(st["bufs"])
+        buf = st["bufs"][k]
+        if buf is None or buf.numel() < n or buf.dtype != src.dtype:
+            buf = st["bufs"][k] = torch.empty(max(n, 1 << 14), dtype=src.dtype).pin_memory()
+        main = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side = st["stream"]
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            buf[:n].copy_(src.reshape(-1), non_blocking=True)
+            self.done = torch.cuda.Event()
+            self.done.record(side)
+        src.record_stream(side)
+        self.buf, self.n = buf, n
+
+    def wait(self):
+        self.done.synchronize()
+        return self.buf[:self.n].numpy()
+
+
 def _fused_base(tensors):
     """If the 8 predictor outputs are column slices of ONE (P, N) fp32 tensor (the fused predictor GEMM,
     roi_weak_predictors.py), return (base, column offsets); else None."""
@@ -120,6 +155,8 @@ class RoIRegLossFused(RoIRegLossComputation):
     def _call(self, class_score, det_score, ref_scores, ref_bbox_preds, sim_feature, clean_pooled_feats,
               feature_extractor, model_sim, proposals, targets, epsilon=1e-8):
         if not self.contra or feature_extractor.rand is None:
+            if callable(sim_feature):
+                sim_feature = sim_feature()
             return super()._call(class_score, det_score, ref_scores, ref_bbox_preds, sim_feature,
                                  clean_pooled_feats, feature_extractor, model_sim, proposals, targets, epsilon)
         lib = L.lib()
@@ -203,7 +240,10 @@ class RoIRegLossFused(RoIRegLossComputation):
                                      L.ptr(img_off), n_img, max_p, L.ptr(pos_cls), L.ptr(n_pos), maxpos,
                                      float(self.p_thres), L.ptr(tops), L.ptr(masks), L.ptr(rows), max_p,
                                      L.ptr(counts), L.stream()), "discover_iou")
-        host_a = state_a[:n_cnt + n_rows].cpu().numpy()                       # host sync 1
+        read_a = _AsyncRead(state_a[:n_cnt + n_rows])                         # host read 1 (side stream)
+        if callable(sim_feature):
+            sim_feature = sim_feature()          # Sim_Net over the clean pass: queued behind discover_iou, runs under the read
+        host_a = read_a.wait()
         counts_h = host_a[:n_cnt].reshape(n_img, maxpos)
         rows_h = host_a[n_cnt:].reshape(n_img, maxpos, max_p)
 
@@ -288,7 +328,40 @@ class RoIRegLossFused(RoIRegLossComputation):
                                      max_p, L.ptr(inst_idx), L.ptr(inst_cnt), L.ptr(fresh_idx), L.ptr(fresh_cnt),
                                      L.ptr(gt_idx), L.ptr(gt_cls), L.ptr(gt_score), L.ptr(gt_cnt), L.stream()),
                 "discover_sim")
-        host_b = state_b[:n_back].cpu().numpy()                                # host sync 2
+        read_b = _AsyncRead(state_b[:n_back])                                  # host read 2 (side stream)
+        # ---- pseudo labels of the three branches (od_layer tail, fused kernel) and the dense losses: everything they
+        # need is on the device (the pseudo-GT counts included), so they are queued BEFORE the host waits for the
+        # discovery lists and run while it assembles the SupCon gather indices
+        pseudo_all = torch.empty((3, sum_p), dtype=torch.int64, device=device)
+        weight_all = torch.empty((3, sum_p), dtype=torch.float32, device=device)
+        target_all = torch.empty((3, sum_p, 4), dtype=torch.float32, device=device)
+        wts = self.od_layer.weights
+        for idx in range(n_img):
+            sl = slice(offs[idx], offs[idx + 1])
+            bx = boxes_all[sl]
+            for i in range(n_ref):
+                # pseudo-GT boxes are gathered inside the kernel from their int32 proposal indices
+                L.check(lib.odw_od_assign_indexed_dev(L.ptr(bx), bx.shape[0], L.ptr(gt_idx[idx, i]), L.ptr(gt_cls[idx, i]),
+                                                      L.ptr(gt_score[idx, i]), L.ptr(gt_cnt[idx, i]), maxpos * max_p,
+                                                      float(self.od_layer.fg_thresh), float(wts[0]), float(wts[1]),
+                                                      float(wts[2]), float(wts[3]), L.ptr(pseudo_all[i, sl]),
+                                                      L.ptr(weight_all[i, sl]), L.ptr(target_all[i, sl]), L.stream()),
+                        "od_assign_indexed")
+        dense = None
+        if ybase is not None and not self.cls_agnostic_bbox_reg:
+            # ---- MIL + refinement losses and their gradient in ONE launch (csrc/refine_loss.hip)
+            import ctypes
+            out = torch.empty((n_img, 16), dtype=torch.float32, device=device)
+            dy = torch.empty_like(ybase)
+            L.check(lib.odw_refine_losses(L.ptr(ybase), ybase.shape[1], ctypes.cast(self._heads, ctypes.c_void_p), C,
+                                          L.ptr(img_off), n_img, sum_p, max_p, L.ptr(final_score), L.ptr(colstat),
+                                          L.ptr(lab_vecs), L.ptr(pseudo_all), L.ptr(weight_all), L.ptr(target_all),
+                                          L.ptr(n_pos), float(epsilon), L.ptr(out), L.ptr(dy), L.ptr(dense_ws), ws_bytes,
+                                          L.stream()), "refine_losses")
+            tot = out.sum(dim=0)
+            col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
+            dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
+        host_b = read_b.wait()
         fresh_h = host_b[:nf].reshape(n_img, 3, maxpos)
         gt_h = host_b[nf:nf + n_img * 3].reshape(n_img, 3)
         inst_h = host_b[nf + n_img * 3:2 * nf + n_img * 3]
@@ -359,43 +432,20 @@ class RoIRegLossFused(RoIRegLossComputation):
         from ..sim_head.sim_loss import _SupConV2Fn
         loss_sim = self.sim_lmda * _SupConV2Fn.apply(features, labels, weights, self.temp)
 
-        # ---- pseudo labels of the three branches (od_layer tail, fused kernel)
-        pseudo_all = torch.empty((3, sum_p), dtype=torch.int64, device=device)
-        weight_all = torch.empty((3, sum_p), dtype=torch.float32, device=device)
-        target_all = torch.empty((3, sum_p, 4), dtype=torch.float32, device=device)
-        for idx in range(n_img):
-            sl = slice(offs[idx], offs[idx + 1])
-            bx = boxes_all[sl]
-            for i in range(n_ref):
-                g = int(gt_h[idx][i])
-                # pseudo-GT boxes are gathered inside the kernel from their int32 proposal indices
-                wts = self.od_layer.weights
-                L.check(lib.odw_od_assign_indexed(L.ptr(bx), bx.shape[0], L.ptr(gt_idx[idx, i]), L.ptr(gt_cls[idx, i]),
-                                                  L.ptr(gt_score[idx, i]), g, float(self.od_layer.fg_thresh),
-                                                  float(wts[0]), float(wts[1]), float(wts[2]), float(wts[3]),
-                                                  L.ptr(pseudo_all[i, sl]), L.ptr(weight_all[i, sl]),
-                                                  L.ptr(target_all[i, sl]), L.stream()), "od_assign_indexed")
-                if tr is not None:
+        if int(gt_h.max()) > 2048:
+            raise RuntimeError("RoIRegLossFused: %d pseudo-GT boxes in one branch (od_assign holds 2048)" % int(gt_h.max()))
+        if tr is not None:
+            for idx in range(n_img):
+                sl = slice(offs[idx], offs[idx + 1])
+                for i in range(n_ref):
                     tr["pseudo_%d_%d" % (idx, i)] = pseudo_all[i, sl].clone()
                     tr["weights_%d_%d" % (idx, i)] = weight_all[i, sl].clone()
 
         names = ["loss_img", "loss_ref_cls0", "loss_ref_reg0", "loss_ref_cls1", "loss_ref_reg1", "loss_ref_cls2",
                  "loss_ref_reg2"]
-        if ybase is not None and not self.cls_agnostic_bbox_reg:
-            # ---- MIL + refinement losses and their gradient in ONE launch (csrc/refine_loss.hip)
-            import ctypes
-            out = torch.empty((n_img, 16), dtype=torch.float32, device=device)
-            dy = torch.empty_like(ybase)
-            L.check(lib.odw_refine_losses(L.ptr(ybase), ybase.shape[1], ctypes.cast(self._heads, ctypes.c_void_p), C,
-                                          L.ptr(img_off), n_img, sum_p, max_p, L.ptr(final_score), L.ptr(colstat),
-                                          L.ptr(lab_vecs), L.ptr(pseudo_all), L.ptr(weight_all), L.ptr(target_all),
-                                          L.ptr(n_pos), float(epsilon), L.ptr(out), L.ptr(dy), L.ptr(dense_ws), ws_bytes,
-                                          L.stream()), "refine_losses")
+        if dense is not None:
             if tr is not None:
                 tr["dense_loss_kernel"] = True
-            tot = out.sum(dim=0)
-            col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
-            dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
             losses = LossDict({"loss_img": dense[0], "loss_sim": loss_sim})
             for k in range(1, 7):
                 losses[names[k]] = dense[k]

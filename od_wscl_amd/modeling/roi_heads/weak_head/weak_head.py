@@ -73,8 +73,12 @@ class ROIWeakRegHead(nn.Module):
                 clean_pooled = fe.forward_pooler(features, proposals)
                 clean_feats, aug_feats = fe.forward_clean_and_aug(clean_pooled)
             if getattr(fe, "sparse_clean", False) and clean_pooled.dim() == 2:
-                with torch.no_grad():       # all P embeddings drive the selection; the rows the loss differentiates
-                    sim_feature = self.model_sim(clean_feats)      # are re-evaluated (fe.recompute_clean_rows)
+                # all P embeddings drive the selection; the rows the loss differentiates are re-evaluated
+                # (fe.recompute_clean_rows).  Deferred: the fused loss launches this evaluation BEHIND its first
+                # selection kernel, so that it runs while the host reads that kernel's result (loss_fused.py)
+                def sim_feature(model_sim=self.model_sim, clean_feats=clean_feats):
+                    with torch.no_grad():
+                        return model_sim(clean_feats)
             else:
                 sim_feature = self.model_sim(clean_feats)
         else:
