@@ -353,6 +353,15 @@ int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, int C, int 
                              int64_t workspace_bytes, void* stream);
 int odw_conv_weight_prep(const float* w, int Co, int Ci, int Cp, void* wk, int ldk, void* wd, int ldd, void* stream);
 int odw_conv_wgrad_unpack(const float* dwk, int ld, int Co, int Ci, int Cp, float* dw, void* stream);
+/* every layer of a body in one launch: host arrays of length n (<= 32) of the arguments of odw_conv_weight_prep */
+int odw_conv_weight_prep_batch(int n, const void* const* w, const int* Co, const int* Ci, const int* Cp,
+                               void* const* wk, const int* ldk, void* const* wd, const int* ldd, void* stream);
+/* convolution weight gradient as one call: dw (Co,Ci,3,3 fp32) (+)= dZ^T im2col(X) from the operands
+ * odw_linear_bwd_prep (dzt: Co x lda) and odw_im2col_t_bf16 (colt: 9*Cp x ldb) write, K = pixels: split-K partial
+ * products into the workspace, then ONE pass that reduces the slices and unpacks [co][tap*Cp+ci] -> [co][ci][tap] */
+int64_t odw_conv_wgrad_workspace(int Co, int Cp, int K, int lda, int ldb);
+int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int ldb, int Co, int Ci, int Cp, int K, float* dw,
+                      int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm, void* stream);
 /* column-block form: this call owns `cols` (>= n_pix, zero padded) columns of a wider (9*C x ldm) matrix */
 int odw_im2col_t_bf16_part(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm, int cols,

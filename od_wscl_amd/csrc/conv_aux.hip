@@ -37,6 +37,30 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Co, int Ci, 
     }
 }
 
+// every layer of a body in ONE launch (blockIdx.y = layer): the per-layer launches were 9 x ~14 us of a few thousand
+// elements each at the head of every forward
+constexpr int kMaxPrepLayers = 32;
+struct PrepLayer { const float* w; unsigned short* wk; unsigned short* wd; int Co, Ci, Cp, ldk, ldd; };
+struct PrepBatch { PrepLayer l[kMaxPrepLayers]; };
+
+__global__ void weight_prep_batch_kernel(PrepBatch b) {
+    const PrepLayer L = b.l[blockIdx.y];
+    const int total_k = L.wk ? L.Co * L.ldk : 0;
+    const int total_d = L.wd ? L.Ci * L.ldd : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_k + total_d; i += gridDim.x * blockDim.x) {
+        if (i < total_k) {
+            const int co = i / L.ldk, k = i - co * L.ldk;
+            const int t = k / L.Cp, ci = k - t * L.Cp;
+            L.wk[i] = (t < 9 && ci < L.Ci) ? f2bf(L.w[((size_t)co * L.Ci + ci) * 9 + t]) : (unsigned short)0;
+        } else {
+            const int j = i - total_k;
+            const int ci = j / L.ldd, k = j - ci * L.ldd;
+            const int t = k / L.Co, co = k - t * L.Co;
+            L.wd[j] = (t < 9) ? f2bf(L.w[((size_t)co * L.Ci + ci) * 9 + t]) : (unsigned short)0;
+        }
+    }
+}
+
 // dw[co][ci][t] = dwk[co][t*Cp + ci]
 __global__ void wgrad_unpack_kernel(const float* __restrict__ dwk, int ld, int Co, int Ci, int Cp,
                                     float* __restrict__ dw) {
@@ -296,6 +320,30 @@ ODW_EXPORT int odw_conv_weight_prep(const float* w, int Co, int Ci, int Cp, void
     weight_prep_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream_>>>(w, Co, Ci, Cp, (unsigned short*)wk, ldk,
                                                                         (unsigned short*)wd, ldd);
     ODW_CHECK_LAUNCH("weight_prep_kernel");
+    return ODW_OK;
+}
+
+// n layers at once; the eight arrays are HOST arrays of length n (pointers: device memory; wk[i] / wd[i] may be null)
+ODW_EXPORT int odw_conv_weight_prep_batch(int n, const void* const* w, const int* Co, const int* Ci, const int* Cp,
+                                          void* const* wk, const int* ldk, void* const* wd, const int* ldd, void* stream_) {
+    ODW_REQUIRE(n >= 0 && n <= kMaxPrepLayers, "conv_weight_prep_batch: %d layers (at most %d per call)", n, kMaxPrepLayers);
+    if (n == 0) return ODW_OK;
+    ODW_REQUIRE(w && Co && Ci && Cp && wk && ldk && wd && ldd, "conv_weight_prep_batch: null array");
+    PrepBatch b;
+    size_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        ODW_REQUIRE(Co[i] > 0 && Ci[i] > 0 && Cp[i] >= Ci[i] && w[i] && (wk[i] || wd[i]), "conv_weight_prep_batch: layer %d", i);
+        ODW_REQUIRE((!wk[i] || ldk[i] >= 9 * Cp[i]) && (!wd[i] || ldd[i] >= 9 * Co[i]),
+                    "conv_weight_prep_batch: leading dimensions of layer %d too small", i);
+        b.l[i].w = (const float*)w[i]; b.l[i].wk = (unsigned short*)wk[i]; b.l[i].wd = (unsigned short*)wd[i];
+        b.l[i].Co = Co[i]; b.l[i].Ci = Ci[i]; b.l[i].Cp = Cp[i]; b.l[i].ldk = ldk[i]; b.l[i].ldd = ldd[i];
+        const size_t e = (wk[i] ? (size_t)Co[i] * ldk[i] : 0) + (wd[i] ? (size_t)Ci[i] * ldd[i] : 0);
+        most = e > most ? e : most;
+    }
+    int gx = blocks_for(most);
+    gx = gx > 1024 ? 1024 : gx;
+    weight_prep_batch_kernel<<<dim3(gx, n), 256, 0, (hipStream_t)stream_>>>(b);
+    ODW_CHECK_LAUNCH("weight_prep_batch_kernel");
     return ODW_OK;
 }
 

@@ -1109,6 +1109,34 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
             arow[i] = hr * kChunksPerRow;
             asw[i] = (hr >> 1) & 7;
         }
+        if (DBG == 0 || DBG == 8) {
+            // the step's 16 fragment reads and 16 MFMAs with the issue order given to the scheduler explicitly: left
+            // alone hipcc emits 4 reads -> s_waitcnt lgkmcnt(0) -> 4 MFMAs per slice (1-2 % slower)
+            bf16x8 ga[4][2], gb[4][2];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int c = kk * 2 + half;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ga[kk][i] = __builtin_bit_cast(bf16x8, sa[arow[i] + (c ^ asw[i])]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) gb[kk][j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb[kk][j], ga[kk][i], acc[i][j], 0, 0, 0);
+            // issue order for the scheduler: the first slice's 4 reads, then one read of the NEXT slice behind each MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        } else
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int c = kk * 2 + half;
@@ -1485,6 +1513,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// Second pass of a convolution's weight gradient: dw[co][ci][t] = sum_s partial[s][co][t * Cp + ci] -- the reduction
+// over the K slices and the unpacking into torch's (Cout, Cin, 3, 3) layout in one pass (was: splitk_reduce into a
+// packed fp32 matrix + wgrad_unpack_kernel).  A thread owns one (co, ci): 9 x S coalesced reads, 36 contiguous bytes out.
+__global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* __restrict__ ws, int S, long long stride_f,
+                                                                  int Co, int Ci, int Cp, int ldw, float* __restrict__ dw,
+                                                                  int accumulate) {
+    const long long total = (long long)Co * Ci;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i / Ci), ci = (int)(i - (long long)co * Ci);
+        const float* p = ws + (size_t)co * ldw + ci;
+        float* out = dw + (size_t)i * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float a = p[t * Cp];
+            for (int sidx = 1; sidx < S; ++sidx) a += p[(size_t)sidx * stride_f + t * Cp];     // fixed order
+            out[t] = accumulate ? out[t] + a : a;
+        }
+    }
+}
+
 // Which kernel serves a product, and in how many K slices.  Variant 0 = register-staged 128x128 (any alignment),
 // 1 = LDS-DMA 128x128 (two workgroups per CU), 2 = LDS-DMA 256x128 three-slot ring, 3 = 256x256 asm-scheduled.
 // The DMA kernels need operand rows padded to a multiple of 64; the 256x256 kernel also 16-byte-aligned rows of C.
@@ -1744,6 +1792,63 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
     return ODW_OK;
 }
 
+// ---- convolution weight gradient: dW = dZ^T im2col(X) as ONE call (partial products + reduce-and-unpack) ----------
+// dzt (Co x ld, K-contiguous bf16) and colt ((9 Cp) x ld) are the operands odw_linear_bwd_prep / odw_im2col_t_bf16 write;
+// dw = the parameter gradient in torch's (Co, Ci, 3, 3) fp32 layout.  workspace: odw_conv_wgrad_workspace bytes.
+ODW_EXPORT int64_t odw_conv_wgrad_workspace(int Co, int Cp, int K, int lda, int ldb) {
+    const int N = 9 * Cp, ldw = (N + 3) / 4 * 4;
+    const Plan p = pick_plan(Co, N, K, lda, ldb, nullptr, ldw, 0, true);
+    return (int64_t)(p.splits > 1 ? p.splits : 1) * Co * ldw * 4;
+}
+
+ODW_EXPORT int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int ldb, int Co, int Ci, int Cp, int K,
+                                 float* dw, int accumulate, void* workspace, int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(Co > 0 && Ci > 0 && Cp >= Ci && K > 0 && dzt && colt && dw && workspace, "conv_wgrad_nt: bad arguments");
+    ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "conv_wgrad_nt: workspace must be 16-byte aligned");
+    const int N = 9 * Cp, ldw = (N + 3) / 4 * 4;
+    Plan plan = pick_plan(Co, N, K, lda, ldb, workspace, ldw, 0, true);
+    const int S = plan.splits > 1 ? plan.splits : 1;
+    ODW_REQUIRE(workspace_bytes >= (int64_t)S * Co * ldw * 4, "conv_wgrad_nt: workspace of %lld bytes, need %lld",
+                (long long)workspace_bytes, (long long)S * Co * ldw * 4);
+    if (S > 1) {
+        // the partial products, exactly as odw_gemm_nt_bf16_ws launches them
+        Epilogue pe;
+        pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.accumulate = 0; pe.alpha = 1.0f;
+        pe.mask = nullptr; pe.ldmask = 0; pe.pm = 0; pe.row_ids = nullptr;
+        for (int i = 0; i < kMaxSeg; ++i) { pe.seg_row[i] = 0; pe.seg_k0[i] = 0; pe.seg_k1[i] = 0; }
+        pe.kchunk = plan.kchunk; pe.split_stride = (long long)Co * ldw * 4;
+        if (plan.variant == 3) {
+            const size_t big_lds = (size_t)5 * GM * kChunksPerRow * sizeof(uint4);
+            const dim3 grid((unsigned)(((Co + GM - 1) / GM) * ((N + GN - 1) / GN)), (unsigned)S);
+            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr");
+            gemm_nt_bf16_big_kernel<false, 7><<<grid, kBigThreads, big_lds, stream>>>(
+                (const unsigned short*)dzt, lda, (const unsigned short*)colt, ldb, Co, N, K, workspace, ldw, pe,
+                (Co + GM - 1) / GM, (N + GN - 1) / GN);
+        } else {
+            const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
+            const dim3 grid((unsigned)(((Co + RM - 1) / RM) * ((N + RN - 1) / RN)), (unsigned)S);
+            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "ring attr");
+            gemm_nt_bf16_ring_kernel<false><<<grid, kRingThreads, ring_lds, stream>>>(
+                (const unsigned short*)dzt, lda, (const unsigned short*)colt, ldb, Co, N, K, workspace, ldw, pe,
+                (Co + RM - 1) / RM, (N + RN - 1) / RN);
+        }
+        ODW_CHECK_HIP(hipGetLastError(), "conv_wgrad_nt partial launch");
+    } else {
+        const int rc = odw_gemm_nt_bf16_ws(dzt, lda, colt, ldb, Co, N, K, workspace, ldw, 0, nullptr, 0, 1.0f, 0.0f, 0, nullptr,
+                                           nullptr, nullptr, 0, nullptr, 0, stream_);
+        if (rc != ODW_OK) return rc;
+    }
+    const long long pairs = (long long)Co * Ci;
+    const int rblocks = (int)((pairs + 255) / 256 < 4096 ? (pairs + 255) / 256 : 4096);
+    wgrad_reduce_unpack_kernel<<<rblocks, 256, 0, stream>>>((const float*)workspace, S, (long long)Co * ldw, Co, Ci, Cp, ldw,
+                                                            dw, accumulate);
+    ODW_CHECK_LAUNCH("wgrad_reduce_unpack_kernel");
+    return ODW_OK;
+}
+
 ODW_EXPORT int odw_transpose_to_bf16_part(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
                                           int out_cols, void* stream_);
 
@@ -1998,7 +2103,7 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
                     hp.tiles_x, hp.tiles_n, hp.splits, hp.cb_per_split);                                           \
             } while (0)
             if (dbg == 1) ODW_LAUNCH_HALO_DBG(1); else if (dbg == 2) ODW_LAUNCH_HALO_DBG(2); else if (dbg == 3) ODW_LAUNCH_HALO_DBG(3);
-            else if (dbg == 4) ODW_LAUNCH_HALO_DBG(4); else if (dbg == 5) ODW_LAUNCH_HALO_DBG(5); else if (dbg == 6) ODW_LAUNCH_HALO_DBG(6); else ODW_LAUNCH_HALO_DBG(7);
+            else if (dbg == 4) ODW_LAUNCH_HALO_DBG(4); else if (dbg == 5) ODW_LAUNCH_HALO_DBG(5); else if (dbg == 6) ODW_LAUNCH_HALO_DBG(6); else if (dbg == 7) ODW_LAUNCH_HALO_DBG(7); else ODW_LAUNCH_HALO_DBG(8);
 #undef ODW_LAUNCH_HALO_DBG
         } else
         if (dilation == 1) { if (out_bf16) ODW_LAUNCH_HALO(true, 1); else ODW_LAUNCH_HALO(false, 1); }

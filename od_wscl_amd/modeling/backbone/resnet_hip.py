@@ -19,7 +19,7 @@ from ... import _lib as L
 from ... import gemm
 from ... import precision as P
 from ...utils.kernel_timer import kernel_timer
-from .vgg16_hip import _conv3x3, _r64
+from .vgg16_hip import _conv3x3, _r64, conv_wgrad
 
 
 def _fold(bn):
@@ -63,10 +63,8 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             colt = torch.empty((9 * ci, m64), dtype=torch.bfloat16, device=dy.device)
             L.check(lib.odw_im2col_t_bf16(L.ptr(x), m, H, W, ci, 1, L.ptr(colt), m64, st), "im2col_t")
-            dwk = torch.empty((co, 9 * ci), dtype=torch.float32, device=dy.device)
-            gemm.gemm_nt(dzt, colt, co, 9 * ci, m, dwk)
             dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
-            L.check(lib.odw_conv_wgrad_unpack(L.ptr(dwk), 9 * ci, co, ci, ci, L.ptr(dw), st), "wgrad_unpack")
+            conv_wgrad(lib, dzt, colt, co, ci, ci, m, dw, st)
         dx = None
         if ctx.needs_input_grad[0] and wd is not None:
             dx = torch.empty((m, ci), dtype=torch.bfloat16, device=dy.device)
@@ -119,10 +117,8 @@ class _SplitConv3x3Fn(torch.autograd.Function):
             for t, pl in enumerate(gb):
                 L.check(lib.odw_im2col_t_bf16_part(L.ptr(planes[pl]), m, H, W, ci, 1, L.ptr(colt[:, t * m64:]), Tg * m64, m64, st),
                         "im2col_t")
-            dwk = torch.empty((co, 9 * ci), dtype=torch.float32, device=dy.device)
-            gemm.gemm_nt(dzt, colt, co, 9 * ci, Tg * m64, dwk)
             dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
-            L.check(lib.odw_conv_wgrad_unpack(L.ptr(dwk), 9 * ci, co, ci, ci, L.ptr(dw), st), "wgrad_unpack")
+            conv_wgrad(lib, dzt, colt, co, ci, ci, Tg * m64, dw, st)
         dx = None
         if ctx.needs_input_grad[0] and wd is not None:
             dx = torch.empty((m, ci), dtype=torch.float32, device=dy.device)

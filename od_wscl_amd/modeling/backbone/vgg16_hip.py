@@ -60,6 +60,16 @@ def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask
                                              L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv3x3")
 
 
+def conv_wgrad(lib, dzt, colt, cout, cin, cp, k, dw, st):
+    """dw (Cout, Cin, 3, 3) fp32 = dZ^T im2col(X) over k reduction columns (pixels; plane products in a split mode) as
+    ONE call: split-K partial products, then one pass that reduces the slices and unpacks into torch's layout."""
+    ws_bytes = lib.odw_conv_wgrad_workspace(cout, cp, k, dzt.stride(0), colt.stride(0))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dzt.device)
+    with kernel_timer.region("conv wgrad split-K+reduce", flops=2.0 * cout * 9 * cp * k):
+        L.check(lib.odw_conv_wgrad_nt(L.ptr(dzt), dzt.stride(0), L.ptr(colt), colt.stride(0), cout, cin, cp, k, L.ptr(dw), 0,
+                                      L.ptr(ws), ws_bytes, st), "conv_wgrad_nt")
+
+
 class _VGGFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, net, *params):
@@ -136,10 +146,7 @@ class _VGGFn(torch.autograd.Function):
                                             L.ptr(dzt), m64, L.ptr(conv.bias.grad), st), "conv bias grad")
             colt = torch.empty((9 * l.cp, m64), dtype=torch.bfloat16, device=dev)
             L.check(lib.odw_im2col_t_bf16(L.ptr(x_in), m, h, w, l.cp, l.dil, L.ptr(colt), m64, st), "im2col_t")
-            dwk = torch.empty((l.cout, 9 * l.cp), dtype=torch.float32, device=dev)
-            gemm.gemm_nt(dzt, colt, l.cout, 9 * l.cp, m, dwk)
-            L.check(lib.odw_conv_wgrad_unpack(L.ptr(dwk), 9 * l.cp, l.cout, l.cin, l.cp, L.ptr(conv.weight.grad), st),
-                    "wgrad_unpack")
+            conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, m, conv.weight.grad, st)
             # ---- input gradient (masked by the ReLU of the producing layer unless that layer was pooled:
             #      then the pool backward of the previous iteration applies the mask)
             if li > first:
@@ -234,10 +241,7 @@ class _VGGSplitFn(torch.autograd.Function):
             for t, pl in enumerate(gb):
                 L.check(lib.odw_im2col_t_bf16_part(L.ptr(planes[pl]), m, h, w, l.cp, l.dil, L.ptr(colt[:, t * m64:]),
                                                    Tg * m64, m64, st), "im2col_t")
-            dwk = torch.empty((l.cout, 9 * l.cp), dtype=torch.float32, device=dev)
-            gemm.gemm_nt(dzt, colt, l.cout, 9 * l.cp, Tg * m64, dwk)
-            L.check(lib.odw_conv_wgrad_unpack(L.ptr(dwk), 9 * l.cp, l.cout, l.cin, l.cp, L.ptr(conv.weight.grad), st),
-                    "wgrad_unpack")
+            conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, Tg * m64, conv.weight.grad, st)
             del dzt, colt
             if li > first:
                 prev = net.layers[li - 1]
@@ -268,6 +272,7 @@ class VGGBackboneHip(nn.Module):
             self.zero_page = torch.zeros(64, dtype=torch.bfloat16, device=dev)
         first = min(i for i, l in enumerate(self.layers) if l.trainable) if any(l.trainable for l in self.layers) else 99
         mode = P.get_precision()
+        todo = []
         for i, l in enumerate(self.layers):
             if not l.trainable and self._frozen_ready and l.mode == mode:
                 continue
@@ -288,10 +293,18 @@ class VGGBackboneHip(nn.Module):
                 l.wk = torch.empty((l.cout, _r64(9 * l.cp)), dtype=torch.bfloat16, device=dev)
                 if l.trainable and i > first:
                     l.wd = torch.empty((l.cin, _r64(9 * l.cout)), dtype=torch.bfloat16, device=dev)
-            L.check(lib.odw_conv_weight_prep(L.ptr(l.conv.weight.detach()), l.cout, l.cin, l.cp, L.ptr(l.wk), l.wk.stride(0),
-                                             L.ptr(l.wd), l.wd.stride(0) if l.wd is not None else 0, L.stream()),
-                    "conv_weight_prep")
+            todo.append(l)
             l.mode = mode
+        if todo:        # the packed bf16 copies of every (trainable) layer in ONE launch
+            import ctypes
+            n = len(todo)
+            vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
+            args = (vp(*[l.conv.weight.data_ptr() for l in todo]), ia(*[l.cout for l in todo]), ia(*[l.cin for l in todo]),
+                    ia(*[l.cp for l in todo]), vp(*[l.wk.data_ptr() for l in todo]), ia(*[l.wk.stride(0) for l in todo]),
+                    vp(*[l.wd.data_ptr() if l.wd is not None else None for l in todo]),
+                    ia(*[l.wd.stride(0) if l.wd is not None else 0 for l in todo]))
+            L.check(lib.odw_conv_weight_prep_batch(n, *[ctypes.cast(a, ctypes.c_void_p) for a in args], L.stream()),
+                    "conv_weight_prep_batch")
         self._frozen_ready = True
 
     def forward(self, images):
