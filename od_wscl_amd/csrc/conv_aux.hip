@@ -43,20 +43,48 @@ constexpr int kMaxPrepLayers = 32;
 struct PrepLayer { const float* w; unsigned short* wk; unsigned short* wd; int Co, Ci, Cp, ldk, ldd; };
 struct PrepBatch { PrepLayer l[kMaxPrepLayers]; };
 
-__global__ void weight_prep_batch_kernel(PrepBatch b) {
+// blockIdx.x walks the layer's work units: first Co units "wk row co" (the row's Ci x 9 floats are one contiguous,
+// coalesced read; through LDS they leave as 9 runs of Cp bf16), then Ci x ceil(Co / 64) units "wd row ci, 64 output
+// channels" (64 reads of 36 contiguous bytes -> 9 runs of 64 bf16).  Zero padding of both layouts included.
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(PrepBatch b) {
+    __shared__ float sm[512 * 9 + 64];
     const PrepLayer L = b.l[blockIdx.y];
-    const int total_k = L.wk ? L.Co * L.ldk : 0;
-    const int total_d = L.wd ? L.Ci * L.ldd : 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_k + total_d; i += gridDim.x * blockDim.x) {
-        if (i < total_k) {
-            const int co = i / L.ldk, k = i - co * L.ldk;
-            const int t = k / L.Cp, ci = k - t * L.Cp;
-            L.wk[i] = (t < 9 && ci < L.Ci) ? f2bf(L.w[((size_t)co * L.Ci + ci) * 9 + t]) : (unsigned short)0;
+    const int nk = L.wk ? L.Co : 0;
+    const int cochunks = (L.Co + 63) / 64;
+    const int nd = L.wd ? L.Ci * cochunks : 0;
+    for (int u = blockIdx.x; u < nk + nd; u += gridDim.x) {
+        if (u < nk) {
+            const int co = u;
+            unsigned short* row = L.wk + (size_t)co * L.ldk;
+            for (int c0 = 0; c0 < L.Cp; c0 += 512) {             // 512 input channels per pass
+                const int nc = L.Ci - c0 < 512 ? (L.Ci - c0 > 0 ? L.Ci - c0 : 0) : 512;
+                const float* src = L.w + ((size_t)co * L.Ci + c0) * 9;
+                for (int k = threadIdx.x; k < nc * 9; k += 256) sm[k] = src[k];
+                __syncthreads();
+                const int np = L.Cp - c0 < 512 ? L.Cp - c0 : 512;
+                for (int k = threadIdx.x; k < 9 * np; k += 256) {
+                    const int t = k / np, ci = k - t * np;
+                    row[t * L.Cp + c0 + ci] = ci < nc ? f2bf(sm[ci * 9 + t]) : (unsigned short)0;
+                }
+                __syncthreads();
+            }
+            for (int k = 9 * L.Cp + threadIdx.x; k < L.ldk; k += 256) row[k] = 0;
         } else {
-            const int j = i - total_k;
-            const int ci = j / L.ldd, k = j - ci * L.ldd;
-            const int t = k / L.Co, co = k - t * L.Co;
-            L.wd[j] = (t < 9) ? f2bf(L.w[((size_t)co * L.Ci + ci) * 9 + t]) : (unsigned short)0;
+            const int v = u - nk, ci = v / cochunks, co0 = (v - ci * cochunks) * 64;
+            const int nco = L.Co - co0 < 64 ? L.Co - co0 : 64;
+            for (int k = threadIdx.x; k < nco * 9; k += 256) {
+                const int c = k / 9, t = k - c * 9;
+                sm[k] = L.w[((size_t)(co0 + c) * L.Ci + ci) * 9 + t];
+            }
+            __syncthreads();
+            unsigned short* row = L.wd + (size_t)ci * L.ldd;
+            for (int k = threadIdx.x; k < 9 * nco; k += 256) {
+                const int t = k / nco, c = k - t * nco;
+                row[t * L.Co + co0 + c] = f2bf(sm[c * 9 + t]);
+            }
+            if (co0 == 0)
+                for (int k = 9 * L.Co + threadIdx.x; k < L.ldd; k += 256) row[k] = 0;
+            __syncthreads();
         }
     }
 }
@@ -337,11 +365,10 @@ ODW_EXPORT int odw_conv_weight_prep_batch(int n, const void* const* w, const int
                     "conv_weight_prep_batch: leading dimensions of layer %d too small", i);
         b.l[i].w = (const float*)w[i]; b.l[i].wk = (unsigned short*)wk[i]; b.l[i].wd = (unsigned short*)wd[i];
         b.l[i].Co = Co[i]; b.l[i].Ci = Ci[i]; b.l[i].Cp = Cp[i]; b.l[i].ldk = ldk[i]; b.l[i].ldd = ldd[i];
-        const size_t e = (wk[i] ? (size_t)Co[i] * ldk[i] : 0) + (wd[i] ? (size_t)Ci[i] * ldd[i] : 0);
+        const size_t e = (wk[i] ? (size_t)Co[i] : 0) + (wd[i] ? (size_t)Ci[i] * ((Co[i] + 63) / 64) : 0);
         most = e > most ? e : most;
     }
-    int gx = blocks_for(most);
-    gx = gx > 1024 ? 1024 : gx;
+    const int gx = (int)(most < 2048 ? most : 2048);
     weight_prep_batch_kernel<<<dim3(gx, n), 256, 0, (hipStream_t)stream_>>>(b);
     ODW_CHECK_LAUNCH("weight_prep_batch_kernel");
     return ODW_OK;

@@ -1515,21 +1515,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Second pass of a convolution's weight gradient: dw[co][ci][t] = sum_s partial[s][co][t * Cp + ci] -- the reduction
 // over the K slices and the unpacking into torch's (Cout, Cin, 3, 3) layout in one pass (was: splitk_reduce into a
-// packed fp32 matrix + wgrad_unpack_kernel).  A thread owns one (co, ci): 9 x S coalesced reads, 36 contiguous bytes out.
+// packed fp32 matrix + wgrad_unpack_kernel).  A workgroup owns (co, 256 input channels): thread j sums the 9 taps of
+// channel ci0 + j over the slices (coalesced 1 KB reads), parks them in LDS as [j][t] (stride 9: conflict-free) and the
+// workgroup writes the 256 x 9 contiguous floats of dw coalesced.
 __global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* __restrict__ ws, int S, long long stride_f,
                                                                   int Co, int Ci, int Cp, int ldw, float* __restrict__ dw,
                                                                   int accumulate) {
-    const long long total = (long long)Co * Ci;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int co = (int)(i / Ci), ci = (int)(i - (long long)co * Ci);
-        const float* p = ws + (size_t)co * ldw + ci;
-        float* out = dw + (size_t)i * 9;
+    __shared__ float sm[256 * 9];
+    const int chunks = (Ci + 255) / 256;
+    for (int b = blockIdx.x; b < Co * chunks; b += gridDim.x) {
+        const int co = b / chunks, ci0 = (b - co * chunks) * 256;
+        const int j = threadIdx.x, ci = ci0 + j;
+        if (ci < Ci) {
+            const float* p = ws + (size_t)co * ldw + ci;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float a = p[t * Cp];
-            for (int sidx = 1; sidx < S; ++sidx) a += p[(size_t)sidx * stride_f + t * Cp];     // fixed order
-            out[t] = accumulate ? out[t] + a : a;
+            for (int t = 0; t < 9; ++t) {
+                float a = p[t * Cp];
+                for (int sidx = 1; sidx < S; ++sidx) a += p[(size_t)sidx * stride_f + t * Cp];     // fixed order
+                sm[j * 9 + t] = a;
+            }
         }
+        __syncthreads();
+        const int n = (Ci - ci0 < 256 ? Ci - ci0 : 256) * 9;
+        float* out = dw + ((size_t)co * Ci + ci0) * 9;
+        for (int k = threadIdx.x; k < n; k += 256) out[k] = accumulate ? out[k] + sm[k] : sm[k];
+        __syncthreads();
     }
 }
 
@@ -1841,8 +1851,8 @@ ODW_EXPORT int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int
                                            nullptr, nullptr, 0, nullptr, 0, stream_);
         if (rc != ODW_OK) return rc;
     }
-    const long long pairs = (long long)Co * Ci;
-    const int rblocks = (int)((pairs + 255) / 256 < 4096 ? (pairs + 255) / 256 : 4096);
+    const long long units = (long long)Co * ((Ci + 255) / 256);
+    const int rblocks = (int)(units < 8192 ? units : 8192);
     wgrad_reduce_unpack_kernel<<<rblocks, 256, 0, stream>>>((const float*)workspace, S, (long long)Co * ldw, Co, Ci, Cp, ldw,
                                                             dw, accumulate);
     ODW_CHECK_LAUNCH("wgrad_reduce_unpack_kernel");

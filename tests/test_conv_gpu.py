@@ -270,3 +270,40 @@ def test_conv_weight_gradient(lib, B, Cin, Cout, H, W, dil):
     ref_w, ref_b = wg[0], wg[1]
     assert (dw - ref_w).abs().max().item() <= 3e-3 * max(1.0, ref_w.abs().max().item())
     assert (db - ref_b).abs().max().item() <= 3e-3 * max(1.0, ref_b.abs().max().item())
+    # the one-call form (split-K partials + ONE reduce-and-unpack pass): the same sums in the same slice order
+    ws_bytes = L.lib().odw_conv_wgrad_workspace(Cout, Cin, m, dzt.stride(0), colt.stride(0))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    dw1 = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    L.check(L.lib().odw_conv_wgrad_nt(L.ptr(dzt), dzt.stride(0), L.ptr(colt), colt.stride(0), Cout, Cin, Cin, m, L.ptr(dw1), 0,
+                                      L.ptr(ws), ws_bytes, L.stream()), "conv_wgrad_nt")
+    assert torch.equal(dw1, dw)
+    L.check(L.lib().odw_conv_wgrad_nt(L.ptr(dzt), dzt.stride(0), L.ptr(colt), colt.stride(0), Cout, Cin, Cin, m, L.ptr(dw1), 1,
+                                      L.ptr(ws), ws_bytes, L.stream()), "conv_wgrad_nt accumulate")
+    assert torch.equal(dw1, dw + dw)
+
+
+def test_conv_weight_prep_batch_equals_per_layer(lib):
+    """odw_conv_weight_prep_batch (every layer in one launch, coalesced through LDS) writes exactly what the per-layer
+    kernel writes, zero padding included: both packed layouts, a padded channel count, a layer without the mirrored copy."""
+    import ctypes
+    L = lib
+    shapes = [(64, 3, 8, True), (128, 64, 64, True), (520, 256, 256, False), (256, 512, 512, True), (72, 40, 64, True)]
+    ws, wk0, wd0, wk1, wd1 = [], [], [], [], []
+    for i, (co, ci, cp, mirrored) in enumerate(shapes):
+        w = rnd(40 + i, (co, ci, 3, 3), 0.1)
+        ws.append(w)
+        for wk, wd in ((wk0, wd0), (wk1, wd1)):
+            wk.append(torch.full((co, r64(9 * cp)), 7.0, dtype=torch.bfloat16, device="cuda"))
+            wd.append(torch.full((ci, r64(9 * co)), 7.0, dtype=torch.bfloat16, device="cuda") if mirrored else None)
+        L.check(L.lib().odw_conv_weight_prep(L.ptr(w), co, ci, cp, L.ptr(wk0[i]), wk0[i].stride(0), L.ptr(wd0[i]),
+                                             wd0[i].stride(0) if mirrored else 0, L.stream()), "prep")
+    n = len(shapes)
+    vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
+    args = (vp(*[w.data_ptr() for w in ws]), ia(*[s[0] for s in shapes]), ia(*[s[1] for s in shapes]), ia(*[s[2] for s in shapes]),
+            vp(*[t.data_ptr() for t in wk1]), ia(*[t.stride(0) for t in wk1]),
+            vp(*[t.data_ptr() if t is not None else None for t in wd1]), ia(*[t.stride(0) if t is not None else 0 for t in wd1]))
+    L.check(L.lib().odw_conv_weight_prep_batch(n, *[ctypes.cast(a, ctypes.c_void_p) for a in args], L.stream()), "prep batch")
+    for i in range(n):
+        assert torch.equal(wk0[i].view(torch.int16), wk1[i].view(torch.int16)), i
+        if wd0[i] is not None:
+            assert torch.equal(wd0[i].view(torch.int16), wd1[i].view(torch.int16)), i
