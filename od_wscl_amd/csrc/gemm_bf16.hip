@@ -1002,6 +1002,13 @@ constexpr int HT = 16;                                        // tile side (pixe
 constexpr int kHaloThreads = 512;
 constexpr int kHaloBStage = RN * kChunksPerRow;               // 1024 uint4 = 16 KB: one (block, tap) weight tile
 
+// MFMA row r (0..31) of a 32-pixel fragment -> (tile row 0 / 1 of the pair, x 0..15).  ds_read_b128 is serviced in the
+// lane groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (not 0-15 / 16-31): the mapping gives each group 16
+// horizontally adjacent pixels = 16 consecutive halo rows, which the slot swizzle makes conflict-free at any tap shift
+// (the plain r -> (r >> 4, r & 15) mapping measured SQ_LDS_BANK_CONFLICT = 28 % of the LDS cycles).
+__device__ __forceinline__ int halo_row_of(int r) { return r < 4 ? 0 : r < 12 ? 1 : r < 16 ? 0 : r < 20 ? 1 : r < 28 ? 0 : 1; }
+__device__ __forceinline__ int halo_x_of(int r) { return r < 4 ? r : r < 12 ? r - 4 : r < 20 ? r - 8 : r < 28 ? r - 12 : r - 16; }
+
 template <int DIL>
 struct Halo {
     static constexpr int HWp = HT + 2 * DIL;                  // patch pitch (pixels)
@@ -1067,8 +1074,7 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
     int hrb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int prow = wm * 64 + i * 32 + l31;
-        hrb[i] = ((prow >> 4) + DIL) * HC::HWp + (prow & 15) + DIL;
+        hrb[i] = (wm * 4 + i * 2 + halo_row_of(l31) + DIL) * HC::HWp + halo_x_of(l31) + DIL;
     }
 
     f32x16 acc[2][2];
@@ -1187,7 +1193,7 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
     band_store<OUT_BF16, 2>(acc, Cv, ldc, N, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds),
                             [&](int r) -> long long {
                                 const int prow = wm * 64 + r;
-                                const int y = y0 + (prow >> 4), x = x0 + (prow & 15);
+                                const int y = y0 + wm * 4 + (r >> 5) * 2 + halo_row_of(r & 31), x = x0 + halo_x_of(r & 31);
                                 if (DBG == 7) return (y < g.H && x < g.W) ? (long long)(prow + 256 * (blockIdx.x & 15)) : -1ll;
                                 return (y < g.H && x < g.W) ? (long long)img * hw + (long long)y * g.W + x : -1ll;
                             });
