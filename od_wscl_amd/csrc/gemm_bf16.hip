@@ -1493,13 +1493,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
             if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
         }
+        // bias and mask of the four columns as one batch of independent loads (clamped; per-element "if (ep.bias) x +=
+        // ep.bias[n]" compiles to a conditional load + s_waitcnt per element)
+        float bq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        unsigned short mq[4] = {1, 1, 1, 1};
+        if (ep.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = ep.bias[n + q < N ? n + q : N - 1];
+        }
+        if (ep.mask) {
+            const unsigned short* mr = ep.mask + (size_t)m * ep.ldmask;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mq[q] = mr[n + q < N ? n + q : N - 1];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (n + q >= N) break;
-            float x = v[q] * ep.alpha;
-            if (ep.bias) x += ep.bias[n + q];
+            float x = v[q] * ep.alpha + bq[q];
             if (ep.relu) x = fmaxf(x, 0.0f);
-            if (ep.mask && (ep.mask[(size_t)m * ep.ldmask + n + q] & 0x7fff) == 0) x = 0.0f;
+            if ((mq[q] & 0x7fff) == 0) x = 0.0f;
             if (ep.drop_p > 0.0f) {
                 const uint32_t lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
                 const uint32_t idx = lrow * (uint32_t)N + (uint32_t)(n + q);
@@ -1509,8 +1521,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
         if (OUT_BF16) {
             unsigned short* c = reinterpret_cast<unsigned short*>(Cv) + (size_t)m * ldc + n;
+            if (n + 3 < N && ((((uintptr_t)c) & 7) == 0)) {
+                *reinterpret_cast<uint2*>(c) = make_uint2(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]));
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (n + q < N) c[q] = f2bf(v[q]);
+                for (int q = 0; q < 4; ++q) if (n + q < N) c[q] = f2bf(v[q]);
+            }
         } else {
             float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
 #pragma unroll
