@@ -1355,10 +1355,10 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_vec_kernel(const void* __
         for (int q = 0; q < 8; ++q) t[ml][ch * 8 + q] = v[q];
         if (m < M && n < ld_z) {         // ld_z % 8 == 0 as well; beyond N the chunk is zero padding
             uint4 o;
-            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-            o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-            o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-            o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+            o.x = f2bf_pk(v[0], v[1]);
+            o.y = f2bf_pk(v[2], v[3]);
+            o.z = f2bf_pk(v[4], v[5]);
+            o.w = f2bf_pk(v[6], v[7]);
             *reinterpret_cast<uint4*>(dZ + (size_t)m * ld_z + n) = o;
         }
     }
@@ -1370,10 +1370,10 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_vec_kernel(const void* __
         const int n = n0 + nl, m = m0 + mc * 8;
         if (n < N && m < t_cols) {
             uint4 o;
-            o.x = (unsigned)f2bf(t[mc * 8 + 0][nl]) | ((unsigned)f2bf(t[mc * 8 + 1][nl]) << 16);
-            o.y = (unsigned)f2bf(t[mc * 8 + 2][nl]) | ((unsigned)f2bf(t[mc * 8 + 3][nl]) << 16);
-            o.z = (unsigned)f2bf(t[mc * 8 + 4][nl]) | ((unsigned)f2bf(t[mc * 8 + 5][nl]) << 16);
-            o.w = (unsigned)f2bf(t[mc * 8 + 6][nl]) | ((unsigned)f2bf(t[mc * 8 + 7][nl]) << 16);
+            o.x = f2bf_pk(t[mc * 8 + 0][nl], t[mc * 8 + 1][nl]);
+            o.y = f2bf_pk(t[mc * 8 + 2][nl], t[mc * 8 + 3][nl]);
+            o.z = f2bf_pk(t[mc * 8 + 4][nl], t[mc * 8 + 5][nl]);
+            o.w = f2bf_pk(t[mc * 8 + 6][nl], t[mc * 8 + 7][nl]);
             *reinterpret_cast<uint4*>(dZT + (size_t)n * ld_t + m) = o;
         }
     }
