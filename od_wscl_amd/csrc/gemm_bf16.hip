@@ -1537,28 +1537,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Second pass of a convolution's weight gradient: dw[co][ci][t] = sum_s partial[s][co][t * Cp + ci] -- the reduction
 // over the K slices and the unpacking into torch's (Cout, Cin, 3, 3) layout in one pass (was: splitk_reduce into a
-// packed fp32 matrix + wgrad_unpack_kernel).  A workgroup owns (co, 256 input channels): thread j sums the 9 taps of
-// channel ci0 + j over the slices (coalesced 1 KB reads), parks them in LDS as [j][t] (stride 9: conflict-free) and the
-// workgroup writes the 256 x 9 contiguous floats of dw coalesced.
+// packed fp32 matrix + wgrad_unpack_kernel).
 __global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* __restrict__ ws, int S, long long stride_f,
                                                                   int Co, int Ci, int Cp, int ldw, float* __restrict__ dw,
                                                                   int accumulate) {
-    __shared__ float sm[256 * 9];
-    const int chunks = (Ci + 255) / 256;
+    // a workgroup = (co, 64 input channels): thread (j = channel, g = tap group) sums taps g, g + 4, g + 8 over the
+    // slices in slice order (256-byte coalesced reads, four slices of loads in flight), LDS [j][t], 576 floats out
+    __shared__ float sm[64 * 9];
+    const int chunks = (Ci + 63) / 64;
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
     for (int b = blockIdx.x; b < Co * chunks; b += gridDim.x) {
-        const int co = b / chunks, ci0 = (b - co * chunks) * 256;
-        const int j = threadIdx.x, ci = ci0 + j;
+        const int co = b / chunks, ci0 = (b - co * chunks) * 64;
+        const int ci = ci0 + j;
         if (ci < Ci) {
-            const float* p = ws + (size_t)co * ldw + ci;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                float a = p[t * Cp];
-                for (int sidx = 1; sidx < S; ++sidx) a += p[(size_t)sidx * stride_f + t * Cp];     // fixed order
+            for (int t = g; t < 9; t += 4) {
+                const float* p = ws + (size_t)co * ldw + t * Cp + ci;
+                float a = p[0];
+                int sidx = 1;
+                for (; sidx + 3 < S; sidx += 4) {
+                    const float x0 = p[(size_t)sidx * stride_f], x1 = p[(size_t)(sidx + 1) * stride_f];
+                    const float x2 = p[(size_t)(sidx + 2) * stride_f], x3 = p[(size_t)(sidx + 3) * stride_f];
+                    a += x0; a += x1; a += x2; a += x3;                  // fixed order
+                }
+                for (; sidx < S; ++sidx) a += p[(size_t)sidx * stride_f];
                 sm[j * 9 + t] = a;
             }
         }
         __syncthreads();
-        const int n = (Ci - ci0 < 256 ? Ci - ci0 : 256) * 9;
+        const int n = (Ci - ci0 < 64 ? Ci - ci0 : 64) * 9;
         float* out = dw + ((size_t)co * Ci + ci0) * 9;
         for (int k = threadIdx.x; k < n; k += 256) out[k] = accumulate ? out[k] + sm[k] : sm[k];
         __syncthreads();
@@ -1873,8 +1879,8 @@ ODW_EXPORT int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int
                                            nullptr, nullptr, 0, nullptr, 0, stream_);
         if (rc != ODW_OK) return rc;
     }
-    const long long units = (long long)Co * ((Ci + 255) / 256);
-    const int rblocks = (int)(units < 8192 ? units : 8192);
+    const long long units = (long long)Co * ((Ci + 63) / 64);
+    const int rblocks = (int)(units < 16384 ? units : 16384);
     wgrad_reduce_unpack_kernel<<<rblocks, 256, 0, stream>>>((const float*)workspace, S, (long long)Co * ldw, Co, Ci, Cp, ldw,
                                                             dw, accumulate);
     ODW_CHECK_LAUNCH("wgrad_reduce_unpack_kernel");
