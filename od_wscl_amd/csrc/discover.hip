@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
     int* ki = reinterpret_cast<int*>(ks + ppow2);                         // ppow2 sort ids / candidate list
     unsigned char* close = reinterpret_cast<unsigned char*>(ki + ppow2);  // ppow2 flags (close / alive)
     float4* sbox = reinterpret_cast<float4*>(smem + sbox_off);           // ppow2 candidate boxes, sorted order
-    __shared__ int s_n, s_k;
+    __shared__ int s_n, s_nx[3];
     __shared__ float s_thr;
 
     const int img = blockIdx.x;
@@ -332,26 +332,33 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
                 close[t] = 1;                                                   // alive flags by sorted position
                 sbox[t] = bx[ki[t]];                                            // boxes in LDS: the greedy chain below
             }                                                                   // must not pay a global load per step
-            if (threadIdx.x == 0) s_k = 0;
+            if (threadIdx.x == 0) s_nx[0] = n;
             __syncthreads();
             int* inst = a.inst_idx + slot * a.pstride;
             int n_inst = 0;
-            while (true) {
-                int k = s_k;
-                if (k >= n) break;
+            // One barrier per kept box: while the threads suppress against box k they also find the next survivor --
+            // the smallest later position that is still alive -- with an LDS atomicMin (was: a second barrier and a
+            // serial scan of the alive flags by thread 0, the bulk of this kernel).  Three rotating slots: the one the
+            // atomics of iteration i go to was reset during iteration i - 1, after everyone had read it in i - 2.
+            int k = 0, it = 0;
+            while (k < n) {
                 // position k is alive by construction
                 const float4 bk = sbox[k];
-                for (int t = k + 1 + threadIdx.x; t < n; t += kThreads)
-                    if (close[t] && tv_overlap(bk, sbox[t], a.nms_thr)) close[t] = 0;
-                if (threadIdx.x == 0) inst[n_inst] = ki[k];
+                if (threadIdx.x == 0) {
+                    inst[n_inst] = ki[k];
+                    s_nx[(it + 1) % 3] = n;
+                }
+                int first = n;
+                for (int t = k + 1 + threadIdx.x; t < n; t += kThreads) {
+                    if (!close[t]) continue;
+                    if (tv_overlap(bk, sbox[t], a.nms_thr)) close[t] = 0;
+                    else if (t < first) first = t;
+                }
+                if (first < n) atomicMin(&s_nx[it % 3], first);
                 ++n_inst;
                 __syncthreads();
-                if (threadIdx.x == 0) {
-                    int nx = k + 1;
-                    while (nx < n && !close[nx]) ++nx;
-                    s_k = nx;
-                }
-                __syncthreads();
+                k = s_nx[it % 3];
+                ++it;
             }
             if (n_inst == 0) {                    // "avoid none" (loss.py:333)
                 if (threadIdx.x == 0) inst[0] = top;
