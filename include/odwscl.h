@@ -362,6 +362,14 @@ int odw_conv_weight_prep_batch(int n, const void* const* w, const int* Co, const
 int64_t odw_conv_wgrad_workspace(int Co, int Cp, int K, int lda, int ldb);
 int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int ldb, int Co, int Ci, int Cp, int K, float* dw,
                       int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/* the same gradient straight from the NHWC operands (dz: n_pix x ld_dz masked output gradient, X: n_pix x Cp layer input):
+ * gemm_tn_bf16_ring_kernel reads both K-major through ds_read_b64_tr_b16 -- no dZ^T, no transposed im2col.
+ * Cp a power of two >= 128. */
+/* out[n] += sum over the M rows of X (bf16, fp32 sums): the bias gradient beside odw_conv_wgrad_tn */
+int odw_colsum_bf16(const void* X, int ld, int M, int N, float* out, void* stream);
+int64_t odw_conv_wgrad_tn_workspace(int Co, int Cp, int n_pix);
+int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation, int Co, int Ci,
+                      float* dw, int accumulate, const void* zero_page, void* workspace, int64_t workspace_bytes, void* stream);
 int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm, void* stream);
 /* column-block form: this call owns `cols` (>= n_pix, zero padded) columns of a wider (9*C x ldm) matrix */
 int odw_im2col_t_bf16_part(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm, int cols,

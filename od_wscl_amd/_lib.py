@@ -84,6 +84,9 @@ SIGNATURES = {
     "odw_conv_weight_prep_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "odw_conv_wgrad_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "odw_conv_wgrad_nt": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p]),
+    "odw_colsum_bf16": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "odw_conv_wgrad_tn_workspace": (c_l, [c_i, c_i, c_i]),
+    "odw_conv_wgrad_tn": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_l, c_p]),
     "odw_im2col_t_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "odw_maxpool2x2_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_maxpool2x2_nhwc_bf16_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),

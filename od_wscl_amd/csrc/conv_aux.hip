@@ -89,6 +89,37 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(PrepBatch b) {
     }
 }
 
+// out[n] += sum_m X[m][n] (bf16 rows, fp32 sums): the bias gradient of a convolution whose weight gradient reads dZ as
+// it is (odw_conv_wgrad_tn) -- linear_bwd_prep would write two copies of dZ only to produce these sums.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ X, int ld, int M, int N,
+                                                          float* __restrict__ out) {
+    __shared__ float sm[32][65];
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 256;
+    const int ch = threadIdx.x & 7, r = threadIdx.x >> 3;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n0 + ch * 8 < N) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = m0 + r + 32 * k;
+            if (m < M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(X + (size_t)m * ld + n0 + ch * 8);
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc[2 * q] += __uint_as_float(w[q] << 16); acc[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u); }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sm[r][ch * 8 + q] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < 64 && n0 + (int)threadIdx.x < N) {
+        float t = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) t += sm[k][threadIdx.x];
+        atomicAdd(out + n0 + threadIdx.x, t);
+    }
+}
+
 // dw[co][ci][t] = dwk[co][t*Cp + ci]
 __global__ void wgrad_unpack_kernel(const float* __restrict__ dwk, int ld, int Co, int Ci, int Cp,
                                     float* __restrict__ dw) {
@@ -371,6 +402,15 @@ ODW_EXPORT int odw_conv_weight_prep_batch(int n, const void* const* w, const int
     const int gx = (int)(most < 2048 ? most : 2048);
     weight_prep_batch_kernel<<<dim3(gx, n), 256, 0, (hipStream_t)stream_>>>(b);
     ODW_CHECK_LAUNCH("weight_prep_batch_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_colsum_bf16(const void* X, int ld, int M, int N, float* out, void* stream_) {
+    ODW_REQUIRE(M >= 0 && N >= 0 && ld >= N, "colsum_bf16: bad dims");
+    if (M == 0 || N == 0) return ODW_OK;
+    ODW_REQUIRE(X && out && N % 8 == 0 && ld % 8 == 0 && (((uintptr_t)X) & 15) == 0, "colsum_bf16: N, ld multiples of 8, X 16-byte aligned");
+    colsum_bf16_kernel<<<dim3((N + 63) / 64, (M + 255) / 256), 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X, ld, M, N, out);
+    ODW_CHECK_LAUNCH("colsum_bf16_kernel");
     return ODW_OK;
 }
 

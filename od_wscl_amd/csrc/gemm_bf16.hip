@@ -1199,6 +1199,179 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
                             });
 }
 
+// ---- "TN" product on the ring pipeline: C[M,N] = sum_k A[k][m] * B[k][n], BOTH operands K-major ----------------------
+// A weight gradient is dW = dZ^T X with dZ (rows x N_out) and X (rows x K_in) stored row-major: the reduction index is
+// the ROW of both operands.  The NT kernels above want it contiguous, which costs a transposed copy of each operand
+// per product (transpose_bf16_vec, the dZ^T of linear_bwd_prep) and, for a convolution, the 9x transposed im2col.
+// gfx950 can read an MFMA fragment out of a K-major LDS tile instead: ds_read_b64_tr_b16 hands lane l the four
+// K-consecutive values of column (l & 15) of a [4 k][16 columns] block whose four 32-byte rows the 16 lanes of the group
+// address (tools/exp/tr_probe.hip prints the mapping); two of them make the 8 k of a 32x32x16 operand.
+// Tile 256 (M) x 128 (N), 8 waves of 64x64, K steps of 64 rows through the same three-slot ring / counted vmcnt as
+// gemm_nt_bf16_ring_kernel; LDS rows are K rows (512 B of A, 256 B of B); 16-byte chunk c of row k sits in slot
+// c ^ 4 (k & 3): the 32 lanes one transposed read is serviced in touch 4 rows x 64 B = all 64 banks once.
+// CONV: B is the implicit im2col of an NHWC activation: column block n0 = (tap, 128 input channels), row k = pixel
+// k + shift(tap), out-of-image pixels (and rows past K, both operands) read the zero page.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s16 lds_v4s16;
+
+template <int PITCH>
+__device__ __forceinline__ bf16x8 tn_frag(const unsigned char* tile, unsigned off) {
+    struct { v4s16 lo, hi; } r;
+    r.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16*)(tile + off));
+    r.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s16*)(tile + off + 4 * PITCH));
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(kRingThreads, 2) void gemm_tn_bf16_ring_kernel(
+    const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N, int K,
+    void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n, ConvGeom g) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [stage][A 64 x 256 | B 64 x 128]
+    int kbase = 0, kend = K;
+    if (ep.kchunk > 0) {
+        kbase = blockIdx.y * ep.kchunk;
+        kend = kbase + ep.kchunk < K ? kbase + ep.kchunk : K;
+        Cv = reinterpret_cast<char*>(Cv) + (long long)blockIdx.y * ep.split_stride;
+    }
+    int tm, tn;
+    tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
+    const int m0 = tm * RM, n0 = tn * RN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- DMA shares of this lane (columns fixed for the whole K walk; rows advance by 64 per step)
+    int a_row[4], b_row[2];
+    unsigned a_col[4], b_col[2];          // element offset of the lane's 16-byte chunk inside an operand row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i;
+        a_row[i] = 2 * q + (lane >> 5);
+        const int chunk = (lane & 31) ^ (4 * (a_row[i] & 3));
+        int col = m0 + chunk * 8;
+        a_col[i] = (unsigned)(col + 8 <= M ? col : (M >= 8 ? M - 8 : 0));
+    }
+    int tap_dh = 0, tap_dw = 0;
+    if (CONV) {
+        const int tap = n0 >> g.logC;
+        const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+        tap_dh = (ty - 1) * g.dil;
+        tap_dw = (tx - 1) * g.dil;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave * 2 + i;
+        b_row[i] = 4 * q + (lane >> 4);
+        const int chunk = (lane & 15) ^ (4 * (b_row[i] & 3));
+        if (CONV) {
+            b_col[i] = (unsigned)((n0 & (g.C - 1)) + chunk * 8);
+        } else {
+            const int col = n0 + chunk * 8;
+            b_col[i] = (unsigned)(col + 8 <= N ? col : (N >= 8 ? N - 8 : 0));
+        }
+    }
+    // CONV: (y, x) of this lane's two B rows, kept incrementally (rows advance by 64 pixels per stage: a division per
+    // row and stage was ~200 VALU instructions per K step beside 16 MFMAs)
+    int b_y[2] = {0, 0}, b_x[2] = {0, 0};
+    if (CONV) {
+        const int hw = g.H * g.W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = (kbase + b_row[i]) % hw;
+            b_y[i] = p / g.W;
+            b_x[i] = p - b_y[i] * g.W;
+        }
+    }
+    auto dma_stage = [&](int k0, uint4* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gk = k0 + a_row[i];
+            const void* src = gk < kend ? static_cast<const void*>(A + (size_t)gk * lda + a_col[i])
+                                        : static_cast<const void*>(g.zero);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wave * 4 + i) * 64), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gk = k0 + b_row[i];
+            const void* src = g.zero;
+            if (gk < kend) {
+                if (CONV) {
+                    const int y = b_y[i] + tap_dh, x = b_x[i] + tap_dw;
+                    if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
+                        src = B + ((size_t)(gk + tap_dh * g.W + tap_dw) << g.logC) + b_col[i];
+                } else {
+                    src = B + (size_t)gk * ldb + b_col[i];
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + RM * 8 + (wave * 2 + i) * 64), 16, 0, 0);
+            if (CONV) {                  // the stages are issued in K order: step this row's pixel by 64
+                b_x[i] += BK;
+                while (b_x[i] >= g.W) { b_x[i] -= g.W; ++b_y[i]; }
+                while (b_y[i] >= g.H) b_y[i] -= g.H;
+            }
+        }
+    };
+
+    // ---- fragment addressing (bytes inside a stage): row of the K slice, swizzled chunk, half chunk
+    const unsigned kq = 8u * (lane >> 5) + ((lane & 15) >> 2);
+    const unsigned swz = 4u * ((lane >> 2) & 3);
+    const unsigned sub = 8u * (lane & 1);
+    const unsigned cbase = 2u * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+    unsigned offa[2], offb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offa[i] = kq * 512u + (((unsigned)(wm * 8 + i * 4) + cbase) ^ swz) * 16u + sub;
+        offb[i] = (unsigned)(RM * 8 * 16) + kq * 256u + (((unsigned)(wn * 8 + i * 4) + cbase) ^ swz) * 16u + sub;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int nk = (kend - kbase + BK - 1) / BK;
+    dma_stage(kbase, lds);
+    if (nk > 1) dma_stage(kbase + BK, lds + kRingStageChunks);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) dma_stage(kbase + (kt + 2) * BK, lds + (size_t)((kt + 2) % kRingStages) * kRingStageChunks);
+        const unsigned char* st = reinterpret_cast<const unsigned char*>(lds + (size_t)(kt % kRingStages) * kRingStageChunks);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = tn_frag<512>(st, offa[i] + kk * 16 * 512);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = tn_frag<256>(st, offb[j] + kk * 16 * 256);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        // issue order: the first slice's 8 transposed reads, then two reads of the next slice behind each MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    const int mw = m0 + wm * 64;
+    auto rowmap = [&](int r) -> long long { return mw + r < M ? (long long)(mw + r) : -1ll; };
+    if (band_store_ok(Cv, ldc, N, 4)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        band_store<false, 2>(acc, Cv, ldc, N, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds), rowmap);
+    } else {
+        band_store_scalar<false, 2>(acc, Cv, ldc, N, n0 + wn * 64, lane, ep, rowmap);
+    }
+}
+
 // ---- layout helpers ---------------------------------------------------------------------
 // out[c][r] = bf16(in[r][c]); in is fp32 or bf16 (IN_F32).  32x32 tiles through LDS.
 template <bool IN_F32>
@@ -1883,6 +2056,71 @@ ODW_EXPORT int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int
     const int rblocks = (int)(units < 16384 ? units : 16384);
     wgrad_reduce_unpack_kernel<<<rblocks, 256, 0, stream>>>((const float*)workspace, S, (long long)Co * ldw, Co, Ci, Cp, ldw,
                                                             dw, accumulate);
+    ODW_CHECK_LAUNCH("wgrad_reduce_unpack_kernel");
+    return ODW_OK;
+}
+
+// ---- convolution weight gradient WITHOUT the transposed operands: dW = dZ^T im2col(X) on gemm_tn_bf16_ring_kernel --------
+// dz (n_pix x ld_dz, the masked output gradient, NHWC bf16) and X (n_pix x Cp, the layer input, NHWC bf16) are read as
+// they are: no dZ^T, no 9x transposed im2col.  Needs Cp a power of two >= 128 (one tap per 128-column tile).
+namespace {
+struct TnPlan { int tiles_m, tiles_n, splits, kchunk; };
+TnPlan conv_wgrad_tn_plan(int Co, int Cp, int K) {
+    TnPlan p;
+    p.tiles_m = (Co + RM - 1) / RM;
+    p.tiles_n = 9 * Cp / RN;
+    int sp = 256 / (p.tiles_m * p.tiles_n);
+    sp = sp < 1 ? 1 : (sp > 32 ? 32 : sp);
+    const char* f = getenv("ODW_GEMM_SPLITK");
+    if (f && atoi(f) > 0) sp = atoi(f);
+    p.kchunk = ((K + sp - 1) / sp + 63) / 64 * 64;
+    if (p.kchunk < 256) p.kchunk = 256;
+    p.splits = (K + p.kchunk - 1) / p.kchunk;
+    return p;
+}
+}  // namespace
+
+ODW_EXPORT int64_t odw_conv_wgrad_tn_workspace(int Co, int Cp, int n_pix) {
+    if (Co <= 0 || Cp < 128 || n_pix <= 0) return 0;
+    const TnPlan p = conv_wgrad_tn_plan(Co, Cp, n_pix);
+    return (int64_t)p.splits * Co * 9 * Cp * 4;
+}
+
+ODW_EXPORT int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
+                                 int Co, int Ci, float* dw, int accumulate, const void* zero_page, void* workspace,
+                                 int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(n_pix > 0 && H > 0 && W > 0 && n_pix % (H * W) == 0 && Co > 0 && Ci > 0 && Cp >= Ci, "conv_wgrad_tn: bad dims");
+    ODW_REQUIRE(Cp >= 128 && (Cp & (Cp - 1)) == 0, "conv_wgrad_tn: Cp=%d must be a power of two >= 128", Cp);
+    ODW_REQUIRE(Co % 8 == 0 && ld_dz % 8 == 0 && ld_dz >= Co, "conv_wgrad_tn: Co=%d / ld_dz=%d must be multiples of 8", Co, ld_dz);
+    ODW_REQUIRE(dilation >= 1 && dilation <= 4, "conv_wgrad_tn: dilation %d", dilation);
+    ODW_REQUIRE(dz && X && dw && zero_page && workspace, "conv_wgrad_tn: null pointer");
+    ODW_REQUIRE((((uintptr_t)dz) & 15) == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)zero_page) & 15) == 0 &&
+                    (((uintptr_t)workspace) & 15) == 0, "conv_wgrad_tn: 16-byte alignment");
+    const TnPlan plan = conv_wgrad_tn_plan(Co, Cp, n_pix);
+    const int N = 9 * Cp;
+    ODW_REQUIRE(workspace_bytes >= (int64_t)plan.splits * Co * N * 4, "conv_wgrad_tn: workspace of %lld bytes, need %lld",
+                (long long)workspace_bytes, (long long)plan.splits * Co * N * 4);
+    ConvGeom g;
+    g.H = H; g.W = W; g.C = Cp; g.dil = dilation; g.sign = 1; g.zero = (const unsigned short*)zero_page;
+    g.logC = 0;
+    while ((1 << g.logC) < Cp) ++g.logC;
+    Epilogue pe;
+    pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.accumulate = 0; pe.alpha = 1.0f;
+    pe.mask = nullptr; pe.ldmask = 0; pe.pm = 0; pe.row_ids = nullptr;
+    for (int i = 0; i < kMaxSeg; ++i) { pe.seg_row[i] = 0; pe.seg_k0[i] = 0; pe.seg_k1[i] = 0; }
+    pe.kchunk = plan.kchunk; pe.split_stride = (long long)Co * N * 4;
+    const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
+    ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_ring_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "tn attr");
+    gemm_tn_bf16_ring_kernel<true><<<dim3((unsigned)(plan.tiles_m * plan.tiles_n), (unsigned)plan.splits), kRingThreads,
+                                     ring_lds, stream>>>((const unsigned short*)dz, ld_dz, (const unsigned short*)X, Cp, Co, N,
+                                                         n_pix, workspace, N, pe, plan.tiles_m, plan.tiles_n, g);
+    ODW_CHECK_HIP(hipGetLastError(), "conv_wgrad_tn launch");
+    const long long units = (long long)Co * ((Ci + 63) / 64);
+    const int rblocks = (int)(units < 16384 ? units : 16384);
+    wgrad_reduce_unpack_kernel<<<rblocks, 256, 0, stream>>>((const float*)workspace, plan.splits, (long long)Co * N, Co, Ci, Cp,
+                                                            N, dw, accumulate);
     ODW_CHECK_LAUNCH("wgrad_reduce_unpack_kernel");
     return ODW_OK;
 }

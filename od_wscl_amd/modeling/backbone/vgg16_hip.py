@@ -140,13 +140,23 @@ class _VGGFn(torch.autograd.Function):
                 conv.bias.grad = torch.zeros_like(conv.bias)
             if conv.weight.grad is None:
                 conv.weight.grad = torch.empty_like(conv.weight)
-            dzc = torch.empty((m, _r64(l.cout)), dtype=torch.bfloat16, device=dev)
-            dzt = torch.empty((l.cout, m64), dtype=torch.bfloat16, device=dev)
-            L.check(lib.odw_linear_bwd_prep(L.ptr(dz), 0, l.cout, None, 0, m, l.cout, 1.0, L.ptr(dzc), dzc.stride(0),
-                                            L.ptr(dzt), m64, L.ptr(conv.bias.grad), st), "conv bias grad")
-            colt = torch.empty((9 * l.cp, m64), dtype=torch.bfloat16, device=dev)
-            L.check(lib.odw_im2col_t_bf16(L.ptr(x_in), m, h, w, l.cp, l.dil, L.ptr(colt), m64, st), "im2col_t")
-            conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, m, conv.weight.grad, st)
+            if l.cp >= 128 and l.cout % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0":
+                # dZ and the layer input as they are (NHWC rows): K-major operands, transposed fragment reads
+                L.check(lib.odw_colsum_bf16(L.ptr(dz), l.cout, m, l.cout, L.ptr(conv.bias.grad), st), "conv bias grad")
+                ws_bytes = lib.odw_conv_wgrad_tn_workspace(l.cout, l.cp, m)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                with kernel_timer.region("conv wgrad TN split-K+reduce", flops=2.0 * m * l.cout * 9 * l.cp):
+                    L.check(lib.odw_conv_wgrad_tn(L.ptr(dz), l.cout, L.ptr(x_in), m, h, w, l.cp, l.dil, l.cout, l.cin,
+                                                  L.ptr(conv.weight.grad), 0, L.ptr(net.zero_page), L.ptr(ws), ws_bytes, st),
+                            "conv_wgrad_tn")
+            else:
+                dzc = torch.empty((m, _r64(l.cout)), dtype=torch.bfloat16, device=dev)
+                dzt = torch.empty((l.cout, m64), dtype=torch.bfloat16, device=dev)
+                L.check(lib.odw_linear_bwd_prep(L.ptr(dz), 0, l.cout, None, 0, m, l.cout, 1.0, L.ptr(dzc), dzc.stride(0),
+                                                L.ptr(dzt), m64, L.ptr(conv.bias.grad), st), "conv bias grad")
+                colt = torch.empty((9 * l.cp, m64), dtype=torch.bfloat16, device=dev)
+                L.check(lib.odw_im2col_t_bf16(L.ptr(x_in), m, h, w, l.cp, l.dil, L.ptr(colt), m64, st), "im2col_t")
+                conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, m, conv.weight.grad, st)
             # ---- input gradient (masked by the ReLU of the producing layer unless that layer was pooled:
             #      then the pool backward of the previous iteration applies the mask)
             if li > first:

@@ -239,7 +239,8 @@ def test_vgg16_backbone_forward_backward(lib):
     assert report["body.features.28.weight"][0] > 0.9999
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W,dil", [(1, 64, 128, 16, 24, 1), (2, 256, 256, 9, 11, 2), (1, 128, 64, 38, 50, 1)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,dil", [(1, 64, 128, 16, 24, 1), (2, 256, 256, 9, 11, 2), (1, 128, 64, 38, 50, 1),
+                                                  (1, 512, 512, 19, 13, 2), (1, 256, 264, 76, 76, 1)])
 def test_conv_weight_gradient(lib, B, Cin, Cout, H, W, dil):
     """bias + weight gradient of one layer: transposed im2col + NT GEMM + unpack vs autograd."""
     from od_wscl_amd import gemm
@@ -280,6 +281,21 @@ def test_conv_weight_gradient(lib, B, Cin, Cout, H, W, dil):
     L.check(L.lib().odw_conv_wgrad_nt(L.ptr(dzt), dzt.stride(0), L.ptr(colt), colt.stride(0), Cout, Cin, Cin, m, L.ptr(dw1), 1,
                                       L.ptr(ws), ws_bytes, L.stream()), "conv_wgrad_nt accumulate")
     assert torch.equal(dw1, dw + dw)
+    # the TN form: the same gradient straight from the NHWC operands (K-major LDS tiles, transposed fragment reads)
+    if Cin >= 128 and Cin & (Cin - 1) == 0:
+        zero = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
+        wsb = L.lib().odw_conv_wgrad_tn_workspace(Cout, Cin, m)
+        ws2 = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        dw2 = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+        L.check(L.lib().odw_conv_wgrad_tn(L.ptr(dyn), dyn.stride(0), L.ptr(xn), m, H, W, Cin, dil, Cout, Cin, L.ptr(dw2), 0,
+                                          L.ptr(zero), L.ptr(ws2), wsb, L.stream()), "conv_wgrad_tn")
+        scale = max(1.0, ref_w.abs().max().item())
+        assert torch.isfinite(dw2).all()
+        assert (dw2 - ref_w).abs().max().item() <= 3e-3 * scale
+        assert (dw2 - dw).abs().max().item() <= 2e-4 * scale       # same bf16 products, another summation order
+        db2 = torch.zeros(Cout, device="cuda")
+        L.check(L.lib().odw_colsum_bf16(L.ptr(dyn), dyn.stride(0), m, Cout, L.ptr(db2), L.stream()), "colsum")
+        assert (db2 - ref_b).abs().max().item() <= 3e-3 * max(1.0, ref_b.abs().max().item())
 
 
 def test_conv_weight_prep_batch_equals_per_layer(lib):
