@@ -12,6 +12,8 @@ NHWC bf16 activations (n_pix x C matrices) end to end:
   * stem (7x7/2 + BN + ReLU, 3x3/2 max pool): csrc/resnet_aux.hip, forward only -- the stem and layer1 are frozen in
     every shipped config (FREEZE_CONV_BODY_AT 2) and nothing below layer2 receives a gradient.
 The parameters stay the nn.Conv2d weights / FrozenBatchNorm2d buffers of the reference-named modules."""
+import os
+
 import torch
 from torch import nn
 
@@ -60,7 +62,15 @@ class _Conv3x3Fn(torch.autograd.Function):
         L.check(lib.odw_linear_bwd_prep(L.ptr(dy), 1 if dy.dtype == torch.float32 else 0, dy.stride(0), L.ptr(y), y.stride(0),
                                         m, co, 1.0, L.ptr(dz), dz.stride(0), L.ptr(dzt), m64, None, st), "conv bwd prep")
         dw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ci >= 128 and ci & (ci - 1) == 0 and co % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0":
+            # dZ and the layer input as they are: K-major operands, transposed fragment reads (odw_conv_wgrad_tn)
+            dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
+            ws_bytes = lib.odw_conv_wgrad_tn_workspace(co, ci, m)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+            with kernel_timer.region("conv wgrad TN split-K+reduce", flops=2.0 * m * co * 9 * ci):
+                L.check(lib.odw_conv_wgrad_tn(L.ptr(dz), dz.stride(0), L.ptr(x), m, H, W, ci, 1, co, ci, L.ptr(dw), 0,
+                                              L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv_wgrad_tn")
+        elif ctx.needs_input_grad[1]:
             colt = torch.empty((9 * ci, m64), dtype=torch.bfloat16, device=dy.device)
             L.check(lib.odw_im2col_t_bf16(L.ptr(x), m, H, W, ci, 1, L.ptr(colt), m64, st), "im2col_t")
             dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
