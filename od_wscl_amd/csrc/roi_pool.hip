@@ -513,34 +513,55 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_pool_stack_bwd_plane_fx(
     }
     for (int i = threadIdx.x; i < HW; i += blockDim.x) iacc[i] = 0;
     __syncthreads();
-    int n = threadIdx.x / nb;
-    int r = threadIdx.x % nb;
-    const int dn = kPlaneThreads / nb, dr = kPlaneThreads % nb;
-    for (; n < R + E; n += dn, r += dr) {
-        if (r >= nb) { r -= nb; ++n; if (n >= R + E) break; }
-        const int roi = n < R ? n : extra_roi[n - R];
-        if ((int)rois[(size_t)roi * 5] != b) continue;
-        const size_t col = (size_t)c * nb + r;
-        float kp = 1.0f;
-        if (n < R && keep) {
-            kp = keep[(size_t)n * nb + r];
-            if (skip_clean && kp == 0.0f) continue;
+    // Four (ROI, bin) items per thread and round, their loads issued as one batch before any of the adds: one item per
+    // iteration is a chain of four dependent 2-/4-byte loads (ROI image, keep, argmax, gradient) per LDS atomic, i.e.
+    // pure L2 latency.  Items that do not contribute (other image, dropped cell, empty bin) add nothing; integer adds
+    // commute, so the result is the same bits as the one-item loop's.
+    const int total = (R + E) * nb;
+    constexpr int kU = 4;
+    for (int base = threadIdx.x; base < total; base += kU * kPlaneThreads) {
+        int nn[kU], roi[kU];
+        size_t col[kU];
+        bool ok[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = base + u * kPlaneThreads;
+            ok[u] = i < total;
+            const int ii = ok[u] ? i : 0;
+            nn[u] = ii / nb;
+            col[u] = (size_t)c * nb + (ii - nn[u] * nb);
         }
-        const unsigned short a = argmax[(size_t)roi * C * nb + col];
-        if (a == 0xFFFF) continue;
-        float g;
-        if (n >= R) {
-            g = extra[(size_t)(n - R) * C * nb + col];
-        } else if (DX_F32) {
-            const float* dX = reinterpret_cast<const float*>(dXv);
-            g = skip_clean ? 0.0f : dX[(size_t)n * ld + col];
-            if (keep) g += ((dX[(size_t)(R + n) * ld + col] * kp) * numel) / sum;
-        } else {
-            const unsigned short* dX = reinterpret_cast<const unsigned short*>(dXv);
-            g = skip_clean ? 0.0f : rp_bf2f(dX[(size_t)n * ld + col]);
-            if (keep) g += ((rp_bf2f(dX[(size_t)(R + n) * ld + col]) * kp) * numel) / sum;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) roi[u] = nn[u] < R ? nn[u] : extra_roi[nn[u] - R];
+        float img[kU], kp[kU], g0[kU], g1[kU];
+        unsigned short am[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            img[u] = rois[(size_t)roi[u] * 5];
+            am[u] = argmax[(size_t)roi[u] * C * nb + col[u]];
+            kp[u] = (nn[u] < R && keep) ? keep[(size_t)nn[u] * nb + (col[u] - (size_t)c * nb)] : 1.0f;
+            g0[u] = 0.0f;
+            g1[u] = 0.0f;
+            if (nn[u] >= R) {
+                g0[u] = extra[(size_t)(nn[u] - R) * C * nb + col[u]];
+            } else if (DX_F32) {
+                const float* dX = reinterpret_cast<const float*>(dXv);
+                if (!skip_clean) g0[u] = dX[(size_t)nn[u] * ld + col[u]];
+                if (keep) g1[u] = dX[(size_t)(R + nn[u]) * ld + col[u]];
+            } else {
+                const unsigned short* dX = reinterpret_cast<const unsigned short*>(dXv);
+                if (!skip_clean) g0[u] = rp_bf2f(dX[(size_t)nn[u] * ld + col[u]]);
+                if (keep) g1[u] = rp_bf2f(dX[(size_t)(R + nn[u]) * ld + col[u]]);
+            }
         }
-        odwfx::add(&iacc[a], g, sc.to_fixed);
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (!ok[u] || (int)img[u] != b || am[u] == 0xFFFF) continue;
+            if (nn[u] < R && keep && skip_clean && kp[u] == 0.0f) continue;
+            float g = g0[u];
+            if (nn[u] < R && keep) g += ((g1[u] * kp[u]) * numel) / sum;
+            odwfx::add(&iacc[am[u]], g, sc.to_fixed);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < HW; i += blockDim.x) dst[i] = (float)iacc[i] * sc.to_float;
