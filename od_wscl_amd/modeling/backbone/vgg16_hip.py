@@ -308,13 +308,14 @@ class VGGBackboneHip(nn.Module):
         if todo:        # the packed bf16 copies of every (trainable) layer in ONE launch
             import ctypes
             n = len(todo)
-            vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
-            args = (vp(*[l.conv.weight.data_ptr() for l in todo]), ia(*[l.cout for l in todo]), ia(*[l.cin for l in todo]),
-                    ia(*[l.cp for l in todo]), vp(*[l.wk.data_ptr() for l in todo]), ia(*[l.wk.stride(0) for l in todo]),
-                    vp(*[l.wd.data_ptr() if l.wd is not None else None for l in todo]),
-                    ia(*[l.wd.stride(0) if l.wd is not None else 0 for l in todo]))
-            L.check(lib.odw_conv_weight_prep_batch(n, *[ctypes.cast(a, ctypes.c_void_p) for a in args], L.stream()),
-                    "conv_weight_prep_batch")
+            key = tuple((l.conv.weight.data_ptr(), l.wk.data_ptr(), l.wd.data_ptr() if l.wd is not None else 0) for l in todo)
+            if getattr(self, "_prep_key", None) != key:      # the argument arrays change only when a buffer moves
+                vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
+                args = (vp(*[k[0] for k in key]), ia(*[l.cout for l in todo]), ia(*[l.cin for l in todo]),
+                        ia(*[l.cp for l in todo]), vp(*[k[1] for k in key]), ia(*[l.wk.stride(0) for l in todo]),
+                        vp(*[k[2] or None for k in key]), ia(*[l.wd.stride(0) if l.wd is not None else 0 for l in todo]))
+                self._prep_key, self._prep_args = key, (args, [ctypes.cast(a, ctypes.c_void_p) for a in args])
+            L.check(lib.odw_conv_weight_prep_batch(n, *self._prep_args[1], L.stream()), "conv_weight_prep_batch")
         self._frozen_ready = True
 
     def forward(self, images):
