@@ -246,6 +246,16 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
                 const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
                 constexpr int kW = kThreads / 64;
                 int r = wave;
+                for (; r + 7 * kW < P; r += 8 * kW) {          // eight rows of loads in flight per wave
+                    float2 x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = reinterpret_cast<const float2*>(E + (size_t)(r + u * kW) * kD)[lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float d = wave_dot_loaded(x[u], etop, lane);
+                        if (lane == 0) close[r + u * kW] = d >= thr ? 1 : 0;
+                    }
+                }
                 for (; r + 3 * kW < P; r += 4 * kW) {
                     float2 x[4];
 #pragma unroll
@@ -291,16 +301,30 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
                     __syncthreads();
                 }
             }
-            // ---- candidates sorted by class score descending (stable): bitonic sort over ppow2 slots
-            for (int r = threadIdx.x; r < ppow2; r += kThreads) {
-                bool in = r < P && close[r];
-                ks[r] = in ? S[(size_t)r * a.C + c + 1] : -__builtin_inff();
-                ki[r] = in ? r : 0x40000000 + r;      // non-candidates sort last
+            // ---- candidates sorted by class score descending, ties by index ascending: the candidates are compacted
+            // first (their order is irrelevant: (score, index) is a total order) and the bitonic network runs over the
+            // next power of two above their NUMBER, not above P (was 66 barrier-separated passes over 2048 slots)
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+            for (int r = threadIdx.x; r < P; r += kThreads) {
+                if (close[r]) {
+                    const int pos = atomicAdd(&s_n, 1);
+                    ks[pos] = S[(size_t)r * a.C + c + 1];
+                    ki[pos] = r;
+                }
             }
             __syncthreads();
-            for (int k = 2; k <= ppow2; k <<= 1) {
+            const int n = s_n;
+            int npow = 2;
+            while (npow < n) npow <<= 1;
+            for (int r = n + threadIdx.x; r < npow; r += kThreads) {
+                ks[r] = -__builtin_inff();
+                ki[r] = 0x40000000 + r;               // padding sorts last
+            }
+            __syncthreads();
+            for (int k = 2; k <= npow; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int t = threadIdx.x; t < ppow2; t += kThreads) {
+                    for (int t = threadIdx.x; t < npow; t += kThreads) {
                         int p = t ^ j;
                         if (p > t) {
                             bool up = ((t & k) == 0);
@@ -313,20 +337,6 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
                     __syncthreads();
                 }
             }
-            // number of candidates
-            {
-                int cnt = 0;
-                for (int r = threadIdx.x; r < P; r += kThreads) cnt += close[r];
-                red[threadIdx.x].i = cnt;
-                __syncthreads();
-                for (int off = kThreads / 2; off > 0; off >>= 1) {
-                    if ((int)threadIdx.x < off) red[threadIdx.x].i += red[threadIdx.x + off].i;
-                    __syncthreads();
-                }
-                if (threadIdx.x == 0) s_n = red[0].i;
-                __syncthreads();
-            }
-            const int n = s_n;
             // ---- greedy NMS in sorted order (torchvision: IoU without +1, suppress when > thr)
             for (int t = threadIdx.x; t < n; t += kThreads) {
                 close[t] = 1;                                                   // alive flags by sorted position
