@@ -188,7 +188,9 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
     int* ki = reinterpret_cast<int*>(ks + ppow2);                         // ppow2 sort ids / candidate list
     unsigned char* close = reinterpret_cast<unsigned char*>(ki + ppow2);  // ppow2 flags (close / alive)
     float4* sbox = reinterpret_cast<float4*>(smem + sbox_off);           // ppow2 candidate boxes, sorted order
-    __shared__ int s_n, s_nx[3];
+    __shared__ int s_n;
+    __shared__ unsigned long long s_mask[64];
+    __shared__ float4 s_kbox[64];
     __shared__ float s_thr;
 
     const int img = blockIdx.x;
@@ -324,15 +326,14 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
             __syncthreads();
             for (int k = 2; k <= npow; k <<= 1) {
                 for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int t = threadIdx.x; t < npow; t += kThreads) {
-                        int p = t ^ j;
-                        if (p > t) {
-                            bool up = ((t & k) == 0);
-                            float sa = ks[t], sb = ks[p];
-                            int ia = ki[t], ib = ki[p];
-                            bool a_first = before(sa, ia, sb, ib);
-                            if (up ? !a_first : a_first) { ks[t] = sb; ks[p] = sa; ki[t] = ib; ki[p] = ia; }
-                        }
+                    // one compare-exchange PAIR per thread and round: pair q -> t = q with a 0 inserted at bit log2(j)
+                    for (int q = threadIdx.x; q < (npow >> 1); q += kThreads) {
+                        const int t = ((q & ~(j - 1)) << 1) | (q & (j - 1)), p = t | j;
+                        const bool up = ((t & k) == 0);
+                        const float sa = ks[t], sb = ks[p];
+                        const int ia = ki[t], ib = ki[p];
+                        const bool a_first = before(sa, ia, sb, ib);
+                        if (up ? !a_first : a_first) { ks[t] = sb; ks[p] = sa; ki[t] = ib; ki[p] = ia; }
                     }
                     __syncthreads();
                 }
@@ -342,33 +343,59 @@ __global__ __launch_bounds__(kThreads) void discover_sim_kernel(SimArgs a, int p
                 close[t] = 1;                                                   // alive flags by sorted position
                 sbox[t] = bx[ki[t]];                                            // boxes in LDS: the greedy chain below
             }                                                                   // must not pay a global load per step
-            if (threadIdx.x == 0) s_nx[0] = n;
             __syncthreads();
             int* inst = a.inst_idx + slot * a.pstride;
             int n_inst = 0;
-            // One barrier per kept box: while the threads suppress against box k they also find the next survivor --
-            // the smallest later position that is still alive -- with an LDS atomicMin (was: a second barrier and a
-            // serial scan of the alive flags by thread 0, the bulk of this kernel).  Three rotating slots: the one the
-            // atomics of iteration i go to was reset during iteration i - 1, after everyone had read it in i - 2.
-            int k = 0, it = 0;
-            while (k < n) {
-                // position k is alive by construction
-                const float4 bk = sbox[k];
-                if (threadIdx.x == 0) {
-                    inst[n_inst] = ki[k];
-                    s_nx[(it + 1) % 3] = n;
-                }
-                int first = n;
-                for (int t = k + 1 + threadIdx.x; t < n; t += kThreads) {
-                    if (!close[t]) continue;
-                    if (tv_overlap(bk, sbox[t], a.nms_thr)) close[t] = 0;
-                    else if (t < first) first = t;
-                }
-                if (first < n) atomicMin(&s_nx[it % 3], first);
-                ++n_inst;
+            // Greedy NMS in windows of 64 sorted positions (was: one barrier-separated round per KEPT box, ~100 rounds):
+            //   1. every pair of the window's alive positions is tested in parallel -> 64 suppression masks in LDS;
+            //   2. one wave resolves the window greedily in registers: position i is kept iff no earlier kept position
+            //      of the window (or of an earlier window: phase 3) suppresses it -- one readlane + mask step per kept position;
+            //   3. everyone suppresses the positions behind the window against the boxes the window kept.
+            // The kept set is exactly the sequential greedy one: j dies iff an earlier KEPT i overlaps it.
+            for (int k0 = 0; k0 < n; k0 += 64) {
+                const int wn = n - k0 < 64 ? n - k0 : 64;
+                if (threadIdx.x < 64) s_mask[threadIdx.x] = 0ull;
                 __syncthreads();
-                k = s_nx[it % 3];
-                ++it;
+                for (int pidx = threadIdx.x; pidx < 64 * 64; pidx += kThreads) {
+                    const int i = pidx >> 6, j = pidx & 63;
+                    if (j > i && j < wn && close[k0 + i] && close[k0 + j] && tv_overlap(sbox[k0 + i], sbox[k0 + j], a.nms_thr))
+                        atomicOr(&s_mask[i], 1ull << j);
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {                     // wave 0
+                    const int l = threadIdx.x;
+                    const unsigned long long m = s_mask[l];
+                    const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+                    const unsigned long long alive = __ballot(l < wn && close[k0 + (l < wn ? l : 0)]);
+                    unsigned long long kept = 0ull, rem = alive;
+                    while (rem) {                           // wave-uniform: one step per KEPT position of the window
+                        const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
+                        const unsigned long long mi = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mlo, i) |
+                                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mhi, i) << 32);
+                        kept |= 1ull << i;
+                        rem &= ~(mi | (1ull << i));
+                    }
+                    const bool mine = (kept >> l) & 1ull;
+                    if (l < wn) close[k0 + l] = mine ? 1 : 0;
+                    if (mine) {
+                        const int pos = __popcll(kept & ((1ull << l) - 1ull));
+                        inst[n_inst + pos] = ki[k0 + l];
+                        s_kbox[pos] = sbox[k0 + l];
+                    }
+                    if (l == 0) s_n = __popcll(kept);
+                }
+                __syncthreads();
+                const int kw = s_n;
+                n_inst += kw;
+                if (kw > 0) {
+                    for (int t = k0 + 64 + threadIdx.x; t < n; t += kThreads) {
+                        if (!close[t]) continue;
+                        const float4 bt = sbox[t];
+                        for (int q = 0; q < kw; ++q)
+                            if (tv_overlap(s_kbox[q], bt, a.nms_thr)) { close[t] = 0; break; }
+                    }
+                }
+                __syncthreads();
             }
             if (n_inst == 0) {                    // "avoid none" (loss.py:333)
                 if (threadIdx.x == 0) inst[0] = top;
