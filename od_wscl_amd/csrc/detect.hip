@@ -50,6 +50,8 @@ __global__ __launch_bounds__(kThreads) void detect_classes_kernel(DetArgs a, int
     int* ki = reinterpret_cast<int*>(ks + ppow2);                   // sort ids
     unsigned char* alive = reinterpret_cast<unsigned char*>(ki + ppow2);
     __shared__ int s_n, s_k;
+    __shared__ unsigned long long s_mask[64];
+    __shared__ float4 s_kbox[64];
 
     const int img = blockIdx.x, j = blockIdx.y + 1;                 // class 0 = background is skipped
     const int base = a.img_off[img], P = a.img_off[img + 1] - base;
@@ -105,15 +107,14 @@ __global__ __launch_bounds__(kThreads) void detect_classes_kernel(DetArgs a, int
     // bitonic sort: descending score, ties by ascending proposal index; non-candidates last
     for (int k = 2; k <= ppow2; k <<= 1) {
         for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int t = threadIdx.x; t < ppow2; t += kThreads) {
-                const int p = t ^ jj;
-                if (p > t) {
-                    const bool up = ((t & k) == 0);
-                    const float sa = ks[t], sb = ks[p];
-                    const int ia = ki[t], ib = ki[p];
-                    const bool a_first = before(sa, ia, sb, ib);
-                    if (up ? !a_first : a_first) { ks[t] = sb; ks[p] = sa; ki[t] = ib; ki[p] = ia; }
-                }
+            // one compare-exchange pair per thread and round: pair q -> t = q with a 0 inserted at bit log2(jj)
+            for (int q = threadIdx.x; q < (ppow2 >> 1); q += kThreads) {
+                const int t = ((q & ~(jj - 1)) << 1) | (q & (jj - 1)), p = t | jj;
+                const bool up = ((t & k) == 0);
+                const float sa = ks[t], sb = ks[p];
+                const int ia = ki[t], ib = ki[p];
+                const bool a_first = before(sa, ia, sb, ib);
+                if (up ? !a_first : a_first) { ks[t] = sb; ks[p] = sa; ki[t] = ib; ki[p] = ia; }
             }
             __syncthreads();
         }
@@ -122,27 +123,57 @@ __global__ __launch_bounds__(kThreads) void detect_classes_kernel(DetArgs a, int
         alive[t] = 1;
         sbox2[t] = sbox[ki[t]];
     }
-    if (threadIdx.x == 0) s_k = 0;
     __syncthreads();
     const size_t slot = ((size_t)img * (a.C - 1) + (j - 1)) * a.pstride;
     int kept = 0;
-    while (true) {
-        const int k = s_k;
-        if (k >= n) break;
-        const float4 bk = sbox2[k];
-        for (int t = k + 1 + threadIdx.x; t < n; t += kThreads)
-            if (alive[t] && tv_overlap(bk, sbox2[t], a.nms_thr)) alive[t] = 0;
-        if (threadIdx.x == 0) {
-            reinterpret_cast<float4*>(a.out_boxes)[slot + kept] = bk;
-            a.out_scores[slot + kept] = ks[k];
-            a.out_index[slot + kept] = ki[k];
-        }
-        ++kept;
+    // Greedy NMS in windows of 64 sorted positions (the scheme of csrc/discover.hip): all pairs of a window tested in
+    // parallel into 64 suppression masks, one wave resolving the window in registers (one readlane + mask step per kept
+    // position), everyone suppressing the tail against the boxes the window kept.  Same kept set and order as the
+    // sequential greedy rule; was one barrier pair + a serial scan by thread 0 per kept box.
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int wn = n - k0 < 64 ? n - k0 : 64;
+        if (threadIdx.x < 64) s_mask[threadIdx.x] = 0ull;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int nx = k + 1;
-            while (nx < n && !alive[nx]) ++nx;
-            s_k = nx;
+        for (int pidx = threadIdx.x; pidx < 64 * 64; pidx += kThreads) {
+            const int i = pidx >> 6, jx = pidx & 63;
+            if (jx > i && jx < wn && alive[k0 + i] && alive[k0 + jx] && tv_overlap(sbox2[k0 + i], sbox2[k0 + jx], a.nms_thr))
+                atomicOr(&s_mask[i], 1ull << jx);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                     // wave 0
+            const int l = threadIdx.x;
+            const unsigned long long m = s_mask[l];
+            const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+            unsigned long long rem = __ballot(l < wn && alive[k0 + (l < wn ? l : 0)]), keptw = 0ull;
+            while (rem) {                           // wave-uniform
+                const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
+                const unsigned long long mi = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mlo, i) |
+                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mhi, i) << 32);
+                keptw |= 1ull << i;
+                rem &= ~(mi | (1ull << i));
+            }
+            const bool mine = (keptw >> l) & 1ull;
+            if (l < wn) alive[k0 + l] = mine ? 1 : 0;
+            if (mine) {
+                const int pos = __popcll(keptw & ((1ull << l) - 1ull));
+                const float4 bk = sbox2[k0 + l];
+                reinterpret_cast<float4*>(a.out_boxes)[slot + kept + pos] = bk;
+                a.out_scores[slot + kept + pos] = ks[k0 + l];
+                a.out_index[slot + kept + pos] = ki[k0 + l];
+                s_kbox[pos] = bk;
+            }
+            if (l == 0) s_k = __popcll(keptw);
+        }
+        __syncthreads();
+        const int kw = s_k;
+        kept += kw;
+        if (kw > 0) {
+            for (int t = k0 + 64 + threadIdx.x; t < n; t += kThreads) {
+                if (!alive[t]) continue;
+                const float4 bt = sbox2[t];
+                for (int q = 0; q < kw; ++q)
+                    if (tv_overlap(s_kbox[q], bt, a.nms_thr)) { alive[t] = 0; break; }
+            }
         }
         __syncthreads();
     }
