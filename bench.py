@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # every precision mode runs on the bf16 matrix cores (bf16x3 / bf16x2 = 6 / 3 bf16 plane products per fp32-grade
 # product, all of them counted as executed FLOPs): one dense peak
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "bf16x2": 2500.0}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "bf16x2": 2500.0, "bf16x2f": 2500.0}
 # The reference trains from ImageNet-pretrained VGG16 at lr 0.01 (configs/voc/*.yaml).  There are no
 # checkpoints here: with random-init weights lr 0.01 diverges to NaN within 4 steps, so the bench
 # keeps the identical work (same SGD update, momentum, weight decay) at a learning rate that stays finite.
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--size", type=int, default=600)
     ap.add_argument("--classes", type=int, default=21)
-    ap.add_argument("--dtype", default=os.environ.get("ODW_DTYPE", "bf16"), choices=["bf16", "bf16x3", "bf16x2"],
+    ap.add_argument("--dtype", default=os.environ.get("ODW_DTYPE", "bf16"), choices=["bf16", "bf16x3", "bf16x2", "bf16x2f"],
                     help="arithmetic of the MFMA products (od_wscl_amd/precision.py): bf16 = the headline; bf16x3 = "
                          "fp32-grade (the mode the reference goldens are asserted in), bf16x2 = two planes")
     ap.add_argument("--global-batch", type=int, default=0,

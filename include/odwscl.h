@@ -203,8 +203,10 @@ int odw_od_assign_indexed_dev(const float* boxes, int P, const int* gt_index, co
  *   epilogue : + bias[N] (nullable), ReLU, dropout(drop_p) with counter-based keys:
  *              nseg row segments (seg_rows[i] = first row, seg_keys[2i..2i+1] = key); element
  *              (m,n) of segment s uses index (m - seg_rows[s]) * N + n   (HOST arrays, <= 4)
- * odw_linear_bwd_prep: dZ = dY * [Y != 0] * scale (Y = saved bf16 output, nullable), emitted
+ * odw_linear_bwd_prep: dZ = dY * [Y != 0] * scale (Y = saved output, nullable), emitted
  *   row-major (ld_z) and transposed (N x ld_t), both zero padded; db[n] += column sums.
+ *   dy_is_f32 is a bit set: bit 0 = dY is fp32 (else bf16), bit 1 = Y is fp32 (else bf16; the saved
+ *   output of a split-precision forward, precision mode "bf16x2f").
  * odw_transpose_to_bf16 / odw_f32_to_bf16: layout + precision helpers for the operands.
  * odw_sgd_momentum: fused SGD step over flat fp32 buffers (solver/build.py:10-24 semantics),
  *   optionally refreshing the bf16 shadow the GEMMs read. */
@@ -377,6 +379,8 @@ int odw_im2col_t_bf16_part(const void* X, int n_pix, int H, int W, int C, int di
 /* the same pooling / layout helpers on fp32 NHWC activations (bf16x3 precision mode, see odw_split_rows_bf16) */
 int odw_maxpool2x2_nhwc_f32(const float* X, int B, int H, int W, int C, float* Y, void* stream);
 int odw_maxpool2x2_nhwc_f32_bwd(const float* X, const float* dY, int B, int H, int W, int C, float* dX, void* stream);
+/* precision mode "bf16x2f" (split forward, bf16 backward): fp32 pooled activation X, bf16 gradients */
+int odw_maxpool2x2_nhwc_f32x_bf16_bwd(const float* X, const void* dY, int B, int H, int W, int C, void* dX, void* stream);
 int odw_nchw_f32_to_nhwc_f32(const float* in, int B, int HW, int C, int Cp, float* out, void* stream);
 int odw_nhwc_f32_to_nchw_f32(const float* in, int B, int HW, int C, int Cp, float* out, void* stream);
 int odw_maxpool2x2_nhwc_bf16(const void* X, int B, int H, int W, int C, void* Y, void* stream);

@@ -112,6 +112,7 @@ SIGNATURES = {
     "odw_im2col_t_bf16_part": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "odw_maxpool2x2_nhwc_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_maxpool2x2_nhwc_f32_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_maxpool2x2_nhwc_f32x_bf16_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_nchw_f32_to_nhwc_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_nhwc_f32_to_nchw_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_split_rows_bf16": (c_i, [c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_l, c_i, c_p]),

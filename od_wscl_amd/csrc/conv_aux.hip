@@ -327,6 +327,33 @@ __global__ void maxpool_f32_bwd_kernel(const float* __restrict__ X, const float*
     }
 }
 
+// precision mode "bf16x2f": the pooled activation X was kept in fp32 by the split-precision forward (the routing must
+// follow ITS first maximum: rounded to bf16, distinct values tie), the gradients travel as bf16
+__global__ void maxpool_f32x_bf16_bwd_kernel(const float* __restrict__ X, const unsigned short* __restrict__ dY, int B, int H,
+                                             int W, int C, unsigned short* __restrict__ dX) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t q = i / C;
+        const int xo = (int)(q % Wo); q /= Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c;
+        const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+        float best = -__builtin_inff();
+        int bi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float f = X[base + off[k]];
+            if (f > best) { best = f; bi = k; }
+        }
+        const unsigned short g = best > 0.0f ? dY[i] : (unsigned short)0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dX[base + off[k]] = k == bi ? g : (unsigned short)0;
+    }
+}
+
 // out[b][p][c] (c < Cp, zero padded) = in[b][c][p], both fp32; TO_NCHW: the inverse (Cp = C)
 template <bool TO_NCHW>
 __global__ __launch_bounds__(256) void layout_f32_kernel(const float* __restrict__ in, int HW, int C, int Cp,
@@ -479,6 +506,15 @@ ODW_EXPORT int odw_maxpool2x2_nhwc_f32(const float* X, int B, int H, int W, int 
     ODW_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && X && Y, "maxpool2x2_f32: bad arguments");
     maxpool_f32_fwd_kernel<<<blocks_for((size_t)B * (H / 2) * (W / 2) * C), 256, 0, (hipStream_t)stream_>>>(X, B, H, W, C, Y);
     ODW_CHECK_LAUNCH("maxpool_f32_fwd_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_maxpool2x2_nhwc_f32x_bf16_bwd(const float* X, const void* dY, int B, int H, int W, int C, void* dX,
+                                                 void* stream_) {
+    ODW_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && X && dY && dX, "maxpool2x2_f32x_bf16_bwd: bad arguments");
+    maxpool_f32x_bf16_bwd_kernel<<<blocks_for((size_t)B * (H / 2) * (W / 2) * C), 256, 0, (hipStream_t)stream_>>>(
+        X, (const unsigned short*)dY, B, H, W, C, (unsigned short*)dX);
+    ODW_CHECK_LAUNCH("maxpool_f32x_bf16_bwd_kernel");
     return ODW_OK;
 }
 

@@ -1450,14 +1450,16 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short*
 // from the saved bf16 output; Y == nullptr -> dZ = dY), written row-major (ld_z, zero padded) AND
 // transposed (N x ld_t, zero padded) for the dgrad / wgrad GEMMs, plus the bias gradient
 // db[n] += sum_m dZ[m][n].  32x32 tiles through LDS; dY is fp32 or bf16.
-template <bool DY_F32>
+template <bool DY_F32, bool Y_F32>
 __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __restrict__ dY, int ld_dy,
-                                                              const unsigned short* __restrict__ Y, int ld_y,
+                                                              const void* __restrict__ Y_, int ld_y,
                                                               int M, int N, float scale,
                                                               unsigned short* __restrict__ dZ, int ld_z,
                                                               unsigned short* __restrict__ dZT, int ld_t, int t_cols,
                                                               float* __restrict__ db) {
     __shared__ float t[32][33];
+    const unsigned short* Y = reinterpret_cast<const unsigned short*>(Y_);
+    const unsigned int* Y32 = reinterpret_cast<const unsigned int*>(Y_);
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -1467,7 +1469,10 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __rest
         if (m < M && n < N) {
             v = DY_F32 ? reinterpret_cast<const float*>(dY)[(size_t)m * ld_dy + n]
                        : __uint_as_float((unsigned int)reinterpret_cast<const unsigned short*>(dY)[(size_t)m * ld_dy + n] << 16);
-            if (Y) v = (Y[(size_t)m * ld_y + n] & 0x7fff) != 0 ? v * scale : 0.0f;
+            if (Y_) {
+                const bool on = Y_F32 ? (Y32[(size_t)m * ld_y + n] & 0x7fffffffu) != 0 : (Y[(size_t)m * ld_y + n] & 0x7fff) != 0;
+                v = on ? v * scale : 0.0f;
+            }
         }
         t[ty + 8 * k][tx] = v;
         if (m < M && n < ld_z) dZ[(size_t)m * ld_z + n] = f2bf(v);
@@ -1488,9 +1493,9 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __rest
 
 // The same prologue with 16-byte accesses: 64 x 64 tiles, fp32 tile in LDS (column sums for the bias gradient in
 // fp32 before any rounding, as above), dZ written as it is loaded, dZ^T as 8 transposed values per lane.
-template <bool DY_F32>
+template <bool DY_F32, bool Y_F32>
 __global__ __launch_bounds__(256) void linear_bwd_prep_vec_kernel(const void* __restrict__ dY, int ld_dy,
-                                                                  const unsigned short* __restrict__ Y, int ld_y,
+                                                                  const void* __restrict__ Y_, int ld_y,
                                                                   int M, int N, float scale,
                                                                   unsigned short* __restrict__ dZ, int ld_z,
                                                                   unsigned short* __restrict__ dZT, int ld_t, int t_cols,
@@ -1514,8 +1519,14 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_vec_kernel(const void* __
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
             }
-            if (Y) {
-                const uint4 yv = *reinterpret_cast<const uint4*>(Y + (size_t)m * ld_y + n);
+            if (Y_ && Y_F32) {         // the saved fp32 output of a split-precision forward (precision "bf16x2f")
+                const uint4 ya = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned int*>(Y_) + (size_t)m * ld_y + n);
+                const uint4 yb = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned int*>(Y_) + (size_t)m * ld_y + n + 4);
+                const unsigned w[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (w[q] & 0x7fffffffu) ? v[q] * scale : 0.0f;
+            } else if (Y_) {
+                const uint4 yv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(Y_) + (size_t)m * ld_y + n);
                 const unsigned w[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -2182,29 +2193,27 @@ ODW_EXPORT int odw_linear_bwd_prep_part(const void* dY, int dy_is_f32, int ld_dy
     ODW_REQUIRE(M >= 0 && N >= 0 && ld_z >= N && t_cols >= M && ld_t >= t_cols && ld_dy >= N, "linear_bwd_prep: bad dims");
     if (M == 0 || N == 0) return ODW_OK;
     ODW_REQUIRE(dY && dZ && dZT, "linear_bwd_prep: null pointer");
+    // dy_is_f32: bit 0 = dY is fp32, bit 1 = Y (the saved output the mask is re-derived from) is fp32
+    const bool dyf = (dy_is_f32 & 1) != 0, yf = (dy_is_f32 & 2) != 0;
     const bool vec = N % 8 == 0 && ld_dy % 8 == 0 && ld_z % 8 == 0 && ld_t % 8 == 0 && t_cols % 8 == 0 && (!Y || ld_y % 8 == 0) &&
                      (((uintptr_t)dY) & 15) == 0 && (((uintptr_t)Y) & 15) == 0 && (((uintptr_t)dZ) & 15) == 0 &&
                      (((uintptr_t)dZT) & 15) == 0;
+#define ODW_PREP_LAUNCH(KERNEL, GRID)                                                                                  \
+    do {                                                                                                               \
+        if (dyf && yf) KERNEL<true, true><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db); \
+        else if (dyf) KERNEL<true, false><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db); \
+        else if (yf) KERNEL<false, true><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db); \
+        else KERNEL<false, false><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db); \
+    } while (0)
     if (vec) {
         dim3 vgrid((ld_z + 63) / 64, (t_cols + 63) / 64);
-        if (dy_is_f32)
-            linear_bwd_prep_vec_kernel<true><<<vgrid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
-                                                                        (unsigned short*)dZ, ld_z, (unsigned short*)dZT,
-                                                                        ld_t, t_cols, db);
-        else
-            linear_bwd_prep_vec_kernel<false><<<vgrid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
-                                                                         (unsigned short*)dZ, ld_z, (unsigned short*)dZT,
-                                                                         ld_t, t_cols, db);
+        ODW_PREP_LAUNCH(linear_bwd_prep_vec_kernel, vgrid);
         ODW_CHECK_LAUNCH("linear_bwd_prep_vec_kernel");
         return ODW_OK;
     }
     dim3 grid((ld_z + 31) / 32, (t_cols + 31) / 32);     // covers the zero padding of both outputs
-    if (dy_is_f32)
-        linear_bwd_prep_kernel<true><<<grid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
-                                                               (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db);
-    else
-        linear_bwd_prep_kernel<false><<<grid, 256, 0, stream>>>(dY, ld_dy, (const unsigned short*)Y, ld_y, M, N, scale,
-                                                                (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db);
+    ODW_PREP_LAUNCH(linear_bwd_prep_kernel, grid);
+#undef ODW_PREP_LAUNCH
     ODW_CHECK_LAUNCH("linear_bwd_prep_kernel");
     return ODW_OK;
 }

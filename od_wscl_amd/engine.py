@@ -162,23 +162,31 @@ class FlatSGD(object):
         if gemm_w:
             from . import gemm
 
-            split = precision.split_mode()
+            mode = precision.get_precision()
+            single_bwd = not precision.bwd_split()      # "bf16" / "bf16x2f": the backward reads one bf16 plane of W
 
             def managed_shadow(weight, o):
                 sh = gemm.Shadow(weight)
-                if not split:       # bf16: W is a slice of the flat shadow the SGD kernel rewrites, W^T refreshed in place
-                    sh.w = self.flat_w16[o:o + weight.numel()].view(weight.shape)
-                    sh.wt = torch.empty((weight.shape[1], (weight.shape[0] + 63) // 64 * 64), dtype=torch.bfloat16, device=dev)
+                n_out, k_in = weight.shape
+                r64 = lambda v: (v + 63) // 64 * 64
+                if single_bwd:      # W (bf16) is a slice of the flat shadow the SGD kernel rewrites, W^T refreshed in place
+                    w16 = self.flat_w16[o:o + weight.numel()].view(weight.shape)
+                    sh.wt = torch.empty((k_in, r64(n_out)), dtype=torch.bfloat16, device=dev)
+                    if mode == "bf16":
+                        sh.w = w16
+                    else:           # "bf16x2f": the forward operand = the bf16 planes of the fp32 master, re-split in place
+                        sh.w16 = w16
+                        sh.w = torch.empty((n_out, len(precision.patterns("gemm")[1]) * r64(k_in)), dtype=torch.bfloat16, device=dev)
                     sh.managed = True
-                    sh.mode = "bf16"
-                # (split precision: the plane layouts are rebuilt from the fp32 master after each step, Shadow.refresh)
+                    sh.mode = mode
+                # ("bf16x3" / "bf16x2": the plane layouts are rebuilt from the fp32 master after each step, Shadow.refresh)
                 # Linears whose gradient is large enough for its read-modify-write to matter get ONE weight-gradient
                 # GEMM per step over all their evaluations (gemm.WgradBatch)
                 sh.batch = gemm.WgradBatch() if (weight.numel() >= (8 << 20) and os.environ.get("ODW_NO_WGRAD_BATCH") != "1") else None
                 self.shadows.append(sh)
                 return sh
 
-            if not split:
+            if single_bwd:
                 self.flat_w16 = torch.empty(n_gemm, dtype=torch.bfloat16, device=dev)
             for n, p in gemm_w:
                 if id(p) in pred_ids:
@@ -197,7 +205,7 @@ class FlatSGD(object):
 
     def _refresh_shadows(self, initial=False):
         from . import gemm
-        if self.flat_w16 is None:           # split precision: invalidate, the next forward re-splits the fp32 master
+        if self.flat_w16 is None:           # "bf16x3" / "bf16x2": invalidate, the next forward re-splits the fp32 master
             for sh in self.shadows:
                 sh.version = -1
                 sh.w = sh.wt = None
@@ -207,7 +215,11 @@ class FlatSGD(object):
                     "f32_to_bf16")
         for sh in self.shadows:
             n, k = sh.weight.shape
-            gemm.transpose_bf16(sh.w, n, k, out=sh.wt)        # in place: same buffer every step, no allocator traffic
+            if sh.mode == "bf16":
+                gemm.transpose_bf16(sh.w, n, k, out=sh.wt)    # in place: same buffer every step, no allocator traffic
+            else:                           # "bf16x2f": W^T from the refreshed bf16 plane, forward planes from the master
+                gemm.transpose_bf16(sh.w16, n, k, out=sh.wt)
+                precision.split_rows(sh.weight.detach(), precision.patterns("gemm")[1], (k + 63) // 64 * 64, out=sh.w)
 
     @staticmethod
     def _is_gemm_weight(model, name, p):
@@ -350,7 +362,8 @@ class FlatSGD(object):
 def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="hip"):
     """One training step on the gfx950 kernels: MFMA GEMMs / implicit-GEMM convolutions, fused flat SGD, flat-buffer
     RCCL all-reduce.  dtype = arithmetic precision of the products (od_wscl_amd.precision): "bf16" (throughput) |
-    "bf16x3" (fp32-grade, the reference's DTYPE float32 on the bf16 matrix cores; "fp32" is an alias) | "bf16x2".
+    "bf16x3" (fp32-grade, the reference's DTYPE float32 on the bf16 matrix cores; "fp32" is an alias) | "bf16x2" |
+    "bf16x2f" (forward as bf16x2 -- the parity bar on losses and selections --, backward on single bf16 planes).
     (The hipBLASLt / MIOpen / torch.optim comparison step lives in tools/torch_baseline.py, outside the product.)"""
     if backend != "hip":
         raise ValueError("od_wscl_amd.engine has one back end (the HIP kernels); the library comparison path is "

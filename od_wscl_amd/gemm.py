@@ -79,9 +79,13 @@ def transpose_bf16(x, rows, cols, out=None):
 
 
 class Shadow(object):
-    """bf16 copies of one fp32 weight the matrix cores read: w (N x K) and wt (K x r64(N)); in a split precision
-    mode (precision.py) the same two matrices as bf16 planes along the reduction axis: w (N x T*r64(K)),
-    wt (K x T*r64(N))."""
+    """bf16 copies of one fp32 weight the matrix cores read: w (N x K) for the forward product and wt (K x r64(N))
+    for the input gradient.  In a split precision mode (precision.py) the same matrices as bf16 planes along the
+    reduction axis: w (N x T*r64(K)), wt (K x T*r64(N)); in "bf16x2f" only the forward operand w is split, wt is the
+    single-plane transposed copy the bf16 backward reads.
+
+    A shadow the optimiser manages (engine.FlatSGD keeps w / wt up to date itself after every step) is bound to
+    the precision mode it was built in: using it under another mode raises instead of reading a stale layout."""
 
     def __init__(self, weight):
         self.weight = weight
@@ -89,28 +93,38 @@ class Shadow(object):
         self.mode = None
         self.w = None
         self.wt = None
-        self.managed = False      # True: the optimiser refreshes w / wt itself (engine.FlatSGD, bf16 mode)
+        self.managed = False      # True: the optimiser refreshes w / wt itself (engine.FlatSGD)
         self.batch = None         # gemm.WgradBatch: one weight-gradient GEMM per step over all evaluations
 
-    def refresh(self):
+    def build(self, w_out=None, wt_out=None):
+        """(Re)build w / wt from the fp32 master in the current mode (into the given buffers when they fit)."""
         w = self.weight
-        mode = P.get_precision()
-        if self.mode == mode and (self.managed or (self.version == w._version and self.w is not None)):
-            return self
         n, k = w.shape
         assert k % 8 == 0, "in_features must be a multiple of 8"
+        wd = w.detach()
+        wd = wd if wd.stride(1) == 1 else wd.contiguous()
         with torch.no_grad():
             if P.split_mode():
-                wd = w.detach()
-                wd = wd if wd.stride(1) == 1 else wd.contiguous()
                 pb = P.patterns("gemm")[1]
-                self.w = P.split_rows(wd, pb, _r64(k))
-                self.wt = P.split_cols(wd, pb, _r64(n))
-            elif not self.managed or self.w is None:
-                self.w = to_bf16(w.detach())
-                self.wt = transpose_bf16(w.detach(), n, k)
+                self.w = P.split_rows(wd, pb, _r64(k), out=w_out)
+                self.wt = P.split_cols(wd, pb, _r64(n), out=wt_out) if P.bwd_split() else transpose_bf16(wd, n, k, out=wt_out)
+            else:
+                self.w = to_bf16(wd)
+                self.wt = transpose_bf16(wd, n, k, out=wt_out)
         self.version = w._version
-        self.mode = mode
+        self.mode = P.get_precision()
+
+    def refresh(self):
+        mode = P.get_precision()
+        if self.managed:
+            if self.mode != mode:
+                raise RuntimeError("gemm.Shadow: this weight's copies are kept by an optimiser built in precision mode %r; "
+                                   "the process-wide mode is now %r (build a new training step after set_precision)"
+                                   % (self.mode, mode))
+            return self
+        if self.mode == mode and self.version == self.weight._version and self.w is not None:
+            return self
+        self.build()
         return self
 
 
@@ -126,7 +140,7 @@ class WgradBatch(object):
 
     def register(self, m):
         """Reserve the column block of an evaluation over m rows (split precision: one block per plane product)."""
-        self.rows.append(_r64(m) * (len(P.patterns("gemm")[0]) if P.split_mode() else 1))
+        self.rows.append(_r64(m) * (len(P.patterns("gemm")[0]) if P.bwd_split() else 1))
         return len(self.rows) - 1
 
     def offset(self, slot):
@@ -198,76 +212,84 @@ class _FusedLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xb, y, weight, bias = ctx.saved_tensors
-        sh, relu, drop_p, x_dtype, tag, grad_rows, slot = ctx.cfg
-        M_all, K = xb.shape
-        N = weight.shape[0]
-        dy = dy.contiguous()
-        if grad_rows is not None:           # rows outside [a, b) neither send nor receive gradient
-            ra, rb = grad_rows[0], grad_rows[1]
-            dy, xb = dy[ra:rb], xb[ra:rb]
-            y = y[ra:rb] if y is not None else None
-        M = xb.shape[0]
-        n8, m8 = _r64(N), _r64(M)
-        dz = torch.empty((M, n8), dtype=torch.bfloat16, device=dy.device)
-        batch = sh.batch if slot is not None else None
-        if batch is not None:                  # this evaluation's column block of the shared dZ^T / X^T matrices
-            dzt_all, xt_all = batch.buffers(N, K, dy.device)
-            off = batch.offset(slot)
-            dzt, ld_t, t_cols = dzt_all[:, off:], dzt_all.stride(0), m8
-        else:
-            dzt = torch.empty((N, m8), dtype=torch.bfloat16, device=dy.device)
-            ld_t, t_cols = m8, m8
-        if bias is not None and bias.requires_grad:
-            if bias.grad is None:
-                bias.grad = torch.zeros_like(bias)
-            db = bias.grad
-        else:
-            db = None           # no bias, or a constant one (the folded shift of a frozen batch-norm)
-        scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
-        if y is not None and y.dtype != torch.bfloat16:
-            y = y.to(torch.bfloat16)
-        L.check(L.lib().odw_linear_bwd_prep_part(L.ptr(dy), 1 if dy.dtype == torch.float32 else 0, dy.stride(0),
-                                                 L.ptr(y), y.stride(0) if y is not None else 0, M, N, scale,
-                                                 L.ptr(dz), n8, L.ptr(dzt), ld_t, t_cols, L.ptr(db), L.stream()),
-                "linear_bwd_prep")
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx_all = torch.empty((M_all, K), dtype=x_dtype, device=dy.device)
-            dx = dx_all
-            if grad_rows is not None:
-                if len(grad_rows) < 3 or grad_rows[2]:      # (a, b, False): the consumer ignores rows outside [a, b)
-                    dx_all[:ra].zero_()
-                    dx_all[rb:].zero_()
-                dx = dx_all[ra:rb]
-            kernel_timer.layer = tag and tag + "_dgrad"
-            gemm_nt(dz, sh.wt, M, K, N, dx)
-            kernel_timer.layer = None
-            dx = dx_all
-        dw = None
-        if weight.requires_grad and batch is not None:
-            L.check(L.lib().odw_transpose_to_bf16_part(L.ptr(xb), 0, xb.stride(0), M, K, L.ptr(xt_all[:, off:]),
-                                                       xt_all.stride(0), m8, L.stream()), "transpose_to_bf16")
-            batch.done[slot] = True
-            batch.filled += 1
-            if batch.filled == len(batch.rows):
-                batch.flush(weight, tag)
-        elif weight.requires_grad:
-            xt = transpose_bf16(xb, M, K)
-            if weight.is_leaf:          # accumulate straight into the parameter's gradient buffer
-                fresh = weight.grad is None or getattr(weight, "_odw_fresh", False)
-                if weight.grad is None:
-                    weight.grad = torch.empty_like(weight)
-                weight._odw_fresh = False
-                target = weight.grad
-            else:                       # a derived weight (e.g. the concatenated predictor heads)
-                fresh = True
-                target = dw = torch.empty_like(weight)
-            kernel_timer.layer = tag and tag + "_wgrad"
-            gemm_nt(dzt, xt, N, K, M, target, accumulate=not fresh)
-            kernel_timer.layer = None
-        if bias is not None and bias.requires_grad and not bias.is_leaf:
-            raise RuntimeError("fused_linear: bias must be a leaf parameter, a constant or None")
+        dx, dw = _backward_single_plane(xb, y, weight, bias, ctx.cfg, dy, ctx.needs_input_grad[0])
         return dx, dw, None, None, None, None, None, None, None, None, None, None
+
+
+def _backward_single_plane(xb, y, weight, bias, cfg, dy, need_dx):
+    """Backward of a fused Linear with every product on ONE bf16 plane per operand ("bf16" and "bf16x2f" modes).
+    xb / y are the saved input / output (bf16, or fp32 after a split-precision forward: the prologue and transpose
+    kernels round to bf16 as they read); dy may be fp32 or bf16; dx comes back in the input's dtype."""
+    sh, relu, drop_p, x_dtype, tag, grad_rows, slot = cfg
+    M_all, K = xb.shape
+    N = weight.shape[0]
+    dy = dy.contiguous()
+    if grad_rows is not None:           # rows outside [a, b) neither send nor receive gradient
+        ra, rb = grad_rows[0], grad_rows[1]
+        dy, xb = dy[ra:rb], xb[ra:rb]
+        y = y[ra:rb] if y is not None else None
+    M = xb.shape[0]
+    n8, m8 = _r64(N), _r64(M)
+    x_f32 = 1 if xb.dtype == torch.float32 else 0
+    dz = torch.empty((M, n8), dtype=torch.bfloat16, device=dy.device)
+    batch = sh.batch if slot is not None else None
+    if batch is not None:                  # this evaluation's column block of the shared dZ^T / X^T matrices
+        dzt_all, xt_all = batch.buffers(N, K, dy.device)
+        off = batch.offset(slot)
+        dzt, ld_t, t_cols = dzt_all[:, off:], dzt_all.stride(0), m8
+    else:
+        dzt = torch.empty((N, m8), dtype=torch.bfloat16, device=dy.device)
+        ld_t, t_cols = m8, m8
+    if bias is not None and bias.requires_grad:
+        if not bias.is_leaf:
+            raise RuntimeError("fused_linear: bias must be a leaf parameter, a constant or None")
+        if bias.grad is None:
+            bias.grad = torch.zeros_like(bias)
+        db = bias.grad
+    else:
+        db = None           # no bias, or a constant one (the folded shift of a frozen batch-norm)
+    scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+    flags = (1 if dy.dtype == torch.float32 else 0) | (2 if (y is not None and y.dtype == torch.float32) else 0)
+    L.check(L.lib().odw_linear_bwd_prep_part(L.ptr(dy), flags, dy.stride(0),
+                                             L.ptr(y), y.stride(0) if y is not None else 0, M, N, scale,
+                                             L.ptr(dz), n8, L.ptr(dzt), ld_t, t_cols, L.ptr(db), L.stream()),
+            "linear_bwd_prep")
+    dx = None
+    if need_dx:
+        dx_all = torch.empty((M_all, K), dtype=x_dtype, device=dy.device)
+        dx = dx_all
+        if grad_rows is not None:
+            if len(grad_rows) < 3 or grad_rows[2]:      # (a, b, False): the consumer ignores rows outside [a, b)
+                dx_all[:ra].zero_()
+                dx_all[rb:].zero_()
+            dx = dx_all[ra:rb]
+        kernel_timer.layer = tag and tag + "_dgrad"
+        gemm_nt(dz, sh.wt, M, K, N, dx)
+        kernel_timer.layer = None
+        dx = dx_all
+    dw = None
+    if weight.requires_grad and batch is not None:
+        L.check(L.lib().odw_transpose_to_bf16_part(L.ptr(xb), x_f32, xb.stride(0), M, K, L.ptr(xt_all[:, off:]),
+                                                   xt_all.stride(0), m8, L.stream()), "transpose_to_bf16")
+        batch.done[slot] = True
+        batch.filled += 1
+        if batch.filled == len(batch.rows):
+            batch.flush(weight, tag)
+    elif weight.requires_grad:
+        xt = transpose_bf16(xb, M, K)
+        if weight.is_leaf:          # accumulate straight into the parameter's gradient buffer
+            fresh = weight.grad is None or getattr(weight, "_odw_fresh", False)
+            if weight.grad is None:
+                weight.grad = torch.empty_like(weight)
+            weight._odw_fresh = False
+            target = weight.grad
+        else:                       # a derived weight (e.g. the concatenated predictor heads)
+            fresh = True
+            target = dw = torch.empty_like(weight)
+        kernel_timer.layer = tag and tag + "_wgrad"
+        gemm_nt(dzt, xt, N, K, M, target, accumulate=not fresh)
+        kernel_timer.layer = None
+    return dx, dw
 
 
 class _SplitLinear(torch.autograd.Function):
@@ -370,12 +392,30 @@ class _SplitLinear(torch.autograd.Function):
         return dx, dw, None, None, None, None, None, None, None, None, None
 
 
+class _MixedLinear(torch.autograd.Function):
+    """Precision mode "bf16x2f": the forward product of _SplitLinear (two bf16 planes per operand, three plane
+    products, fp32 in / fp32 out -- what the loss values and every index selection depend on), the backward of
+    _FusedLinear (dZ, X and W each rounded to one bf16 plane; dX comes back as fp32)."""
+
+    forward = staticmethod(_SplitLinear.forward)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x32, y, weight, bias = ctx.saved_tensors
+        sh, relu, drop_p, x_dtype, tag, grad_rows, slot = ctx.cfg
+        cfg = (sh, relu, drop_p, torch.float32, tag, grad_rows, slot)
+        dx, dw = _backward_single_plane(x32, y, weight, bias, cfg, dy, ctx.needs_input_grad[0])
+        if dx is not None and x_dtype != torch.float32:
+            dx = dx.to(x_dtype)
+        return dx, dw, None, None, None, None, None, None, None, None, None
+
+
 def fused_linear(x, weight, bias, shadow, relu=False, drop_p=0.0, segs=None, out_f32=False, tag=None, grad_rows=None,
                  row_ids=None):
     """dropout(relu(x W^T + b)) on the matrix cores.  bf16 mode: bf16 operands, bf16 (or, out_f32, fp32) result;
     split precision modes: fp32 in, fp32 out (precision.py)."""
     if P.split_mode():
-        return _SplitLinear.apply(x, weight, bias, shadow, relu, drop_p, segs, tag, grad_rows, row_ids,
-                                  torch.is_grad_enabled())
+        fn = _SplitLinear if P.bwd_split() else _MixedLinear
+        return fn.apply(x, weight, bias, shadow, relu, drop_p, segs, tag, grad_rows, row_ids, torch.is_grad_enabled())
     return _FusedLinear.apply(x, weight, bias, shadow, relu, drop_p, segs, out_f32, tag, grad_rows, row_ids,
                               torch.is_grad_enabled())      # (grad mode is always off INSIDE Function.forward)

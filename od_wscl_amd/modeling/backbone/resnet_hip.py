@@ -52,35 +52,42 @@ class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, wd, zero_page = ctx.saved_tensors
-        B, H, W, co, ci = ctx.dims
-        lib, st = L.lib(), L.stream()
-        m = B * H * W
-        m64 = _r64(m)
-        dy = dy.contiguous()
-        dz = torch.empty((m, _r64(co)), dtype=torch.bfloat16, device=dy.device)
-        dzt = torch.empty((co, m64), dtype=torch.bfloat16, device=dy.device)
-        L.check(lib.odw_linear_bwd_prep(L.ptr(dy), 1 if dy.dtype == torch.float32 else 0, dy.stride(0), L.ptr(y), y.stride(0),
-                                        m, co, 1.0, L.ptr(dz), dz.stride(0), L.ptr(dzt), m64, None, st), "conv bwd prep")
-        dw = None
-        if ctx.needs_input_grad[1] and ci >= 128 and ci & (ci - 1) == 0 and co % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0":
-            # dZ and the layer input as they are: K-major operands, transposed fragment reads (odw_conv_wgrad_tn)
-            dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
-            ws_bytes = lib.odw_conv_wgrad_tn_workspace(co, ci, m)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
-            with kernel_timer.region("conv wgrad TN split-K+reduce", flops=2.0 * m * co * 9 * ci):
-                L.check(lib.odw_conv_wgrad_tn(L.ptr(dz), dz.stride(0), L.ptr(x), m, H, W, ci, 1, co, ci, L.ptr(dw), 0,
-                                              L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv_wgrad_tn")
-        elif ctx.needs_input_grad[1]:
-            colt = torch.empty((9 * ci, m64), dtype=torch.bfloat16, device=dy.device)
-            L.check(lib.odw_im2col_t_bf16(L.ptr(x), m, H, W, ci, 1, L.ptr(colt), m64, st), "im2col_t")
-            dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
-            conv_wgrad(lib, dzt, colt, co, ci, ci, m, dw, st)
-        dx = None
-        if ctx.needs_input_grad[0] and wd is not None:
-            dx = torch.empty((m, ci), dtype=torch.bfloat16, device=dy.device)
-            dzc = dz if dz.shape[1] == co else dz[:, :co].contiguous()
-            _conv3x3(lib, dzc, m, H, W, co, 1, 1, wd, ci, dx, None, False, None, 0, zero_page, st, 2.0 * m * co * 9 * ci)
-        return dx, dw, None, None, None, None
+        return _conv3x3_backward_single_plane(ctx, dy, x, y, wd, zero_page, torch.bfloat16)
+
+
+def _conv3x3_backward_single_plane(ctx, dy, x, y, wd, zero_page, dx_dtype):
+    """Backward of a 3x3 layer with one bf16 plane per operand: x = the layer input as NHWC bf16 rows, y = the saved
+    output (bf16, or fp32 after a split-precision forward) the ReLU mask is re-derived from."""
+    B, H, W, co, ci = ctx.dims
+    lib, st = L.lib(), L.stream()
+    m = B * H * W
+    m64 = _r64(m)
+    dy = dy.contiguous()
+    dz = torch.empty((m, _r64(co)), dtype=torch.bfloat16, device=dy.device)
+    dzt = torch.empty((co, m64), dtype=torch.bfloat16, device=dy.device)
+    flags = (1 if dy.dtype == torch.float32 else 0) | (2 if y.dtype == torch.float32 else 0)
+    L.check(lib.odw_linear_bwd_prep(L.ptr(dy), flags, dy.stride(0), L.ptr(y), y.stride(0),
+                                    m, co, 1.0, L.ptr(dz), dz.stride(0), L.ptr(dzt), m64, None, st), "conv bwd prep")
+    dw = None
+    if ctx.needs_input_grad[1] and ci >= 128 and ci & (ci - 1) == 0 and co % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0":
+        # dZ and the layer input as they are: K-major operands, transposed fragment reads (odw_conv_wgrad_tn)
+        dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
+        ws_bytes = lib.odw_conv_wgrad_tn_workspace(co, ci, m)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+        with kernel_timer.region("conv wgrad TN split-K+reduce", flops=2.0 * m * co * 9 * ci):
+            L.check(lib.odw_conv_wgrad_tn(L.ptr(dz), dz.stride(0), L.ptr(x), m, H, W, ci, 1, co, ci, L.ptr(dw), 0,
+                                          L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv_wgrad_tn")
+    elif ctx.needs_input_grad[1]:
+        colt = torch.empty((9 * ci, m64), dtype=torch.bfloat16, device=dy.device)
+        L.check(lib.odw_im2col_t_bf16(L.ptr(x), m, H, W, ci, 1, L.ptr(colt), m64, st), "im2col_t")
+        dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=dy.device)
+        conv_wgrad(lib, dzt, colt, co, ci, ci, m, dw, st)
+    dx = None
+    if ctx.needs_input_grad[0] and wd is not None:
+        dx = torch.empty((m, ci), dtype=dx_dtype, device=dy.device)
+        dzc = dz if dz.shape[1] == co else dz[:, :co].contiguous()
+        _conv3x3(lib, dzc, m, H, W, co, 1, 1, wd, ci, dx, None, False, None, 0, zero_page, st, 2.0 * m * co * 9 * ci)
+    return dx, dw, None, None, None, None
 
 
 class _SplitConv3x3Fn(torch.autograd.Function):
@@ -135,6 +142,39 @@ class _SplitConv3x3Fn(torch.autograd.Function):
             dzs = P.split_rows(dz, pa, co)
             _conv3x3(lib, dzs, m, H, W, T * co, 1, 1, wd, ci, dx, None, False, None, 0, zero_page, st, 2.0 * m * co * 9 * ci * T)
         return dx, dw, None, None, None, None
+
+
+class _MixedConv3x3Fn(torch.autograd.Function):
+    """Precision mode "bf16x2f": the forward of _SplitConv3x3Fn (fp32 rows in and out, plane products), the backward of
+    _Conv3x3Fn (one bf16 plane per operand; the input gradient comes back as fp32 rows)."""
+
+    @staticmethod
+    def forward(ctx, x, w, shift, geom, zero_page, need_dx):
+        lib, st = L.lib(), L.stream()
+        B, H, W = geom
+        co, ci = w.shape[0], w.shape[1]
+        m = B * H * W
+        pa, pb = P.patterns("conv")
+        T = len(pa)
+        wd32 = w.detach().contiguous()
+        wk = P.pack_conv_weight(wd32.permute(0, 2, 3, 1).reshape(co * 9, ci).contiguous(), pb, ci, co)
+        wd = None
+        if need_dx:
+            wd = torch.empty((ci, _r64(9 * co)), dtype=torch.bfloat16, device=x.device)
+            L.check(lib.odw_conv_weight_prep(L.ptr(wd32), co, ci, ci, None, 0, L.ptr(wd), wd.stride(0), st), "conv_weight_prep")
+        x = x.contiguous()
+        xs = P.split_rows(x, pa, ci)
+        y = torch.empty((m, co), dtype=torch.float32, device=x.device)
+        _conv3x3(lib, xs, m, H, W, T * ci, 1, 0, wk, co, y, shift, True, None, 0, zero_page, st, 2.0 * m * co * 9 * ci * T)
+        x16 = P.split_rows(x, (0,), ci) if ctx.needs_input_grad[1] else None
+        ctx.save_for_backward(x16, y, wd, zero_page)
+        ctx.dims = (B, H, W, co, ci)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, y, wd, zero_page = ctx.saved_tensors
+        return _conv3x3_backward_single_plane(ctx, dy, x16, y, wd, zero_page, torch.float32)
 
 
 class _AddReLU(torch.autograd.Function):
@@ -237,7 +277,7 @@ class ResNetBackboneHip(nn.Module):
         f = self._const(conv, bn)
         assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
         w = conv.weight * f.scale[:, None, None, None]
-        fn = _SplitConv3x3Fn if P.split_mode() else _Conv3x3Fn
+        fn = (_SplitConv3x3Fn if P.bwd_split() else _MixedConv3x3Fn) if P.split_mode() else _Conv3x3Fn
         return fn.apply(x, w, f.shift, geom, self.zero_page, need_dx)
 
     @staticmethod

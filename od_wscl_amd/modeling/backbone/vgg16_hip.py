@@ -114,59 +114,66 @@ class _VGGFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeat):
-        lib = L.lib()
-        net, saved, B = ctx.net, ctx.saved_acts, ctx.batch
-        st = L.stream()
-        dev = dfeat.device
-        _, C, h, w = dfeat.shape
-        dz = torch.empty((B * h * w, C), dtype=torch.bfloat16, device=dev)
-        L.check(lib.odw_nchw_f32_to_nhwc_bf16(L.ptr(dfeat.contiguous()), B, h * w, C, C, L.ptr(dz), st), "nchw_to_nhwc")
-        first = min(i for i, l in enumerate(net.layers) if l.trainable)
-        for li in range(len(net.layers) - 1, first - 1, -1):
-            l = net.layers[li]
-            x_in, pre, h, w = saved[li]
-            if l.pool:       # dz arrives at the pooled resolution: route through the pool (+ ReLU mask of `pre`)
-                d_pre = torch.empty((B * h * w, l.cout), dtype=torch.bfloat16, device=dev)
-                L.check(lib.odw_maxpool2x2_nhwc_bf16_bwd(L.ptr(pre), L.ptr(dz), B, h, w, l.cout, L.ptr(d_pre), st),
-                        "maxpool_bwd")
-                dz = d_pre
-            m = B * h * w
-            m64 = _r64(m)
-            if getattr(net, "debug", None) is not None:      # tests: gradient w.r.t. this layer's pre-activation
-                net.debug[li] = dz.float().reshape(B, h, w, l.cout).permute(0, 3, 1, 2).clone()
-            # ---- bias + weight gradient
-            conv = l.conv
-            if conv.bias.grad is None:
-                conv.bias.grad = torch.zeros_like(conv.bias)
-            if conv.weight.grad is None:
-                conv.weight.grad = torch.empty_like(conv.weight)
-            if l.cp >= 128 and l.cout % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0":
-                # dZ and the layer input as they are (NHWC rows): K-major operands, transposed fragment reads
-                L.check(lib.odw_colsum_bf16(L.ptr(dz), l.cout, m, l.cout, L.ptr(conv.bias.grad), st), "conv bias grad")
-                ws_bytes = lib.odw_conv_wgrad_tn_workspace(l.cout, l.cp, m)
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                with kernel_timer.region("conv wgrad TN split-K+reduce", flops=2.0 * m * l.cout * 9 * l.cp):
-                    L.check(lib.odw_conv_wgrad_tn(L.ptr(dz), l.cout, L.ptr(x_in), m, h, w, l.cp, l.dil, l.cout, l.cin,
-                                                  L.ptr(conv.weight.grad), 0, L.ptr(net.zero_page), L.ptr(ws), ws_bytes, st),
-                            "conv_wgrad_tn")
-            else:
-                dzc = torch.empty((m, _r64(l.cout)), dtype=torch.bfloat16, device=dev)
-                dzt = torch.empty((l.cout, m64), dtype=torch.bfloat16, device=dev)
-                L.check(lib.odw_linear_bwd_prep(L.ptr(dz), 0, l.cout, None, 0, m, l.cout, 1.0, L.ptr(dzc), dzc.stride(0),
-                                                L.ptr(dzt), m64, L.ptr(conv.bias.grad), st), "conv bias grad")
-                colt = torch.empty((9 * l.cp, m64), dtype=torch.bfloat16, device=dev)
-                L.check(lib.odw_im2col_t_bf16(L.ptr(x_in), m, h, w, l.cp, l.dil, L.ptr(colt), m64, st), "im2col_t")
-                conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, m, conv.weight.grad, st)
-            # ---- input gradient (masked by the ReLU of the producing layer unless that layer was pooled:
-            #      then the pool backward of the previous iteration applies the mask)
-            if li > first:
-                prev = net.layers[li - 1]
-                dx = torch.empty((m, l.cin), dtype=torch.bfloat16, device=dev)
-                mask = x_in if (prev.relu and not prev.pool) else None
-                _conv3x3(lib, dz, m, h, w, l.cout, l.dil, 1, l.wd, l.cin, dx, None, False, mask,
-                         l.cin if mask is not None else 0, net.zero_page, st, 2.0 * m * l.cout * 9 * l.cin)
-                dz = dx
-        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        return _backward_single_plane(ctx, dfeat)
+
+
+def _backward_single_plane(ctx, dfeat):
+    """Backward of the body with one bf16 plane per operand ("bf16", and "bf16x2f" after its split-precision
+    forward): saved layer inputs are NHWC bf16; a pooled layer's saved pre-pool activation is bf16 or ("bf16x2f") the
+    fp32 tensor of the forward, whose first maximum routes the gradient."""
+    lib = L.lib()
+    net, saved, B = ctx.net, ctx.saved_acts, ctx.batch
+    st = L.stream()
+    dev = dfeat.device
+    _, C, h, w = dfeat.shape
+    dz = torch.empty((B * h * w, C), dtype=torch.bfloat16, device=dev)
+    L.check(lib.odw_nchw_f32_to_nhwc_bf16(L.ptr(dfeat.contiguous()), B, h * w, C, C, L.ptr(dz), st), "nchw_to_nhwc")
+    first = min(i for i, l in enumerate(net.layers) if l.trainable)
+    for li in range(len(net.layers) - 1, first - 1, -1):
+        l = net.layers[li]
+        x_in, pre, h, w = saved[li]
+        if l.pool:       # dz arrives at the pooled resolution: route through the pool (+ ReLU mask of `pre`)
+            d_pre = torch.empty((B * h * w, l.cout), dtype=torch.bfloat16, device=dev)
+            pool_bwd = lib.odw_maxpool2x2_nhwc_f32x_bf16_bwd if pre.dtype == torch.float32 else lib.odw_maxpool2x2_nhwc_bf16_bwd
+            L.check(pool_bwd(L.ptr(pre), L.ptr(dz), B, h, w, l.cout, L.ptr(d_pre), st), "maxpool_bwd")
+            dz = d_pre
+        m = B * h * w
+        m64 = _r64(m)
+        if getattr(net, "debug", None) is not None:      # tests: gradient w.r.t. this layer's pre-activation
+            net.debug[li] = dz.float().reshape(B, h, w, l.cout).permute(0, 3, 1, 2).clone()
+        # ---- bias + weight gradient
+        conv = l.conv
+        if conv.bias.grad is None:
+            conv.bias.grad = torch.zeros_like(conv.bias)
+        if conv.weight.grad is None:
+            conv.weight.grad = torch.empty_like(conv.weight)
+        if l.cp >= 128 and l.cout % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0":
+            # dZ and the layer input as they are (NHWC rows): K-major operands, transposed fragment reads
+            L.check(lib.odw_colsum_bf16(L.ptr(dz), l.cout, m, l.cout, L.ptr(conv.bias.grad), st), "conv bias grad")
+            ws_bytes = lib.odw_conv_wgrad_tn_workspace(l.cout, l.cp, m)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            with kernel_timer.region("conv wgrad TN split-K+reduce", flops=2.0 * m * l.cout * 9 * l.cp):
+                L.check(lib.odw_conv_wgrad_tn(L.ptr(dz), l.cout, L.ptr(x_in), m, h, w, l.cp, l.dil, l.cout, l.cin,
+                                              L.ptr(conv.weight.grad), 0, L.ptr(net.zero_page), L.ptr(ws), ws_bytes, st),
+                        "conv_wgrad_tn")
+        else:
+            dzc = torch.empty((m, _r64(l.cout)), dtype=torch.bfloat16, device=dev)
+            dzt = torch.empty((l.cout, m64), dtype=torch.bfloat16, device=dev)
+            L.check(lib.odw_linear_bwd_prep(L.ptr(dz), 0, l.cout, None, 0, m, l.cout, 1.0, L.ptr(dzc), dzc.stride(0),
+                                            L.ptr(dzt), m64, L.ptr(conv.bias.grad), st), "conv bias grad")
+            colt = torch.empty((9 * l.cp, m64), dtype=torch.bfloat16, device=dev)
+            L.check(lib.odw_im2col_t_bf16(L.ptr(x_in), m, h, w, l.cp, l.dil, L.ptr(colt), m64, st), "im2col_t")
+            conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, m, conv.weight.grad, st)
+        # ---- input gradient (masked by the ReLU of the producing layer unless that layer was pooled:
+        #      then the pool backward of the previous iteration applies the mask)
+        if li > first:
+            prev = net.layers[li - 1]
+            dx = torch.empty((m, l.cin), dtype=torch.bfloat16, device=dev)
+            mask = x_in if (prev.relu and not prev.pool) else None
+            _conv3x3(lib, dz, m, h, w, l.cout, l.dil, 1, l.wd, l.cin, dx, None, False, mask,
+                     l.cin if mask is not None else 0, net.zero_page, st, 2.0 * m * l.cout * 9 * l.cin)
+            dz = dx
+    return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
 class _VGGSplitFn(torch.autograd.Function):
@@ -264,6 +271,57 @@ class _VGGSplitFn(torch.autograd.Function):
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+class _VGGMixedFn(torch.autograd.Function):
+    """Precision mode "bf16x2f": the forward of _VGGSplitFn (fp32 NHWC activations, every convolution over the bf16
+    planes of its input -- the feature map the ROI pooling, the losses and every selection depend on is fp32-grade),
+    the backward of _VGGFn (dZ, layer inputs and weights each as one bf16 plane).  What is saved per trainable layer is
+    the hi plane of its input (NHWC bf16: the weight-gradient operand and the ReLU mask) and, for a pooled layer, the
+    fp32 pre-pool activation."""
+
+    @staticmethod
+    def forward(ctx, images, net, *params):
+        lib = L.lib()
+        B, C, H, W = images.shape
+        dev = images.device
+        st = L.stream()
+        pa, _ = P.patterns("conv")
+        T = len(pa)
+        cp0 = net.layers[0].cp
+        x = torch.empty((B * H * W, cp0), dtype=torch.float32, device=dev)
+        L.check(lib.odw_nchw_f32_to_nhwc_f32(L.ptr(images.contiguous()), B, H * W, C, cp0, L.ptr(x), st), "nchw_to_nhwc_f32")
+        saved = []
+        h, w = H, W
+        for l in net.layers:
+            m = B * h * w
+            xs = P.split_rows(x, pa, l.cp)
+            x16 = P.split_rows(x, (0,), l.cp) if l.trainable else None
+            y = torch.empty((m, l.cout), dtype=torch.float32, device=dev)
+            _conv3x3(lib, xs, m, h, w, T * l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
+                     2.0 * m * l.cout * 9 * l.cin * T)
+            del xs
+            pre = None
+            if l.pool:
+                pre = y
+                p = torch.empty((B * (h // 2) * (w // 2), l.cout), dtype=torch.float32, device=dev)
+                L.check(lib.odw_maxpool2x2_nhwc_f32(L.ptr(y), B, h, w, l.cout, L.ptr(p), st), "maxpool_f32")
+                y = p
+            saved.append((x16, pre if l.trainable else None, h, w))
+            if l.pool:
+                h, w = h // 2, w // 2
+            x = y
+        cl = net.layers[-1].cout
+        feat = torch.empty((B, cl, h, w), dtype=torch.float32, device=dev)
+        L.check(lib.odw_nhwc_f32_to_nchw_f32(L.ptr(x), B, h * w, cl, cl, L.ptr(feat), st), "nhwc_to_nchw_f32")
+        ctx.net, ctx.saved_acts, ctx.batch = net, saved, B
+        net.last_nhwc = None
+        net.last_nhwc_f32 = x       # the fp32 NHWC map (read by the fused pooling of this mode)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        return _backward_single_plane(ctx, dfeat)
+
+
 class VGGBackboneHip(nn.Module):
     """Drop-in for VGG_Base.forward: same parameters, gfx950 kernels."""
 
@@ -282,10 +340,12 @@ class VGGBackboneHip(nn.Module):
             self.zero_page = torch.zeros(64, dtype=torch.bfloat16, device=dev)
         first = min(i for i, l in enumerate(self.layers) if l.trainable) if any(l.trainable for l in self.layers) else 99
         mode = P.get_precision()
+        mixed = P.split_mode() and not P.bwd_split()      # "bf16x2f": split forward operand, single-plane dgrad operand
         todo = []
         for i, l in enumerate(self.layers):
             if not l.trainable and self._frozen_ready and l.mode == mode:
                 continue
+            fresh = l.mode != mode
             if P.split_mode():
                 # packed weights as bf16 planes: rows (co, tap) x [T blocks of Cp] and rows (ci, tap) x [T blocks of Cout]
                 _, pb = P.patterns("conv")
@@ -293,14 +353,24 @@ class VGGBackboneHip(nn.Module):
                 wr = torch.zeros((l.cout, 9, l.cp), dtype=torch.float32, device=dev)
                 wr[:, :, :l.cin] = wt.permute(0, 2, 3, 1).reshape(l.cout, 9, l.cin)
                 l.wk = P.pack_conv_weight(wr.view(l.cout * 9, l.cp), pb, l.cp, l.cout)
-                l.wd = None
-                if l.trainable and i > first:
-                    wr2 = wt.permute(1, 2, 3, 0).reshape(l.cin * 9, l.cout).contiguous()
-                    l.wd = P.pack_conv_weight(wr2, pb, l.cout, l.cin)
+                if not mixed:
+                    l.wd = None
+                    if l.trainable and i > first:
+                        wr2 = wt.permute(1, 2, 3, 0).reshape(l.cin * 9, l.cout).contiguous()
+                        l.wd = P.pack_conv_weight(wr2, pb, l.cout, l.cin)
+                    l.mode = mode
+                    continue
+                if fresh:
+                    l.wd = None
+                    if l.trainable and i > first:
+                        l.wd = torch.empty((l.cin, _r64(9 * l.cout)), dtype=torch.bfloat16, device=dev)
+                if l.wd is not None:
+                    todo.append(l)
                 l.mode = mode
                 continue
-            if l.wk is None or l.mode != mode:
+            if l.wk is None or fresh:
                 l.wk = torch.empty((l.cout, _r64(9 * l.cp)), dtype=torch.bfloat16, device=dev)
+                l.wd = None
                 if l.trainable and i > first:
                     l.wd = torch.empty((l.cin, _r64(9 * l.cout)), dtype=torch.bfloat16, device=dev)
             todo.append(l)
@@ -308,11 +378,12 @@ class VGGBackboneHip(nn.Module):
         if todo:        # the packed bf16 copies of every (trainable) layer in ONE launch
             import ctypes
             n = len(todo)
-            key = tuple((l.conv.weight.data_ptr(), l.wk.data_ptr(), l.wd.data_ptr() if l.wd is not None else 0) for l in todo)
+            key = tuple((l.conv.weight.data_ptr(), 0 if mixed else l.wk.data_ptr(), l.wd.data_ptr() if l.wd is not None else 0)
+                        for l in todo)
             if getattr(self, "_prep_key", None) != key:      # the argument arrays change only when a buffer moves
                 vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
                 args = (vp(*[k[0] for k in key]), ia(*[l.cout for l in todo]), ia(*[l.cin for l in todo]),
-                        ia(*[l.cp for l in todo]), vp(*[k[1] for k in key]), ia(*[l.wk.stride(0) for l in todo]),
+                        ia(*[l.cp for l in todo]), vp(*[k[1] or None for k in key]), ia(*[_r64(9 * l.cp) for l in todo]),
                         vp(*[k[2] or None for k in key]), ia(*[l.wd.stride(0) if l.wd is not None else 0 for l in todo]))
                 self._prep_key, self._prep_args = key, (args, [ctypes.cast(a, ctypes.c_void_p) for a in args])
             L.check(lib.odw_conv_weight_prep_batch(n, *self._prep_args[1], L.stream()), "conv_weight_prep_batch")
@@ -323,7 +394,7 @@ class VGGBackboneHip(nn.Module):
         with torch.no_grad():
             self._prep()
         params = [p for l in self.layers for p in (l.conv.weight, l.conv.bias)]
-        fn = _VGGSplitFn if P.split_mode() else _VGGFn
+        fn = (_VGGSplitFn if P.bwd_split() else _VGGMixedFn) if P.split_mode() else _VGGFn
         feat = fn.apply(images.float(), self, *params)
         feat._odw_nhwc = self.last_nhwc
         return [feat]

@@ -180,6 +180,35 @@ def test_bf16x2_mode_meets_the_loss_and_selection_bars(name):
             assert abs(p.grad.double().norm().item() - ref) <= 5e-3 * ref + 1e-6, n
 
 
+MIXED_GRAD_TOL = 1e-2          # observed: <= 3.8e-3 on the five goldens
+
+
+@pytest.mark.parametrize("name", E2E_ALL)
+def test_bf16x2f_mode_meets_the_loss_and_selection_bars(name):
+    """The bench's default mode since round 3: forward products on two bf16 planes (as "bf16x2"), backward products on
+    one.  BASELINE.json's bar -- losses within 1e-3, every selected index set the reference's -- holds on all five
+    goldens; the gradients (not part of that bar) carry the bf16 rounding of the backward operands."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    losses, trace, model, g = _run_golden(name, "bf16x2f")
+    for k, v in losses.items():
+        ref = float(g["loss/" + k])
+        assert abs(float(v.detach()) - ref) <= LOSS_RTOL * max(abs(ref), 1e-6), (k, float(v.detach()), ref)
+    for k in g.files:
+        if k.startswith(("pseudo_", "pgt_instance_")):
+            np.testing.assert_array_equal(trace[k].cpu().numpy(), g[k], err_msg=k)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        key = "gradnorm/" + n
+        if key in g.files and float(g[key]) > 1e-5:
+            ref = float(g[key])
+            dev = abs(p.grad.double().norm().item() - ref) / ref
+            worst = max(worst, dev)
+            assert dev <= MIXED_GRAD_TOL, (n, dev)
+    print("MIXEDREPORT", name, "worst gradient-norm deviation", worst,
+          {k: (float(v.detach()), float(g["loss/" + k])) for k, v in losses.items()})
+
+
 # observed deviation of the single-plane bf16 mode from the reference (profiles/r02/precision_deviation.json, re-measured
 # with the halo-tile convolution, whose K walk -- channel block major -- re-associates the fp32 sums and so moves which
 # near-threshold selections the bf16 rounding flips): worst loss 18 % / 2.2 % / 13 % / 4.6 % / 3.9 %, worst gradient norm
