@@ -40,34 +40,57 @@ __device__ __forceinline__ void planes(float x, unsigned short (&p)[4]) {
     p[2] = f2bf(r2);
 }
 
-// one thread = 8 consecutive columns of one row: T 16-byte stores
+// two values -> one packed pair of plane p's bf16 (v_cvt_pk_bf16_f32 rounds to nearest even like f2bf)
+__device__ __forceinline__ unsigned pk(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float finite_or_zero(float x, float r) {      // inf / nan live in the hi plane alone
+    return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u ? 0.0f : r;
+}
+
+// one thread = 4 consecutive columns of one row: one 16-byte load (lanes contiguous), T 8-byte stores -- the shape that
+// reaches the copy ceiling for these bytes (tools/exp/split_rate.hip: 6.06 TB/s on the 4096 x 25088 fc6 weight against
+// 5.3 for 8 columns per thread; the round-2 kernel, software rounding + 64-bit index division, ran at 0.85 TB/s).
+// The pattern is wave-uniform, so picking a plane is a scalar branch.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ in, long long ld_in, int R, int Cc,
                                                          Pattern pat, unsigned short* __restrict__ out,
                                                          long long ld_out, int block) {
-    const int chunks = block / 8;
-    const long long total = (long long)R * chunks;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / chunks), c0 = (int)(i % chunks) * 8;
+    const unsigned chunks = (unsigned)block / 4u;
+    const unsigned total = (unsigned)R * chunks;
+    bool need_lo = false;
+    for (int t = 0; t < pat.T; ++t) need_lo |= pat.p[t] == 2;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / chunks;
+        const int c0 = (int)(i - r * chunks) * 4;
         const float* src = in + (long long)r * ld_in + c0;
-        unsigned short pl[8][4];
-        if (c0 + 8 <= Cc && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-            const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
-            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) planes(v[j], pl[j]);
+        float v[4];
+        if (c0 + 4 <= Cc && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) planes(c0 + j < Cc ? src[j] : 0.0f, pl[j]);
+            for (int j = 0; j < 4; ++j) v[j] = c0 + j < Cc ? src[j] : 0.0f;
+        }
+        uint2 hi, mid, lo = make_uint2(0, 0);
+        hi.x = pk(v[0], v[1]); hi.y = pk(v[2], v[3]);
+        float r1[4];                        // both subtractions are exact in fp32
+        r1[0] = finite_or_zero(v[0], v[0] - __uint_as_float(hi.x << 16));
+        r1[1] = finite_or_zero(v[1], v[1] - __uint_as_float(hi.x & 0xffff0000u));
+        r1[2] = finite_or_zero(v[2], v[2] - __uint_as_float(hi.y << 16));
+        r1[3] = finite_or_zero(v[3], v[3] - __uint_as_float(hi.y & 0xffff0000u));
+        mid.x = pk(r1[0], r1[1]); mid.y = pk(r1[2], r1[3]);
+        if (need_lo) {
+            lo.x = pk(r1[0] - __uint_as_float(mid.x << 16), r1[1] - __uint_as_float(mid.x & 0xffff0000u));
+            lo.y = pk(r1[2] - __uint_as_float(mid.y << 16), r1[3] - __uint_as_float(mid.y & 0xffff0000u));
         }
         unsigned short* dst = out + (long long)r * ld_out + c0;
         for (int t = 0; t < pat.T; ++t) {
             const int p = pat.p[t];
-            uint4 o;
-            o.x = (unsigned)pl[0][p] | ((unsigned)pl[1][p] << 16);
-            o.y = (unsigned)pl[2][p] | ((unsigned)pl[3][p] << 16);
-            o.z = (unsigned)pl[4][p] | ((unsigned)pl[5][p] << 16);
-            o.w = (unsigned)pl[6][p] | ((unsigned)pl[7][p] << 16);
-            *reinterpret_cast<uint4*>(dst + (long long)t * block) = o;
+            const uint2 o = p == 0 ? hi : (p == 1 ? mid : (p == 2 ? lo : make_uint2(0, 0)));
+            *reinterpret_cast<uint2*>(dst + (long long)t * block) = o;
         }
     }
 }
@@ -172,7 +195,8 @@ ODW_EXPORT int odw_split_rows_bf16(const float* in, int64_t ld_in, int R, int Cc
                 "split_rows: bad dims R=%d C=%d block=%d", R, Cc, block);
     if (R == 0 || block == 0) return ODW_OK;
     ODW_REQUIRE(in && out && (((uintptr_t)out) & 15) == 0, "split_rows: pointers");
-    const long long total = (long long)R * (block / 8);
+    const long long total = (long long)R * (block / 4);
+    ODW_REQUIRE(total < (1ll << 31), "split_rows: R * block / 4 must stay below 2^31");
     const long long blocks = (total + 255) / 256;
     split_rows_kernel<<<(int)(blocks > 65536 ? 65536 : blocks), 256, 0, (hipStream_t)stream_>>>(
         in, ld_in, R, Cc, pat, (unsigned short*)out, ld_out, block);
