@@ -73,6 +73,17 @@ int64_t odw_roi_pool_stack_nhwc_workspace(int R, int B, int C, int H, int W);
 int odw_roi_pool_stack_forward_nhwc(const void* feat_nhwc_bf16, const float* rois, float spatial_scale, int B, int C,
                                     int H, int W, int R, const float* keep, const float* keep_sum, void* X_bf16, int ld,
                                     void* argmax_u16, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same pooling on an fp32 NHWC map with the results written as bf16 PLANES (precision mode "bf16x2f": the split-
+ * precision forward of the first head GEMM reads its operand as `T` column blocks of width `block` >= C*49 holding
+ * plane pattern[t] (0 hi, 1 mid, 2 lo, 3 zeros; HOST array) of each value): X_planes (2R x ld) bf16, rows [0,R) the
+ * pooled maxima, rows [R,2R) their DropBlock view (keep nullable: clean rows only); pooled_f32 (R x C*49, nullable)
+ * the fp32 maxima themselves; argmax_u16 as above.  Replaces roi_pool_forward + stack_clean_aug_f32 + split_rows_bf16. */
+int64_t odw_roi_pool_stack_nhwc_f32_workspace(int R, int B, int C, int H, int W);
+int odw_roi_pool_stack_forward_nhwc_f32(const float* feat_nhwc, const float* rois, float spatial_scale, int B, int C,
+                                        int H, int W, int R, const float* keep, const float* keep_sum,
+                                        const int* pattern, int T, void* X_planes, int64_t ld, int block,
+                                        float* pooled_f32, void* argmax_u16, void* workspace,
+                                        int64_t workspace_bytes, void* stream);
 int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld, const void* argmax_u16, const float* rois,
                                 const float* keep, const float* keep_sum, const float* extra, const int* extra_roi,
                                 int E, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW, float* grad_in,

@@ -52,6 +52,9 @@ SIGNATURES = {
     "odw_roi_pool_stack_forward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p]),
     "odw_roi_pool_stack_nhwc_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "odw_roi_pool_stack_forward_nhwc": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p]),
+    "odw_roi_pool_stack_nhwc_f32_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
+    "odw_roi_pool_stack_forward_nhwc_f32": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_p,
+                                                  c_p, c_p, c_l, c_p]),
     "odw_roi_pool_stack_backward": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                           c_i, c_p, c_p]),
     "odw_roi_pool_stack_backward_ws": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i,

@@ -18,6 +18,7 @@
 //   * planes that do not fit in LDS fall back to direct global kernels.
 #include "odw_common.h"
 #include "odw_fixed.h"
+#include "odw_planes.h"
 #include <float.h>
 #include <stdlib.h>
 
@@ -581,6 +582,132 @@ int pick_cg(int B, int C, int HW) {
     return fit ? 1 : 0;  // small problems: most parallelism; 0 = does not fit
 }
 
+// ---- the same (ROI, 64-channel) pooling on an fp32 NHWC map, results written as bf16 PLANES --------------------
+// Precision mode "bf16x2f" (split-precision forward): the backbone's feature map is fp32 and the first head GEMM reads
+// its operand as planes [hi hi mid] along K.  This kernel pools straight from the fp32 map and writes the planes of
+// both halves of the stacked operand itself (clean rows, DropBlock rows), the 16-bit argmax, and -- optionally -- the
+// fp32 pooled values (the sampled-row views of the contrastive loss read those rows exactly).  It replaces the
+// operator-form ROIPool (fp32 out + int32 argmax, 400 MB), stack_clean_aug (400 MB in, 400 MB out) and split_rows
+// (400 MB in, 600 MB out).  Values and positions no longer fit one 32-bit key: a thread keeps (ordinal, cell) pairs
+// and takes a cell only on a strictly greater ordinal -- cells arrive in row-major order, so the first maximum wins
+// like the reference's scan (ROIPool_cuda.cu:62-70).
+// pre-pass: order-preserving u32 image of the map; -0.0 folded onto +0.0 (they compare equal in the reference's `>`),
+// NaN -> 0 (never greater than anything, like a NaN in that scan)
+__global__ __launch_bounds__(256) void nhwc_ord_f32_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = in[i];
+        unsigned d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned u = d[q];
+            if (u == 0x80000000u) u = 0;
+            const bool nan = (u & 0x7fffffffu) > 0x7f800000u;
+            u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+            d[q] = nan ? 0u : u;
+        }
+        out[i] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+}
+
+constexpr unsigned kOrdLowest = 0x00800000u;      // ordinal of -FLT_MAX: the reference's initial maxval (only `>` it wins)
+
+template <int FLY>
+__global__ __launch_bounds__(512) void roi_pool_stack_fwd_nhwc_f32(const unsigned* __restrict__ feat,
+                                                                   const int* __restrict__ tab, int C, int H, int W, int R,
+                                                                   const float* __restrict__ keep,
+                                                                   const float* __restrict__ keep_sum, odwpl::Pattern pat,
+                                                                   unsigned short* __restrict__ X, long long ld, int block,
+                                                                   float* __restrict__ pooled,
+                                                                   unsigned short* __restrict__ argmax) {
+    __shared__ __attribute__((aligned(16))) float s_val[64 * 49];
+    __shared__ __attribute__((aligned(16))) unsigned short s_arg[64 * 49];
+    __shared__ float s_keep[49];
+    __shared__ int s_tab[29];
+    const int n = blockIdx.x, c0 = blockIdx.y * 64;
+    if (threadIdx.x < 29) s_tab[threadIdx.x] = tab[(size_t)n * 29 + threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 49) s_keep[threadIdx.x - 64] = keep ? keep[(size_t)n * 49 + threadIdx.x - 64] : 0.0f;
+    __syncthreads();
+    const int bin = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    if (bin < 49) {
+        const int ph = bin / 7, pw = bin - ph * 7;
+        const int b = s_tab[0], hs = s_tab[1 + ph], he = s_tab[8 + ph], ws = s_tab[15 + pw], we = s_tab[22 + pw];
+        unsigned bv[8], bp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bv[q] = kOrdLowest; bp[q] = 0xFFFFu; }
+        const unsigned* base = feat + ((size_t)b * H * W) * C + c0 + cg * 8;
+        // the window as ONE sequence of cells, FLY cells (2 FLY 16-byte loads) in flight; past the end the last cell is
+        // repeated -- an equal ordinal never replaces the held one -- so the loads carry no branch
+        const int nw = we - ws, ncell = (he > hs && nw > 0) ? (he - hs) * nw : 0;
+        int h = hs, w = ws;
+        for (int i = 0; i < ncell; i += FLY) {
+            int cell[FLY];
+#pragma unroll
+            for (int u = 0; u < FLY; ++u) {
+                cell[u] = h * W + w;
+                if (i + u + 1 < ncell) { if (++w == we) { w = ws; ++h; } }
+            }
+            uint4 va[FLY], vb[FLY];
+#pragma unroll
+            for (int u = 0; u < FLY; ++u) {
+                va[u] = *reinterpret_cast<const uint4*>(base + (size_t)cell[u] * C);
+                vb[u] = *reinterpret_cast<const uint4*>(base + (size_t)cell[u] * C + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < FLY; ++u) {
+                const unsigned d[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool up = d[q] > bv[q];
+                    bv[q] = up ? d[q] : bv[q];
+                    bp[q] = up ? (unsigned)cell[u] : bp[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            // empty bin: 0 and "no cell" (ROIPool_cuda.cu:60); otherwise the ordinal decoded (a bin whose every cell is
+            // <= -FLT_MAX keeps the initial -FLT_MAX and no cell, like the reference)
+            const unsigned bits = (bv[q] & 0x80000000u) ? (bv[q] ^ 0x80000000u) : ~bv[q];
+            s_val[(cg * 8 + q) * 49 + bin] = ncell ? __uint_as_float(bits) : 0.0f;
+            s_arg[(cg * 8 + q) * 49 + bin] = (unsigned short)bp[q];
+        }
+    }
+    __syncthreads();
+    // 64 channels x 49 bins = 3136 values = 392 vectors of 8, contiguous in the output row
+    if (threadIdx.x < 392) {
+        const int e0 = threadIdx.x * 8;
+        const size_t col = (size_t)c0 * 49 + e0;
+        const float4 a = *reinterpret_cast<const float4*>(s_val + e0), bq = *reinterpret_cast<const float4*>(s_val + e0 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+        bool need_lo = false;
+        for (int t = 0; t < pat.T; ++t) need_lo |= pat.p[t] == 2;
+        *reinterpret_cast<uint4*>(argmax + (size_t)n * C * 49 + col) = *reinterpret_cast<const uint4*>(s_arg + e0);
+        if (pooled) {
+            *reinterpret_cast<float4*>(pooled + (size_t)n * C * 49 + col) = a;
+            *reinterpret_cast<float4*>(pooled + (size_t)n * C * 49 + col + 4) = bq;
+        }
+        const float numel = (float)((double)R * 49), sum = keep ? *keep_sum : 1.0f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half == 1 && !keep) break;
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = half == 0 ? v[j] : ((v[j] * s_keep[(e0 + j) % 49]) * numel) / sum;
+            unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) odwpl::split2(x[2 * j], x[2 * j + 1], need_lo, hi[j], mid[j], lo[j]);
+            unsigned short* dst = X + (size_t)(half == 0 ? n : R + n) * ld + col;
+            for (int t = 0; t < pat.T; ++t) {
+                const int p = pat.p[t];
+                const uint4 o = p == 0 ? make_uint4(hi[0], hi[1], hi[2], hi[3])
+                              : (p == 1 ? make_uint4(mid[0], mid[1], mid[2], mid[3])
+                              : (p == 2 ? make_uint4(lo[0], lo[1], lo[2], lo[3]) : make_uint4(0, 0, 0, 0)));
+                *reinterpret_cast<uint4*>(dst + (size_t)t * block) = o;
+            }
+        }
+    }
+}
+
 template <typename K>
 hipError_t allow_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -863,6 +990,54 @@ __global__ __launch_bounds__(512) void roi_pool_stack_fwd_nhwc(const unsigned sh
             *reinterpret_cast<uint4*>(X + (size_t)(R + n) * ld + col) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
+}
+
+ODW_EXPORT int64_t odw_roi_pool_stack_nhwc_f32_workspace(int R, int B, int C, int H, int W) {
+    return odw_align_up(odw_roi_pool_workspace(R, 7, 7), 256) + (int64_t)B * H * W * C * 4;
+}
+
+ODW_EXPORT int odw_roi_pool_stack_forward_nhwc_f32(const float* feat_nhwc, const float* rois, float spatial_scale, int B, int C,
+                                                   int H, int W, int R, const float* keep, const float* keep_sum,
+                                                   const int* pattern, int T, void* X_planes, int64_t ld, int block,
+                                                   float* pooled_f32, void* argmax_u16, void* workspace,
+                                                   int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    odwpl::Pattern pat;
+    ODW_REQUIRE(odwpl::pattern_ok(pattern, T, pat), "roi_pool_stack_forward_nhwc_f32: pattern = up to %d plane codes in 0..3", odwpl::kMaxTerms);
+    ODW_REQUIRE(B >= 1 && C > 0 && C % 64 == 0 && H > 0 && W > 0 && R >= 0, "roi_pool_stack_forward_nhwc_f32: bad dims (C %% 64)");
+    if (R == 0) return ODW_OK;
+    ODW_REQUIRE(feat_nhwc && rois && X_planes && argmax_u16 && (!keep || keep_sum), "roi_pool_stack_forward_nhwc_f32: null pointer");
+    ODW_REQUIRE((long)H * W < 65535, "roi_pool_stack_forward_nhwc_f32: %dx%d feature map does not fit a 16-bit argmax", H, W);
+    ODW_REQUIRE(block >= C * 49 && block % 8 == 0 && ld >= (int64_t)T * block && ld % 8 == 0 && (((uintptr_t)X_planes) & 15) == 0 &&
+                    (((uintptr_t)argmax_u16) & 15) == 0 && (((uintptr_t)feat_nhwc) & 15) == 0 && (((uintptr_t)pooled_f32) & 15) == 0,
+                "roi_pool_stack_forward_nhwc_f32: alignment / ld / block");
+    const int64_t need = odw_roi_pool_stack_nhwc_f32_workspace(R, B, C, H, W);
+    if (workspace_bytes < need || !workspace) {
+        odw_set_error("roi_pool_stack_forward_nhwc_f32: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        return ODW_EWORKSPACE;
+    }
+    ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "roi_pool_stack_forward_nhwc_f32: workspace alignment");
+    int* tab = (int*)workspace;
+    unsigned* ordmap = (unsigned*)((char*)workspace + odw_align_up(odw_roi_pool_workspace(R, 7, 7), 256));
+    roi_bins_kernel<<<(R + 255) / 256, 256, 0, stream>>>(rois, spatial_scale, R, 7, 7, H, W, tab);
+    ODW_CHECK_LAUNCH("roi_bins_kernel");
+    const size_t n16 = (size_t)B * H * W * C / 4;
+    nhwc_ord_f32_kernel<<<(unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096), 256, 0, stream>>>(
+        (const uint4*)feat_nhwc, (uint4*)ordmap, n16);
+    ODW_CHECK_LAUNCH("nhwc_ord_f32_kernel");
+    static const int fly = getenv("ODW_POOL_F32_FLY") ? atoi(getenv("ODW_POOL_F32_FLY")) : 2;
+    const dim3 grid((unsigned)R, (unsigned)(C / 64));
+    if (fly == 4)
+        roi_pool_stack_fwd_nhwc_f32<4><<<grid, 512, 0, stream>>>(ordmap, tab, C, H, W, R, keep, keep_sum, pat, (unsigned short*)X_planes,
+                                                                 (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16);
+    else if (fly == 1)
+        roi_pool_stack_fwd_nhwc_f32<1><<<grid, 512, 0, stream>>>(ordmap, tab, C, H, W, R, keep, keep_sum, pat, (unsigned short*)X_planes,
+                                                                 (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16);
+    else
+        roi_pool_stack_fwd_nhwc_f32<2><<<grid, 512, 0, stream>>>(ordmap, tab, C, H, W, R, keep, keep_sum, pat, (unsigned short*)X_planes,
+                                                                 (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16);
+    ODW_CHECK_LAUNCH("roi_pool_stack_fwd_nhwc_f32");
+    return ODW_OK;
 }
 
 ODW_EXPORT int64_t odw_roi_pool_stack_nhwc_workspace(int R, int B, int C, int H, int W) {

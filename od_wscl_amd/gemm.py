@@ -299,16 +299,22 @@ class _SplitLinear(torch.autograd.Function):
     over K' = T * K with the same fused epilogue (bias, ReLU, counter-based dropout, accumulate)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, shadow, relu, drop_p, segs, timer_tag, grad_rows, row_ids, grad_mode):
+    def forward(ctx, x, weight, bias, shadow, relu, drop_p, segs, timer_tag, grad_rows, row_ids, grad_mode, planes=None):
+        """planes: the operand already laid out as bf16 planes (M x T*r64(K), pattern A of the mode) by its producer
+        (ROI pooling in "bf16x2f"); x is then only the autograd handle of that operand (see planes_handle)."""
         sh = shadow.refresh()
         pa, pb = P.patterns("gemm")
         T = len(pa)
         M, K = x.shape
         N = weight.shape[0]
-        x32 = x if x.dtype == torch.float32 else x.float()
-        x32 = x32 if x32.stride(1) == 1 else x32.contiguous()
         kp = _r64(K)
-        xs = P.split_rows(x32, pa, kp)
+        if planes is not None:
+            assert planes.shape == (M, T * kp) and planes.dtype == torch.bfloat16 and planes.stride(1) == 1
+            xs, x32 = planes, planes[:, :K]          # backward reads the hi plane (bf16, row stride T*kp)
+        else:
+            x32 = x if x.dtype == torch.float32 else x.float()
+            x32 = x32 if x32.stride(1) == 1 else x32.contiguous()
+            xs = P.split_rows(x32, pa, kp)
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         kernel_timer.layer = timer_tag and timer_tag + "_fwd"
         gemm_nt(xs, sh.w, M, N, T * kp, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs, row_ids=row_ids)
@@ -325,6 +331,8 @@ class _SplitLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x32, y, weight, bias = ctx.saved_tensors
+        if x32.dtype != torch.float32:
+            raise RuntimeError("_SplitLinear: a pre-split operand is only supported by the single-plane backward (bf16x2f)")
         sh, relu, drop_p, x_dtype, tag, grad_rows, slot = ctx.cfg
         pa, pb = P.patterns("gemm")
         T = len(pa)
@@ -389,7 +397,7 @@ class _SplitLinear(torch.autograd.Function):
             kernel_timer.layer = tag and tag + "_wgrad"
             gemm_nt(dzt, xt, N, K, T * m64, target, accumulate=not fresh)
             kernel_timer.layer = None
-        return dx, dw, None, None, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None, None, None
 
 
 class _MixedLinear(torch.autograd.Function):
@@ -407,7 +415,15 @@ class _MixedLinear(torch.autograd.Function):
         dx, dw = _backward_single_plane(x32, y, weight, bias, cfg, dy, ctx.needs_input_grad[0])
         if dx is not None and x_dtype != torch.float32:
             dx = dx.to(x_dtype)
-        return dx, dw, None, None, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None, None, None
+
+
+def planes_handle(device, rows, cols):
+    """The autograd stand-in of an operand that exists only as bf16 planes: a (rows x cols) fp32 tensor of zero strides
+    (4 bytes of storage) that carries the graph edge and the gradient's shape / dtype.  Its producer (an autograd
+    Function) returns it and attaches the planes as `_odw_planes`; fused_linear() picks them up; nothing ever reads
+    the handle's values (never call .contiguous() on one: that would materialise rows x cols zeros)."""
+    return torch.zeros(1, dtype=torch.float32, device=device).expand(rows, cols)
 
 
 def fused_linear(x, weight, bias, shadow, relu=False, drop_p=0.0, segs=None, out_f32=False, tag=None, grad_rows=None,
@@ -416,6 +432,7 @@ def fused_linear(x, weight, bias, shadow, relu=False, drop_p=0.0, segs=None, out
     split precision modes: fp32 in, fp32 out (precision.py)."""
     if P.split_mode():
         fn = _SplitLinear if P.bwd_split() else _MixedLinear
-        return fn.apply(x, weight, bias, shadow, relu, drop_p, segs, tag, grad_rows, row_ids, torch.is_grad_enabled())
+        return fn.apply(x, weight, bias, shadow, relu, drop_p, segs, tag, grad_rows, row_ids, torch.is_grad_enabled(),
+                        getattr(x, "_odw_planes", None))
     return _FusedLinear.apply(x, weight, bias, shadow, relu, drop_p, segs, out_f32, tag, grad_rows, row_ids,
                               torch.is_grad_enabled())      # (grad mode is always off INSIDE Function.forward)

@@ -13,8 +13,10 @@ import torch.nn.functional as F
 from ..dropblock import DropBlock2D
 from ..poolers import Pooler
 from ... import _lib as L
+from ... import gemm
 from ... import precision
 from ...layers.linear import Linear
+from ...utils.kernel_timer import kernel_timer
 
 
 class _StackCleanAug(torch.autograd.Function):
@@ -83,7 +85,11 @@ class _RowViews(torch.autograd.Function):
     src = the fp32 pooled tensor (P,C,h,w), or the bf16 stacked operand of _PoolStack (its first P rows)."""
 
     @staticmethod
-    def forward(ctx, src, groups, holder, gamma, S):
+    def forward(ctx, src, groups, holder, gamma, S, values=None):
+        """values: the fp32 pooled tensor to read when `src` is only the autograd handle of a planes operand
+        (_PoolStackPlanes: its gradient is parked in `holder` like that of the bf16 stacked operand)."""
+        if values is not None:
+            src = values
         src = src.contiguous()
         from_bf16 = src.dtype == torch.bfloat16
         CS = src.shape[1] if from_bf16 else src.shape[1] * src.shape[2] * src.shape[3]
@@ -127,14 +133,14 @@ class _RowViews(torch.autograd.Function):
 
         if holder is not None and not holder.done:
             holder.pending.append(fold)          # the stacked node has not produced its gradient yet: it folds this in
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if from_bf16:      # (never taken in the training step) dense gradient of the stacked operand itself
             d = torch.zeros((shape[0], C * S), dtype=torch.float32, device=dx.device)
             fold(d, False)
-            return d.to(torch.bfloat16), None, None, None, None
+            return d.to(torch.bfloat16), None, None, None, None, None
         dp = torch.zeros(shape, dtype=torch.float32, device=dx.device)
         fold(dp, False)
-        return dp, None, None, None, None
+        return dp, None, None, None, None, None
 
 
 class _RowGather(torch.autograd.Function):
@@ -142,12 +148,19 @@ class _RowGather(torch.autograd.Function):
     pooling node (entries [e0, e0+R) of its fp32 side buffer)."""
 
     @staticmethod
-    def forward(ctx, stacked, rows, holder, e0):
+    def forward(ctx, stacked, rows, holder, e0, planes=None):
+        """planes: `stacked` is the handle of a planes operand (_PoolStackPlanes) -- its rows are gathered from the
+        planes and come back as a new handle (the caller attaches the gathered planes, returned second)."""
         ctx.args = (holder, e0, int(rows.numel()))
+        if planes is not None:
+            picked = planes.index_select(0, rows)
+            ctx.mark_non_differentiable(picked)
+            ctx.set_materialize_grads(False)        # (or autograd hands backward a zero tensor the size of `picked`)
+            return gemm.planes_handle(planes.device, int(rows.numel()), stacked.shape[1]), picked
         return stacked.index_select(0, rows)
 
     @staticmethod
-    def backward(ctx, dx):
+    def backward(ctx, dx, *unused):
         holder, e0, n = ctx.args
 
         def fold(extra, identity_rows):
@@ -157,7 +170,7 @@ class _RowGather(torch.autograd.Function):
         if holder is None or holder.done:
             raise RuntimeError("_RowGather: the pooling node already ran its backward")
         holder.pending.append(fold)
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class _PoolStack(torch.autograd.Function):
@@ -218,6 +231,47 @@ class _PoolStack(torch.autograd.Function):
                                                        L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph, pw,
                                                        L.ptr(dfeat), L.ptr(ws), 64, L.stream()), "roi_pool_stack_backward")
         return dfeat, None, None, None, None, None, None, None, None
+
+
+class _PoolStackPlanes(torch.autograd.Function):
+    """_PoolStack in the precision mode "bf16x2f": ROIPool of the fp32 NHWC feature map written directly as the bf16
+    PLANES of the stacked operand of the first head GEMM (csrc/roi_pool.hip: roi_pool_stack_fwd_nhwc_f32), with the
+    16-bit argmax and the fp32 pooled values (the sampled-row views read those).  Returns (handle, planes, pooled32):
+    the handle is the autograd stand-in of the (2R x C*49) operand (gemm.planes_handle).  Backward = _PoolStack's."""
+
+    @staticmethod
+    def forward(ctx, feat, nhwc32, rois5, keep, keep_sum, holder, scale, ph, pw):
+        rois5 = rois5.contiguous().float()
+        B, C, H, W = feat.shape
+        R, nb = rois5.shape[0], ph * pw
+        K = C * nb
+        pa, _ = precision.patterns("gemm")
+        T, blk = len(pa), (K + 63) // 64 * 64
+        planes = torch.empty((2 * R, T * blk), dtype=torch.bfloat16, device=feat.device)
+        if blk != K:
+            planes.zero_()                      # (never for C % 64 == 0 and 7 x 7: C*49 is then a multiple of 64)
+        pooled32 = torch.empty((R, C, ph, pw), dtype=torch.float32, device=feat.device)
+        argmax = torch.empty((R, K), dtype=torch.int16, device=feat.device)
+        lib = L.lib()
+        ws_bytes = lib.odw_roi_pool_stack_nhwc_f32_workspace(R, B, C, H, W)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=feat.device)
+        import ctypes
+        pat = (ctypes.c_int * T)(*pa)
+        with kernel_timer.region("roi_pool_stack_fwd_nhwc_f32", nbytes=float(B * C * H * W * 4 + 2 * R * T * K * 2 + R * K * 6)):
+            L.check(lib.odw_roi_pool_stack_forward_nhwc_f32(L.ptr(nhwc32), L.ptr(rois5), scale, B, C, H, W, R, L.ptr(keep),
+                                                            L.ptr(keep_sum), ctypes.cast(pat, ctypes.c_void_p), T, L.ptr(planes),
+                                                            planes.stride(0), blk, L.ptr(pooled32), L.ptr(argmax), L.ptr(ws),
+                                                            ws_bytes, L.stream()), "roi_pool_stack_forward_nhwc_f32")
+        ctx.save_for_backward(rois5, keep, keep_sum, argmax)
+        ctx.dims = (B, C, H, W, R, ph, pw)
+        ctx.holder = holder
+        ctx.mark_non_differentiable(planes, pooled32)
+        ctx.set_materialize_grads(False)            # (or autograd hands backward 800 MB of zeros for the two)
+        return gemm.planes_handle(feat.device, 2 * R, K), planes, pooled32
+
+    @staticmethod
+    def backward(ctx, dx, *unused):
+        return _PoolStack.backward(ctx, dx)
 
 
 class TwoFCROIFeatureExtractor(nn.Module):
@@ -303,12 +357,13 @@ class TwoFCROIFeatureExtractor(nn.Module):
         int32 device list of the sampled ROIs, group after group).  Returns (x, segs6, segs7) with the random
         draws numbered in the reference's order (per group: drop mask, fc6, fc7 of the drop view; noise, fc6, fc7
         of the noise view), or None when the fused kernels do not apply."""
-        stacked = pooled.dim() == 2 and pooled.dtype == torch.bfloat16
+        planes = getattr(pooled, "_odw_planes", None)          # (bf16x2f) `pooled` is the handle of a planes operand
+        stacked = pooled.dim() == 2 and (pooled.dtype == torch.bfloat16 or planes is not None)
         res = self.pooler.output_size
         S = res[0] * res[1]
         if not (self.rand is not None and pooled.is_cuda
                 and (stacked or pooled.dtype == torch.float32) and self.sim_drop.block_size == 1 and S >= 4
-                and (pooled[0].numel() % 64 == 0) and hasattr(self.rand, "key")):
+                and (pooled.shape[1:].numel() % 64 == 0) and hasattr(self.rand, "key")):
             if stacked:
                 raise RuntimeError("sampled_row_views: the stacked pooling path needs the fused kernels")
             return None
@@ -326,16 +381,22 @@ class TwoFCROIFeatureExtractor(nn.Module):
             segs6 += [(row0,) + k6d, (row0 + k,) + k6n]
             segs7 += [(row0,) + k7d, (row0 + k,) + k7n]
             row0 += 2 * k
-        x = _RowViews.apply(pooled, specs, holder, float(self.sim_drop.drop_prob), S)
+        x = _RowViews.apply(pooled, specs, holder, float(self.sim_drop.drop_prob), S,
+                            pooled._odw_pooled32 if planes is not None else None)
         return x, segs6, segs7
 
     def can_pool_stack(self, features):
         """ROI pooling may write the stacked bf16 operand directly (csrc/roi_pool.hip: roi_pool_stack_*; its 32-bit
         (value, position) keys hold bf16 values: a split precision mode pools in fp32 with the operator form)."""
-        if not (not precision.split_mode() and self.rand is not None and hasattr(self, "dropblock")
+        if not (self.rand is not None and hasattr(self, "dropblock")
                 and self.training and len(features) == 1 and os.environ.get("ODW_NO_POOL_STACK") != "1"):
             return False
         f = features[0]
+        if precision.split_mode():
+            # "bf16x2f": the fp32 NHWC map pooled straight into the bf16 planes of the operand (_PoolStackPlanes); the
+            # modes whose backward is split too keep the operator form (their weight gradient wants the fp32 operand)
+            if precision.bwd_split() or getattr(f, "_odw_nhwc_f32", None) is None or f.shape[1] % 64 != 0:
+                return False
         pool = self.pooler.poolers[0]
         res = self.pooler.output_size
         return (type(pool).__name__ == "ROIPool" and f.is_cuda and f.dtype == torch.float32 and f.dim() == 4
@@ -358,8 +419,14 @@ class TwoFCROIFeatureExtractor(nn.Module):
             raise RuntimeError("the gradient of the previous step's sampled-row views was never folded")
         self._grad_holder = _GradHolder("extra")
         nhwc = getattr(feat, "_odw_nhwc", None) if os.environ.get("ODW_POOL_NHWC") != "0" else None
-        x = _PoolStack.apply(feat, rois5, block.contiguous(), block.sum(), self._grad_holder,
-                             float(self.pooler.poolers[0].spatial_scale), res[0], res[1], nhwc)
+        if precision.split_mode():
+            x, planes, pooled32 = _PoolStackPlanes.apply(feat, feat._odw_nhwc_f32, rois5, block.contiguous(), block.sum(),
+                                                         self._grad_holder, float(self.pooler.poolers[0].spatial_scale),
+                                                         res[0], res[1])
+            x._odw_planes, x._odw_pooled32 = planes, pooled32
+        else:
+            x = _PoolStack.apply(feat, rois5, block.contiguous(), block.sum(), self._grad_holder,
+                                 float(self.pooler.poolers[0].spatial_scale), res[0], res[1], nhwc)
         # The clean half feeds only Sim_Net, and the contrastive loss touches a few hundred of its P rows: the stacked
         # evaluation takes part in backward with its DropBlock half only (grad_rows); the clean rows the loss ends
         # up using are re-evaluated by recompute_clean_rows with their original dropout draws (row_ids).
@@ -375,7 +442,12 @@ class TwoFCROIFeatureExtractor(nn.Module):
         with the dropout draws those rows had in the stacked pass; their input gradient is parked as extra rows
         [first_entry, first_entry + len(rows)) of the pooling node's side buffer."""
         k1, k2 = self._clean_keys
-        x = _RowGather.apply(stacked, rows, self._grad_holder, first_entry)
+        planes = getattr(stacked, "_odw_planes", None)
+        if planes is not None:
+            x, picked = _RowGather.apply(stacked, rows, self._grad_holder, first_entry, planes)
+            x._odw_planes = picked
+        else:
+            x = _RowGather.apply(stacked, rows, self._grad_holder, first_entry)
         return self._fc(x, segs6=[(0,) + k1], segs7=[(0,) + k2], row_ids=rows)
 
     def forward(self, x, proposals):

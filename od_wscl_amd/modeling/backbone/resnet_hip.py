@@ -339,4 +339,5 @@ class ResNetBackboneHip(nn.Module):
                         x, geom = self._block(x, geom, blk, need_dx=False)
         feat = _ToNCHW.apply(x, geom)
         feat._odw_nhwc = x.detach() if x.dtype == torch.bfloat16 else None     # the NHWC bf16 map: the fused ROI pooling reads it
+        feat._odw_nhwc_f32 = x.detach().contiguous() if x.dtype == torch.float32 else None   # ("bf16x2f": the fp32 one)
         return [feat]

@@ -397,4 +397,5 @@ class VGGBackboneHip(nn.Module):
         fn = (_VGGSplitFn if P.bwd_split() else _VGGMixedFn) if P.split_mode() else _VGGFn
         feat = fn.apply(images.float(), self, *params)
         feat._odw_nhwc = self.last_nhwc
+        feat._odw_nhwc_f32 = getattr(self, "last_nhwc_f32", None) if fn is _VGGMixedFn else None
         return [feat]

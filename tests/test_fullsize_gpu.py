@@ -140,6 +140,69 @@ def test_pool_stack_nhwc_is_bit_exact_against_the_oracle(P, C, H, W):
     np.testing.assert_array_equal(x[P:].float().cpu().numpy().reshape(P, C, 49), want_aug.numpy())
 
 
+def _bf16_rn(x):
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("P,C,H,W", [(2000, 512, 76, 76), (300, 128, 38, 50)])
+def test_pool_stack_planes_f32_is_bit_exact_against_the_oracle(P, C, H, W):
+    """roi_pool_stack_forward_nhwc_f32 (the pooling of the bench's default mode "bf16x2f": fp32 NHWC map -> bf16 planes
+    [hi hi mid] of the stacked operand + fp32 pooled values + 16-bit argmax) against the C oracle's ROIPool
+    (csrc/cuda/ROIPool_cuda.cu:17-108 restated): maxima and first-maximum positions bit for bit (ties, +-0.0 windows,
+    empty and out-of-image ROIs), planes = the exact plane decomposition of the fp32 results."""
+    import ctypes
+    from oracle import native
+    from od_wscl_amd import _lib as L
+    from od_wscl_amd import synthetic
+    from od_wscl_amd.utils import rng
+    feat = rng.normal(22, 1, C * H * W).reshape(1, C, H, W).astype(np.float32)
+    feat[0, :, 3, 4] = feat[0, :, 3, 5]                                  # ties: first cell wins
+    feat[0, :8, 38:46, 28:38] = np.minimum(feat[0, :8, 38:46, 28:38] if H > 46 else 0.0, 0.0) if H > 46 else 0.0
+    if H > 46:
+        feat[0, :8, 40:44, 30:36] = 0.0                                  # a window of +-0.0 maxima: -0.0 == +0.0
+        feat[0, :8, 40:44, 31] = -0.0
+    nhwc = torch.from_numpy(np.ascontiguousarray(feat[0].transpose(1, 2, 0))).cuda()      # (H, W, C) fp32
+    boxes = synthetic.make_proposals(22, 0, P, H * 8, W * 8, min_size=4)
+    rois = np.concatenate([np.zeros((P, 1), np.float32), boxes], 1)
+    rois[:4] = [[0, 0, 0, W * 8 - 1, H * 8 - 1], [0, 5, 5, 5, 5], [0, -30, -30, 9, 9], [0, W * 8 + 50, 10, W * 8 + 90, 40]]
+    keep = (torch.from_numpy(rng.uniform(22, 3, P * 49).reshape(P, 49)) > 0.3).float().cuda()
+    ksum = keep.sum()
+    K = C * 49
+    pat = (0, 0, 1)
+    planes = torch.empty((2 * P, 3 * K), dtype=torch.bfloat16, device="cuda")
+    pooled = torch.empty((P, K), dtype=torch.float32, device="cuda")
+    arg = torch.empty((P, K), dtype=torch.int16, device="cuda")
+    lib = L.lib()
+    r = torch.from_numpy(rois).cuda()
+    ws_bytes = lib.odw_roi_pool_stack_nhwc_f32_workspace(P, 1, C, H, W)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    cpat = (ctypes.c_int * 3)(*pat)
+    L.check(lib.odw_roi_pool_stack_forward_nhwc_f32(L.ptr(nhwc), L.ptr(r), 0.125, 1, C, H, W, P, L.ptr(keep), L.ptr(ksum),
+                                                    ctypes.cast(cpat, ctypes.c_void_p), 3, L.ptr(planes), planes.stride(0), K,
+                                                    L.ptr(pooled), L.ptr(arg), L.ptr(ws), ws_bytes, L.stream()), "planes")
+    out, amax = native.roi_pool_fwd(feat, rois, 0.125, 7, 7)
+    np.testing.assert_array_equal(pooled.cpu().numpy().reshape(P, C, 7, 7), out)
+    got_arg = arg.cpu().numpy().view(np.uint16).astype(np.int64).reshape(P, C, 7, 7)
+    got_arg[got_arg == 0xFFFF] = -1
+    np.testing.assert_array_equal(got_arg, amax)
+    pl = planes.float().cpu().numpy()
+    flat = out.reshape(P, K)
+    hi = _bf16_rn(flat)
+    mid = _bf16_rn((flat - hi).astype(np.float32))
+    np.testing.assert_array_equal(pl[:P, :K], hi)
+    np.testing.assert_array_equal(pl[:P, K:2 * K], hi)
+    np.testing.assert_array_equal(pl[:P, 2 * K:], mid)
+    numel = np.float32(float(P) * 49)
+    aug = (torch.from_numpy(out).reshape(P, C, 49) * keep.cpu()[:, None, :] * numel / ksum.cpu()).reshape(P, K).numpy()
+    ahi = _bf16_rn(aug)
+    amid = _bf16_rn((aug - ahi).astype(np.float32))
+    np.testing.assert_array_equal(pl[P:, :K], ahi)
+    np.testing.assert_array_equal(pl[P:, K:2 * K], ahi)
+    np.testing.assert_array_equal(pl[P:, 2 * K:], amid)
+
+
 @pytest.mark.parametrize("dx_f32,skip_clean", [(False, False), (False, True), (True, False)])
 def test_pool_stack_backward_matches_the_oracle_scatter(dx_f32, skip_clean):
     """roi_pool_stack_backward_ws (the pooling backward the training step runs: both halves of the stacked operand's
