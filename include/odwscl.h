@@ -341,7 +341,7 @@ int odw_detect_filter(const float* prob, int C, const float* boxes_pc, const int
  * replaces the cuDNN convolutions behind torch.nn.Conv2d in VGG_Base
  * (modeling/backbone/vgg16.py:34-36,58-83: 3x3, stride 1, padding = dilation).
  * odw_conv3x3_nhwc_bf16: Y[m][n] = act( sum_{tap,c} X[m+shift(tap)][c] * Wk[n][tap*C+c] + bias[n] ),
- *   X (n_pix x C) NHWC bf16 with C a power of two >= 8, n_pix = B*H*W; Wk rows zero padded to a
+ *   X (n_pix x C) NHWC bf16 with C a power of two >= 8 or any multiple of 64, n_pix = B*H*W; Wk rows zero padded to a
  *   multiple of 64 (ldw); mirror=1 flips the taps (input gradient with the [ci][tap*Cout+co] copy);
  *   mask (bf16, n_pix x ldmask, nullable) zeroes the result where mask == 0 (ReLU backward);
  *   zero_page = >= 16 bytes of zeros in device memory (source of padding taps).

@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
         const int hy = hr / HC::HWp, hx = hr - hy * HC::HWp;
         const int y = y0 - DIL + hy, x = x0 - DIL + hx;
         const bool ok = hr < HC::kRows && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-        voff[i] = ok ? ((unsigned)((img * g.H + y) * g.W + x) << g.logC) * 2u + (unsigned)c * 16u : 0xffffffffu;
+        voff[i] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)g.C) * 2u + (unsigned)c * 16u : 0xffffffffu;   // (C: any multiple of 64)
     }
     auto dma_patch = [&](int cb, uint4* buf) {
         const char* base = reinterpret_cast<const char*>(X) + (size_t)cb * 128;
@@ -2331,7 +2331,6 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
                                         const void* zero_page, void* workspace, int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(n_pix >= 0 && H > 0 && W > 0 && N > 0 && n_pix % (H * W) == 0, "conv3x3: bad dims");
-    ODW_REQUIRE(C >= 8 && (C & (C - 1)) == 0, "conv3x3: channel count %d must be a power of two >= 8", C);
     ODW_REQUIRE(dilation >= 1 && dilation <= 4, "conv3x3: dilation %d", dilation);
     if (n_pix == 0) return ODW_OK;
     ODW_REQUIRE(X && Wk && Y && zero_page, "conv3x3: null pointer");
@@ -2350,6 +2349,10 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
     HaloPlan hp = halo_plan(n_pix, H, W, C, N, dilation);
     // its epilogue stores 16-byte vectors: rows of Y must be 16-byte aligned (every layer of the bodies is)
     if (hp.use && ((((uintptr_t)Y) & 15) != 0 || ((size_t)ldy * (y_is_bf16 ? 2 : 4)) % 16 != 0 || N % 8 != 0)) hp.use = false;
+    // the halo-tile kernel takes any multiple of 64 channels (three plane blocks of a split-precision operand); the
+    // 128x128 kernel decodes (tap, channel) with shifts
+    ODW_REQUIRE(C >= 8 && (hp.use || (C & (C - 1)) == 0), "conv3x3: channel count %d must be a power of two >= 8 (or a multiple "
+                "of 64 with 16-byte aligned output rows)", C);
     if (hp.use) {
         if (hp.splits > 1 && (!workspace || workspace_bytes < (int64_t)hp.splits * n_pix * N * 4)) {
             hp.splits = 1; hp.cb_per_split = C / 64;           // no room for partials: one slice

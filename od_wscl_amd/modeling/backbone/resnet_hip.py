@@ -154,7 +154,7 @@ class _MixedConv3x3Fn(torch.autograd.Function):
         B, H, W = geom
         co, ci = w.shape[0], w.shape[1]
         m = B * H * W
-        pa, pb = P.patterns("conv")
+        pa, pb = P.conv_patterns(ci)
         T = len(pa)
         wd32 = w.detach().contiguous()
         wk = P.pack_conv_weight(wd32.permute(0, 2, 3, 1).reshape(co * 9, ci).contiguous(), pb, ci, co)

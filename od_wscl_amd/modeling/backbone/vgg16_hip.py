@@ -284,8 +284,6 @@ class _VGGMixedFn(torch.autograd.Function):
         B, C, H, W = images.shape
         dev = images.device
         st = L.stream()
-        pa, _ = P.patterns("conv")
-        T = len(pa)
         cp0 = net.layers[0].cp
         x = torch.empty((B * H * W, cp0), dtype=torch.float32, device=dev)
         L.check(lib.odw_nchw_f32_to_nhwc_f32(L.ptr(images.contiguous()), B, H * W, C, cp0, L.ptr(x), st), "nchw_to_nhwc_f32")
@@ -293,6 +291,8 @@ class _VGGMixedFn(torch.autograd.Function):
         h, w = H, W
         for l in net.layers:
             m = B * h * w
+            pa, _ = P.conv_patterns(l.cp)
+            T = len(pa)
             xs = P.split_rows(x, pa, l.cp)
             x16 = P.split_rows(x, (0,), l.cp) if l.trainable else None
             y = torch.empty((m, l.cout), dtype=torch.float32, device=dev)
@@ -348,7 +348,7 @@ class VGGBackboneHip(nn.Module):
             fresh = l.mode != mode
             if P.split_mode():
                 # packed weights as bf16 planes: rows (co, tap) x [T blocks of Cp] and rows (ci, tap) x [T blocks of Cout]
-                _, pb = P.patterns("conv")
+                _, pb = P.conv_patterns(l.cp) if mixed else P.patterns("conv")
                 wt = l.conv.weight.detach()
                 wr = torch.zeros((l.cout, 9, l.cp), dtype=torch.float32, device=dev)
                 wr[:, :, :l.cin] = wt.permute(0, 2, 3, 1).reshape(l.cout, 9, l.cin)

@@ -72,6 +72,16 @@ def patterns(kind="gemm"):
     return _PATTERNS[(_MODE, kind)]
 
 
+def conv_patterns(cp):
+    """(pattern of the activation operand, pattern of the packed weight) of a 3x3 convolution over `cp` (padded) input
+    channels.  "bf16x2f" runs the three useful plane products when three blocks of cp channels make a multiple of 64
+    (the halo-tile kernel's granule) -- the four-block form carries a fourth, mid.mid, only because the 128x128
+    kernel decodes (tap, channel) with shifts and wants a power of two."""
+    if _MODE == "bf16x2f" and (3 * cp) % 64 == 0:
+        return _PATTERNS[("bf16x2f", "gemm")]
+    return _PATTERNS[(_MODE, "conv")]
+
+
 def r64(n):
     return (n + 63) // 64 * 64
 
