@@ -193,9 +193,10 @@ class _PoolStack(torch.autograd.Function):
             # the backbone's own NHWC bf16 map (`feat` is its fp32 NCHW copy): (ROI, 64-channel) workgroups
             ws_bytes = lib.odw_roi_pool_stack_nhwc_workspace(R, B, C, H, W)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=feat.device)
-            L.check(lib.odw_roi_pool_stack_forward_nhwc(L.ptr(nhwc), L.ptr(rois5), scale, B, C, H, W, R, L.ptr(keep),
-                                                        L.ptr(keep_sum), L.ptr(x), x.stride(0), L.ptr(argmax), L.ptr(ws),
-                                                        ws_bytes, L.stream()), "roi_pool_stack_forward_nhwc")
+            with kernel_timer.region("roi_pool_stack_fwd_nhwc", nbytes=float(B * C * H * W * 2 + 2 * R * C * nb * 2 + R * C * nb * 2)):
+                L.check(lib.odw_roi_pool_stack_forward_nhwc(L.ptr(nhwc), L.ptr(rois5), scale, B, C, H, W, R, L.ptr(keep),
+                                                            L.ptr(keep_sum), L.ptr(x), x.stride(0), L.ptr(argmax), L.ptr(ws),
+                                                            ws_bytes, L.stream()), "roi_pool_stack_forward_nhwc")
         else:
             L.check(lib.odw_roi_pool_stack_forward(L.ptr(feat), L.ptr(rois5), scale, B, C, H, W, R, ph, pw, L.ptr(keep),
                                                    L.ptr(keep_sum), L.ptr(x), x.stride(0), L.ptr(argmax), L.ptr(ws),
@@ -226,10 +227,13 @@ class _PoolStack(torch.autograd.Function):
         dfeat = torch.empty((B, C, H, W), dtype=torch.float32, device=dx.device)
         skip_clean = 1 if (holder is not None and holder.clean_rows == 0) else 0      # sparse backward: clean half unset
         ws = torch.empty(64, dtype=torch.uint8, device=dx.device)       # the launch's fixed-point scale (odw_fixed.h)
-        L.check(L.lib().odw_roi_pool_stack_backward_ws(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
-                                                       L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
-                                                       L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph, pw,
-                                                       L.ptr(dfeat), L.ptr(ws), 64, L.stream()), "roi_pool_stack_backward")
+        K = C * ph * pw
+        nbytes = float((R if skip_clean else 2 * R) * K * dx.element_size() + R * K * 2 + E * K * 4 + B * C * H * W * 4)
+        with kernel_timer.region("roi_pool_stack_backward", nbytes=nbytes):
+            L.check(L.lib().odw_roi_pool_stack_backward_ws(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
+                                                           L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
+                                                           L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph, pw,
+                                                           L.ptr(dfeat), L.ptr(ws), 64, L.stream()), "roi_pool_stack_backward")
         return dfeat, None, None, None, None, None, None, None, None
 
 

@@ -49,6 +49,7 @@ class KernelTimer(object):
 
     def reset(self):
         self.records = {}       # name -> list of (start_event, end_event, flops, bytes)
+        self.timed_steps = 0    # steps whose launches carried events (set by the caller: flops_per_timed_step)
 
     def region(self, name, flops=0.0, nbytes=0.0):
         """with kernel_timer.region(symbol, flops=...): <one launch on torch's current stream>"""
@@ -65,6 +66,29 @@ class KernelTimer(object):
                              flops=sum(r[2] for r in recs) / len(recs), bytes=sum(r[3] for r in recs) / len(recs))
         return out
 
+    def hbm_entries(self, hbm_peak_gbps):
+        """Regions that carry algorithmic BYTES (the HBM-bound kernels of the step: ROI pooling forward / backward):
+        name -> average launch time, bytes, achieved GB/s and fraction of the HBM roofline."""
+        out = {}
+        for name, v in self.summary().items():
+            if v["bytes"] > 0 and not name.startswith("layer/"):
+                gbps = v["bytes"] / (v["avg_ms"] * 1e-3) / 1e9
+                out[name] = {"bound": "hbm", "avg_launch_us": round(v["avg_ms"] * 1e3, 2), "launches": v["launches"],
+                             "algorithmic_bytes": int(v["bytes"]), "achieved_GBps": round(gbps, 1),
+                             "peak_GBps": hbm_peak_gbps, "frac": round(gbps / hbm_peak_gbps, 4)}
+        return out
+
+    def flops_per_timed_step(self):
+        """MFMA work issued per step: the sum of 2MNK over every timed GEMM / convolution launch divided by the number
+        of steps that carried events (regions are recorded once per launch; "layer/" entries are views of the same)."""
+        total, steps = 0.0, 0
+        for name, recs in self.records.items():
+            if name.startswith("layer/"):
+                continue
+            total += sum(r[2] for r in recs)
+        steps = getattr(self, "timed_steps", 0)
+        return total / steps if steps else None
+
     def roofline(self, dtype, mfma_peaks, hbm_peak_gbps, dominant=None):
         """The `roofline` object of bench.py for the dominant KERNEL SYMBOL (keys not starting with
         "layer/"): achieved = algorithmic FLOPs of its launches / their measured duration."""
@@ -74,7 +98,7 @@ class KernelTimer(object):
             return None
         # a region named "<symbol> split-K+reduce" brackets two kernels (the GEMM and its reduction pass): it is
         # reported with the others but it is not a kernel symbol, so it cannot be "the dominant kernel"
-        single = {k: v for k, v in kern.items() if " " not in k.split(">")[-1]} or kern
+        single = {k: v for k, v in kern.items() if " " not in k.split(">")[-1] and v["flops"] > 0} or kern
         name = dominant if dominant in kern else max(single, key=lambda k: single[k]["total_ms"])
         r = kern[name]
         layers = {k[6:]: {"ms_per_launch": round(v["avg_ms"], 4), "TFLOP/s": round(v["flops"] / (v["avg_ms"] * 1e-3) / 1e12, 1),
