@@ -371,6 +371,35 @@ def _top2_gap(col):
     return ((v[0] - v[1]) / v[0].abs().clamp(min=1e-30)) if v.numel() > 1 else torch.tensor(1.0)
 
 
+def discover(boxes, cand, score_col, top, pgt_index_c, nms_thr):
+    """The tail of one object-discovery iteration (roi_heads/weak_head/loss.py:330-340) given its candidate set:
+    NMS inside the candidates in descending class-score order (utils/utils.py:28-33), top-1 fallback, then the
+    proposals not yet in the class's index list.  Returns (pgt_instance entry, fresh indices)."""
+    with torch.no_grad():
+        close = cand[nms_tv(boxes[cand], score_col[cand], nms_thr)]
+    if close.numel() == 0:
+        close = torch.cat((close, top.view(-1)))
+    inst = close.clone()
+    both = torch.cat((close, pgt_index_c))
+    u, cnt = both.unique(return_counts=True)
+    dup = u[cnt > 1]
+    u2, cnt2 = torch.cat((close, dup)).unique(return_counts=True)
+    close = u2[cnt2 == 1]
+    if close.numel() == 0:
+        close = torch.cat((close, top.view(-1)))
+    return inst, close
+
+
+def candidates_from_margins(sim_margin, neg, member=None):
+    """The candidate set of one discovery iteration from the recorded comparisons (loss.py:319-329): sim >= threshold,
+    then per negative class the bool-vs-float comparison of quirk Q3.  `member` (bool tensor, optional) overrides the
+    threshold decision of individual proposals (a test replaying a near-threshold flip)."""
+    close = torch.ge(sim_margin, 0) if member is None else member.clone()
+    for s_neg in neg:
+        close = torch.ge(close.to(s_neg.dtype), s_neg)                                 # Q3
+    return close.nonzero(as_tuple=False).view(-1)
+
+
 # --------------------------------------------------------------------------- the loss
 def roi_reg_loss(cls_logit, det_logit, ref_logits, bbox_preds, sim_feature, clean_pooled, sd, rand,
                  boxes_per_image, labels_per_image, cfg, trace=None):
@@ -459,19 +488,18 @@ def roi_reg_loss(cls_logit, det_logit, ref_logits, bbox_preds, sim_feature, clea
                 if close.numel() > 1:
                     ss = torch.sort(pscore[:, c][close].detach(), descending=True)[0]
                     _note_margin(tr, "nms_order_rel", ((ss[:-1] - ss[1:]) / ss[:-1].abs().clamp(min=1e-30)).min())
-                with torch.no_grad():                                                 # utils/utils.py:28-33
-                    close = close[nms_tv(boxes[close], pscore[:, c][close].detach(), nms_thr)]
-                if close.numel() == 0:
-                    close = torch.cat((close, top.view(-1)))
-                pgt_instance[idx][i][c] = torch.cat((pgt_instance[idx][i][c], close))
-                tr["pgt_instance_%d_%d_%d" % (idx, i, c)] = close.clone()
-                both = torch.cat((close, pgt_index[idx][c]))
-                u, cnt = both.unique(return_counts=True)
-                dup = u[cnt > 1]
-                u2, cnt2 = torch.cat((close, dup)).unique(return_counts=True)
-                close = u2[cnt2 == 1]
-                if close.numel() == 0:
-                    close = torch.cat((close, top.view(-1)))
+                if tr.get("_decisions"):
+                    # everything a test needs to tell a legitimate near-threshold flip from a wrong selection: the signed
+                    # distance of every proposal from each comparison that decides its candidacy, the candidates, the
+                    # scores NMS orders them by
+                    negs = [int(nc) for nc in pos_classes[idx][pos_classes[idx] != c]] if pos_classes[idx].shape[0] > 1 else []
+                    tr["dec/%d_%d_%d" % (idx, i, c)] = dict(
+                        top=int(top), top_gap=float(_top2_gap(pscore[:, c])), sim_margin=(sim_mat[top] - thr).detach().clone(),
+                        neg=[sim_mat[torch.argmax(pscore[:, nc])].detach().clone() for nc in negs],
+                        cand=close.clone(), score=pscore[:, c].detach().clone(), pgt_index=pgt_index[idx][c].clone())
+                inst, close = discover(boxes, close, pscore[:, c].detach(), top, pgt_index[idx][c], nms_thr)
+                pgt_instance[idx][i][c] = torch.cat((pgt_instance[idx][i][c], inst))
+                tr["pgt_instance_%d_%d_%d" % (idx, i, c)] = inst.clone()
                 tr["sim_new_%d_%d_%d" % (idx, i, c)] = close.clone()
                 pgt_update[c] = torch.cat((pgt_update[c], E[close]))
                 pgt_index[idx][c] = torch.cat((pgt_index[idx][c], close)).unique()
@@ -497,6 +525,8 @@ def roi_reg_loss(cls_logit, det_logit, ref_logits, bbox_preds, sim_feature, clea
         losses["loss_img"] = losses["loss_img"] + F.binary_cross_entropy(img_score, lab.clamp(0, 1))
         for i in range(n_ref):
             pseudo, weights, targets = od_layer(boxes, source(idx, i).detach(), lab, pgt_instance[idx][i])
+            if tr.get("_decisions"):
+                tr["dec_source/%d_%d" % (idx, i)] = source(idx, i).detach().clone()
             tr["pseudo_%d_%d" % (idx, i)] = pseudo.clone()
             tr["weights_%d_%d" % (idx, i)] = weights.clone()
             lam = 3 if i == 0 else 1

@@ -1,17 +1,22 @@
-"""Full-size parity (BASELINE.json configs C1 / C2 / C4 -- every committed e2e golden is <= 128 px / <= 64 proposals):
+"""Full-size parity (BASELINE.json configs C1 / C2 / C4 / C5 -- every committed e2e golden is <= 128 px / <= 64 proposals):
 
-  * one training step of the product (fp32-grade mode "bf16x3", HIP body, fused loss) against the CPU oracle
-    (oracle/hotpath_ref.py) on the same formula-generated inputs at P = 500 @ 300 px, P = 2000 @ 600 px (608^2) and
-    P = 4000 / 81 classes @ 800 px, and the R-50-C5 body at P = 2000 @ 600 px (config 5);
-  * the fused pooling kernel of the training step (roi_pool_stack_fwd_nhwc: stacked operand + 16-bit argmax written
-    straight from the backbone's NHWC map) bit-exact against the C oracle's ROIPool at the C2 shape.
+  * one training step of the product (HIP body, fused loss) against the CPU oracle (oracle/hotpath_ref.py) on the same
+    formula-generated inputs at P = 500 @ 300 px, P = 2000 @ 600 px (608^2), P = 4000 / 81 classes @ 800 px and @ 688 px
+    (two scales of the COCO config's multi-scale training), the R-50-C5 body at P = 2000 @ 600 px (config 5), and the
+    reference's single-GPU setup -- 8 images of 2000 proposals on one device (README.md:99-100) -- in BOTH parity
+    modes: "bf16x2f" (what bench.py times) and "bf16x3" (fp32-grade);
+  * the fused pooling kernels of the training step bit-exact against the C oracle's ROIPool at the C2 shape.
 
-At these sizes thousands of threshold decisions are taken per step and the closest one sits within fp32
-re-association noise of its threshold IN THE ORACLE ITSELF (tools/fullsize_seed_scan.py prints the margins: similarity
-threshold gaps ~1e-6, NMS score-order gaps ~1e-7 for every seed tried) -- two correct fp32 implementations with
-different summation orders legitimately differ in a handful of picks.  So here the index sets are compared as SETS
-with a small allowance, the losses with the tolerance that allowance implies; bit-exactness of the selection logic
-itself is what the goldens (margins >= 2e-4 by construction) and the operator tests assert."""
+How the selections are compared.  At these sizes thousands of threshold decisions are taken per step and the closest one
+sits within rounding noise of its threshold IN THE ORACLE ITSELF (similarity-threshold gaps ~1e-6).  The oracle therefore
+records, for every object-discovery iteration, the signed distance of every proposal from each comparison that decides
+its candidacy (`dec/*` entries of its trace).  A proposal whose every distance exceeds TOL[mode] must be decided exactly
+like the oracle; only proposals closer than that may differ, and then the product's result must be EXACTLY what the
+oracle's own discovery tail (NMS in score order, top-1 fallback, set difference: hotpath_ref.discover) produces from
+the candidate set with those proposals flipped -- so a flip is accepted only if everything downstream of it is
+bit-exact.  The pseudo labels are compared with the oracle's od_layer applied to the accepted instances.  When no
+decision flipped (the usual case) this is plain equality of every index list and the losses are held to 1e-3."""
+import itertools
 import os
 import sys
 
@@ -26,16 +31,100 @@ from conftest import weights_for  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = {"c1": 303, "c2": 301, "c4": 305, "c5": 300}
+SEEDS = {"c1": 303, "c2": 301, "c4": 305, "c5": 300, "c4s": 306, "b8": 302}
+MODES = ("bf16x2f", "bf16x3")
+# distance from a threshold below which a decision may legitimately differ from the fp32 oracle's: the deviation of the
+# product's similarity values from the oracle's is <= ~2e-7 in "bf16x3" (fp32 re-association) and <= ~2e-5 in "bf16x2f"
+# (two-plane products: 2^-16 per term) -- printed by the test as `sim deviation`
+TOL = {"bf16x3": 1e-5, "bf16x2f": 1e-4}
+# relative gap of two class scores below which NMS may visit them in the other order (the scores are softmax outputs:
+# their relative deviation is the ABSOLUTE deviation of the logits; the worst relative deviation over all assigned
+# proposals is printed as `score deviation`, ~1e-4 in both modes because it is dominated by near-cancelling logits); a
+# swap is accepted only if the survivors are the same proposals.  Observed: no swap in "bf16x3", one at C4 (gap 1.25e-4)
+# in "bf16x2f"
+ORDER_TOL = {"bf16x3": 1e-5, "bf16x2f": 5e-4}
+GRAD_TOL = {"bf16x3": 1e-3, "bf16x2f": 1e-2}      # observed: 7e-5 / 2.6e-3
+MAX_UNCERTAIN = 12
 
 
-def _sets_close(a, b, allow_frac=0.02, allow_abs=2):
-    a, b = set(np.asarray(a).ravel().tolist()), set(np.asarray(b).ravel().tolist())
-    diff = len(a ^ b)
-    return diff <= max(allow_abs, int(allow_frac * max(len(a), len(b)))), diff, len(a), len(b)
+def _replay_selections(H, tr, trace, boxes, labels, classes, tol, order_tol, nms_thr=0.1):
+    """Compare every index selection of the product (`trace`) with the oracle's (`tr`), decision by decision.
+    Returns (number of iterations in which a near-threshold proposal was decided differently, report lines)."""
+    n_img = len(boxes)
+    pgt_index = {}
+    for k, v in tr.items():                                   # loop 1: integer IoU tests behind an argmax -> exact
+        if k.startswith("iou_samples_"):
+            assert k in trace, k
+            np.testing.assert_array_equal(trace[k].cpu().numpy(), v.numpy(), err_msg=k)
+            idx, c = (int(x) for x in k.split("_")[2:])
+            pgt_index[(idx, c)] = v.clone()
+    inst_r = [[[torch.zeros(0, dtype=torch.long) for _ in range(classes - 1)] for _ in range(3)] for _ in range(n_img)]
+    flips, lines = 0, []
+    for k, d in tr.items():                                   # loop 2, in the oracle's iteration order
+        if not k.startswith("dec/"):
+            continue
+        idx, i, c = (int(x) for x in k[4:].split("_"))
+        assert d["top_gap"] > tol, ("seed unusable: arg-max gap %.2e of %s" % (d["top_gap"], k))
+        sm = d["sim_margin"]
+        unsure = sm.abs() <= tol
+        below = sm < 0
+        for s_neg in d["neg"]:                                 # quirk Q3: True rows test 1 >= s, False rows 0 >= s
+            unsure |= torch.where(below, s_neg.abs() <= tol, (1.0 - s_neg).abs() <= tol)
+        U = unsure.nonzero().view(-1).tolist()
+        assert len(U) <= MAX_UNCERTAIN, ("seed unusable: %d proposals within %.0e of a threshold in %s" % (len(U), tol, k))
+        cand_o = set(d["cand"].tolist())
+        got_inst = trace["pgt_instance_%d_%d_%d" % (idx, i, c)].cpu()
+        got_new = trace["sim_new_%d_%d_%d" % (idx, i, c)].cpu()
+        top = torch.tensor(d["top"])
+        accepted = None
+        for r in range(len(U) + 1):                            # fewest flips first: r = 0 is the oracle's own decision
+            for S in itertools.combinations(U, r):
+                cand = sorted(cand_o.symmetric_difference(S))
+                inst, new = H.discover(boxes[idx], torch.tensor(cand, dtype=torch.long), d["score"], top,
+                                       pgt_index[(idx, c)], nms_thr)
+                ok = torch.equal(new, got_new) and (torch.equal(inst, got_inst) or _same_up_to_score_ties(inst, got_inst, d["score"], order_tol))
+                if ok:
+                    accepted = (S, inst)
+                    break
+            if accepted is not None:
+                break
+        if accepted is None:
+            o_inst = tr["pgt_instance_%d_%d_%d" % (idx, i, c)]
+            diff = sorted(set(o_inst.tolist()) ^ set(got_inst.tolist()))
+            raise AssertionError("selection differs beyond near-threshold flips in %s: uncertain %s (margins %s); instance "
+                                 "lists differ in %s (their margins %s, neg %s, in oracle candidates %s); oracle new %s product new %s"
+                                 % (k, U, [float(sm[q]) for q in U], diff, [float(sm[q]) for q in diff],
+                                    [[float(sn[q]) for q in diff] for sn in d["neg"]], [q in cand_o for q in diff],
+                                    sorted(set(tr["sim_new_%d_%d_%d" % (idx, i, c)].tolist()) ^ set(got_new.tolist())),
+                                    [(int(a), int(b), float(d["score"][a]), float(d["score"][b])) for a, b in zip(o_inst.tolist(), got_inst.tolist()) if a != b][:10]
+                                    + [("len", len(o_inst), len(got_inst)), ("new equal", torch.equal(tr["sim_new_%d_%d_%d" % (idx, i, c)], got_new))]))
+        if accepted[0]:
+            flips += 1
+            lines.append("%s: flipped %s (margins %s)" % (k, list(accepted[0]), [float(sm[p]) for p in accepted[0]]))
+        inst_r[idx][i][c] = got_inst
+        pgt_index[(idx, c)] = torch.cat((pgt_index[(idx, c)], got_new)).unique()
+    score_dev = 0.0
+    for idx in range(n_img):                                   # pseudo labels: the oracle's od_layer on the accepted instances
+        lab = H.image_label_vector(classes, labels[idx].unique())
+        for i in range(3):
+            pseudo, weights, _ = H.od_layer(boxes[idx], tr["dec_source/%d_%d" % (idx, i)], lab, inst_r[idx][i])
+            np.testing.assert_array_equal(trace["pseudo_%d_%d" % (idx, i)].cpu().numpy(), pseudo.numpy(), err_msg="pseudo_%d_%d" % (idx, i))
+            got_w = trace["weights_%d_%d" % (idx, i)].cpu().numpy()
+            np.testing.assert_allclose(got_w, weights.numpy(), rtol=2e-3, atol=1e-7)
+            score_dev = max(score_dev, float(np.max(np.abs(got_w - weights.numpy()) / np.maximum(np.abs(weights.numpy()), 1e-12))))
+    return flips, lines, score_dev
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c5"])
+def _same_up_to_score_ties(a, b, score, tol):
+    """Two NMS survivor lists (descending class score) that hold the same proposals and differ only in the order of
+    entries whose scores are within `tol` (relative) of each other."""
+    if a.numel() != b.numel() or not torch.equal(a.sort()[0], b.sort()[0]):
+        return False
+    sa, sb = score[a], score[b]
+    return bool(((sa - sb).abs() <= tol * sa.abs().clamp(min=1e-30)).all())
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c4s", "c5", "b8"])
 def test_full_size_step_matches_the_oracle(name):
     import fullsize_seed_scan as S
     from oracle import hotpath_ref as H
@@ -44,62 +133,73 @@ def test_full_size_step_matches_the_oracle(name):
     from od_wscl_amd.structures import BoxList, to_image_list
     from od_wscl_amd.utils.device_rand import DeviceRand
     seed = SEEDS[name]
-    size, p, classes, labels = S.CASES[name][:4]
+    size, p, classes = S.CASES[name][:3]
     arch = S.arch_of(name)
     batch, boxes, lab, _ = S.inputs(name, seed)
     w_np = weights_for(arch, classes)
-    # ---- oracle (CPU, fp32): forward with its selection trace, backward for the gradient norms (not at C4: time)
+    # ---- oracle (CPU, fp32): forward with its decision records, backward for the gradient norms
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     frozen = H.FROZEN if arch == "vgg16" else H.FROZEN_RESNET
     param_names = set(n for n, _ in H.param_shapes(classes, arch))
     sd = {}
     for k, v in w_np.items():
         t = torch.from_numpy(v.copy())
-        if k in param_names and not k.startswith(frozen) and name != "c4":
+        if k in param_names and not k.startswith(frozen):
             t.requires_grad_(True)
         sd[k] = t
     cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", sampling_ratio=0, arch=arch,
                scale=0.125 if arch == "vgg16" else 0.0625)
-    tr = {}
-    ctx = torch.no_grad() if name == "c4" else torch.enable_grad()
-    with ctx:
-        ref_losses, ref_accs = H.forward(batch, boxes, lab, sd, H.Rand(seed), cfg, tr)
-        if name != "c4":
-            sum(ref_losses.values()).backward()
-    # ---- product
-    precision.set_precision("bf16x3")
-    model = build_model("ROIPool", w_np, "fused", arch, classes)
-    rois = [BoxList(boxes[0].cuda(), (size, size), "xyxy")]
-    t = BoxList(torch.zeros((len(labels), 4)).cuda(), (size, size), "xyxy")
-    t.add_field("labels", lab[0].cuda())
-    trace = {}
-    model.roi_heads.loss_evaluator.trace = trace
-    rand = DeviceRand(seed)
-    losses, accs = model(to_image_list(batch.cuda()), [t], rois, rand=rand)
-    sum(losses.values()).backward()
-    # ---- same number of random draws; every index set equal up to near-threshold picks
-    worst = 0
-    for k, v in tr.items():
-        if k.startswith(("pgt_instance_", "iou_samples_", "sim_new_")):
-            assert k in trace, k
-            ok, diff, na, nb = _sets_close(trace[k].cpu().numpy(), v.numpy())
-            worst = max(worst, diff)
-            assert ok, (k, diff, na, nb)
-        if k.startswith("pseudo_"):
-            got = trace[k].cpu().numpy()
-            assert (got != v.numpy()).mean() <= 0.02, (k, float((got != v.numpy()).mean()))
-    report = {k: (float(losses[k].detach()), float(ref_losses[k])) for k in ref_losses}
-    print("FULLSIZE", name, "seed", seed, "worst set difference", worst, report)
-    for k, (got, ref) in report.items():           # observed: <= 1e-5 relative with zero set differences (profiles/r02)
-        assert abs(got - ref) <= 1e-3 * max(abs(ref), 1e-5), (k, got, ref)
-    for k in ref_accs:
-        assert abs(float(accs[k]) - float(ref_accs[k])) < 1e-6, k
-    if name != "c4":
+    tr = {"_decisions": True}
+    ref_losses, ref_accs = H.forward(batch, boxes, lab, sd, H.Rand(seed), cfg, tr)
+    sum(ref_losses.values()).backward()
+    ref_grad = {n: sd[n].grad.double().norm().item() for n in sd if sd[n].grad is not None}
+    E_ref = tr["sim_feature"]
+    for t in sd.values():
+        t.grad = None
+    # ---- product, in each parity mode
+    for mode in MODES:
+        precision.set_precision(mode)
+        model = build_model("ROIPool", w_np, "fused", arch, classes)
+        rois = [BoxList(b.cuda(), (size, size), "xyxy") for b in boxes]
+        targets = []
+        for l in lab:
+            t = BoxList(torch.zeros((len(l), 4)).cuda(), (size, size), "xyxy")
+            t.add_field("labels", l.cuda())
+            targets.append(t)
+        trace = {}
+        model.roi_heads.loss_evaluator.trace = trace
+        emb = []
+        hook = model.roi_heads.model_sim.register_forward_hook(lambda m, a, out: emb.append(out.detach()))
+        losses, accs = model(to_image_list(batch.cuda()), targets, rois, rand=DeviceRand(seed))
+        hook.remove()
+        sum(losses.values()).backward()
+        E = [e for e in emb if e.shape[0] == E_ref.shape[0]][0].float().cpu()
+        offs = np.cumsum([0] + [len(b) for b in boxes])
+        sim_dev = 0.0
+        for k, d in tr.items():
+            if k.startswith("dec/"):
+                idx = int(k[4:].split("_")[0])
+                a, b = E[offs[idx]:offs[idx + 1]], E_ref[offs[idx]:offs[idx + 1]]
+                sim_dev = max(sim_dev, float((a @ a[d["top"]] - b @ b[d["top"]]).abs().max()))
+        flips, lines, score_dev = _replay_selections(H, tr, trace, boxes, lab, classes, TOL[mode], ORDER_TOL[mode])
+        report = {k: (float(losses[k].detach()), float(ref_losses[k])) for k in ref_losses}
+        worst_loss = max(abs(g - r) / max(abs(r), 1e-5) for g, r in report.values())
+        worst_grad = 0.0
         for n, p_ in model.named_parameters():
-            if n in sd and sd[n].grad is not None:
-                ref = sd[n].grad.double().norm().item()
-                got = p_.grad.double().norm().item()
-                assert abs(got - ref) <= 2e-2 * ref + 1e-6, (n, got, ref)
+            if n in ref_grad and ref_grad[n] > 1e-6:
+                worst_grad = max(worst_grad, abs(p_.grad.double().norm().item() - ref_grad[n]) / ref_grad[n])
+        print("FULLSIZE %s %s seed %d: decisions flipped %d, sim deviation %.2e, score deviation %.2e, worst loss deviation %.2e, "
+              "worst gradient-norm deviation %.2e %s" % (name, mode, seed, flips, sim_dev, score_dev, worst_loss, worst_grad, lines))
+        assert sim_dev <= 0.5 * TOL[mode], ("TOL[%s] no longer covers the similarity deviation" % mode, sim_dev)
+        loss_tol = 1e-3 if flips == 0 else 5e-2        # a flipped pick moves the pseudo labels of its neighbourhood
+        for k, (got, ref) in report.items():
+            assert abs(got - ref) <= loss_tol * max(abs(ref), 1e-5), (k, got, ref, mode)
+        for k in ref_accs:
+            assert abs(float(accs[k]) - float(ref_accs[k])) < 1e-6, k
+        if flips == 0:
+            assert worst_grad <= GRAD_TOL[mode], (mode, worst_grad)
+        del model, losses
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("P,C,H,W", [(2000, 512, 76, 76), (300, 128, 38, 50)])

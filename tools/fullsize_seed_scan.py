@@ -16,27 +16,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-CASES = {  # name: (size, proposals, classes, labels[, arch])
+CASES = {  # name: (size, proposals, classes, labels[, arch]); labels = one list, or a list of lists = several images
     "c1": (300, 500, 21, [4, 11]),
     "c2": (600, 2000, 21, [3, 9]),
     "c4": (800, 4000, 81, [17]),
     "c5": (600, 2000, 21, [7, 12], "r50"),       # R-50-C5 body (configs/voc/voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml)
+    "c4s": (688, 4000, 81, [42]),                # another scale of the COCO config's multi-scale training (480-800)
+    # the reference's own single-GPU setup: IMS_PER_BATCH 8 on one device (README.md:99-100), VOC shape
+    "b8": (600, 2000, 21, [[3, 9], [15], [5, 12], [8], [1, 19], [14], [7], [2, 11]]),
 }
 
 
 def arch_of(name):
     return CASES[name][4] if len(CASES[name]) > 4 else "vgg16"
+
+
+def labels_of(name):
+    """list (one entry per image) of label lists"""
+    lab = CASES[name][3]
+    return lab if isinstance(lab[0], (list, tuple)) else [lab]
 FLOORS = {"argmax_rel": 1e-3, "sim_thresh_abs": 1e-4, "q3_abs": 1e-4, "nms_order_rel": 1e-3}
 
 
 def inputs(name, seed):
     from od_wscl_amd import synthetic
-    size, p, classes, labels = CASES[name][:4]
+    size, p, classes = CASES[name][:3]
+    labels = labels_of(name)
     pad = synthetic.pad_to(size)
-    batch = torch.zeros(1, 3, pad, pad)
-    batch[0, :, :size, :size] = torch.from_numpy(synthetic.make_image(seed, 0, size, size)[:, :size, :size].copy())
-    boxes = [torch.from_numpy(synthetic.make_proposals(seed, 0, p, size, size, min_size=32 if arch_of(name) != "vgg16" else 20))]
-    return batch, boxes, [torch.tensor(labels, dtype=torch.int64)], classes
+    batch = torch.zeros(len(labels), 3, pad, pad)
+    boxes = []
+    for k in range(len(labels)):
+        batch[k, :, :size, :size] = torch.from_numpy(synthetic.make_image(seed, k, size, size)[:, :size, :size].copy())
+        boxes.append(torch.from_numpy(synthetic.make_proposals(seed, k, p, size, size, min_size=32 if arch_of(name) != "vgg16" else 20)))
+    return batch, boxes, [torch.tensor(l, dtype=torch.int64) for l in labels], classes
 
 
 def main():
