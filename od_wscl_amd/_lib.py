@@ -88,6 +88,8 @@ SIGNATURES = {
     "odw_conv_wgrad_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "odw_conv_wgrad_nt": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p]),
     "odw_colsum_bf16": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "odw_colsum_workspace": (c_l, [c_i, c_i]),
+    "odw_colsum_bf16_ws": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "odw_conv_wgrad_tn_workspace": (c_l, [c_i, c_i, c_i]),
     "odw_conv_wgrad_tn": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_l, c_p]),
     "odw_im2col_t_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),

@@ -507,7 +507,11 @@ ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void*
         pairwise_split_kernel<<<(P * 16 + 255) / 256, 256, 0, stream>>>(E, P, E3);
         ODW_CHECK_LAUNCH("pairwise_split_kernel");
         const int nb = (P + kPsRows - 1) / kPsRows;
+#ifdef ODW_EXPERIMENTS      // timing experiments that skip compute or stores (WRONG results): experiment builds only
         static const int dbg = getenv("ODW_PAIRWISE_DBG") ? atoi(getenv("ODW_PAIRWISE_DBG")) : 0;
+#else
+        const int dbg = 0;
+#endif
         ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_sim_split_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kPsSide), "pairwise attr");
         pairwise_sim_split_kernel<<<nb * (nb + 1) / 2, 256, 2 * kPsSide, stream>>>(E3, P, S, nb, dbg);

@@ -120,6 +120,53 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* 
     }
 }
 
+// The same sums with ONE summation order whatever the arrival order of the workgroups (the float atomicAdd above makes
+// the bias gradient differ from run to run): every row block parks its 64 column sums, the LAST block of a column
+// group to arrive (ticket counter) adds the parked sums in row-block order.  `tickets` must be zero on entry and is
+// left zero (the last block resets its counter), so one persistent buffer serves every call.
+__global__ __launch_bounds__(256) void colsum_bf16_det_kernel(const unsigned short* __restrict__ X, int ld, int M, int N,
+                                                              float* __restrict__ out, float* __restrict__ part,
+                                                              unsigned* __restrict__ tickets) {
+    __shared__ float sm[32][65];
+    __shared__ unsigned s_last;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 256;
+    const int ch = threadIdx.x & 7, r = threadIdx.x >> 3;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n0 + ch * 8 < N) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = m0 + r + 32 * k;
+            if (m < M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(X + (size_t)m * ld + n0 + ch * 8);
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc[2 * q] += __uint_as_float(w[q] << 16); acc[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u); }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sm[r][ch * 8 + q] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < 64 && n0 + (int)threadIdx.x < N) {
+        float t = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) t += sm[k][threadIdx.x];
+        part[(size_t)blockIdx.y * N + n0 + threadIdx.x] = t;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(tickets + blockIdx.x, 1u) == gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < 64 && n0 + (int)threadIdx.x < N) {
+        float t = 0.0f;
+        for (unsigned k = 0; k < gridDim.y; ++k) t += __builtin_nontemporal_load(part + (size_t)k * N + n0 + threadIdx.x);
+        out[n0 + threadIdx.x] += t;
+    }
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0u;
+}
+
 // dw[co][ci][t] = dwk[co][t*Cp + ci]
 __global__ void wgrad_unpack_kernel(const float* __restrict__ dwk, int ld, int Co, int Ci, int Cp,
                                     float* __restrict__ dw) {
@@ -438,6 +485,28 @@ ODW_EXPORT int odw_colsum_bf16(const void* X, int ld, int M, int N, float* out, 
     ODW_REQUIRE(X && out && N % 8 == 0 && ld % 8 == 0 && (((uintptr_t)X) & 15) == 0, "colsum_bf16: N, ld multiples of 8, X 16-byte aligned");
     colsum_bf16_kernel<<<dim3((N + 63) / 64, (M + 255) / 256), 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X, ld, M, N, out);
     ODW_CHECK_LAUNCH("colsum_bf16_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int64_t odw_colsum_workspace(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return odw_align_up((int64_t)((N + 63) / 64) * 4, 256) + (int64_t)((M + 255) / 256) * N * 4;
+}
+
+// deterministic form: workspace = odw_colsum_workspace(M, N) bytes whose FIRST 4 * ceil(N / 64) bytes are zero on entry
+// (they are left zero: allocate once with zeros, reuse for every call)
+ODW_EXPORT int odw_colsum_bf16_ws(const void* X, int ld, int M, int N, float* out, void* workspace, int64_t workspace_bytes,
+                                  void* stream_) {
+    ODW_REQUIRE(M >= 0 && N >= 0 && ld >= N, "colsum_bf16: bad dims");
+    if (M == 0 || N == 0) return ODW_OK;
+    ODW_REQUIRE(X && out && N % 8 == 0 && ld % 8 == 0 && (((uintptr_t)X) & 15) == 0, "colsum_bf16: N, ld multiples of 8, X 16-byte aligned");
+    ODW_REQUIRE(workspace && workspace_bytes >= odw_colsum_workspace(M, N) && (((uintptr_t)workspace) & 15) == 0,
+                "colsum_bf16_ws: workspace of odw_colsum_workspace(M, N) bytes, 16-byte aligned");
+    unsigned* tickets = (unsigned*)workspace;
+    float* part = (float*)((char*)workspace + odw_align_up((int64_t)((N + 63) / 64) * 4, 256));
+    colsum_bf16_det_kernel<<<dim3((N + 63) / 64, (M + 255) / 256), 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X, ld, M, N,
+                                                                                                     out, part, tickets);
+    ODW_CHECK_LAUNCH("colsum_bf16_det_kernel");
     return ODW_OK;
 }
 

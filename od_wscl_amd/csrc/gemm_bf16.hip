@@ -1966,8 +1966,12 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
             gemm_nt_bf16_big_kernel<true><<<btiles_m * btiles_n, kBigThreads, big_lds, stream>>>(
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n);
         } else {
+#ifdef ODW_EXPERIMENTS      // x = 1..6: timing experiments that knowingly produce WRONG results (experiment builds only)
             const char* xe = getenv("ODW_GEMM_EXP");
             const int x = xe ? atoi(xe) : 0;
+#else
+            const int x = 0;
+#endif
 #define ODW_BIG_X(XV)                                                                                            \
             do {                                                                                                 \
                 ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, XV>), \
@@ -2378,6 +2382,7 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
                 (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y,    \
                 hp.tiles_x, hp.tiles_n, hp.splits, hp.cb_per_split);                                               \
         } while (0)
+#ifdef ODW_EXPERIMENTS      // timing experiments that knowingly produce WRONG results: compiled only into experiment builds
         const char* de = getenv("ODW_HALO_DBG");      // timing experiments (wrong results): 1 no DMA, 2 no LDS reads,
         const int dbg = de ? atoi(de) : 0;            // 3 no MFMA, 4 no stores, 5 no weight DMA, 6 no patch DMA
         if (dbg > 0 && out_bf16 && dilation == 1) {
@@ -2394,6 +2399,7 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
             else if (dbg == 4) ODW_LAUNCH_HALO_DBG(4); else if (dbg == 5) ODW_LAUNCH_HALO_DBG(5); else if (dbg == 6) ODW_LAUNCH_HALO_DBG(6); else if (dbg == 7) ODW_LAUNCH_HALO_DBG(7); else ODW_LAUNCH_HALO_DBG(8);
 #undef ODW_LAUNCH_HALO_DBG
         } else
+#endif
         if (dilation == 1) { if (out_bf16) ODW_LAUNCH_HALO(true, 1); else ODW_LAUNCH_HALO(false, 1); }
         else { if (out_bf16) ODW_LAUNCH_HALO(true, 2); else ODW_LAUNCH_HALO(false, 2); }
 #undef ODW_LAUNCH_HALO

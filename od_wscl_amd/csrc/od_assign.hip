@@ -24,7 +24,16 @@ __global__ __launch_bounds__(256) void od_assign_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float sh[];   // G x 5: box + area
     if (g_dev) {                    // the count lives on the device (written by the discovery kernels): G = its capacity
         const int g = *g_dev;
-        G = g < 1 ? 1 : (g < G ? g : G);
+        if (g < 1) {                // an image without a pseudo-GT box (no positive label): every proposal is background
+            const int i = blockIdx.x * blockDim.x + threadIdx.x;         // with weight 0, like od_layer's early return
+            if (i < P) {                                                 // (pseudo_label_generator.py:167-170)
+                labels[i] = 0;
+                weights[i] = 0.0f;
+                reinterpret_cast<float4*>(targets)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            return;
+        }
+        G = g < G ? g : G;
     }
     for (int j = threadIdx.x; j < G; j += blockDim.x) {
         const float4 q = INDEXED ? reinterpret_cast<const float4*>(boxes)[reinterpret_cast<const int*>(gt_boxes)[j]]

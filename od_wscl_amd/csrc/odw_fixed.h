@@ -64,11 +64,14 @@ struct Scale {
 
 __device__ __forceinline__ Scale scale_of(unsigned absmax_bits) {
     Scale s;
-    const float amax = __uint_as_float(absmax_bits);
-    if (!(amax > 0.0f)) { s.to_fixed = 0.0f; s.to_float = 0.0f; s.state = 0; return s; }
-    if (!(amax < __builtin_inff())) { s.to_fixed = 0.0f; s.to_float = 0.0f; s.state = 2; return s; }
+    s.to_fixed = 0.0f; s.to_float = 0.0f;
+    // classified on the BIT PATTERN: the pre-pass sorts NaN (0x7fc00000) above inf, and a float comparison with a NaN
+    // maximum is false both ways -- `!(amax > 0)` used to file a diverged step under "all-zero gradient"
+    if (absmax_bits >= 0x7f800000u) { s.state = 2; return s; }
+    if (absmax_bits == 0u) { s.state = 0; return s; }
     int e;
-    frexpf(amax, &e);                                        // amax < 2^e
+    frexpf(__uint_as_float(absmax_bits), &e);                // amax < 2^e
+    e = e < -86 ? -86 : e;                                   // (denormal-sized gradients: 2^(40-e) must stay finite)
     s.to_fixed = ldexpf(1.0f, 40 - e);
     s.to_float = ldexpf(1.0f, e - 40);
     s.state = 1;

@@ -204,14 +204,13 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_pool_bwd_plane_det(
     const int c = blockIdx.x % C;
     const int HW = H * W;
     float* dst = grad_in + ((size_t)b * C + c) * HW;
-    const float amax = __uint_as_float(*absmax_bits);
-    if (!(amax > 0.0f) || !(amax < __builtin_inff())) {      // all-zero gradient (or inf / nan: propagate it like a sum would)
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) dst[i] = amax > 0.0f ? amax : 0.0f;
-        if (!(amax > 0.0f)) return;
+    const odwfx::Scale sc = odwfx::scale_of(*absmax_bits);
+    if (sc.state != 1) {                     // all-zero gradient, or inf / nan somewhere (no finite scale exists: the
+        const float fill = sc.state == 0 ? 0.0f : __uint_as_float(0x7fc00000u);      // plane becomes NaN, like a sum would)
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) dst[i] = fill;
+        return;
     }
-    int e;
-    frexpf(amax, &e);                                        // amax < 2^e
-    const float scale = ldexpf(1.0f, 40 - e), inv = ldexpf(1.0f, e - 40);
+    const float scale = sc.to_fixed, inv = sc.to_float;
     for (int lo = 0; lo < HW; lo += cells_per_pass) {
         const int hi = min(HW, lo + cells_per_pass);
         for (int i = threadIdx.x; i < hi - lo; i += blockDim.x) iacc[i] = 0;

@@ -296,13 +296,16 @@ class FlatSGD(object):
         saved under that factor)."""
         self.lr_scale = lr_factor(self.cfg, iteration) if iteration > 0 else 1.0
 
-    def begin_step(self):
+    def begin_step(self, accumulate=False):
         """Gradient buffer state for a new step: GEMM weights are overwritten by their first wgrad
-        launch; everything autograd accumulates into (convs, predictor heads, biases) is zeroed."""
-        for p in self.gemm_params:
-            p._odw_fresh = True
-        self.flat_g[self.n_gemm:].zero_()
+        launch; everything autograd accumulates into (convs, predictor heads, biases) is zeroed.
+        accumulate: a later micro-step of a SOLVER.ITER_SIZE group -- every gradient is added to what is there."""
+        if not accumulate:
+            for p in self.gemm_params:
+                p._odw_fresh = True
+            self.flat_g[self.n_gemm:].zero_()
         self.early_done = False
+        self.hold = False
 
     def _sgd_region(self, i, paced=0):
         """paced = workgroup cap of an update that runs BESIDE other kernels (head_grads_ready): at full width the
@@ -324,7 +327,8 @@ class FlatSGD(object):
         all-reduce + SGD + shadow refresh of the head on the side stream, overlapping the backbone's backward.
         (Measured alternative: SGD deferred to overlap the NEXT step's backbone forward instead -- same step time:
         the optimiser pass is 3.4 GB of HBM traffic wherever it runs.)"""
-        if self.side is None or self.n_gemm == 0 or self.early_done or os.environ.get("ODW_NO_OVERLAP") == "1":
+        if (self.side is None or self.n_gemm == 0 or self.early_done or getattr(self, "hold", False)
+                or os.environ.get("ODW_NO_OVERLAP") == "1"):
             return
         self.flush_wgrad()
         self.side.wait_stream(torch.cuda.current_stream())
@@ -389,14 +393,27 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         conv_desc = "od_wscl_amd HIP implicit-GEMM conv3x3 (NHWC, MFMA)"
     else:
         conv_desc = "od_wscl_amd HIP: 1x1 convs on the MFMA GEMM, implicit-GEMM conv3x3, folded frozen BN (NHWC)"
-    model.roi_heads.loss_evaluator.amp = False
     opt = FlatSGD(cfg, model, world)
     model.roi_heads.head_grads_ready = opt.head_grads_ready
 
+    # SOLVER.ITER_SIZE (config/defaults.py:459-461, engine/trainer.py:86,118-120): gradients are summed over ITER_SIZE
+    # consecutive iterations, the optimiser steps after the last of them and the schedule advances once per group
+    # (before its first iteration).  The reference's DDP averages every micro-batch's gradients over the ranks as
+    # they are produced; the sum of those means is the mean of the sums: ONE exchange per group here.
+    iter_size = max(1, int(cfg.SOLVER.ITER_SIZE))
+    micro = [0]
+
     def step(images, targets, rois, rand, iteration=None):
+        k = (iteration - 1) % iter_size if iteration is not None else micro[0] % iter_size      # position in the group
+        micro[0] += 1
+        last = k == iter_size - 1
         if iteration is not None:           # WarmupMultiStepLR + update_momentum (solver/lr_scheduler.py, trainer.py:38-51)
-            opt.set_iteration(iteration)
-        opt.begin_step()
+            opt.set_iteration((iteration - 1) // iter_size + 1)
+        opt.begin_step(accumulate=k > 0)
+        opt.hold = not last                 # the head's early exchange + update waits for the group's last backward
+        hip = getattr(model, "backbone_hip", None)
+        if hip is not None:
+            hip.accumulate = k > 0
         losses, accs = model(images, targets, rois, rand=rand)
         mark("forward")
         loss = getattr(losses, "total", None)
@@ -404,8 +421,11 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             loss = sum(losses.values())
         loss.backward()
         mark("backward")
-        opt.all_reduce()
-        opt.step()
+        if last:
+            opt.all_reduce()
+            opt.step()
+        else:
+            opt.flush_wgrad()
         mark("optimizer")
         if "loss" in debug:
             print("[odw] losses", {k: round(float(v), 5) for k, v in losses.items()}, flush=True)

@@ -60,14 +60,14 @@ def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask
                                              L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv3x3")
 
 
-def conv_wgrad(lib, dzt, colt, cout, cin, cp, k, dw, st):
+def conv_wgrad(lib, dzt, colt, cout, cin, cp, k, dw, st, accumulate=0):
     """dw (Cout, Cin, 3, 3) fp32 = dZ^T im2col(X) over k reduction columns (pixels; plane products in a split mode) as
     ONE call: split-K partial products, then one pass that reduces the slices and unpacks into torch's layout."""
     ws_bytes = lib.odw_conv_wgrad_workspace(cout, cp, k, dzt.stride(0), colt.stride(0))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dzt.device)
     with kernel_timer.region("conv wgrad split-K+reduce", flops=2.0 * cout * 9 * cp * k):
-        L.check(lib.odw_conv_wgrad_nt(L.ptr(dzt), dzt.stride(0), L.ptr(colt), colt.stride(0), cout, cin, cp, k, L.ptr(dw), 0,
-                                      L.ptr(ws), ws_bytes, st), "conv_wgrad_nt")
+        L.check(lib.odw_conv_wgrad_nt(L.ptr(dzt), dzt.stride(0), L.ptr(colt), colt.stride(0), cout, cin, cp, k, L.ptr(dw),
+                                      accumulate, L.ptr(ws), ws_bytes, st), "conv_wgrad_nt")
 
 
 class _VGGFn(torch.autograd.Function):
@@ -129,6 +129,7 @@ def _backward_single_plane(ctx, dfeat):
     dz = torch.empty((B * h * w, C), dtype=torch.bfloat16, device=dev)
     L.check(lib.odw_nchw_f32_to_nhwc_bf16(L.ptr(dfeat.contiguous()), B, h * w, C, C, L.ptr(dz), st), "nchw_to_nhwc")
     first = min(i for i, l in enumerate(net.layers) if l.trainable)
+    acc = 1 if getattr(net, "accumulate", False) else 0      # SOLVER.ITER_SIZE: later micro-steps add to the gradients
     for li in range(len(net.layers) - 1, first - 1, -1):
         l = net.layers[li]
         x_in, pre, h, w = saved[li]
@@ -149,12 +150,16 @@ def _backward_single_plane(ctx, dfeat):
             conv.weight.grad = torch.empty_like(conv.weight)
         if l.cp >= 128 and l.cout % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0":
             # dZ and the layer input as they are (NHWC rows): K-major operands, transposed fragment reads
-            L.check(lib.odw_colsum_bf16(L.ptr(dz), l.cout, m, l.cout, L.ptr(conv.bias.grad), st), "conv bias grad")
+            cs_bytes = lib.odw_colsum_workspace(m, l.cout)
+            if getattr(net, "colsum_ws", None) is None or net.colsum_ws.numel() < cs_bytes:
+                net.colsum_ws = torch.zeros(cs_bytes, dtype=torch.uint8, device=dev)     # tickets: zero once, left zero
+            L.check(lib.odw_colsum_bf16_ws(L.ptr(dz), l.cout, m, l.cout, L.ptr(conv.bias.grad), L.ptr(net.colsum_ws),
+                                           net.colsum_ws.numel(), st), "conv bias grad")
             ws_bytes = lib.odw_conv_wgrad_tn_workspace(l.cout, l.cp, m)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             with kernel_timer.region("conv wgrad TN split-K+reduce", flops=2.0 * m * l.cout * 9 * l.cp):
                 L.check(lib.odw_conv_wgrad_tn(L.ptr(dz), l.cout, L.ptr(x_in), m, h, w, l.cp, l.dil, l.cout, l.cin,
-                                              L.ptr(conv.weight.grad), 0, L.ptr(net.zero_page), L.ptr(ws), ws_bytes, st),
+                                              L.ptr(conv.weight.grad), acc, L.ptr(net.zero_page), L.ptr(ws), ws_bytes, st),
                         "conv_wgrad_tn")
         else:
             dzc = torch.empty((m, _r64(l.cout)), dtype=torch.bfloat16, device=dev)
@@ -163,7 +168,7 @@ def _backward_single_plane(ctx, dfeat):
                                             L.ptr(dzt), m64, L.ptr(conv.bias.grad), st), "conv bias grad")
             colt = torch.empty((9 * l.cp, m64), dtype=torch.bfloat16, device=dev)
             L.check(lib.odw_im2col_t_bf16(L.ptr(x_in), m, h, w, l.cp, l.dil, L.ptr(colt), m64, st), "im2col_t")
-            conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, m, conv.weight.grad, st)
+            conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, m, conv.weight.grad, st, acc)
         # ---- input gradient (masked by the ReLU of the producing layer unless that layer was pooled:
         #      then the pool backward of the previous iteration applies the mask)
         if li > first:
@@ -258,7 +263,8 @@ class _VGGSplitFn(torch.autograd.Function):
             for t, pl in enumerate(gb):
                 L.check(lib.odw_im2col_t_bf16_part(L.ptr(planes[pl]), m, h, w, l.cp, l.dil, L.ptr(colt[:, t * m64:]),
                                                    Tg * m64, m64, st), "im2col_t")
-            conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, Tg * m64, conv.weight.grad, st)
+            conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, Tg * m64, conv.weight.grad, st,
+                       1 if getattr(net, "accumulate", False) else 0)
             del dzt, colt
             if li > first:
                 prev = net.layers[li - 1]

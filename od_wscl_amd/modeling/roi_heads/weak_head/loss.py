@@ -68,7 +68,6 @@ class RoIRegLossComputation(object):
             raise ValueError("only loss='supconv2' is functional in the reference (SURVEY.md item 5)")
         self.sim_loss = SupConLossV2(self.temp)
         self.trace = None       # set to a dict to record the selected index sets (tests)
-        self.amp = False        # True: the K-row fc6/fc7/Sim_Net passes run under bf16 autocast
 
     def __call__(self, class_score, det_score, ref_scores, ref_bbox_preds, sim_feature, clean_pooled_feats,
                  feature_extractor, model_sim, proposals, targets, epsilon=1e-8):
@@ -77,14 +76,12 @@ class RoIRegLossComputation(object):
             if callable(t):             # a deferred evaluation (weak_head: Sim_Net on the clean pass): stays deferred
                 return lambda: t().float()
             return t.float()
-        with torch.autocast("cuda", enabled=False):
-            return self._call([f32(t) for t in class_score], [f32(t) for t in det_score],
-                              [f32(t) for t in ref_scores], [f32(t) for t in ref_bbox_preds], f32(sim_feature),
-                              clean_pooled_feats, feature_extractor, model_sim, proposals, targets, epsilon)
+        return self._call([f32(t) for t in class_score], [f32(t) for t in det_score],
+                          [f32(t) for t in ref_scores], [f32(t) for t in ref_bbox_preds], f32(sim_feature),
+                          clean_pooled_feats, feature_extractor, model_sim, proposals, targets, epsilon)
 
     def _neck_embed(self, feature_extractor, model_sim, pooled):
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            return model_sim(feature_extractor.forward_neck(pooled)).float()
+        return model_sim(feature_extractor.forward_neck(pooled)).float()
 
     def _call(self, class_score, det_score, ref_scores, ref_bbox_preds, sim_feature, clean_pooled_feats,
               feature_extractor, model_sim, proposals, targets, epsilon=1e-8):

@@ -320,7 +320,7 @@ class RoIRegLossFused(RoIRegLossComputation):
         inst_idx = state_b[o:o + nf * max_p].view(shp + (max_p,)); o += nf * max_p
         gt_idx = state_b[o:o + n_gt].view(n_img, 3, maxpos * max_p); o += n_gt
         gt_cls = state_b[o:o + n_gt].view(n_img, 3, maxpos * max_p); o += n_gt
-        gt_score = torch.empty((n_img, 3, maxpos * max_p), dtype=torch.float32, device=device)
+        gt_score = torch.zeros((n_img, 3, maxpos * max_p), dtype=torch.float32, device=device)
         E = sim_feature.detach().contiguous()
         L.check(lib.odw_discover_sim(L.ptr(E), L.ptr(srcs[0]), L.ptr(srcs[1]), L.ptr(srcs[2]), C, L.ptr(boxes_all),
                                      L.ptr(img_off), n_img, max_p, L.ptr(pos_cls), L.ptr(n_pos), maxpos, L.ptr(tops),

@@ -368,3 +368,67 @@ def test_engine_step_with_several_images_per_rank(monkeypatch):
     torch.cuda.synchronize()
     assert step.model.roi_heads.loss_evaluator._staging.width > 64
     assert torch.isfinite(step.optimizer.flat_p).all() and not torch.equal(step.optimizer.flat_p, p0)
+
+
+def test_iter_size_accumulates_gradients_over_a_group(monkeypatch):
+    """SOLVER.ITER_SIZE = 2 (config/defaults.py:459-461, engine/trainer.py:86,118-120): no parameter moves after the
+    first iteration of a group; after the second the momentum buffer (first optimiser step: buf = g + wd * p) holds the
+    SUM of the two iterations' gradients -- checked against two single-iteration steps from the same weights."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from od_wscl_amd import engine
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("ODW_NO_TIMER", "1")
+    batches = [bench.synthetic_batch(1234, r, 224, 150, 21, dev) for r in (0, 1)]
+    rands = lambda it: DeviceRand(1234, first_stream=(1 << 20) + (it << 12), device=dev)
+
+    def build(iter_size):
+        cfg = bench.build_cfg(21)
+        cfg.merge_from_list(["SOLVER.ITER_SIZE", iter_size, "SOLVER.WEIGHT_DECAY", 0.0, "SOLVER.WEIGHT_DECAY_BIAS", 0.0])
+        return engine.build_training_step(cfg, dev, dtype="bf16x2f", world=1, seed=cfg.SEED)[0]
+
+    step = build(2)
+    p0 = step.optimizer.flat_p.clone()
+    step(*batches[0], rands(0), iteration=1)
+    torch.cuda.synchronize()
+    assert torch.equal(step.optimizer.flat_p, p0), "the optimiser stepped inside an ITER_SIZE group"
+    step(*batches[1], rands(1), iteration=2)
+    torch.cuda.synchronize()
+    assert not torch.equal(step.optimizer.flat_p, p0)
+    m_group = step.optimizer.flat_m.clone()
+    del step
+    singles = []
+    for k in (0, 1):
+        one = build(-1)
+        one(*batches[k], rands(k), iteration=1)
+        torch.cuda.synchronize()
+        singles.append(one.optimizer.flat_m.clone())
+        slices = dict(one.optimizer.slices)
+        del one
+    want = singles[0] + singles[1]
+    for n, (o, k) in slices.items():
+        a, b = m_group[o:o + k], want[o:o + k]
+        assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item() + 1e-9, n
+
+
+def test_mixed_batch_with_an_unlabelled_image_gets_background_labels():
+    """odw_od_assign_indexed_dev with a device-side pseudo-GT count of 0 (an image without a positive label inside a
+    batch that has some): every proposal background with weight 0 and zero targets, like od_layer's early return
+    (pseudo_label_generator.py:167-170) -- not an assignment against uninitialised list entries."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd import _lib as L
+    from od_wscl_amd import synthetic
+    boxes = torch.from_numpy(synthetic.make_proposals(3, 0, 300, 200, 200)).cuda()
+    idx = torch.full((64,), 7, dtype=torch.int32, device="cuda")
+    cls = torch.full((64,), 5, dtype=torch.int32, device="cuda")
+    sc = torch.full((64,), float("nan"), device="cuda")
+    n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lab = torch.full((300,), -1, dtype=torch.int64, device="cuda")
+    w = torch.full((300,), -1.0, device="cuda")
+    t = torch.full((300, 4), -1.0, device="cuda")
+    L.check(L.lib().odw_od_assign_indexed_dev(L.ptr(boxes), 300, L.ptr(idx), L.ptr(cls), L.ptr(sc), L.ptr(n), 64, 0.5, 10.0, 10.0, 5.0,
+                                              5.0, L.ptr(lab), L.ptr(w), L.ptr(t), L.stream()), "od_assign")
+    assert int(lab.abs().sum()) == 0 and float(w.abs().sum()) == 0.0 and float(t.abs().sum()) == 0.0

@@ -219,3 +219,24 @@ def test_layers_autograd(C):
             rg = native.roi_align_bwd(g, rois, 0.125, feat.shape, 7, 7, 0)
         np.testing.assert_allclose(out.detach().cpu().numpy(), ro, rtol=0, atol=2e-6)
         np.testing.assert_allclose(x.grad.cpu().numpy(), rg, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_roi_backward_propagates_non_finite_gradients(bad):
+    """A NaN or inf in grad_out must reach grad_in as NaN (what a float sum would give), not be filed under "all-zero
+    gradient" by the fixed-point scale (csrc/odw_fixed.h: the absmax pre-pass sorts NaN above inf)."""
+    from od_wscl_amd import _C
+    from od_wscl_amd import synthetic
+    torch.manual_seed(0)
+    feat = torch.randn(1, 8, 20, 24, device="cuda")
+    boxes = synthetic.make_proposals(5, 0, 32, 160, 192, min_size=12)
+    rois = torch.from_numpy(np.concatenate([np.zeros((32, 1), np.float32), boxes], 1)).cuda()
+    out, arg = _C.roi_pool_forward(feat, rois, 0.125, 7, 7)
+    g = torch.randn_like(out)
+    g[3, 2, 1, 1] = bad
+    gin = _C.roi_pool_backward(g, feat, rois, arg, 0.125, 7, 7, 1, 8, 20, 24)
+    assert torch.isnan(gin).any(), "ROIPool backward swallowed a non-finite gradient"
+    ga = _C.roi_align_backward(g, rois, 0.125, 7, 7, 1, 8, 20, 24, 2)
+    assert torch.isnan(ga).any(), "ROIAlign backward swallowed a non-finite gradient"
+    gin0 = _C.roi_pool_backward(torch.zeros_like(out), feat, rois, arg, 0.125, 7, 7, 1, 8, 20, 24)
+    assert float(gin0.abs().sum()) == 0.0

@@ -112,6 +112,8 @@ def main():
     elif weight and rank == 0:
         print("MODEL.WEIGHT %r is not a local file: training from the formula initialisation" % weight, flush=True)
 
+    if cfg.SOLVER.ITER_SIZE > 1:            # reference tools/train_net.py:344-355: MAX_ITER counts optimiser steps
+        cfg.SOLVER.MAX_ITER = cfg.SOLVER.MAX_ITER * cfg.SOLVER.ITER_SIZE
     max_iter = cfg.SOLVER.MAX_ITER
     period = getattr(cfg.SOLVER, "CHECKPOINT_PERIOD", 0)
     out_dir = cfg.OUTPUT_DIR
