@@ -114,6 +114,11 @@ def make_defaults():
     # build-specific switches (not in the reference)
     c.ODW = CN()
     c.ODW.LOSS_IMPL = "fused"     # "fused": selection logic on the device; "loops": straight-line restatement
+    # data-parallel gradient exchange (engine.GradExchange): element type on the wire -- "fp32" (the reference's DDP) or
+    # "bf16" (half the xGMI bytes; gradients rounded once before the sum, fp32 again in the optimiser) -- and the
+    # number of row blocks a large Linear's weight gradient is produced AND exchanged in
+    c.ODW.GRAD_EXCHANGE = "fp32"
+    c.ODW.WGRAD_SLICES = 4
     c.SEED = -1
     c.min_size = 20                                           # :550
     return c

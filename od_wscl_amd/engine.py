@@ -85,6 +85,80 @@ def all_reduce_flat(flat, world, chunk_elems=64 * 1024 * 1024, group=None):
         w.wait()
 
 
+class GradExchange(object):
+    """The data-parallel exchange of ONE flat gradient buffer, piece by piece, as the pieces become final.
+
+    The reference wraps the model in DistributedDataParallel (tools/train_net.py:50-55), whose buckets are all-reduced
+    as autograd fills them.  Here the gradients already live in one flat buffer, so a "bucket" is just a range of it:
+    `ready(lo, hi)` says that flat[lo:hi) will not change any more in this step and starts its sum-all-reduce at once
+    (on the side stream, behind an event recorded on the producing stream); `finish(lo, hi)` exchanges whatever part
+    of [lo, hi) was not announced and waits for everything.  Pieces larger than `chunk` are cut so that several
+    collectives are in flight.  dtype "bf16": the piece is rounded to bf16 into a persistent staging buffer, summed in
+    bf16 on the wire (half the xGMI bytes), and written back as fp32 -- the optimiser still accumulates in fp32.
+    The mean's 1/world stays folded into the SGD kernel.  world == 1: every call is a no-op."""
+
+    def __init__(self, flat, world, dtype="fp32", chunk_elems=32 * 1024 * 1024, side=None, group=None):
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError("GradExchange: dtype %r (fp32 | bf16)" % (dtype,))
+        self.flat, self.world, self.dtype, self.chunk, self.side, self.group = flat, world, dtype, chunk_elems, side, group
+        self.stage = torch.empty_like(flat, dtype=torch.bfloat16) if (dtype == "bf16" and world > 1) else None
+        self.done, self.works = [], []
+
+    def begin(self):
+        self.done, self.works = [], []
+
+    def _issue(self, lo, hi):
+        for a in range(lo, hi, self.chunk):
+            b = min(hi, a + self.chunk)
+            piece = self.flat[a:b]
+            if self.stage is not None:
+                st = self.stage[a:b]
+                st.copy_(piece)
+                self.works.append((dist.all_reduce(st, async_op=True, group=self.group), a, b))
+            else:
+                self.works.append((dist.all_reduce(piece, async_op=True, group=self.group), a, b))
+
+    def ready(self, lo, hi):
+        """flat[lo:hi) is final: exchange it now (asynchronously)."""
+        if self.world <= 1 or hi <= lo:
+            return
+        self.done.append((lo, hi))
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self._issue(lo, hi)
+        else:
+            self._issue(lo, hi)
+
+    def pending(self, lo, hi):
+        """The parts of [lo, hi) no ready() call covered, as a sorted list of ranges."""
+        out, pos = [], lo
+        for a, b in sorted(self.done):
+            a, b = max(a, lo), min(b, hi)
+            if b <= a:
+                continue
+            if a > pos:
+                out.append((pos, a))
+            pos = max(pos, b)
+        if pos < hi:
+            out.append((pos, hi))
+        return out
+
+    def finish(self, lo, hi):
+        """Exchange what is left of [lo, hi) and wait for every collective issued since begin() (the caller runs this
+        on the stream that consumes the gradients)."""
+        if self.world <= 1:
+            return
+        for a, b in self.pending(lo, hi):
+            self.done.append((a, b))
+            self._issue(a, b)
+        for w, a, b in self.works:
+            w.wait()
+            if self.stage is not None:
+                self.flat[a:b].copy_(self.stage[a:b])
+        self.works = []
+
+
 def reduce_loss_dict(loss_dict, world=None, dst=0, group=None):
     """Logging reduce of the reference's trainer (engine/trainer.py:14-36): the per-rank loss values summed onto rank
     `dst` in ONE small collective (the dictionary's values stacked in sorted-key order) and divided by the world size
@@ -152,6 +226,9 @@ class FlatSGD(object):
         self.gemm_params = [p for _, p in gemm_w]
         self.n_gemm = n_gemm
         self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        odw = getattr(cfg, "ODW", None)
+        self.exchange = GradExchange(self.flat_g, world, dtype=getattr(odw, "GRAD_EXCHANGE", "fp32"), side=self.side)
+        self.wgrad_slices = int(getattr(odw, "WGRAD_SLICES", 4)) if world > 1 else 1
         self.early_done = False
         self.first = True
         self.lr_scale = 1.0
@@ -183,6 +260,12 @@ class FlatSGD(object):
                 # Linears whose gradient is large enough for its read-modify-write to matter get ONE weight-gradient
                 # GEMM per step over all their evaluations (gemm.WgradBatch)
                 sh.batch = gemm.WgradBatch() if (weight.numel() >= (8 << 20) and os.environ.get("ODW_NO_WGRAD_BATCH") != "1") else None
+                if sh.batch is not None and self.world > 1 and os.environ.get("ODW_NO_OVERLAP") != "1":
+                    # its gradient is produced by ONE GEMM per step (the batch): hand it to the exchange as it retires,
+                    # the largest ones (fc6: 411 MB) in row blocks
+                    weight._odw_grad_ready = self._on_grad_ready
+                    weight._odw_flat_offset = o
+                    weight._odw_slice_rows = (-(-n_out // self.wgrad_slices) + 255) // 256 * 256 if weight.numel() >= (64 << 20) else 0
                 self.shadows.append(sh)
                 return sh
 
@@ -296,6 +379,14 @@ class FlatSGD(object):
         saved under that factor)."""
         self.lr_scale = lr_factor(self.cfg, iteration) if iteration > 0 else 1.0
 
+    def _on_grad_ready(self, weight, r0, r1):
+        """gemm.WgradBatch: rows [r0, r1) of `weight`'s gradient are final (called from backward)."""
+        if getattr(self, "hold", False):
+            return                      # inside a SOLVER.ITER_SIZE group: exchanged once, after its last backward
+        k = weight.shape[1]
+        o = weight._odw_flat_offset
+        self.exchange.ready(o + r0 * k, o + r1 * k)
+
     def begin_step(self, accumulate=False):
         """Gradient buffer state for a new step: GEMM weights are overwritten by their first wgrad
         launch; everything autograd accumulates into (convs, predictor heads, biases) is zeroed.
@@ -306,6 +397,7 @@ class FlatSGD(object):
             self.flat_g[self.n_gemm:].zero_()
         self.early_done = False
         self.hold = False
+        self.exchange.begin()
 
     def _sgd_region(self, i, paced=0):
         """paced = workgroup cap of an update that runs BESIDE other kernels (head_grads_ready): at full width the
@@ -333,15 +425,24 @@ class FlatSGD(object):
         self.flush_wgrad()
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
-            all_reduce_flat(self.flat_g[:self.n_gemm], self.world)
+            self.exchange.finish(0, self.n_gemm)       # what the weight-gradient GEMMs did not hand over as they retired
             # (paced only without an exchange in front of it: at N > 1 the all-reduce already takes the window)
             self._sgd_region(0, paced=int(os.environ.get("ODW_SGD_PACE", "256")) if self.world == 1 else 0)
             self._refresh_shadows()
         self.early_done = True
 
     def all_reduce(self):
-        """Whatever has not been exchanged by head_grads_ready (the backbone and the biases, or everything)."""
-        all_reduce_flat(self.flat_g[self.n_gemm:] if self.early_done else self.flat_g, self.world)
+        """Whatever has not been exchanged yet (the backbone and the biases, or everything)."""
+        if self.early_done:
+            self.exchange.finish(self.n_gemm, self.total)
+        elif self.side is not None and self.exchange.works:
+            # pieces were issued on the side stream but the head's early step did not run (ODW_NO_OVERLAP, ITER_SIZE)
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.exchange.finish(0, self.total)
+            torch.cuda.current_stream().wait_stream(self.side)
+        else:
+            self.exchange.finish(0, self.total)
 
     def flush_wgrad(self):
         """Weight-gradient batches whose last registered evaluation never ran its backward (e.g. a loss that does not

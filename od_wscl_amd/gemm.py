@@ -173,7 +173,21 @@ class WgradBatch(object):
             weight.grad = torch.empty_like(weight)
         weight._odw_fresh = False
         kernel_timer.layer = tag and tag + "_wgrad"
-        gemm_nt(self.dzt, self.xt, weight.shape[0], weight.shape[1], self.kpad, weight.grad, accumulate=not fresh)
+        n_out, k_in = weight.shape
+        # data-parallel runs (engine.GradExchange): the product is cut into row blocks of the gradient -- contiguous
+        # pieces of the flat gradient buffer -- and each block is handed to the exchange as it retires, so that the
+        # all-reduce of fc6's 411 MB runs under the rest of this GEMM and of the backward instead of after it
+        ready = getattr(weight, "_odw_grad_ready", None)
+        rows = int(getattr(weight, "_odw_slice_rows", 0)) if ready is not None else 0
+        if rows <= 0 or rows >= n_out:
+            gemm_nt(self.dzt, self.xt, n_out, k_in, self.kpad, weight.grad, accumulate=not fresh)
+            if ready is not None:
+                ready(weight, 0, n_out)
+        else:
+            for r0 in range(0, n_out, rows):
+                r1 = min(n_out, r0 + rows)
+                gemm_nt(self.dzt[r0:r1], self.xt, r1 - r0, k_in, self.kpad, weight.grad[r0:r1], accumulate=not fresh)
+                ready(weight, r0, r1)
         kernel_timer.layer = None
         self.reset()
 
@@ -254,8 +268,9 @@ def _backward_single_plane(xb, y, weight, bias, cfg, dy, need_dx):
                                              L.ptr(y), y.stride(0) if y is not None else 0, M, N, scale,
                                              L.ptr(dz), n8, L.ptr(dzt), ld_t, t_cols, L.ptr(db), L.stream()),
             "linear_bwd_prep")
-    dx = None
-    if need_dx:
+    def input_gradient():
+        if not need_dx:
+            return None
         dx_all = torch.empty((M_all, K), dtype=x_dtype, device=dy.device)
         dx = dx_all
         if grad_rows is not None:
@@ -266,7 +281,12 @@ def _backward_single_plane(xb, y, weight, bias, cfg, dy, need_dx):
         kernel_timer.layer = tag and tag + "_dgrad"
         gemm_nt(dz, sh.wt, M, K, N, dx)
         kernel_timer.layer = None
-        dx = dx_all
+        return dx_all
+
+    # a weight whose gradient is exchanged as it retires (N > 1 ranks): its gradient first, so that the collective
+    # also runs under this layer's input-gradient GEMM
+    wgrad_first = batch is not None and getattr(weight, "_odw_grad_ready", None) is not None
+    dx = None if wgrad_first else input_gradient()
     dw = None
     if weight.requires_grad and batch is not None:
         L.check(L.lib().odw_transpose_to_bf16_part(L.ptr(xb), x_f32, xb.stride(0), M, K, L.ptr(xt_all[:, off:]),
@@ -275,6 +295,8 @@ def _backward_single_plane(xb, y, weight, bias, cfg, dy, need_dx):
         batch.filled += 1
         if batch.filled == len(batch.rows):
             batch.flush(weight, tag)
+        if wgrad_first:
+            dx = input_gradient()
     elif weight.requires_grad:
         xt = transpose_bf16(xb, M, K)
         if weight.is_leaf:          # accumulate straight into the parameter's gradient buffer

@@ -37,6 +37,26 @@ def _worker(rank, world, port, out_dir):
     g = torch.from_numpy(synthetic.fill_weights(7 + rank, 5, (n,), 1.0).copy())
     local = g.clone()
     engine.all_reduce_flat(g, world, chunk_elems=400000)
+    # 2b) the same exchange piece by piece, as the pieces become final (engine.GradExchange: what the training step
+    #     runs -- weight-gradient row blocks announced from backward, the rest swept up at the end), fp32 and bf16 wire
+    gx = local.clone()
+    ex = engine.GradExchange(gx, world, chunk_elems=150000)
+    ex.begin()
+    ex.ready(300000, 700000)          # e.g. fc6's gradient, block by block
+    ex.ready(700000, 700100)
+    ex.ready(10, 1234)
+    left = ex.pending(0, n)
+    ex.finish(0, 900000)              # the head ...
+    ex.finish(900000, n)              # ... then the backbone and the biases
+    g16 = local.clone()
+    try:
+        e16 = engine.GradExchange(g16, world, dtype="bf16", chunk_elems=400000)
+        e16.begin()
+        e16.ready(0, 500000)
+        e16.finish(0, n)
+        bf16_ok = True
+    except RuntimeError:              # a gloo build without bf16 reductions: the wire format is exercised on the GPU box
+        bf16_ok = False
     # 3) the update the fused kernel performs with grad_scale = 1/world (torch restatement)
     p = torch.from_numpy(synthetic.fill_weights(3, 9, (n,), 0.1).copy())
     buf = torch.zeros(n)
@@ -47,7 +67,8 @@ def _worker(rank, world, port, out_dir):
     # 4) the logging reduce of the reference's trainer (engine/trainer.py:14-36)
     red = engine.reduce_loss_dict({"loss_b": torch.tensor(float(rank + 1)), "loss_a": torch.tensor(10.0 * (rank + 1))}, world)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), red_a=float(red["loss_a"]), red_b=float(red["loss_b"]), boxes=rois[0].bbox.numpy(), labels=targets[0].get_field("labels").numpy(),
-             img_sum=float(images.tensors.sum()), w=w, g=g.numpy(), local=local.numpy(), p_new=p_new.numpy())
+             img_sum=float(images.tensors.sum()), w=w, g=g.numpy(), local=local.numpy(), p_new=p_new.numpy(), gx=gx.numpy(),
+             left=np.array(left), g16=g16.numpy(), bf16_ok=np.array(int(bf16_ok)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,6 +84,13 @@ def test_two_rank_gloo_allreduce_and_sharding(tmp_path):
     np.testing.assert_array_equal(r0["g"], r1["g"])                                         # all-reduced
     np.testing.assert_allclose(r0["g"], r0["local"] + r1["local"], rtol=1e-6, atol=1e-6)   # = sum over ranks
     np.testing.assert_array_equal(r0["p_new"], r1["p_new"])                                 # replicas stay in sync
+    np.testing.assert_array_equal(r0["gx"], r0["g"])               # piecewise schedule == the monolithic exchange, bit for bit
+    np.testing.assert_array_equal(r0["gx"], r1["gx"])
+    assert r0["left"].tolist() == [[0, 10], [1234, 300000], [700100, 1000003]]
+    if int(r0["bf16_ok"]):                                         # bf16 on the wire: both ranks agree, within bf16 of the sum
+        np.testing.assert_array_equal(r0["g16"], r1["g16"])
+        want = r0["local"] + r1["local"]
+        assert np.abs(r0["g16"] - want).max() <= 2.0 ** -7 * np.abs(want).max()
     assert float(r0["red_a"]) == 15.0 and float(r0["red_b"]) == 1.5                          # rank 0: mean over the ranks
 
 
@@ -71,6 +99,9 @@ def test_world_one_is_a_noop():
     g = torch.ones(10)
     engine.all_reduce_flat(g, 1)
     assert torch.equal(g, torch.ones(10))
+    ex = engine.GradExchange(g, 1, dtype="bf16")
+    ex.begin(); ex.ready(0, 5); ex.finish(0, 10)
+    assert torch.equal(g, torch.ones(10)) and ex.stage is None
     d = {"loss": torch.tensor(2.0)}
     assert engine.reduce_loss_dict(d, 1) is d
 

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, overlap):
+def _worker(rank, world, port, out_dir, overlap, dtype="bf16"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       ODW_NO_TIMER="1", ODW_NO_OVERLAP="0" if overlap else "1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,8 +34,11 @@ def _worker(rank, world, port, out_dir, overlap):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     cfg = bench.build_cfg(21)
-    step, _ = engine.build_training_step(cfg, dev, dtype="bf16", world=world, seed=cfg.SEED, backend="hip")
+    step, _ = engine.build_training_step(cfg, dev, dtype=dtype, world=world, seed=cfg.SEED, backend="hip")
     images, targets, rois = bench.synthetic_batch(cfg.SEED, rank, 224, 120, 21, dev)
+    fc6 = step.model.roi_heads.feature_extractor.fc6.weight
+    # with the overlap on, the large weight gradients are handed to the exchange from backward, fc6's in row blocks
+    assert (getattr(fc6, "_odw_grad_ready", None) is not None) == overlap and (not overlap or 0 < fc6._odw_slice_rows < fc6.shape[0])
     losses = []
     for it in range(3):
         l, _ = step(images, targets, rois, DeviceRand(cfg.SEED + rank, first_stream=(1 << 20) + (it << 12), device=dev))
@@ -48,12 +51,16 @@ def _worker(rank, world, port, out_dir, overlap):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_keeps_replicas_identical(tmp_path):
+@pytest.mark.parametrize("dtype", ["bf16x2f", "bf16"])
+def test_two_rank_step_keeps_replicas_identical(tmp_path, dtype):
+    """overlap True: the weight gradients of fc6 / fc7 / Sim_Net are all-reduced as their GEMMs retire (fc6 in row
+    blocks, the gradient GEMM itself cut to match), the rest of the head right after the pooling backward, the backbone
+    after backward; overlap False: ONE exchange of the whole buffer after backward.  Same parameters either way."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     res = {}
     for overlap in (True, False):
-        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), overlap), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), overlap, dtype), nprocs=2, join=True)
         res[overlap] = [np.load(tmp_path / ("r%d_%d.npz" % (r, int(overlap)))) for r in range(2)]
     for overlap, (a, b) in res.items():
         assert np.isfinite(a["losses"]).all() and np.isfinite(b["losses"]).all()
@@ -86,13 +93,17 @@ def _rccl_worker(rank, port, out_dir):
         engine.all_reduce_flat(flat, 2, chunk_elems=1 << 20)         # world=2 forces the collective path; the group has 1 rank
     torch.cuda.current_stream().wait_stream(side)
     assert torch.equal(flat, want)
-    cfg = bench.build_cfg(21)
-    step, _ = engine.build_training_step(cfg, dev, dtype="bf16", world=2, seed=cfg.SEED, backend="hip")   # grad_scale 1/2
-    images, targets, rois = bench.synthetic_batch(cfg.SEED, 0, 224, 120, 21, dev)
     vals = []
-    for it in range(2):
-        l, _ = step(images, targets, rois, DeviceRand(cfg.SEED, first_stream=(1 << 20) + (it << 12), device=dev))
-        vals.append(float(sum(l.values())))
+    for wire in ("fp32", "bf16"):      # bf16 on the wire: RCCL's bf16 sum through the staging buffer, fp32 back
+        cfg = bench.build_cfg(21)
+        cfg.merge_from_list(["ODW.GRAD_EXCHANGE", wire])
+        step, _ = engine.build_training_step(cfg, dev, dtype="bf16x2f", world=2, seed=cfg.SEED, backend="hip")   # grad_scale 1/2
+        assert step.optimizer.exchange.dtype == wire and (step.optimizer.exchange.stage is not None) == (wire == "bf16")
+        images, targets, rois = bench.synthetic_batch(cfg.SEED, 0, 224, 120, 21, dev)
+        for it in range(2):
+            l, _ = step(images, targets, rois, DeviceRand(cfg.SEED, first_stream=(1 << 20) + (it << 12), device=dev))
+            vals.append(float(sum(l.values())))
+        del step
     dist.barrier()
     t = torch.tensor([1.5], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
