@@ -19,6 +19,10 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
+# experiment builds (tools/exp, timing studies that knowingly produce wrong results): ODW_EXTRA_FLAGS="-DODW_EXPERIMENTS"
+FLAGS += [f for f in os.environ.get("ODW_EXTRA_FLAGS", "").split() if f]
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 

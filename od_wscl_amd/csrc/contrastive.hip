@@ -95,205 +95,262 @@ __global__ __launch_bounds__(256) void pairwise_sim_kernel(const float* __restri
     }
 }
 
-// ------------------------------------------------------------------ pairwise, split-bf16 form
+// ------------------------------------------------------------------ pairwise, split-bf16 form (round 3)
 // The same E E^T on the bf16 matrix cores at fp32 grade: every fp32 value is carried as three bf16 planes
 // hi + mid + lo (csrc/split.hip) and a product as the six plane products of order <= 2 -- 6 x 2.5 PF-class MFMAs
-// instead of one 157 TF-class fp32 MFMA chain: the 32x32 tile costs 48 x 32 = 1536 MFMA cycles instead of 4096, and
-// more to the point the kernel becomes what its roofline says it is: a 4 P^2-byte WRITE of S (64 MB at P = 4000).
-//   * a pre-pass splits E once into planes (512 k values; in the main kernel the ~25 VALU operations per value,
-//     repeated by every workgroup that stages the row, were the whole run time: 64 of 73 us);
-//   * one 4-wave workgroup = one 128x128 block of the upper triangle (diagonal blocks last), each wave a 64x64
-//     quarter = 2x2 MFMA tiles, 64 accumulator registers; two workgroups per CU;
-//   * the 128 + 128 rows are staged 32 k at a time: 192 contiguous bytes per row -> LDS (80-byte row pitch: the
-//     16-lane phases of ds_read_b128 hit 16 distinct bank groups), the next stage's global loads in flight under
-//     the current stage's 48 MFMAs per wave;
-//   * the mirrored block is written from the same accumulators: the C layout gives a lane 4 consecutive rows of one
-//     column = 4 consecutive COLUMNS of one row of the mirror -> 16-byte stores; the direct block leaves as 128-byte
-//     row segments.  Diagonal 32x32 tiles write their upper triangle twice, so S == S^T bit for bit.
-// Measured (tools/pairwise_bench.py, P = 4000): 38 us against 73 us for the exact-fp32 chain and 57 us for rocBLAS;
-// with the stores suppressed 25 us, with the compute suppressed 18 us (the store pattern alone reaches 0.45-0.59 of
-// the 8 TB/s roofline; a plain fill of S takes 10.8 us = 0.73).  What is left is a fixed ~14 us (two launches and one
-// block's dependent chain of four staged loads -- the grid is a single round) and the L2 -> LDS fill rate of the
-// 135 MB of plane reads; non-temporal stores of S were tried and are worse (63 us: partial lines no longer merge).
+// instead of one 157 TF-class fp32 MFMA chain.  The kernel is then what its roofline says it is: a 4 P^2-byte WRITE
+// of S (64 MB at P = 4000), and its structure exists to keep that write stream busy from the first microsecond:
+//   * ONE launch.  A workgroup (8 waves) owns a 256-row panel of S and a run of 32-column blocks of it (upper
+//     triangle only; the runs are cut so that the 256 workgroups carry equal numbers of blocks).  Each wave keeps
+//     the three planes of ITS 32 rows of E for the whole K = 128 in registers (96 VGPRs): the A operand never
+//     touches LDS again.
+//   * The 32 rows of E of a column block are fetched as fp32 (512 coalesced bytes per row), split into planes in
+//     registers by the thread that fetched them (no pre-pass, no second launch: the split of round 2's pre-pass is
+//     ~14 VALU instructions per thread and block here) and parked in LDS, double buffered: 0.5 KB of LDS reads per
+//     MFMA, one barrier per block, the next block's loads in flight under the current block's 48 MFMAs per wave.
+//   * Every block ends with its stores -- the direct tile as 128-byte row segments, the mirrored tile through a
+//     wave-private padded LDS transpose so that it, too, leaves as full 128-byte lines -- and the wave moves on:
+//     stores of block b drain under the MFMAs of block b + 1, all through the kernel, instead of one burst at its end
+//     (round 2's one-round grid ran load -> MFMA -> store in lock-step across the chip: 25 + 18 us ~ the 38 us
+//     measured at P = 4000).
+//   * Diagonal 32x32 tiles write their upper triangle to both places, so S == S^T bit for bit.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ps_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ps_f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned short ps_f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+__device__ __forceinline__ unsigned ps_pk(float a, float b) {
+    const ps_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ps_bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
 }
 
-// 4 fp32 -> 3 planes x 4 bf16 (8 bytes each)
-__device__ __forceinline__ void ps_split4(const float4 v, uint2 (&pl)[3]) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned short h[4], m[4], l[4];
+// 8 fp32 -> hi / mid / lo planes, 8 bf16 (16 bytes) each; both subtractions are exact in fp32
+__device__ __forceinline__ void ps_split8(const float4 a, const float4 b, uint4& hi, uint4& mid, uint4& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[4], m[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = ps_f2bf(x[i]);
-        const float r1 = x[i] - __uint_as_float((unsigned)h[i] << 16);
-        m[i] = ps_f2bf(r1);
-        const float r2 = r1 - __uint_as_float((unsigned)m[i] << 16);
-        l[i] = ps_f2bf(r2);
+    for (int q = 0; q < 4; ++q) {
+        h[q] = ps_pk(x[2 * q], x[2 * q + 1]);
+        const float r0 = x[2 * q] - __uint_as_float(h[q] << 16), r1 = x[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u);
+        m[q] = ps_pk(r0, r1);
+        l[q] = ps_pk(r0 - __uint_as_float(m[q] << 16), r1 - __uint_as_float(m[q] & 0xffff0000u));
     }
-    pl[0] = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    pl[1] = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-    pl[2] = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    mid = make_uint4(m[0], m[1], m[2], m[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-constexpr int kPsPitch = 80;                         // bytes per staged row: 32 k x 2 B + 16 B pad
-constexpr int kPsRows = 128;                         // rows per side of a workgroup's block
-constexpr int kPsPlane = kPsRows * kPsPitch;         // one plane of one side
-constexpr int kPsSide = 3 * kPsPlane;                // 30720 B; two sides = 61440 B -> two workgroups per CU
+constexpr int kPwWaves = 8;                          // 7 compute waves + 1 loader wave
+constexpr int kPwCompute = kPwWaves - 1;
+constexpr int kPwPanel = 32 * kPwCompute;            // rows of S per workgroup panel (224)
+constexpr int kPwPitch = 16 * 16 + 16;               // bytes per staged plane row: 128 k x 2 B + 16 B pad (bank spread)
+constexpr int kPwSlot = 3 * 32 * kPwPitch;           // one column block: 3 planes x 32 rows
+constexpr int kPwTrPitch = 36;                       // floats per row of a wave's 32 x 32 transpose scratch
+constexpr int kPwLds = 2 * kPwSlot + kPwCompute * 32 * kPwTrPitch * 4;      // 52224 + 32256 bytes
 
-// pre-pass: E (P x 128 fp32) -> E3 (P x 384 bf16), row layout [stage 0..3][plane hi|mid|lo][32 k]: what one staging
-// step of the main kernel reads for a row is 192 contiguous bytes.  512 k values in all: the split costs ~25 VALU
-// operations per value, which is why it is NOT done in the main kernel (each row is staged by ~60 workgroups).
-__global__ __launch_bounds__(256) void pairwise_split_kernel(const float* __restrict__ E, int P, unsigned short* __restrict__ E3) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;          // (row, 8-k chunk)
-    const int row = id >> 4, c = id & 15;
-    if (row >= P) return;
-    const float4* src = reinterpret_cast<const float4*>(E + (size_t)row * kD + c * 8);
-    uint2 a[3], b[3];
-    ps_split4(src[0], a);
-    ps_split4(src[1], b);
-    unsigned short* dst = E3 + (size_t)row * 384 + (c >> 2) * 96 + (c & 3) * 8;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(dst + p * 32) = make_uint4(a[p].x, a[p].y, b[p].x, b[p].y);
+// number of 32-column blocks panel p works on: from its first row's block to the last block of S
+__device__ __host__ inline int pw_blocks_of(int p, int nblk32) { const int b = nblk32 - p * (kPwPanel / 32); return b > 0 ? b : 0; }
+
+#ifdef ODW_EXPERIMENTS          // timing studies (WRONG results): 1 no direct stores, 2 no mirror stores, 4 no MFMAs
+#define PW_DBG(bit) (dbg & (bit))
+#else
+#define PW_DBG(bit) false
+#endif
+// How this structure was arrived at (P = 4000, rocprofv3 + PMC, tools/exp/pairwise_dbg.sh, tools/pmc_pairwise.sh).  The
+// first form -- eight symmetric waves, each fetching its share of the next column block, running its MFMAs and storing
+// its tile -- took 26-28 us whatever the order of its instructions: without stores 20, without MFMAs 20, without both
+// 13, i.e. MFMA time (7 us), store time (7 us) and the fetch / barrier skeleton simply ADDED UP, and
+// SQ_WAIT_INST_ANY showed every wave spending 8 us in s_waitcnt.  gfx950 counts loads and stores in ONE counter
+// (vmcnt) and the two kinds may retire out of order, so a wave that has stores in flight can only consume a fetched
+// row after vmcnt(0): every block waited for the previous tile's stores to be acknowledged (>= 1.5 us under a chip-wide
+// store burst) before the next barrier could be reached.  (__syncthreads() has the same wait built in: pw_barrier.)
+// Hence the roles: ONE loader wave per workgroup fetches, splits and parks the next column block and never stores;
+// SEVEN compute waves read fragments, run MFMAs and store, and never wait on vmcnt at all -- their stores drain under
+// the next tile's MFMAs.
+struct PwRows { float4 a0, a1; };
+
+// Workgroup barrier that orders LDS traffic ONLY (see above).  The stores of S are never read back inside the kernel.
+__device__ __forceinline__ void pw_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void pairwise_sim_split_kernel(const unsigned short* __restrict__ E3, int P,
-                                                                 float* __restrict__ S, int nb, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];          // 2 * kPsSide
-    // linear block id -> (bi <= bj): off-diagonal blocks first (row bi holds nb - 1 - bi of them), the nb lighter
-    // diagonal blocks last (they fill the tail of the grid)
-    int bi, bj;
-    {
-        const int noff = nb * (nb - 1) / 2;
-        int t = blockIdx.x;
-        if (t >= noff) {
-            bi = bj = t - noff;
-        } else {
-            const float n2 = 2.0f * nb - 1.0f;
-            bi = (int)((n2 - sqrtf(n2 * n2 - 8.0f * (float)t)) * 0.5f);
-            bi = bi < 0 ? 0 : (bi >= nb - 1 ? nb - 2 : bi);
-            while (bi > 0 && bi * (nb - 1) - (bi * (bi - 1)) / 2 > t) --bi;
-            while ((bi + 1) * (nb - 1) - ((bi + 1) * bi) / 2 <= t) ++bi;
-            bj = bi + 1 + (t - (bi * (nb - 1) - (bi * (bi - 1)) / 2));
-        }
-    }
+__global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(const float* __restrict__ E, int P,
+                                                                              float* __restrict__ S, int total_items, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wy = wave >> 1, wx = wave & 1;
-    const int I = bi * kPsRows, J = bj * kPsRows;
-
-    // staging: 256 rows (A side then B side) x 12 uint4 (3 planes x 4 chunks of 8 k) per stage = 3072 / 256 threads
-    uint4 pre[12];
-    auto load_stage = [&](int s) {
-#pragma unroll
-        for (int it = 0; it < 12; ++it) {
-            const int id = tid + it * 256;
-            const int r = id / 12, q = id - r * 12;
-            const int grow = (r < kPsRows ? I + r : J + r - kPsRows);
-            pre[it] = grow < P ? *reinterpret_cast<const uint4*>(E3 + (size_t)grow * 384 + s * 96 + q * 8) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bool idle = bi == bj && wy > wx;              // the strictly-lower quarter of a diagonal block
-
-    load_stage(0);
-#pragma unroll 1
-    for (int s = 0; s < ((dbg & 2) ? 0 : 4); ++s) {
-#pragma unroll
-        for (int it = 0; it < 12; ++it) {
-            const int id = tid + it * 256;
-            const int r = id / 12, q = id - r * 12;
-            const int side = r >= kPsRows, rr = r - side * kPsRows;
-            *reinterpret_cast<uint4*>(lds + side * kPsSide + (q >> 2) * kPsPlane + rr * kPsPitch + (q & 3) * 16) = pre[it];
-        }
-        __syncthreads();
-        if (s < 3) load_stage(s + 1);                    // in flight under the MFMAs below
-        if (!idle) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int c = (2 * ks + half) * 16;      // this lane's 8 k of the 32-k row
-                bf16x8 fa[2][3], fb[2][3];
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        fa[r][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-                            lds + p * kPsPlane + (wy * 64 + r * 32 + l31) * kPsPitch + c));
-                        fb[r][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-                            lds + kPsSide + p * kPsPlane + (wx * 64 + r * 32 + l31) * kPsPitch + c));
-                    }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        f32x16 a = acc[i][j];
-                        // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], a, 0, 0, 0);
-                        acc[i][j] = a;
-                    }
-            }
-        }
-        __syncthreads();
+    const bool loader = wave == kPwCompute;
+    const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
+    // this workgroup's run of (panel, block) items in panel-major order
+    const long long lo_it = (long long)total_items * blockIdx.x / gridDim.x, hi_it = (long long)total_items * (blockIdx.x + 1) / gridDim.x;
+    if (lo_it >= hi_it) return;
+    int panel = 0, blk;
+    {
+        long long rest = lo_it;
+        while (panel < npanel && rest >= pw_blocks_of(panel, nblk32)) { rest -= pw_blocks_of(panel, nblk32); ++panel; }
+        blk = panel * (kPwPanel / 32) + (int)rest;
     }
-    if (idle) return;
-    if ((dbg & 1) && acc[0][0][0] != 12345.0f) return;
-
+    float* const scratch = reinterpret_cast<float*>(lds + 2 * kPwSlot) + (loader ? 0 : wave) * 32 * kPwTrPitch;
     const bool vec = (P & 3) == 0;
+    const bool small = (unsigned long long)P * (unsigned long long)P < (1ull << 30);      // 32-bit element offsets
+
+    // (row, 8-k chunk) items of a 32-row block: rows past the end are clamped to the last row (their products are
+    // never stored), so every load is unconditional
+    auto fetch_item = [&](int row, int chunk) {
+        PwRows r;
+        const float4* src = reinterpret_cast<const float4*>(E + (size_t)min(row, P - 1) * kD + chunk * 8);
+        r.a0 = src[0]; r.a1 = src[1];
+        return r;
+    };
+    auto park_item = [&](const PwRows& r, int slot, int row, int chunk) {
+        uint4 h, m, l;
+        unsigned char* base = lds + slot * kPwSlot + row * kPwPitch + chunk * 16;
+        ps_split8(r.a0, r.a1, h, m, l);
+        *reinterpret_cast<uint4*>(base) = h;
+        *reinterpret_cast<uint4*>(base + 32 * kPwPitch) = m;
+        *reinterpret_cast<uint4*>(base + 64 * kPwPitch) = l;
+    };
+    auto advance = [&](int& pn, int& b) {                // (panel, block) after (pn, b)
+        if (++b >= nblk32) { ++pn; b = pn * (kPwPanel / 32); }
+    };
+    const int srow = tid >> 4, schunk = tid & 15;        // all 512 threads: one item each of a 32-row block
+    const int lrow = lane >> 4, lchunk = lane & 15;      // loader wave: items (4 q + lrow, lchunk), q = 0..7
+
+    bf16x8 aH[8], aM[8], aL[8];
+    int have_panel = -1, slot = 0;
+    int p1 = panel, b1 = blk;
+    advance(p1, b1);
+    bool parked = false;
+
+    for (long long it = lo_it; it < hi_it; ++it) {
+        if (panel != have_panel) {
+            // ---- this workgroup's 224 rows of E: seven 32-row pieces fetched with coalesced rows by all eight waves (all
+            // fetches issued before the first wait), split, parked in the two block slots two at a time; compute wave w
+            // takes piece w's planes for the whole K into registers (lane: row l31, 8 k at 16 kk + 8 half)
+            if (parked) pw_barrier();                    // every wave is done reading the slots
+            PwRows pr[kPwCompute];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int q = 0; q < kPwCompute; ++q) pr[q] = fetch_item(panel * kPwPanel + q * 32 + srow, schunk);
+            const PwRows first = fetch_item(blk * 32 + srow, schunk);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int I0 = I + wy * 64 + i * 32, J0 = J + wx * 64 + j * 32;
-            if (J0 < I0 || I0 >= P || J0 >= P) continue;          // strictly-lower tiles of a diagonal block; past the end
-            const int col = J0 + l31;
-            if (I0 == J0) {
-                // diagonal tile: (r, c) and (c, r) were accumulated in different term orders -- write the upper
-                // triangle to both places so that S is exactly symmetric
+            for (int hp = 0; hp < (kPwCompute + 1) / 2; ++hp) {
+                park_item(pr[2 * hp], 0, srow, schunk);
+                if (2 * hp + 1 < kPwCompute) park_item(pr[2 * hp + 1 < kPwCompute ? 2 * hp + 1 : 0], 1, srow, schunk);
+                pw_barrier();
+                if (!loader && (wave >> 1) == hp) {
+                    const unsigned char* sa = lds + (wave & 1) * kPwSlot + l31 * kPwPitch + half * 16;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int r = crow(k, half);
-                    if (r <= l31 && col < P) {
-                        S[(size_t)(I0 + r) * P + col] = acc[i][j][k];
-                        S[(size_t)col * P + I0 + r] = acc[i][j][k];
+                    for (int kk = 0; kk < 8; ++kk) {
+                        aH[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + kk * 32));
+                        aM[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + 32 * kPwPitch + kk * 32));
+                        aL[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + 64 * kPwPitch + kk * 32));
                     }
                 }
-                continue;
+                pw_barrier();
             }
+            park_item(first, 0, srow, schunk);
+            slot = 0;
+            have_panel = panel;
+            parked = true;
+        }
+        pw_barrier();                                    // block `blk` is parked in `slot`; the other slot is free
+        if (loader) {
+            // ---- the loader wave: the next block's 32 rows (8 items per lane, 16 loads in flight), split, parked in the
+            // other slot.  Unconditional (past the end of the run the slot receives rows nobody reads).  Its vmcnt
+            // only ever counts loads.  (Fetching two blocks ahead -- the rows parked here loaded during the previous
+            // iteration -- measured no faster: in steady state a block lasts as long as the chip needs to WRITE the
+            // 14.7 MB that 256 x 7 tiles produce, ~3 us, not as long as this wave's load latency.)
+            const int nb = min(b1, nblk32 - 1) * 32;
+            PwRows q8[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {                        // direct tile: 128-byte row segments
-                const int r = I0 + crow(k, half);
-                if (r < P && col < P) S[(size_t)r * P + col] = acc[i][j][k];
-            }
-            if (col < P) {                                        // mirror: this lane's row `col`, 4 x 4 consecutive columns
-                float* dst = S + (size_t)col * P + I0 + 4 * half;
+            for (int q = 0; q < 8; ++q) q8[q] = fetch_item(nb + 4 * q + lrow, lchunk);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c0 = I0 + 8 * q + 4 * half;
-                    if (vec && c0 + 3 < P) {
-                        *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1],
-                                                                              acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            for (int q = 0; q < 8; ++q) park_item(q8[q], slot ^ 1, 4 * q + lrow, lchunk);
+        } else {
+            const int r0 = panel * kPwPanel + wave * 32, c0 = blk * 32;
+            if (c0 >= r0 && r0 < P) {                    // this wave's tile lies on or above the diagonal
+                const unsigned char* sb = lds + slot * kPwSlot + l31 * kPwPitch + half * 16;
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc;
+                if (!PW_DBG(4))
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const bf16x8 bH = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + kk * 32));
+                    const bf16x8 bM = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + 32 * kPwPitch + kk * 32));
+                    const bf16x8 bL = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + 64 * kPwPitch + kk * 32));
+                    // two accumulators, alternated (shorter dependent chains); per accumulator the smaller terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL[kk], bH, acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM[kk], bH, acc1, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH[kk], bL, acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH[kk], bM, acc1, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM[kk], bM, acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH[kk], bH, acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] += acc1[k];
+                const int col = c0 + l31;
+                const bool full = small && vec && r0 + 32 <= P && c0 + 32 <= P;      // wave-uniform: no per-element predicates
+                if (c0 == r0) {
+                    // diagonal tile: (r, c) and (c, r) were accumulated in different term orders -- the upper triangle
+                    // goes to both places so that S is exactly symmetric
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int r = crow(k, half);
+                        if (r <= l31 && col < P) {
+                            S[(size_t)(r0 + r) * P + col] = acc[k];
+                            S[(size_t)col * P + r0 + r] = acc[k];
+                        }
+                    }
+                } else {
+                    // mirror S[c0 + n][r0 + m]: the lane holds row n = l31 as 4 runs of 4 consecutive m -- parked in the
+                    // wave's scratch as rows of 32 floats, read back 8 lanes per row, stored as full 128-byte lines
+                    // (the wave's own LDS traffic is ordered: no barrier)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(scratch + l31 * kPwTrPitch + 8 * q + 4 * half) =
+                            make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                    if (full) {
+                        // interior tile: 32-bit element offsets from the kernel-argument base, no predicates
+                        const unsigned dbase = (unsigned)(r0 + 4 * half) * (unsigned)P + (unsigned)col;
+                        if (!PW_DBG(1))
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)      // direct tile: one 128-byte row segment per half-wave
+                            S[dbase + (unsigned)((k & 3) + 8 * (k >> 2)) * (unsigned)P] = acc[k];
+                        const unsigned mbase = (unsigned)(c0 + (lane >> 3)) * (unsigned)P + (unsigned)(r0 + (lane & 7) * 4);
+                        if (!PW_DBG(2))
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            *reinterpret_cast<float4*>(S + (mbase + (unsigned)(8 * t) * (unsigned)P)) =
+                                *reinterpret_cast<const float4*>(scratch + (t * 8 + (lane >> 3)) * kPwTrPitch + (lane & 7) * 4);
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c0 + e < P) dst[8 * q + e] = acc[i][j][4 * q + e];
+                        for (int k = 0; k < 16; ++k) {
+                            const int r = r0 + crow(k, half);
+                            if (r < P && col < P) S[(size_t)r * P + col] = acc[k];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int n = t * 8 + (lane >> 3), m4 = (lane & 7) * 4;
+                            const float4 v = *reinterpret_cast<const float4*>(scratch + n * kPwTrPitch + m4);
+                            const int row = c0 + n, cc = r0 + m4;
+                            if (row < P) {
+                                float* dst = S + (size_t)row * P + cc;
+                                if (vec && cc + 3 < P) *reinterpret_cast<float4*>(dst) = v;
+                                else {
+                                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) if (cc + u < P) dst[u] = e[u];
+                                }
+                            }
+                        }
                     }
                 }
             }
         }
+        slot ^= 1;
+        blk = b1; panel = p1;
+        advance(p1, b1);
+    }
 }
 
 // any D (multiple of 4): plain wave-per-row kernel, used when D != 128
@@ -500,22 +557,23 @@ ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void*
     ODW_REQUIRE(E && S, "pairwise_sim: null pointer");
     ODW_REQUIRE((((uintptr_t)E) & 15) == 0, "pairwise_sim: E must be 16-byte aligned");
     static const bool fp32_chain = getenv("ODW_PAIRWISE_FP32") != nullptr;      // force the exact-fp32 MFMA form (comparison)
-    if (D == kD && !fp32_chain && workspace && workspace_bytes >= odw_pairwise_sim_workspace(P, D) &&
-        (((uintptr_t)S) & 15) == 0 && (((uintptr_t)workspace) & 15) == 0) {
-        // split-bf16 form: planes once, then the 128 x 128 blocks of the upper triangle
-        unsigned short* E3 = (unsigned short*)workspace;
-        pairwise_split_kernel<<<(P * 16 + 255) / 256, 256, 0, stream>>>(E, P, E3);
-        ODW_CHECK_LAUNCH("pairwise_split_kernel");
-        const int nb = (P + kPsRows - 1) / kPsRows;
-#ifdef ODW_EXPERIMENTS      // timing experiments that skip compute or stores (WRONG results): experiment builds only
+    if (D == kD && !fp32_chain && (((uintptr_t)S) & 15) == 0) {
+        // split-bf16 panel form: one launch, no workspace (the planes are made in registers)
+        (void)workspace; (void)workspace_bytes;
+        const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
+        long long items = 0;
+        for (int pnl = 0; pnl < npanel; ++pnl) items += pw_blocks_of(pnl, nblk32);
+        const int grid = (int)(items < ODW_NUM_CU ? items : ODW_NUM_CU);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_sim_panel_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPwLds);      // once
+        ODW_CHECK_HIP(attr, "pairwise attr");
+#ifdef ODW_EXPERIMENTS
         static const int dbg = getenv("ODW_PAIRWISE_DBG") ? atoi(getenv("ODW_PAIRWISE_DBG")) : 0;
 #else
         const int dbg = 0;
 #endif
-        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_sim_split_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kPsSide), "pairwise attr");
-        pairwise_sim_split_kernel<<<nb * (nb + 1) / 2, 256, 2 * kPsSide, stream>>>(E3, P, S, nb, dbg);
-        ODW_CHECK_LAUNCH("pairwise_sim_split_kernel");
+        pairwise_sim_panel_kernel<<<grid, kPwWaves * 64, kPwLds, stream>>>(E, P, S, (int)items, dbg);
+        ODW_CHECK_LAUNCH("pairwise_sim_panel_kernel");
     } else if (D == kD) {
         const int nb = (P + 63) / 64;
         pairwise_sim_kernel<<<dim3(nb, nb), 256, 0, stream>>>(E, P, S);
@@ -530,7 +588,7 @@ ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void*
 }
 
 ODW_EXPORT int odw_pairwise_sim(const float* E, int P, int D, float* S, void* stream_) {
-    return odw_pairwise_sim_ws(E, P, D, S, nullptr, 0, stream_);          // no workspace: the exact-fp32 MFMA chain
+    return odw_pairwise_sim_ws(E, P, D, S, nullptr, 0, stream_);          // (the panel kernel needs no workspace)
 }
 
 ODW_EXPORT int64_t odw_supcon_workspace(int N) {
