@@ -193,14 +193,22 @@ def pairwise_sim_live(device, sizes=(2000, 4000, 8000), iters=30):
             L.check(lib.odw_pairwise_sim_ws(L.ptr(e), p, 128, L.ptr(s_mat), L.ptr(ws), wsb, L.stream()), "pairwise_sim")
         for _ in range(5):
             launch()
+        torch.cuda.synchronize()
+        # `iters` launches captured in ONE HIP graph and replayed: the events then bracket back-to-back kernels, not the
+        # host's launch calls (a 13 us kernel launched through ctypes is host-bound)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(iters):
+                launch()
+        graph.replay()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record()
-        for _ in range(iters):
-            launch()
+        graph.replay()
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) / iters * 1e3
+        del graph
         nbytes = 4.0 * p * p + 512.0 * p
         out["pairwise_sim P=%d" % p] = {"bound": "hbm", "avg_launch_us": round(us, 2), "algorithmic_bytes": int(nbytes),
                                         "achieved_GBps": round(nbytes / us / 1e3, 1), "peak_GBps": HBM_PEAK_GBPS,
