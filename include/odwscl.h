@@ -380,9 +380,8 @@ int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int ldb, int C
  * Cp a power of two >= 128. */
 /* out[n] += sum over the M rows of X (bf16, fp32 sums): the bias gradient beside odw_conv_wgrad_tn */
 int odw_colsum_bf16(const void* X, int ld, int M, int N, float* out, void* stream);
-/* the same sums in ONE summation order (run-to-run identical bias gradients): row-block partials parked in the
- * workspace, added in order by the last block to arrive.  The first 4 * ceil(N / 64) bytes of the workspace must be zero
- * on entry and are left zero -- allocate odw_colsum_workspace(M, N) bytes of zeros once and reuse them. */
+/* the same sums in ONE summation order (run-to-run identical bias gradients): row-chunk partials parked in the
+ * workspace (odw_colsum_workspace(M, N) bytes of scratch), added in chunk order by a second small launch. */
 int64_t odw_colsum_workspace(int M, int N);
 int odw_colsum_bf16_ws(const void* X, int ld, int M, int N, float* out, void* workspace, int64_t workspace_bytes,
                        void* stream);

@@ -120,25 +120,28 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* 
     }
 }
 
-// The same sums with ONE summation order whatever the arrival order of the workgroups (the float atomicAdd above makes
-// the bias gradient differ from run to run): every row block parks its 64 column sums, the LAST block of a column
-// group to arrive (ticket counter) adds the parked sums in row-block order.  `tickets` must be zero on entry and is
-// left zero (the last block resets its counter), so one persistent buffer serves every call.
-__global__ __launch_bounds__(256) void colsum_bf16_det_kernel(const unsigned short* __restrict__ X, int ld, int M, int N,
-                                                              float* __restrict__ out, float* __restrict__ part,
-                                                              unsigned* __restrict__ tickets) {
+// The same sums with ONE summation order (the float atomicAdd above makes the bias gradient differ from run to run): the
+// rows are cut into `chunks` contiguous pieces, a workgroup adds its piece in a fixed order (8 rows in flight per
+// thread group, 32 thread groups combined in order through LDS) and parks 64 column sums; a second small launch adds the
+// parked sums of each column in chunk order.  (A single launch with a ticket counter -- the last block to arrive doing
+// the final sum -- was tried: its device-scope __threadfence() is an L2 write-back on this multi-XCD part, 43-54 us
+// per call against ~10 for the atomic form.)
+__global__ __launch_bounds__(256) void colsum_bf16_part_kernel(const unsigned short* __restrict__ X, int ld, int M, int N,
+                                                               int rows_per_chunk, float* __restrict__ part) {
     __shared__ float sm[32][65];
-    __shared__ unsigned s_last;
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 256;
+    const int n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
     const int ch = threadIdx.x & 7, r = threadIdx.x >> 3;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (n0 + ch * 8 < N) {
+        const unsigned short* col = X + n0 + ch * 8;
+        for (int m = m0 + r; m < m1; m += 32 * 4) {
+            uint4 v[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int m = m0 + r + 32 * k;
-            if (m < M) {
-                const uint4 v = *reinterpret_cast<const uint4*>(X + (size_t)m * ld + n0 + ch * 8);
-                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+            for (int u = 0; u < 4; ++u) v[u] = m + 32 * u < m1 ? *reinterpret_cast<const uint4*>(col + (size_t)(m + 32 * u) * ld) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { acc[2 * q] += __uint_as_float(w[q] << 16); acc[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u); }
             }
@@ -153,18 +156,20 @@ __global__ __launch_bounds__(256) void colsum_bf16_det_kernel(const unsigned sho
         for (int k = 0; k < 32; ++k) t += sm[k][threadIdx.x];
         part[(size_t)blockIdx.y * N + n0 + threadIdx.x] = t;
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(tickets + blockIdx.x, 1u) == gridDim.y - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x < 64 && n0 + (int)threadIdx.x < N) {
-        float t = 0.0f;
-        for (unsigned k = 0; k < gridDim.y; ++k) t += __builtin_nontemporal_load(part + (size_t)k * N + n0 + threadIdx.x);
-        out[n0 + threadIdx.x] += t;
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int chunks, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float t = 0.0f;
+    for (int c0 = 0; c0 < chunks; c0 += 16) {        // 16 loads in flight, added in chunk order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = c0 + u < chunks ? part[(size_t)(c0 + u) * N + n] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += v[u];
     }
-    if (threadIdx.x == 0) tickets[blockIdx.x] = 0u;
+    out[n] += t;
 }
 
 // dw[co][ci][t] = dwk[co][t*Cp + ci]
@@ -488,13 +493,22 @@ ODW_EXPORT int odw_colsum_bf16(const void* X, int ld, int M, int N, float* out, 
     return ODW_OK;
 }
 
+namespace {
+int colsum_chunks(int M, int N) {          // enough workgroups to fill the chip, at least 256 rows each
+    const int groups = (N + 63) / 64;
+    int c = (2 * ODW_NUM_CU + groups - 1) / groups;
+    const int most = (M + 255) / 256;
+    c = c > most ? most : c;
+    return c < 1 ? 1 : (c > 64 ? 64 : c);
+}
+}  // namespace
+
 ODW_EXPORT int64_t odw_colsum_workspace(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    return odw_align_up((int64_t)((N + 63) / 64) * 4, 256) + (int64_t)((M + 255) / 256) * N * 4;
+    return (int64_t)colsum_chunks(M, N) * N * 4;
 }
 
-// deterministic form: workspace = odw_colsum_workspace(M, N) bytes whose FIRST 4 * ceil(N / 64) bytes are zero on entry
-// (they are left zero: allocate once with zeros, reuse for every call)
+// deterministic form: workspace = odw_colsum_workspace(M, N) bytes of scratch (no initial contents required)
 ODW_EXPORT int odw_colsum_bf16_ws(const void* X, int ld, int M, int N, float* out, void* workspace, int64_t workspace_bytes,
                                   void* stream_) {
     ODW_REQUIRE(M >= 0 && N >= 0 && ld >= N, "colsum_bf16: bad dims");
@@ -502,11 +516,13 @@ ODW_EXPORT int odw_colsum_bf16_ws(const void* X, int ld, int M, int N, float* ou
     ODW_REQUIRE(X && out && N % 8 == 0 && ld % 8 == 0 && (((uintptr_t)X) & 15) == 0, "colsum_bf16: N, ld multiples of 8, X 16-byte aligned");
     ODW_REQUIRE(workspace && workspace_bytes >= odw_colsum_workspace(M, N) && (((uintptr_t)workspace) & 15) == 0,
                 "colsum_bf16_ws: workspace of odw_colsum_workspace(M, N) bytes, 16-byte aligned");
-    unsigned* tickets = (unsigned*)workspace;
-    float* part = (float*)((char*)workspace + odw_align_up((int64_t)((N + 63) / 64) * 4, 256));
-    colsum_bf16_det_kernel<<<dim3((N + 63) / 64, (M + 255) / 256), 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X, ld, M, N,
-                                                                                                     out, part, tickets);
-    ODW_CHECK_LAUNCH("colsum_bf16_det_kernel");
+    const int chunks = colsum_chunks(M, N);
+    const int rows = ((M + chunks - 1) / chunks + 31) / 32 * 32;
+    float* part = (float*)workspace;
+    colsum_bf16_part_kernel<<<dim3((N + 63) / 64, chunks), 256, 0, (hipStream_t)stream_>>>((const unsigned short*)X, ld, M, N, rows, part);
+    ODW_CHECK_LAUNCH("colsum_bf16_part_kernel");
+    colsum_finish_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream_>>>(part, chunks, N, out);
+    ODW_CHECK_LAUNCH("colsum_finish_kernel");
     return ODW_OK;
 }
 

@@ -152,7 +152,7 @@ def _backward_single_plane(ctx, dfeat):
             # dZ and the layer input as they are (NHWC rows): K-major operands, transposed fragment reads
             cs_bytes = lib.odw_colsum_workspace(m, l.cout)
             if getattr(net, "colsum_ws", None) is None or net.colsum_ws.numel() < cs_bytes:
-                net.colsum_ws = torch.zeros(cs_bytes, dtype=torch.uint8, device=dev)     # tickets: zero once, left zero
+                net.colsum_ws = torch.empty(cs_bytes, dtype=torch.uint8, device=dev)
             L.check(lib.odw_colsum_bf16_ws(L.ptr(dz), l.cout, m, l.cout, L.ptr(conv.bias.grad), L.ptr(net.colsum_ws),
                                            net.colsum_ws.numel(), st), "conv bias grad")
             ws_bytes = lib.odw_conv_wgrad_tn_workspace(l.cout, l.cp, m)

@@ -296,6 +296,17 @@ def test_conv_weight_gradient(lib, B, Cin, Cout, H, W, dil):
         db2 = torch.zeros(Cout, device="cuda")
         L.check(L.lib().odw_colsum_bf16(L.ptr(dyn), dyn.stride(0), m, Cout, L.ptr(db2), L.stream()), "colsum")
         assert (db2 - ref_b).abs().max().item() <= 3e-3 * max(1.0, ref_b.abs().max().item())
+        # the two-stage form the training step uses: same sums, ONE summation order -> identical from run to run, added
+        # onto what `out` holds
+        csb = L.lib().odw_colsum_workspace(m, Cout)
+        cws = torch.empty(csb, dtype=torch.uint8, device="cuda")
+        outs = []
+        for _ in range(3):
+            db3 = torch.full((Cout,), 0.5, device="cuda")
+            L.check(L.lib().odw_colsum_bf16_ws(L.ptr(dyn), dyn.stride(0), m, Cout, L.ptr(db3), L.ptr(cws), csb, L.stream()), "colsum_ws")
+            outs.append(db3 - 0.5)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        assert (outs[0] - ref_b).abs().max().item() <= 3e-3 * max(1.0, ref_b.abs().max().item())
 
 
 def test_conv_weight_prep_batch_equals_per_layer(lib):
