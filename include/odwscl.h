@@ -458,6 +458,12 @@ int odw_maxpool3x3s2_nhwc_f32(const float* X, int B, int H, int W, int C, float*
  * convolution of the fp32 NCHW image, weight (Co,3,3,3) fp32, + bias + ReLU -> NHWC bf16 (B*H*W, Co), direct form. */
 int odw_stem_conv3x3_bias_relu(const float* img_nchw, const float* weight, const float* bias, int B, int H, int W, int Co,
                                void* out_nhwc_bf16, void* stream);
+/* the same layer with the result written as bf16 PLANES of the fp32 values (see odw_split_rows_bf16): out_planes
+ * (B*H*W x ld) bf16, T column blocks of `block` >= Co channels holding plane pattern[t] -- the operand of the next
+ * convolution in the split-precision modes, without an fp32 tensor and a split pass in between */
+int odw_stem_conv3x3_bias_relu_planes(const float* img_nchw, const float* weight, const float* bias, int B, int H, int W,
+                                      int Co, const int* pattern, int T, void* out_planes, int64_t ld, int block,
+                                      void* stream);
 
 /* ---- fp32-grade products on the bf16 matrix cores: operand splitting ("bf16x3") ---------------
  * replaces the fp32 cuBLAS / cuDNN arithmetic behind torch.nn.Linear / Conv2d in the reference

@@ -107,6 +107,7 @@ SIGNATURES = {
     "odw_relu_bwd_bf16": (c_i, [c_p, c_p, c_p, c_l, c_p]),
     "odw_stem_conv7x7_bn_relu": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_stem_conv3x3_bias_relu": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "odw_stem_conv3x3_bias_relu_planes": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_i, c_p]),
     "odw_maxpool3x3s2_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_detect_decode": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
     "odw_detect_filter": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p]),

@@ -7,6 +7,7 @@
 //   maxpool3x3s2    3x3 / stride 2 / pad 1 max pool (:404)
 // The stem and layer1 are frozen in every shipped config (FREEZE_CONV_BODY_AT 2), so the last two are forward-only.
 #include "odw_common.h"
+#include "odw_planes.h"
 
 namespace {
 
@@ -110,9 +111,14 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
 // runs at 14 TF (90 us at 608x608, + 11 us for the layout pass of the image); it is 47 MB of output and 0.64 GFLOP.
 // (First version, one thread per pixel x 8 channels: 80 us, issue-bound on its 27 loads per 216 FMAs.)
 // One thread = one pixel x 8 output channels; weights [tap*3 + ci][co] fp32 and the bias in LDS.
+// PLANES: the result leaves as bf16 planes of the fp32 values (precision mode "bf16x2f": the input operand of the
+// next convolution, T column blocks of `block` channels holding plane pat[t]) instead of rounded bf16 -- the kernel's
+// arithmetic is an fp32 fmaf chain either way, so the split-precision modes need no MFMA pass for the 3-channel layer.
+template <bool PLANES>
 __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int B, int H, int W, int Co,
-                                                           unsigned short* __restrict__ out) {
+                                                           unsigned short* __restrict__ out, odwpl::Pattern pat, int ld,
+                                                           int block) {
     extern __shared__ float w_lds[];                // 27*Co weights, then Co bias
     float* s_bias = w_lds + 27 * Co;
     for (int i = threadIdx.x; i < 27 * Co; i += blockDim.x) {
@@ -140,7 +146,10 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) v[(ky * 3 + kx) * 3 + ci] = ok ? base[((size_t)ci * H + y) * W + x] : 0.0f;
             }
-        uint4* o = reinterpret_cast<uint4*>(out + p * Co);
+        uint4* o = reinterpret_cast<uint4*>(out + p * (PLANES ? (size_t)ld : (size_t)Co));
+        bool need_lo = false;
+        if (PLANES)
+            for (int t = 0; t < pat.T; ++t) need_lo |= pat.p[t] == 2;
         for (int g = 0; g < Co / 8; ++g) {
             float acc[8];
 #pragma unroll
@@ -150,6 +159,19 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
                 const float* wk = w_lds + k * Co + g * 8;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) acc[q] = fmaf(v[k], wk[q], acc[q]);
+            }
+            if (PLANES) {
+                unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    odwpl::split2(fmaxf(acc[2 * q], 0.0f), fmaxf(acc[2 * q + 1], 0.0f), need_lo, hi[q], mid[q], lo[q]);
+                for (int t = 0; t < pat.T; ++t) {
+                    const int pl = pat.p[t];
+                    o[(t * block) / 8 + g] = pl == 0 ? make_uint4(hi[0], hi[1], hi[2], hi[3])
+                                           : (pl == 1 ? make_uint4(mid[0], mid[1], mid[2], mid[3])
+                                           : (pl == 2 ? make_uint4(lo[0], lo[1], lo[2], lo[3]) : make_uint4(0, 0, 0, 0)));
+                }
+                continue;
             }
             unsigned wo[4];
 #pragma unroll
@@ -310,8 +332,28 @@ ODW_EXPORT int odw_stem_conv3x3_bias_relu(const float* img_nchw, const float* we
     const size_t total = (size_t)B * H * W;
     const size_t lds = (size_t)28 * Co * sizeof(float);
     const int grid = blocks_for(total) > 4096 ? 4096 : blocks_for(total);
-    stem_conv3x3_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(img_nchw, weight, bias, B, H, W, Co,
-                                                                 (unsigned short*)out_nhwc_bf16);
+    odwpl::Pattern none;
+    none.T = 0;
+    stem_conv3x3_kernel<false><<<grid, 256, lds, (hipStream_t)stream_>>>(img_nchw, weight, bias, B, H, W, Co,
+                                                                        (unsigned short*)out_nhwc_bf16, none, 0, 0);
+    ODW_CHECK_LAUNCH("stem_conv3x3_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_stem_conv3x3_bias_relu_planes(const float* img_nchw, const float* weight, const float* bias, int B, int H,
+                                                 int W, int Co, const int* pattern, int T, void* out_planes, int64_t ld,
+                                                 int block, void* stream_) {
+    odwpl::Pattern pat;
+    ODW_REQUIRE(odwpl::pattern_ok(pattern, T, pat), "stem_conv3x3_planes: pattern = up to %d plane codes in 0..3", odwpl::kMaxTerms);
+    ODW_REQUIRE(B > 0 && H > 0 && W > 0 && Co > 0 && Co % 8 == 0 && Co <= 256, "stem_conv3x3_planes: bad dims");
+    ODW_REQUIRE(block >= Co && block % 8 == 0 && ld >= (int64_t)T * block && ld % 8 == 0 && ld < (1ll << 31),
+                "stem_conv3x3_planes: block / ld");
+    ODW_REQUIRE(img_nchw && weight && out_planes && (((uintptr_t)out_planes) & 15) == 0, "stem_conv3x3_planes: pointers");
+    const size_t total = (size_t)B * H * W;
+    const size_t lds = (size_t)28 * Co * sizeof(float);
+    const int grid = blocks_for(total) > 4096 ? 4096 : blocks_for(total);
+    stem_conv3x3_kernel<true><<<grid, 256, lds, (hipStream_t)stream_>>>(img_nchw, weight, bias, B, H, W, Co,
+                                                                       (unsigned short*)out_planes, pat, (int)ld, block);
     ODW_CHECK_LAUNCH("stem_conv3x3_kernel");
     return ODW_OK;
 }

@@ -290,17 +290,45 @@ class _VGGMixedFn(torch.autograd.Function):
         B, C, H, W = images.shape
         dev = images.device
         st = L.stream()
-        cp0 = net.layers[0].cp
-        x = torch.empty((B * H * W, cp0), dtype=torch.float32, device=dev)
-        L.check(lib.odw_nchw_f32_to_nhwc_f32(L.ptr(images.contiguous()), B, H * W, C, cp0, L.ptr(x), st), "nchw_to_nhwc_f32")
+        import ctypes
+        l0 = net.layers[0]
+        # a frozen 3-channel first layer runs as the direct fp32 kernel of the bf16 mode (an fmaf chain per output:
+        # fp32-grade as it is) and writes the PLANES the second layer reads -- no NHWC copy of the image, no K = 27
+        # MFMA pass, no fp32 activation + split pass
+        direct0 = (not l0.trainable and l0.cin == 3 and l0.dil == 1 and l0.relu and not l0.pool and l0.cout % 8 == 0
+                   and len(net.layers) > 1 and os.environ.get("ODW_NO_STEM") != "1")
+        x = None
+        if not direct0:
+            cp0 = l0.cp
+            x = torch.empty((B * H * W, cp0), dtype=torch.float32, device=dev)
+            L.check(lib.odw_nchw_f32_to_nhwc_f32(L.ptr(images.contiguous()), B, H * W, C, cp0, L.ptr(x), st), "nchw_to_nhwc_f32")
         saved = []
         h, w = H, W
-        for l in net.layers:
+        xs_ready = None                     # the next layer's plane operand, when its producer wrote it itself
+        for li, l in enumerate(net.layers):
             m = B * h * w
+            if li == 0 and direct0:
+                nxt = net.layers[1]
+                pn, _ = P.conv_patterns(nxt.cp)
+                xs_ready = torch.empty((m, len(pn) * nxt.cp), dtype=torch.bfloat16, device=dev)
+                if nxt.cp != l.cout:
+                    xs_ready.zero_()
+                cpat = (ctypes.c_int * len(pn))(*pn)
+                L.check(lib.odw_stem_conv3x3_bias_relu_planes(L.ptr(images.contiguous()), L.ptr(l.conv.weight.detach()),
+                                                              L.ptr(l.conv.bias.detach()), B, H, W, l.cout,
+                                                              ctypes.cast(cpat, ctypes.c_void_p), len(pn), L.ptr(xs_ready),
+                                                              xs_ready.stride(0), nxt.cp, st), "stem_conv3x3_planes")
+                saved.append((None, None, h, w))
+                continue
             pa, _ = P.conv_patterns(l.cp)
             T = len(pa)
-            xs = P.split_rows(x, pa, l.cp)
-            x16 = P.split_rows(x, (0,), l.cp) if l.trainable else None
+            if xs_ready is not None:
+                xs, xs_ready = xs_ready, None
+                assert not l.trainable
+                x16 = None
+            else:
+                xs = P.split_rows(x, pa, l.cp)
+                x16 = P.split_rows(x, (0,), l.cp) if l.trainable else None
             y = torch.empty((m, l.cout), dtype=torch.float32, device=dev)
             _conv3x3(lib, xs, m, h, w, T * l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
                      2.0 * m * l.cout * 9 * l.cin * T)
