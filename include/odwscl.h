@@ -369,6 +369,12 @@ int odw_conv_wgrad_unpack(const float* dwk, int ld, int Co, int Ci, int Cp, floa
 /* every layer of a body in one launch: host arrays of length n (<= 32) of the arguments of odw_conv_weight_prep */
 int odw_conv_weight_prep_batch(int n, const void* const* w, const int* Co, const int* Ci, const int* Cp,
                                void* const* wk, const int* ldk, void* const* wd, const int* ldd, void* stream);
+/* the same with wk written as bf16 PLANES of the fp32 weights (the forward operand of the split-precision modes):
+ * T[i] (0 = plain bf16, 1..4) blocks of Cp[i] channels per tap, block tt holding plane patterns[4 i + tt]
+ * (0 hi, 1 mid, 2 lo, 3 zeros); ldk[i] >= 9 * T[i] * Cp[i]; wd stays single-plane bf16.  T = NULL: plain. */
+int odw_conv_weight_prep_planes_batch(int n, const void* const* w, const int* Co, const int* Ci, const int* Cp,
+                                      void* const* wk, const int* ldk, void* const* wd, const int* ldd,
+                                      const int* T, const int* patterns, void* stream);
 /* convolution weight gradient as one call: dw (Co,Ci,3,3 fp32) (+)= dZ^T im2col(X) from the operands
  * odw_linear_bwd_prep (dzt: Co x lda) and odw_im2col_t_bf16 (colt: 9*Cp x ldb) write, K = pixels: split-K partial
  * products into the workspace, then ONE pass that reduces the slices and unpacks [co][tap*Cp+ci] -> [co][ci][tap] */

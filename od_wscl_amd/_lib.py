@@ -85,6 +85,7 @@ SIGNATURES = {
     "odw_conv_weight_prep": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_p]),
     "odw_conv_wgrad_unpack": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_conv_weight_prep_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "odw_conv_weight_prep_planes_batch": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "odw_conv_wgrad_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "odw_conv_wgrad_nt": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_l, c_p]),
     "odw_colsum_bf16": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),

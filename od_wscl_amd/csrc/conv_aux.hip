@@ -40,7 +40,8 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Co, int Ci, 
 // every layer of a body in ONE launch (blockIdx.y = layer): the per-layer launches were 9 x ~14 us of a few thousand
 // elements each at the head of every forward
 constexpr int kMaxPrepLayers = 32;
-struct PrepLayer { const float* w; unsigned short* wk; unsigned short* wd; int Co, Ci, Cp, ldk, ldd; };
+// T > 0: wk holds PLANES of the fp32 weight (csrc/split.hip): per tap T blocks of Cp channels, block tt = plane pat[tt]
+struct PrepLayer { const float* w; unsigned short* wk; unsigned short* wd; int Co, Ci, Cp, ldk, ldd, T; int pat[4]; };
 struct PrepBatch { PrepLayer l[kMaxPrepLayers]; };
 
 // blockIdx.x walks the layer's work units: first Co units "wk row co" (the row's Ci x 9 floats are one contiguous,
@@ -62,13 +63,26 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(PrepBatch b) {
                 for (int k = threadIdx.x; k < nc * 9; k += 256) sm[k] = src[k];
                 __syncthreads();
                 const int np = L.Cp - c0 < 512 ? L.Cp - c0 : 512;
+                if (L.T > 0) {
+                    for (int k = threadIdx.x; k < 9 * np; k += 256) {
+                        const int t = k / np, ci = k - t * np;
+                        const float x = ci < nc ? sm[ci * 9 + t] : 0.0f;
+                        unsigned short pl[4];               // hi, mid, lo, zeros (both subtractions exact in fp32)
+                        pl[0] = f2bf(x);
+                        const float r1 = x - bf2f(pl[0]);
+                        pl[1] = f2bf(r1);
+                        pl[2] = f2bf(r1 - bf2f(pl[1]));
+                        pl[3] = 0;
+                        for (int tt = 0; tt < L.T; ++tt) row[(t * L.T + tt) * L.Cp + c0 + ci] = pl[L.pat[tt] & 3];
+                    }
+                } else
                 for (int k = threadIdx.x; k < 9 * np; k += 256) {
                     const int t = k / np, ci = k - t * np;
                     row[t * L.Cp + c0 + ci] = ci < nc ? f2bf(sm[ci * 9 + t]) : (unsigned short)0;
                 }
                 __syncthreads();
             }
-            for (int k = 9 * L.Cp + threadIdx.x; k < L.ldk; k += 256) row[k] = 0;
+            for (int k = 9 * L.Cp * (L.T > 0 ? L.T : 1) + threadIdx.x; k < L.ldk; k += 256) row[k] = 0;
         } else {
             const int v = u - nk, ci = v / cochunks, co0 = (v - ci * cochunks) * 64;
             const int nco = L.Co - co0 < 64 ? L.Co - co0 : 64;
@@ -461,9 +475,22 @@ ODW_EXPORT int odw_conv_weight_prep(const float* w, int Co, int Ci, int Cp, void
     return ODW_OK;
 }
 
+ODW_EXPORT int odw_conv_weight_prep_planes_batch(int n, const void* const* w, const int* Co, const int* Ci, const int* Cp,
+                                                 void* const* wk, const int* ldk, void* const* wd, const int* ldd,
+                                                 const int* T, const int* patterns, void* stream_);
+
 // n layers at once; the eight arrays are HOST arrays of length n (pointers: device memory; wk[i] / wd[i] may be null)
 ODW_EXPORT int odw_conv_weight_prep_batch(int n, const void* const* w, const int* Co, const int* Ci, const int* Cp,
                                           void* const* wk, const int* ldk, void* const* wd, const int* ldd, void* stream_) {
+    return odw_conv_weight_prep_planes_batch(n, w, Co, Ci, Cp, wk, ldk, wd, ldd, nullptr, nullptr, stream_);
+}
+
+// The same with wk written as bf16 PLANES of the fp32 weights (split-precision forward operand, csrc/split.hip):
+// T[i] (0 = plain bf16, else 1..4) blocks of Cp[i] channels per tap, block tt = plane patterns[4 i + tt] (0 hi, 1 mid,
+// 2 lo, 3 zeros); ldk[i] >= 9 * T[i] * Cp[i].  wd (the input-gradient copy) stays single-plane bf16.  T == NULL: plain.
+ODW_EXPORT int odw_conv_weight_prep_planes_batch(int n, const void* const* w, const int* Co, const int* Ci, const int* Cp,
+                                                 void* const* wk, const int* ldk, void* const* wd, const int* ldd,
+                                                 const int* T, const int* patterns, void* stream_) {
     ODW_REQUIRE(n >= 0 && n <= kMaxPrepLayers, "conv_weight_prep_batch: %d layers (at most %d per call)", n, kMaxPrepLayers);
     if (n == 0) return ODW_OK;
     ODW_REQUIRE(w && Co && Ci && Cp && wk && ldk && wd && ldd, "conv_weight_prep_batch: null array");
@@ -471,10 +498,14 @@ ODW_EXPORT int odw_conv_weight_prep_batch(int n, const void* const* w, const int
     size_t most = 0;
     for (int i = 0; i < n; ++i) {
         ODW_REQUIRE(Co[i] > 0 && Ci[i] > 0 && Cp[i] >= Ci[i] && w[i] && (wk[i] || wd[i]), "conv_weight_prep_batch: layer %d", i);
-        ODW_REQUIRE((!wk[i] || ldk[i] >= 9 * Cp[i]) && (!wd[i] || ldd[i] >= 9 * Co[i]),
+        const int Ti = T ? T[i] : 0;
+        ODW_REQUIRE(Ti >= 0 && Ti <= 4 && (Ti == 0 || patterns), "conv_weight_prep_batch: layer %d: T = %d (0..4)", i, Ti);
+        ODW_REQUIRE((!wk[i] || ldk[i] >= 9 * Cp[i] * (Ti > 0 ? Ti : 1)) && (!wd[i] || ldd[i] >= 9 * Co[i]),
                     "conv_weight_prep_batch: leading dimensions of layer %d too small", i);
         b.l[i].w = (const float*)w[i]; b.l[i].wk = (unsigned short*)wk[i]; b.l[i].wd = (unsigned short*)wd[i];
         b.l[i].Co = Co[i]; b.l[i].Ci = Ci[i]; b.l[i].Cp = Cp[i]; b.l[i].ldk = ldk[i]; b.l[i].ldd = ldd[i];
+        b.l[i].T = Ti;
+        for (int tt = 0; tt < 4; ++tt) b.l[i].pat[tt] = (Ti > 0 && tt < Ti) ? patterns[4 * i + tt] : 3;
         const size_t e = (wk[i] ? (size_t)Co[i] : 0) + (wd[i] ? (size_t)Ci[i] * ((Co[i] + 63) / 64) : 0);
         most = e > most ? e : most;
     }

@@ -380,47 +380,45 @@ class VGGBackboneHip(nn.Module):
             if not l.trainable and self._frozen_ready and l.mode == mode:
                 continue
             fresh = l.mode != mode
-            if P.split_mode():
-                # packed weights as bf16 planes: rows (co, tap) x [T blocks of Cp] and rows (ci, tap) x [T blocks of Cout]
-                _, pb = P.conv_patterns(l.cp) if mixed else P.patterns("conv")
+            if P.split_mode() and not mixed:
+                # "bf16x3" / "bf16x2": both packed copies as bf16 planes -- rows (co, tap) x [T blocks of Cp] and rows
+                # (ci, tap) x [T blocks of Cout] (a handful of small torch passes per layer: the parity modes)
+                _, pb = P.patterns("conv")
                 wt = l.conv.weight.detach()
                 wr = torch.zeros((l.cout, 9, l.cp), dtype=torch.float32, device=dev)
                 wr[:, :, :l.cin] = wt.permute(0, 2, 3, 1).reshape(l.cout, 9, l.cin)
                 l.wk = P.pack_conv_weight(wr.view(l.cout * 9, l.cp), pb, l.cp, l.cout)
-                if not mixed:
-                    l.wd = None
-                    if l.trainable and i > first:
-                        wr2 = wt.permute(1, 2, 3, 0).reshape(l.cin * 9, l.cout).contiguous()
-                        l.wd = P.pack_conv_weight(wr2, pb, l.cout, l.cin)
-                    l.mode = mode
-                    continue
-                if fresh:
-                    l.wd = None
-                    if l.trainable and i > first:
-                        l.wd = torch.empty((l.cin, _r64(9 * l.cout)), dtype=torch.bfloat16, device=dev)
-                if l.wd is not None:
-                    todo.append(l)
+                l.wd = None
+                if l.trainable and i > first:
+                    wr2 = wt.permute(1, 2, 3, 0).reshape(l.cin * 9, l.cout).contiguous()
+                    l.wd = P.pack_conv_weight(wr2, pb, l.cout, l.cin)
                 l.mode = mode
                 continue
+            # "bf16": wk and wd as packed bf16.  "bf16x2f": wk as the forward PLANES (T blocks of Cp per tap), wd as packed
+            # bf16 -- every layer's copies in ONE launch (weight_prep_batch_kernel; the per-layer torch passes of the
+            # parity modes -- fill, permuted copy, split, pad -- were 36 launches and 0.5 ms of launch gaps at the head of
+            # every step)
+            t_blocks = len(P.conv_patterns(l.cp)[1]) if mixed else 1
             if l.wk is None or fresh:
-                l.wk = torch.empty((l.cout, _r64(9 * l.cp)), dtype=torch.bfloat16, device=dev)
+                l.wk = torch.empty((l.cout, _r64(9 * t_blocks * l.cp)), dtype=torch.bfloat16, device=dev)
                 l.wd = None
                 if l.trainable and i > first:
                     l.wd = torch.empty((l.cin, _r64(9 * l.cout)), dtype=torch.bfloat16, device=dev)
             todo.append(l)
             l.mode = mode
-        if todo:        # the packed bf16 copies of every (trainable) layer in ONE launch
+        if todo:
             import ctypes
             n = len(todo)
-            key = tuple((l.conv.weight.data_ptr(), 0 if mixed else l.wk.data_ptr(), l.wd.data_ptr() if l.wd is not None else 0)
-                        for l in todo)
+            key = (mode,) + tuple((l.conv.weight.data_ptr(), l.wk.data_ptr(), l.wd.data_ptr() if l.wd is not None else 0) for l in todo)
             if getattr(self, "_prep_key", None) != key:      # the argument arrays change only when a buffer moves
                 vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
-                args = (vp(*[k[0] for k in key]), ia(*[l.cout for l in todo]), ia(*[l.cin for l in todo]),
-                        ia(*[l.cp for l in todo]), vp(*[k[1] or None for k in key]), ia(*[_r64(9 * l.cp) for l in todo]),
-                        vp(*[k[2] or None for k in key]), ia(*[l.wd.stride(0) if l.wd is not None else 0 for l in todo]))
+                pats = [list(P.conv_patterns(l.cp)[1]) if mixed else [] for l in todo]
+                args = (vp(*[k[0] for k in key[1:]]), ia(*[l.cout for l in todo]), ia(*[l.cin for l in todo]),
+                        ia(*[l.cp for l in todo]), vp(*[k[1] for k in key[1:]]), ia(*[l.wk.stride(0) for l in todo]),
+                        vp(*[k[2] or None for k in key[1:]]), ia(*[l.wd.stride(0) if l.wd is not None else 0 for l in todo]),
+                        ia(*[len(pt) for pt in pats]), (ctypes.c_int * (4 * n))(*[v for pt in pats for v in (pt + [3] * 4)[:4]]))
                 self._prep_key, self._prep_args = key, (args, [ctypes.cast(a, ctypes.c_void_p) for a in args])
-            L.check(lib.odw_conv_weight_prep_batch(n, *self._prep_args[1], L.stream()), "conv_weight_prep_batch")
+            L.check(lib.odw_conv_weight_prep_planes_batch(n, *self._prep_args[1], L.stream()), "conv_weight_prep_batch")
         self._frozen_ready = True
 
     def forward(self, images):

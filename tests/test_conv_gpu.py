@@ -334,3 +334,37 @@ def test_conv_weight_prep_batch_equals_per_layer(lib):
         assert torch.equal(wk0[i].view(torch.int16), wk1[i].view(torch.int16)), i
         if wd0[i] is not None:
             assert torch.equal(wd0[i].view(torch.int16), wd1[i].view(torch.int16)), i
+
+
+def test_conv_weight_prep_planes_batch_equals_the_split_of_the_packed_weight(lib):
+    """odw_conv_weight_prep_planes_batch ("bf16x2f": the forward operand of every convolution as bf16 planes, all layers
+    in one launch) writes exactly what precision.pack_conv_weight builds from torch passes -- per tap T blocks of Cp
+    channels holding plane pattern[t], rows zero padded to a multiple of 64 -- and the plain bf16 mirrored copy beside it."""
+    import ctypes
+    from od_wscl_amd import precision as P
+    L = lib
+    shapes = [(64, 64, 64, (0, 1, 0)), (256, 128, 128, (0, 1, 0)), (72, 40, 64, (0, 1, 2, 0)), (64, 3, 8, (0, 1, 0, 1))]
+    ws, wk, wd, want = [], [], [], []
+    for i, (co, ci, cp, pat) in enumerate(shapes):
+        w = rnd(60 + i, (co, ci, 3, 3), 0.1)
+        ws.append(w)
+        T = len(pat)
+        wk.append(torch.full((co, r64(9 * T * cp)), 7.0, dtype=torch.bfloat16, device="cuda"))
+        wd.append(torch.full((ci, r64(9 * co)), 7.0, dtype=torch.bfloat16, device="cuda"))
+        wr = torch.zeros((co, 9, cp), dtype=torch.float32, device="cuda")
+        wr[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
+        want.append(P.pack_conv_weight(wr.view(co * 9, cp), pat, cp, co))
+    n = len(shapes)
+    vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
+    pats = [list(s[3]) for s in shapes]
+    args = (vp(*[w.data_ptr() for w in ws]), ia(*[s[0] for s in shapes]), ia(*[s[1] for s in shapes]), ia(*[s[2] for s in shapes]),
+            vp(*[t.data_ptr() for t in wk]), ia(*[t.stride(0) for t in wk]), vp(*[t.data_ptr() for t in wd]),
+            ia(*[t.stride(0) for t in wd]), ia(*[len(pt) for pt in pats]),
+            (ctypes.c_int * (4 * n))(*[v for pt in pats for v in (pt + [3] * 4)[:4]]))
+    L.check(L.lib().odw_conv_weight_prep_planes_batch(n, *[ctypes.cast(a, ctypes.c_void_p) for a in args], L.stream()), "prep planes")
+    for i, (co, ci, cp, pat) in enumerate(shapes):
+        assert want[i].shape == wk[i].shape, (want[i].shape, wk[i].shape)
+        assert torch.equal(want[i].view(torch.int16), wk[i].view(torch.int16)), i
+        plain = torch.empty_like(wd[i])
+        L.check(L.lib().odw_conv_weight_prep(L.ptr(ws[i]), co, ci, cp, None, 0, L.ptr(plain), plain.stride(0), L.stream()), "prep")
+        assert torch.equal(plain.view(torch.int16), wd[i].view(torch.int16)), i
