@@ -489,7 +489,11 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             torch.cuda.synchronize()
             print("[odw] ok", tag, flush=True)
 
-    model.hip_body()
+    hip_body = model.hip_body()
+    # the static launch sequences of the VGG body as HIP graphs (one pair per input shape); not inside SOLVER.ITER_SIZE
+    # groups, whose later micro-steps ACCUMULATE into the gradients (different kernel arguments)
+    if hasattr(hip_body, "use_graphs") and max(1, int(cfg.SOLVER.ITER_SIZE)) == 1 and os.environ.get("ODW_NO_GRAPHS") != "1":
+        hip_body.use_graphs = True
     if cfg.MODEL.BACKBONE.CONV_BODY.startswith("VGG16"):
         conv_desc = "od_wscl_amd HIP implicit-GEMM conv3x3 (NHWC, MFMA)"
     else:

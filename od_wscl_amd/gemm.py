@@ -440,6 +440,45 @@ class _MixedLinear(torch.autograd.Function):
         return dx, dw, None, None, None, None, None, None, None, None, None, None
 
 
+class _ReuseLinear(torch.autograd.Function):
+    """A Linear evaluation whose OUTPUT already exists: rows `rows` of `y_full`, computed by an earlier, larger evaluation
+    of the same layer on the same inputs with the same dropout draws and no autograd (the clean half of the stacked
+    fc6 / fc7 / Sim_Net pass).  forward = a row gather (no GEMM); backward = the layer's ordinary single-plane backward
+    over those rows (input gradient, weight-gradient batch slot, bias gradient, ReLU / dropout mask from the gathered
+    output).  Round 2 RE-EVALUATED these rows (gather -> fc6 -> fc7 -> Sim_Net: three weight-streaming GEMMs of a few
+    hundred rows, 0.5 ms of the bf16x2f step); the values are the same bits either way."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, shadow, y_full, rows, relu, drop_p, timer_tag, planes):
+        sh = shadow.refresh()
+        M, K = x.shape
+        N = weight.shape[0]
+        assert y_full.shape[1] == N and rows.numel() == M
+        y = y_full.index_select(0, rows.long() if rows.dtype != torch.int64 and rows.dtype != torch.int32 else rows)
+        xb = planes[:, :K] if planes is not None else (x if x.stride(1) == 1 else x.contiguous())
+        ctx.save_for_backward(xb, y if (relu or drop_p > 0) else None, weight, bias)
+        slot = None
+        batch = getattr(sh, "batch", None)
+        if batch is not None and weight.is_leaf and weight.requires_grad:
+            slot = batch.register(M)
+        ctx.cfg = (sh, relu, drop_p, x.dtype, timer_tag, None, slot)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, y, weight, bias = ctx.saved_tensors
+        dx, dw = _backward_single_plane(xb, y, weight, bias, ctx.cfg, dy, ctx.needs_input_grad[0])
+        return dx, dw, None, None, None, None, None, None, None, None
+
+
+def reuse_linear(x, weight, bias, shadow, y_full, rows, relu=False, drop_p=0.0, tag=None):
+    """Rows `rows` of an evaluation of this Linear that already ran without autograd, re-attached to the graph (see
+    _ReuseLinear).  Single-plane backward only ("bf16", "bf16x2f")."""
+    if P.bwd_split():
+        raise RuntimeError("reuse_linear: the split-precision backward keeps no single-plane operands")
+    return _ReuseLinear.apply(x, weight, bias, shadow, y_full, rows, relu, drop_p, tag, getattr(x, "_odw_planes", None))
+
+
 def planes_handle(device, rows, cols):
     """The autograd stand-in of an operand that exists only as bf16 planes: a (rows x cols) fp32 tensor of zero strides
     (4 bytes of storage) that carries the graph edge and the gradient's shape / dtype.  Its producer (an autograd

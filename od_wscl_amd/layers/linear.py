@@ -28,5 +28,12 @@ class Linear(nn.Linear):
                                  segs=segs if drop_p > 0 else None, out_f32=out_f32, tag=self.tag,
                                  grad_rows=grad_rows, row_ids=row_ids)
 
+    def reuse(self, x, y_full, rows, relu=False, drop_p=0.0):
+        """Rows `rows` of an earlier no-autograd evaluation `y_full` of this layer, re-attached to the graph with `x` as
+        their input (gemm.reuse_linear): backward as usual, no forward GEMM."""
+        if self._shadow is None or self._shadow.weight is not self.weight:
+            self._shadow = gemm.Shadow(self.weight)
+        return gemm.reuse_linear(x, self.weight, self.bias, self._shadow, y_full, rows, relu=relu, drop_p=drop_p, tag=self.tag)
+
     def forward(self, x):
         return self.fused(x)

@@ -310,7 +310,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
     def fc7(self):
         return self.classifier[self.fc_index[1]]
 
-    def _fc(self, x, segs6=None, segs7=None, grad_rows=None, row_ids=None):
+    def _fc(self, x, segs6=None, segs7=None, grad_rows=None, row_ids=None, keep=None):
         """Linear, ReLU, Dropout, Linear, ReLU, Dropout (vgg16.py:121-127).  With a counter-based `rand`
         the two dropouts are fused into the GEMM epilogues; `segs*` carry per-pass keys when
         several passes are stacked along the row dimension."""
@@ -324,6 +324,8 @@ class TwoFCROIFeatureExtractor(nn.Module):
             k6, k7 = self.rand.key(), self.rand.key()
             segs6, segs7 = [(0, k6[0], k6[1])], [(0, k7[0], k7[1])]
         x = fc6.fused(x, relu=True, drop_p=0.5, segs=segs6, grad_rows=grad_rows, row_ids=row_ids)
+        if keep is not None:
+            keep["h6"] = x.detach()
         return fc7.fused(x, relu=True, drop_p=0.5, segs=segs7, grad_rows=grad_rows, row_ids=row_ids)
 
     def forward_clean_and_aug(self, pooled):
@@ -436,9 +438,13 @@ class TwoFCROIFeatureExtractor(nn.Module):
         # up using are re-evaluated by recompute_clean_rows with their original dropout draws (row_ids).
         self.sparse_clean = os.environ.get("ODW_NO_SPARSE") != "1"
         self._clean_keys = (k1, k2)
+        keep = {} if self.sparse_clean else None
         h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5],
-                     grad_rows=(P, 2 * P, False) if self.sparse_clean else None)   # consumers skip the clean half:
+                     grad_rows=(P, 2 * P, False) if self.sparse_clean else None, keep=keep)   # consumers skip the clean half:
         self._grad_holder.clean_rows = 0 if self.sparse_clean else P                       # fc6's slices it, pooling below
+        # the clean half's fc6 / fc7 outputs stay around: the rows the contrastive loss differentiates are re-attached
+        # to the graph from them (reuse_clean_rows) instead of being evaluated a second time
+        self._clean_acts = (keep["h6"], h.detach()) if self.sparse_clean else None
         return (h[:P].detach() if self.sparse_clean else h[:P]), h[P:], x
 
     def recompute_clean_rows(self, stacked, rows, first_entry):
@@ -453,6 +459,23 @@ class TwoFCROIFeatureExtractor(nn.Module):
         else:
             x = _RowGather.apply(stacked, rows, self._grad_holder, first_entry)
         return self._fc(x, segs6=[(0,) + k1], segs7=[(0,) + k2], row_ids=rows)
+
+    def reuse_clean_rows(self, stacked, rows, first_entry):
+        """The same rows as recompute_clean_rows WITHOUT evaluating them again: their fc6 / fc7 outputs were computed by
+        the stacked pass (same inputs, same dropout draws); they are gathered and re-attached to the graph
+        (Linear.reuse), so that backward runs over them as usual and their input gradient is parked for the pooling
+        node.  The result carries `_odw_reuse_rows` so that Sim_Net does the same with ITS stacked-pass outputs."""
+        h6, h7 = self._clean_acts
+        planes = getattr(stacked, "_odw_planes", None)
+        if planes is not None:
+            x, picked = _RowGather.apply(stacked, rows, self._grad_holder, first_entry, planes)
+            x._odw_planes = picked
+        else:
+            x = _RowGather.apply(stacked, rows, self._grad_holder, first_entry)
+        a6 = self.fc6.reuse(x, h6, rows, relu=True, drop_p=0.5)
+        a7 = self.fc7.reuse(a6, h7, rows, relu=True, drop_p=0.5)
+        a7._odw_reuse_rows = rows
+        return a7
 
     def forward(self, x, proposals):
         pooled = self.pooler(x, proposals)

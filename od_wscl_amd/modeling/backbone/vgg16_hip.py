@@ -366,6 +366,7 @@ class VGGBackboneHip(nn.Module):
         self.zero_page = None
         self.last_nhwc = None
         self._frozen_ready = False
+        self._graphs = {}
 
     def _prep(self):
         lib = L.lib()
@@ -421,13 +422,93 @@ class VGGBackboneHip(nn.Module):
             L.check(lib.odw_conv_weight_prep_planes_batch(n, *self._prep_args[1], L.stream()), "conv_weight_prep_batch")
         self._frozen_ready = True
 
+    # ---- HIP graphs (engine.build_training_step sets use_graphs): the body's forward (weight packing included) and its
+    # backward are two static launch sequences per input shape -- ~50 and ~60 launches that the host issues one ctypes
+    # call at a time while the GPU, in the backward half of the step, runs them faster than they arrive.  Captured once
+    # per (B, H, W) and replayed: inputs are copied into the graph's static buffers, every tensor the launches touch
+    # lives in the graph's memory pool, the gradients land in the parameters' .grad views as in the eager path.
+    use_graphs = False
+
+    def _graph_for(self, fn, images):
+        key = (fn.__name__, tuple(images.shape), P.get_precision(), bool(getattr(self, "accumulate", False)))
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = _GraphedBody(self, fn, images)
+        return g
+
     def forward(self, images):
         L.need_gpu(images)
-        with torch.no_grad():
-            self._prep()
         params = [p for l in self.layers for p in (l.conv.weight, l.conv.bias)]
         fn = (_VGGSplitFn if P.bwd_split() else _VGGMixedFn) if P.split_mode() else _VGGFn
-        feat = fn.apply(images.float(), self, *params)
+        trainable = any(l.trainable for l in self.layers)
+        if (self.use_graphs and torch.is_grad_enabled() and trainable and fn is not _VGGSplitFn
+                and all(p.grad is not None for l in self.layers if l.trainable for p in (l.conv.weight, l.conv.bias))
+                and getattr(self, "debug", None) is None and os.environ.get("ODW_NO_GRAPHS") != "1"):
+            feat = _GraphedVGGFn.apply(images.float(), self, self._graph_for(fn, images), *params)
+        else:
+            with torch.no_grad():
+                self._prep()
+            feat = fn.apply(images.float(), self, *params)
         feat._odw_nhwc = self.last_nhwc
         feat._odw_nhwc_f32 = getattr(self, "last_nhwc_f32", None) if fn is _VGGMixedFn else None
         return [feat]
+
+
+class _Ctx(object):
+    """Stand-in for the autograd context of the body's Function when its forward / backward run under graph capture."""
+    needs_input_grad = ()
+
+
+class _GraphedBody(object):
+    """The forward and the backward of one body for one input shape as two captured HIP graphs."""
+
+    def __init__(self, net, fn, images):
+        from ...utils.kernel_timer import kernel_timer as kt
+        self.net, self.fn = net, fn
+        dev = images.device
+        self.img = torch.empty(tuple(images.shape), dtype=torch.float32, device=dev)
+        self.img.copy_(images)
+        self.ctx = _Ctx()
+        self.ctx.needs_input_grad = (False, False) + (False,) * (2 * len(net.layers))
+        was = kt.active
+        kt.active = False                              # no event records inside a capture
+        try:
+            # warm-up on a side stream (allocator and lazily-built constants settle), then capture
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                net._prep()
+                feat = fn.forward(self.ctx, self.img, net)
+                fn.backward(self.ctx, torch.zeros_like(feat))
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.g_fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fwd), torch.no_grad():
+                net._prep()
+                self.feat = fn.forward(self.ctx, self.img, net)
+            self.nhwc = net.last_nhwc
+            self.nhwc_f32 = getattr(net, "last_nhwc_f32", None)
+            self.dfeat = torch.zeros_like(self.feat)
+            self.g_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()), torch.no_grad():
+                fn.backward(self.ctx, self.dfeat)
+        finally:
+            kt.active = was
+
+
+class _GraphedVGGFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, net, graphed, *params):
+        graphed.img.copy_(images)
+        graphed.g_fwd.replay()
+        net.last_nhwc = graphed.nhwc
+        net.last_nhwc_f32 = graphed.nhwc_f32
+        ctx.graphed = graphed
+        return graphed.feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        g = ctx.graphed
+        g.dfeat.copy_(dfeat)
+        g.g_bwd.replay()
+        return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

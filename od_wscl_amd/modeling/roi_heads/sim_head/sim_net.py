@@ -41,7 +41,18 @@ class Sim_Net(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, roi_feat):
+    kept = None        # (mlp[0] output, mlp[2] output) of the last no-autograd evaluation with keep=True
+
+    def forward(self, roi_feat, keep=False):
+        rows = getattr(roi_feat, "_odw_reuse_rows", None)
+        if rows is not None and self.kept is not None:
+            # rows of the evaluation that already ran over the whole clean pass: gathered and re-attached to the graph
+            # (layers.Linear.reuse) instead of two more GEMMs; the normalisation of a few hundred rows is redone
+            h = self.mlp[0].reuse(roi_feat, self.kept[0], rows, relu=True)
+            e = self.mlp[2].reuse(h, self.kept[1], rows)
+            return _L2NormRows.apply(e.float(), 1e-12)
         h = self.mlp[0].fused(roi_feat, relu=True)
         e = self.mlp[2].fused(h, out_f32=True)
+        if keep:
+            self.kept = (h.detach(), e.detach())
         return _L2NormRows.apply(e, 1e-12)

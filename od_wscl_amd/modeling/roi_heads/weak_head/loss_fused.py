@@ -412,7 +412,11 @@ class RoIRegLossFused(RoIRegLossComputation):
             holder = feature_extractor._grad_holder
             first_entry = int(sum(m[3] for m in meta))
             holder.roi_index = list(holder.roi_index or []) + [act_d]
-            e_act = model_sim(feature_extractor.recompute_clean_rows(clean_pooled_feats, act_d, first_entry)).float()
+            import os as _os
+            if _os.environ.get("ODW_RECOMPUTE_CLEAN") == "1" or getattr(feature_extractor, "_clean_acts", None) is None:
+                e_act = model_sim(feature_extractor.recompute_clean_rows(clean_pooled_feats, act_d, first_entry)).float()
+            else:       # their stacked-pass outputs re-attached to the graph: no second evaluation
+                e_act = model_sim(feature_extractor.reuse_clean_rows(clean_pooled_feats, act_d, first_entry)).float()
             features = torch.cat([e_act, emb], dim=0).index_select(0, feat_index)
         else:
             feat_index, labels, w_fs_d, w_cs_d = self._staging.upload(

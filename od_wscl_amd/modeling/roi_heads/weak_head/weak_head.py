@@ -78,7 +78,7 @@ class ROIWeakRegHead(nn.Module):
                 # selection kernel, so that it runs while the host reads that kernel's result (loss_fused.py)
                 def sim_feature(model_sim=self.model_sim, clean_feats=clean_feats):
                     with torch.no_grad():
-                        return model_sim(clean_feats)
+                        return model_sim(clean_feats, keep=True)       # its two Linear outputs are reused, not recomputed
             else:
                 sim_feature = self.model_sim(clean_feats)
         else:

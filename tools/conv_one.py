@@ -8,17 +8,20 @@ lib = L.lib()
 LAYERS = {"conv2": (128, 128, 1, 304, 0), "conv3": (256, 256, 1, 152, 0), "conv4": (512, 512, 1, 76, 0),
           "conv5": (512, 512, 2, 76, 0), "conv4_dgrad": (512, 512, 1, 76, 1), "conv3_dgrad": (256, 256, 1, 152, 1)}
 cin, cout, dil, h, mirror = LAYERS[os.environ.get("ODW_CONV_LAYER", "conv4")]
+T = int(os.environ.get("ODW_CONV_PLANES", "1"))         # 3 = the forward of the "bf16x2f" mode: three plane blocks, fp32 out
+cin_real = cin
+cin *= T
 m = h * h
 zero = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
 x = torch.randn(m, cin, device="cuda").bfloat16()
 wk = (torch.randn(cout, _r64(9 * cin), device="cuda") * 0.05).bfloat16()
-y = torch.empty(m, cout, device="cuda", dtype=torch.bfloat16)
+y = torch.empty(m, cout, device="cuda", dtype=torch.bfloat16 if T == 1 else torch.float32)
 bias = torch.zeros(cout, device="cuda")
 wsb = lib.odw_conv3x3_workspace_hw(m, h, h, cin, cout, dil)
 ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
 for _ in range(8):
-    L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, h, cin, dil, mirror, L.ptr(wk), wk.stride(0), cout, L.ptr(y), cout, 1,
+    L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, h, cin, dil, mirror, L.ptr(wk), wk.stride(0), cout, L.ptr(y), cout, 1 if T == 1 else 0,
                                          L.ptr(bias), 0 if mirror else 1, None, 0, L.ptr(zero), L.ptr(ws) if wsb else None, wsb,
                                          L.stream()), "conv")
 torch.cuda.synchronize()
-print("layer", os.environ.get("ODW_CONV_LAYER", "conv4"), "M", m, "N", cout, "K", 9 * cin, "GFLOP", 2e-9 * m * cout * 9 * cin, "split bytes", wsb)
+print("layer", os.environ.get("ODW_CONV_LAYER", "conv4"), "M", m, "N", cout, "K", 9 * cin, "GFLOP issued", 2e-9 * m * cout * 9 * cin, "plane blocks", T, "split bytes", wsb)
