@@ -3,7 +3,7 @@ gemm_nt_bf16_big_kernel<true, 0>, M=4000 N=4096 K=25088, bf16 output with bias +
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from od_wscl_amd import gemm
-M, N, K = 4000, 4096, 25088
+M, N, K = 4000, 4096, 25088 * int(os.environ.get("ODW_ONE_PLANES", "1"))     # 3: the bf16x2f stacked fc6 forward (K' = 3 K)
 a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16(); b = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
 bias = torch.randn(N, device="cuda")
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if os.environ.get("ODW_ONE_F32") != "1" else torch.float32)

@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--data-dir", default="", help="root of the dataset catalog (default: ./datasets)")
     ap.add_argument("--size", type=int, default=600)
     ap.add_argument("--proposals", type=int, default=2000)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x3", "bf16x2", "f32"])
+    ap.add_argument("--dtype", default="bf16x2f", choices=["bf16x2f", "bf16", "bf16x3", "bf16x2", "f32"],
+                    help="arithmetic of the MFMA products (od_wscl_amd/precision.py); bf16x2f = forward at the parity bar, bf16 backward")
     ap.add_argument("--log-period", type=int, default=20)
     ap.add_argument("--allow-random-init", action="store_true",
                     help="train from the formula initialisation when MODEL.WEIGHT cannot be resolved locally")
