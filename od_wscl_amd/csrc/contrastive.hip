@@ -155,6 +155,14 @@ __device__ __host__ inline int pw_blocks_of(int p, int nblk32) { const int b = n
 #else
 #define PW_DBG(bit) false
 #endif
+// tools/exp/pairwise_timeline.hip compiles this file with ODW_PW_TIMELINE: lane 0 of every wave stamps wall_clock64()
+// (100 MHz) at the phase boundaries of its first iterations
+#ifdef ODW_PW_TIMELINE
+__device__ long long g_pw_tl[1024 * 8 * 32];
+#define PW_T(i) do { if (lane == 0 && (i) < 32) g_pw_tl[(blockIdx.x * 8 + wave) * 32 + (i)] = wall_clock64(); } while (0)
+#else
+#define PW_T(i) do { } while (0)
+#endif
 // How this structure was arrived at (P = 4000, rocprofv3 + PMC, tools/exp/pairwise_dbg.sh, tools/pmc_pairwise.sh).  The
 // first form -- eight symmetric waves, each fetching its share of the next column block, running its MFMAs and storing
 // its tile -- took 26-28 us whatever the order of its instructions: without stores 20, without MFMAs 20, without both
@@ -185,6 +193,7 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
     // this workgroup's run of (panel, block) items in panel-major order
     const long long lo_it = (long long)total_items * blockIdx.x / gridDim.x, hi_it = (long long)total_items * (blockIdx.x + 1) / gridDim.x;
     if (lo_it >= hi_it) return;
+    PW_T(0);
     int panel = 0, blk;
     {
         long long rest = lo_it;
@@ -253,8 +262,10 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
             slot = 0;
             have_panel = panel;
             parked = true;
+            PW_T(1);
         }
         pw_barrier();                                    // block `blk` is parked in `slot`; the other slot is free
+        PW_T(2 + 3 * (int)(it - lo_it));
         if (loader) {
             // ---- the loader wave: the next block's 32 rows (8 items per lane, 16 loads in flight), split, parked in the
             // other slot.  Unconditional (past the end of the run the slot receives rows nobody reads).  Its vmcnt
@@ -288,6 +299,7 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
                 }
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] += acc1[k];
+                PW_T(3 + 3 * (int)(it - lo_it));
                 const int col = c0 + l31;
                 const bool full = small && vec && r0 + 32 <= P && c0 + 32 <= P;      // wave-uniform: no per-element predicates
                 if (c0 == r0) {
@@ -347,10 +359,12 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
                 }
             }
         }
+        PW_T(4 + 3 * (int)(it - lo_it));
         slot ^= 1;
         blk = b1; panel = p1;
         advance(p1, b1);
     }
+    PW_T(31);
 }
 
 // any D (multiple of 4): plain wave-per-row kernel, used when D != 128

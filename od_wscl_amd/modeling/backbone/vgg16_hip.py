@@ -89,7 +89,6 @@ class _VGGFn(torch.autograd.Function):
         h, w = H, W
         for li, l in enumerate(net.layers):
             m = B * h * w
-            net.prep_join(li)
             y = torch.empty((m, l.cout), dtype=torch.bfloat16, device=dev)
             if li == 0 and direct0:
                 L.check(lib.odw_stem_conv3x3_bias_relu(L.ptr(images.contiguous()), L.ptr(l.conv.weight.detach()),
@@ -109,7 +108,6 @@ class _VGGFn(torch.autograd.Function):
             x = y
         feat = torch.empty((B, net.layers[-1].cout, h, w), dtype=torch.float32, device=dev)
         L.check(lib.odw_nhwc_bf16_to_nchw_f32(L.ptr(x), B, h * w, net.layers[-1].cout, L.ptr(feat), st), "nhwc_to_nchw")
-        net.prep_join(len(net.layers))
         ctx.net, ctx.saved_acts, ctx.batch = net, saved, B
         net.last_nhwc = x           # the NHWC bf16 map itself: the fused ROI pooling reads it directly
         return feat
@@ -203,9 +201,8 @@ class _VGGSplitFn(torch.autograd.Function):
         L.check(lib.odw_nchw_f32_to_nhwc_f32(L.ptr(images.contiguous()), B, H * W, C, cp0, L.ptr(x), st), "nchw_to_nhwc_f32")
         saved = []
         h, w = H, W
-        for li, l in enumerate(net.layers):
+        for l in net.layers:
             m = B * h * w
-            net.prep_join(li)
             xs = P.split_rows(x, pa, l.cp)
             y = torch.empty((m, l.cout), dtype=torch.float32, device=dev)
             _conv3x3(lib, xs, m, h, w, T * l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
@@ -224,7 +221,6 @@ class _VGGSplitFn(torch.autograd.Function):
         cl = net.layers[-1].cout
         feat = torch.empty((B, cl, h, w), dtype=torch.float32, device=dev)
         L.check(lib.odw_nhwc_f32_to_nchw_f32(L.ptr(x), B, h * w, cl, cl, L.ptr(feat), st), "nhwc_to_nchw_f32")
-        net.prep_join(len(net.layers))
         ctx.net, ctx.saved_acts, ctx.batch = net, saved, B
         net.last_nhwc = None
         return feat
@@ -311,7 +307,6 @@ class _VGGMixedFn(torch.autograd.Function):
         xs_ready = None                     # the next layer's plane operand, when its producer wrote it itself
         for li, l in enumerate(net.layers):
             m = B * h * w
-            net.prep_join(li)
             if li == 0 and direct0:
                 nxt = net.layers[1]
                 pn, _ = P.conv_patterns(nxt.cp)
@@ -351,7 +346,6 @@ class _VGGMixedFn(torch.autograd.Function):
         cl = net.layers[-1].cout
         feat = torch.empty((B, cl, h, w), dtype=torch.float32, device=dev)
         L.check(lib.odw_nhwc_f32_to_nchw_f32(L.ptr(x), B, h * w, cl, cl, L.ptr(feat), st), "nhwc_to_nchw_f32")
-        net.prep_join(len(net.layers))
         ctx.net, ctx.saved_acts, ctx.batch = net, saved, B
         net.last_nhwc = None
         net.last_nhwc_f32 = x       # the fp32 NHWC map (read by the fused pooling of this mode)
@@ -425,31 +419,8 @@ class VGGBackboneHip(nn.Module):
                         vp(*[k[2] or None for k in key[1:]]), ia(*[l.wd.stride(0) if l.wd is not None else 0 for l in todo]),
                         ia(*[len(pt) for pt in pats]), (ctypes.c_int * (4 * n))(*[v for pt in pats for v in (pt + [3] * 4)[:4]]))
                 self._prep_key, self._prep_args = key, (args, [ctypes.cast(a, ctypes.c_void_p) for a in args])
-            # once the frozen layers are packed, the launch refreshes the TRAINABLE layers only and the body starts with
-            # frozen ones (stem, conv1_2, conv2_x: ~0.5 ms): it runs on a side stream beside them and is joined in front
-            # of the first layer that reads a refreshed copy (prep_join; inside a graph capture the fork / join become
-            # graph edges)
-            first_fresh = min(self.layers.index(l) for l in todo)
-            if self._frozen_ready and first_fresh > 1 and dev.type == "cuda" and os.environ.get("ODW_PREP_INLINE") != "1":
-                if self._prep_side is None:
-                    self._prep_side = torch.cuda.Stream(device=dev)
-                self._prep_side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._prep_side):
-                    L.check(lib.odw_conv_weight_prep_planes_batch(n, *self._prep_args[1], L.stream()), "conv_weight_prep_batch")
-                self._prep_first = first_fresh
-            else:
-                L.check(lib.odw_conv_weight_prep_planes_batch(n, *self._prep_args[1], L.stream()), "conv_weight_prep_batch")
+            L.check(lib.odw_conv_weight_prep_planes_batch(n, *self._prep_args[1], L.stream()), "conv_weight_prep_batch")
         self._frozen_ready = True
-
-    _prep_side = None
-    _prep_first = None
-
-    def prep_join(self, li):
-        """Called by the forward in front of layer `li`: wait for the side-stream weight refresh if this layer (or an
-        earlier one) reads it."""
-        if self._prep_first is not None and li >= self._prep_first:
-            torch.cuda.current_stream().wait_stream(self._prep_side)
-            self._prep_first = None
 
     # ---- HIP graphs (engine.build_training_step sets use_graphs): the body's forward (weight packing included) and its
     # backward are two static launch sequences per input shape -- ~50 and ~60 launches that the host issues one ctypes

@@ -5,7 +5,7 @@ import bench
 from od_wscl_amd import engine
 from od_wscl_amd.utils.device_rand import DeviceRand
 cfg = bench.build_cfg(21); dev = torch.device("cuda", 0)
-step, info = engine.build_training_step(cfg, dev, dtype="bf16", world=1, backend="hip")
+step, info = engine.build_training_step(cfg, dev, dtype=(sys.argv[1] if len(sys.argv) > 1 else "bf16x2f"), world=1, backend="hip")
 images, targets, rois = bench.synthetic_batch(1234, 0, 600, 2000, 21, dev)
 for it in range(5):
     step(images, targets, rois, DeviceRand(1234, first_stream=(1 << 20) + (it << 12), device=dev))
