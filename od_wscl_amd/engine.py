@@ -500,6 +500,13 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         conv_desc = "od_wscl_amd HIP: 1x1 convs on the MFMA GEMM, implicit-GEMM conv3x3, folded frozen BN (NHWC)"
     opt = FlatSGD(cfg, model, world)
     model.roi_heads.head_grads_ready = opt.head_grads_ready
+    # the dense losses' backward is queued from inside the loss, before its second host read (loss_fused.early_backward);
+    # evaluations of the large Linears that register with their weight-gradient batch after that get reserved columns
+    le = getattr(model.roi_heads, "loss_evaluator", None)
+    if hasattr(le, "early_backward") and os.environ.get("ODW_NO_EARLY_BWD") != "1":
+        from . import gemm as _gemm
+        le.early_backward = True
+        _gemm.WgradBatch.reserve = 1024
 
     # SOLVER.ITER_SIZE (config/defaults.py:459-461, engine/trainer.py:86,118-120): gradients are summed over ITER_SIZE
     # consecutive iterations, the optimiser steps after the last of them and the schedule advances once per group
@@ -521,10 +528,14 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             hip.accumulate = k > 0
         losses, accs = model(images, targets, rois, rand=rand)
         mark("forward")
-        loss = getattr(losses, "total", None)
-        if loss is None:
-            loss = sum(losses.values())
-        loss.backward()
+        finish = getattr(losses, "finish_backward", None)
+        if finish is not None:              # the dense losses' backward already ran inside the loss (early_backward)
+            finish()
+        else:
+            loss = getattr(losses, "total", None)
+            if loss is None:
+                loss = sum(losses.values())
+            loss.backward()
         mark("backward")
         if last:
             opt.all_reduce()

@@ -135,12 +135,29 @@ class WgradBatch(object):
     runs the GEMM over all rows -- instead of one read-modify-write pass over the (411 MB for fc6) gradient per
     evaluation.  Evaluations register at forward time; engine.FlatSGD flushes a step that ended early."""
 
+    # columns kept free behind the blocks registered when the buffers are first asked for: an evaluation may register
+    # AFTER another one's backward has run (the fused loss runs the dense losses' backward while the host still waits
+    # for the discovery lists, weak_head/loss_fused.py: early_backward; the clean rows re-attached afterwards are a
+    # few hundred).  Beyond the reserve the buffers are re-allocated and the filled blocks copied.
+    reserve = 0
+
     def __init__(self):
-        self.rows, self.filled, self.dzt, self.xt, self.kpad = [], 0, None, None, 0
+        self.rows, self.filled, self.dzt, self.xt, self.kpad, self.done = [], 0, None, None, 0, []
 
     def register(self, m):
         """Reserve the column block of an evaluation over m rows (split precision: one block per plane product)."""
         self.rows.append(_r64(m) * (len(P.patterns("gemm")[0]) if P.bwd_split() else 1))
+        if self.dzt is not None:
+            self.done.append(False)
+            need = sum(self.rows)
+            if need > self.dzt.shape[1]:
+                old = need - self.rows[-1]
+                dzt = torch.empty((self.dzt.shape[0], need + self.reserve), dtype=torch.bfloat16, device=self.dzt.device)
+                xt = torch.empty((self.xt.shape[0], need + self.reserve), dtype=torch.bfloat16, device=self.xt.device)
+                dzt[:, :old].copy_(self.dzt[:, :old])
+                xt[:, :old].copy_(self.xt[:, :old])
+                self.dzt, self.xt = dzt, xt
+            self.kpad = need
         return len(self.rows) - 1
 
     def offset(self, slot):
@@ -149,13 +166,14 @@ class WgradBatch(object):
     def buffers(self, n_out, k_in, device):
         if self.dzt is None:
             self.kpad = sum(self.rows)
-            self.dzt = torch.empty((n_out, self.kpad), dtype=torch.bfloat16, device=device)
-            self.xt = torch.empty((k_in, self.kpad), dtype=torch.bfloat16, device=device)
+            cap = self.kpad + self.reserve
+            self.dzt = torch.empty((n_out, cap), dtype=torch.bfloat16, device=device)
+            self.xt = torch.empty((k_in, cap), dtype=torch.bfloat16, device=device)
             self.done = [False] * len(self.rows)
         return self.dzt, self.xt
 
     def reset(self):
-        self.rows, self.filled, self.dzt, self.xt, self.kpad = [], 0, None, None, 0
+        self.rows, self.filled, self.dzt, self.xt, self.kpad, self.done = [], 0, None, None, 0, []
 
     def flush(self, weight, tag=None):
         """Run the GEMM over whatever was filled (blocks of evaluations whose backward never ran are zeroed)."""

@@ -133,6 +133,27 @@ class LossDict(dict):
     (sum(losses.values()) is 7 add kernels forward and 21 fill/copy/add kernels backward in the part of the step
     where the GPU waits for every launch)."""
     total = None
+    # set by RoIRegLossFused.early_backward: the dense losses' backward has ALREADY run down to the stacked fc6 operand;
+    # finish_backward() runs the rest (contrastive loss, ROI pooling, body).  engine.build_training_step calls it
+    # instead of total.backward().
+    finish_backward = None
+
+
+def _leaves_between(root_fn, stop_fn):
+    """The leaf tensors (AccumulateGrad nodes) reachable from autograd node `root_fn` without passing `stop_fn`."""
+    seen, stack, leaves = set(), [root_fn], []
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn is stop_fn or fn in seen:
+            continue
+        seen.add(fn)
+        var = getattr(fn, "variable", None)
+        if var is not None:
+            leaves.append(var)
+            continue
+        for nxt, _ in fn.next_functions:
+            stack.append(nxt)
+    return leaves
 
 
 class _DenseLossFn(torch.autograd.Function):
@@ -152,6 +173,10 @@ class _DenseLossFn(torch.autograd.Function):
 
 @registry.ROI_WEAK_LOSS.register("RoIRegLossFused")
 class RoIRegLossFused(RoIRegLossComputation):
+    # engine.build_training_step switches this on (the caller must then finish the backward through
+    # LossDict.finish_backward instead of total.backward()); plain callers of the model keep the ordinary graph
+    early_backward = False
+
     def _call(self, class_score, det_score, ref_scores, ref_bbox_preds, sim_feature, clean_pooled_feats,
               feature_extractor, model_sim, proposals, targets, epsilon=1e-8):
         if not self.contra or feature_extractor.rand is None:
@@ -348,6 +373,7 @@ class RoIRegLossFused(RoIRegLossComputation):
                                                       L.ptr(weight_all[i, sl]), L.ptr(target_all[i, sl]), L.stream()),
                         "od_assign_indexed")
         dense = None
+        early = None
         if ybase is not None and not self.cls_agnostic_bbox_reg:
             # ---- MIL + refinement losses and their gradient in ONE launch (csrc/refine_loss.hip)
             import ctypes
@@ -361,6 +387,29 @@ class RoIRegLossFused(RoIRegLossComputation):
             tot = out.sum(dim=0)
             col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
             dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
+            if (self.early_backward and torch.is_grad_enabled() and clean_pooled_feats.dim() == 2
+                    and clean_pooled_feats.requires_grad and clean_pooled_feats.grad_fn is not None):
+                # ---- the backward of the seven dense losses NOW: predictor, the DropBlock half of the stacked fc7 /
+                # fc6 pass (input and weight gradients: ~1.5 ms of large GEMMs at P = 2000) down to the gradient of the
+                # stacked operand.  Nothing on that path depends on the discovery lists, so it is queued before the host
+                # waits for them: the GPU works through it while the host reads the lists, assembles the SupCon gather
+                # indices and issues the ~150 small launches of the contrastive loss and of its backward -- the stretch
+                # of the step in which the GPU used to idle for ~1 ms waiting for launches (profiles/r03/hip_v2_gaps.csv).
+                # The rest of the backward (finish_backward) starts from loss_sim AND from this gradient.
+                # (leaf tensors on the way whose gradient autograd itself delivers -- the Linear layers write theirs in
+                # place -- are asked for too and accumulated by hand: e.g. the eight predictor heads behind a torch.cat
+                # when the optimiser does not lay them out as one matrix)
+                dsum = dense.sum()
+                leaves = _leaves_between(dsum.grad_fn, clean_pooled_feats.grad_fn)
+                grads = torch.autograd.grad(dsum, [clean_pooled_feats] + leaves, allow_unused=True)
+                for leaf, gl in zip(leaves, grads[1:]):
+                    if gl is not None:
+                        if leaf.grad is None:
+                            leaf.grad = gl.detach().clone()
+                        else:
+                            leaf.grad.add_(gl)
+                early = (clean_pooled_feats, grads[0])
+                dense = dense.detach()
         host_b = read_b.wait()
         fresh_h = host_b[:nf].reshape(n_img, 3, maxpos)
         gt_h = host_b[nf:nf + n_img * 3].reshape(n_img, 3)
@@ -454,6 +503,10 @@ class RoIRegLossFused(RoIRegLossComputation):
             for k in range(1, 7):
                 losses[names[k]] = dense[k]
             losses.total = dense.sum() + loss_sim
+            if early is not None:
+                def finish_backward(loss_sim=loss_sim, x=early[0], dx=early[1]):
+                    torch.autograd.backward([loss_sim, x], [None, dx])
+                losses.finish_backward = finish_backward
             accs = {"acc_img": tot[7], "acc_ref0": tot[8], "acc_ref1": tot[9], "acc_ref2": tot[10]}
             return losses, accs
 

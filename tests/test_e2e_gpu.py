@@ -432,3 +432,40 @@ def test_mixed_batch_with_an_unlabelled_image_gets_background_labels():
     L.check(L.lib().odw_od_assign_indexed_dev(L.ptr(boxes), 300, L.ptr(idx), L.ptr(cls), L.ptr(sc), L.ptr(n), 64, 0.5, 10.0, 10.0, 5.0,
                                               5.0, L.ptr(lab), L.ptr(w), L.ptr(t), L.stream()), "od_assign")
     assert int(lab.abs().sum()) == 0 and float(w.abs().sum()) == 0.0 and float(t.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_early_dense_backward_equals_the_ordinary_backward(monkeypatch, fuse):
+    """engine.build_training_step lets the fused loss run the backward of the dense losses (predictor, DropBlock half of the
+    stacked fc7 / fc6 pass) BEFORE it waits for the discovery lists, and finishes from loss_sim and the gradient of the
+    stacked operand (LossDict.finish_backward).  Same kernels on the same operands: the gradients of one step must
+    equal those of the ordinary single backward (up to the summation order of the bias-gradient atomics), with the
+    predictor laid out as one matrix and as eight heads behind a torch.cat (whose gradients autograd delivers)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from od_wscl_amd import engine
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("ODW_NO_TIMER", "1")
+    monkeypatch.setenv("ODW_NO_PRED_FUSE", "0" if fuse else "1")
+    grads, losses = {}, {}
+    for early in (True, False):
+        monkeypatch.setenv("ODW_NO_EARLY_BWD", "0" if early else "1")
+        cfg = bench.build_cfg(21)
+        step, _ = engine.build_training_step(cfg, dev, dtype="bf16x2f", world=1, seed=cfg.SEED, backend="hip")
+        assert step.model.roi_heads.loss_evaluator.early_backward == early
+        images, targets, rois = bench.synthetic_batch(cfg.SEED, 0, 224, 150, 21, dev)
+        l, _ = step(images, targets, rois, DeviceRand(cfg.SEED, first_stream=1 << 20, device=dev))
+        torch.cuda.synchronize()
+        assert (getattr(l, "finish_backward", None) is not None) == early
+        opt = step.optimizer
+        grads[early] = {n: opt.flat_g[o:o + k].double().clone() for n, (o, k) in opt.slices.items()}
+        losses[early] = {k: float(v.detach()) for k, v in l.items()}
+        del step, opt
+    assert losses[True] == losses[False]
+    for n, g in grads[False].items():
+        if n.endswith("det_score.bias"):
+            continue        # a softmax over the proposals is shift invariant: this gradient is rounding noise around 0
+        d = (grads[True][n] - g).abs().max().item()
+        assert d <= 1e-6 * g.abs().max().item() + 1e-9, (n, d, g.abs().max().item())
