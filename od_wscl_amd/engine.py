@@ -507,6 +507,9 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         from . import gemm as _gemm
         le.early_backward = True
         _gemm.WgradBatch.reserve = 1024
+        # (measured and rejected, tools/exp/ab_early.sh: the stacked pass's weight gradient as its own GEMM in the early
+        # part -- more cover for the host's small launches, but a second read-modify-write of fc6's 411 MB gradient and
+        # a 100 MB transposed copy of its own: 10.6-11.2 ms against 9.9-10.1)
 
     # SOLVER.ITER_SIZE (config/defaults.py:459-461, engine/trainer.py:86,118-120): gradients are summed over ITER_SIZE
     # consecutive iterations, the optimiser steps after the last of them and the schedule advances once per group
