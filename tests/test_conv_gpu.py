@@ -343,7 +343,8 @@ def test_conv_weight_prep_planes_batch_equals_the_split_of_the_packed_weight(lib
     import ctypes
     from od_wscl_amd import precision as P
     L = lib
-    shapes = [(64, 64, 64, (0, 1, 0)), (256, 128, 128, (0, 1, 0)), (72, 40, 64, (0, 1, 2, 0)), (64, 3, 8, (0, 1, 0, 1))]
+    shapes = [(64, 64, 64, (0, 1, 0)), (256, 128, 128, (0, 1, 0)), (72, 40, 64, (0, 1, 2, 0)), (64, 3, 8, (0, 1, 0, 1)),
+              (512, 256, 256, (0, 1, 0)), (96, 192, 192, (0, 1, 2, 0))]      # the last two: the tiled form
     ws, wk, wd, want = [], [], [], []
     for i, (co, ci, cp, pat) in enumerate(shapes):
         w = rnd(60 + i, (co, ci, 3, 3), 0.1)
