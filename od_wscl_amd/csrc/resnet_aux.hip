@@ -184,6 +184,73 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
     }
 }
 
+// The planes form of the layer for Co = 64 (VGG's conv1_1): 16 lanes share a pixel, each owns 4 output channels whose
+// 108 weights stay in REGISTERS for the whole kernel, and walks runs of 4 consecutive pixels of a row with a sliding
+// 3 x 6 x 3 input window (13.5 loads per 108 FMAs).  The 16 lanes of a pixel write 128 contiguous bytes per plane
+// block.  Same fmaf chain per output as stem_conv3x3_kernel (bias first, then tap-major, channel-minor): same bits.
+// (The one-thread-per-pixel form above keeps the weights in LDS -- one broadcast ds_read_b128 per 8 FMAs -- and stores
+// 16-byte pieces 384 bytes apart: 145 us at 608 x 608 in this mode, against 142 MB of output.)
+__global__ __launch_bounds__(256, 2) void stem_conv3x3_planes64_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                                       const float* __restrict__ bias, int B, int H, int W,
+                                                                       unsigned short* __restrict__ out, odwpl::Pattern pat,
+                                                                       int ld, int block) {
+    const int cg = threadIdx.x & 15;                 // channels 4 cg .. 4 cg + 3
+    float wr[27][4], bs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bs[q] = bias ? bias[cg * 4 + q] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k)                 // k = tap*3 + ci ; source layout (Co, 3, 3, 3)
+            wr[k][q] = w[((size_t)(cg * 4 + q) * 3 + (k % 3)) * 9 + (k / 3)];
+    }
+    bool need_lo = false;
+    for (int t = 0; t < pat.T; ++t) need_lo |= pat.p[t] == 2;
+    const int runs_w = (W + 3) / 4;
+    const long long runs = (long long)B * H * runs_w;
+    for (long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); r < runs; r += (long long)gridDim.x * 16) {
+        const int xr = (int)(r % runs_w), y0 = (int)((r / runs_w) % H), b = (int)(r / ((long long)runs_w * H));
+        const int x0 = xr * 4;
+        const float* base = img + (size_t)b * 3 * H * W;
+        float win[3][6][3];                          // [ky][column x0 - 1 + j][ci], zero in the padding
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int y = y0 - 1 + ky, x = x0 - 1 + j;
+                const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) win[ky][j][ci] = ok ? base[((size_t)ci * H + y) * W + x] : 0.0f;
+            }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            float acc[4] = {bs[0], bs[1], bs[2], bs[3]};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        const float v = win[ky][px + kx][ci];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] = fmaf(v, wr[(ky * 3 + kx) * 3 + ci][q], acc[q]);
+                    }
+            if (x0 + px < W) {
+                unsigned hi[2], mid[2], lo[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    odwpl::split2(fmaxf(acc[2 * q], 0.0f), fmaxf(acc[2 * q + 1], 0.0f), need_lo, hi[q], mid[q], lo[q]);
+                unsigned short* o = out + ((size_t)(b * H + y0) * W + x0 + px) * (size_t)ld + cg * 4;
+                for (int t = 0; t < pat.T; ++t) {
+                    const int pl = pat.p[t];
+                    *reinterpret_cast<uint2*>(o + (size_t)t * block) = pl == 0 ? make_uint2(hi[0], hi[1])
+                                                                     : (pl == 1 ? make_uint2(mid[0], mid[1])
+                                                                     : (pl == 2 ? make_uint2(lo[0], lo[1]) : make_uint2(0, 0)));
+                }
+            }
+        }
+    }
+}
+
 // NHWC bf16 3x3 / stride 2 / pad 1 max pool, 8 channels per thread (padding never wins: -inf)
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint4* __restrict__ X, int B, int H, int W, int C8, int Ho,
                                                            int Wo, uint4* __restrict__ Y) {
@@ -352,6 +419,15 @@ ODW_EXPORT int odw_stem_conv3x3_bias_relu_planes(const float* img_nchw, const fl
     const size_t total = (size_t)B * H * W;
     const size_t lds = (size_t)28 * Co * sizeof(float);
     const int grid = blocks_for(total) > 4096 ? 4096 : blocks_for(total);
+    static const bool old_form = getenv("ODW_STEM_OLD") != nullptr;      // (comparison runs)
+    if (Co == 64 && !old_form) {
+        const long long runs = (long long)B * H * ((W + 3) / 4);
+        const long long want = (runs + 15) / 16;
+        stem_conv3x3_planes64_kernel<<<(int)(want < 2 * ODW_NUM_CU ? want : 2 * ODW_NUM_CU), 256, 0, (hipStream_t)stream_>>>(
+            img_nchw, weight, bias, B, H, W, (unsigned short*)out_planes, pat, (int)ld, block);
+        ODW_CHECK_LAUNCH("stem_conv3x3_planes64_kernel");
+        return ODW_OK;
+    }
     stem_conv3x3_kernel<true><<<grid, 256, lds, (hipStream_t)stream_>>>(img_nchw, weight, bias, B, H, W, Co,
                                                                        (unsigned short*)out_planes, pat, (int)ld, block);
     ODW_CHECK_LAUNCH("stem_conv3x3_kernel");

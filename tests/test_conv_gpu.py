@@ -369,3 +369,31 @@ def test_conv_weight_prep_planes_batch_equals_the_split_of_the_packed_weight(lib
         plain = torch.empty_like(wd[i])
         L.check(L.lib().odw_conv_weight_prep(L.ptr(ws[i]), co, ci, cp, None, 0, L.ptr(plain), plain.stride(0), L.stream()), "prep")
         assert torch.equal(plain.view(torch.int16), wd[i].view(torch.int16)), i
+
+
+@pytest.mark.parametrize("hw", [(37, 50), (64, 64)])
+def test_stem_planes64_kernel_equals_the_per_pixel_form(lib, hw):
+    """odw_stem_conv3x3_bias_relu_planes with Co = 64 runs the register-resident-weights kernel (16 lanes per pixel, runs of
+    four pixels); with any other channel count the one-thread-per-pixel kernel.  Both evaluate the same fmaf chain per
+    output: the 64 channels of the first must equal, bit for bit, the first 64 of a 72-channel launch of the second
+    (same weights), plane block by plane block, at image sizes that are not multiples of the run length."""
+    import ctypes
+    L = lib
+    H, W = hw
+    B = 2
+    img = rnd(70, (B, 3, H, W), 1.0)
+    w72 = rnd(71, (72, 3, 3, 3), 0.2)
+    b72 = rnd(72, (72,), 0.1)
+    pat = (ctypes.c_int * 3)(0, 0, 1)
+    out = {}
+    for co, blk in ((64, 64), (72, 72)):
+        o = torch.full((B * H * W, 3 * blk), 7.0, dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().odw_stem_conv3x3_bias_relu_planes(L.ptr(img), L.ptr(w72[:co].contiguous()), L.ptr(b72[:co].contiguous()),
+                                                          B, H, W, co, ctypes.cast(pat, ctypes.c_void_p), 3, L.ptr(o),
+                                                          o.stride(0), blk, L.stream()), "stem planes")
+        out[co] = o.view(B * H * W, 3, blk)[:, :, :64].contiguous()
+    assert torch.equal(out[64].view(torch.int16), out[72].view(torch.int16))
+    # and it is the convolution: hi + mid of the planes against torch's fp32 conv + ReLU
+    ref = torch.relu(torch.nn.functional.conv2d(img, w72[:64], b72[:64], padding=1)).permute(0, 2, 3, 1).reshape(B * H * W, 64)
+    got = out[64][:, 0].float() + out[64][:, 2].float()
+    assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
