@@ -314,6 +314,7 @@ class FlatSGD(object):
     def sync_from_params(self):
         """After weights were loaded into the model (utils/checkpoint.load_checkpoint copies into the flat views):
         rebuild the bf16 shadows the matrix cores read."""
+        self.join_side()
         if self.shadows:
             self._refresh_shadows(initial=True)
 
@@ -324,6 +325,7 @@ class FlatSGD(object):
             base = self.cfg.SOLVER.BASE_LR
             corr = momentum_correction(base * self.lr_scale, base * f)
             if corr is not None and not self.first:
+                self.join_side()
                 self.flat_m.mul_(corr)
             self.lr_scale = f
 
@@ -337,6 +339,7 @@ class FlatSGD(object):
         """torch.optim.SGD.state_dict() layout: group i / state i = the i-th trainable parameter of
         model.named_parameters(); momentum buffers are views of the flat momentum copied out."""
         s = self.cfg.SOLVER
+        self.join_side()
         groups, state = [], {}
         for i, n in enumerate(self._param_order(model)):
             off, numel = self.slices[n]
@@ -351,6 +354,7 @@ class FlatSGD(object):
 
     def load_state_dict(self, model, sd):
         """Momentum buffers of a checkpoint written by state_dict() above or by the reference's torch.optim.SGD."""
+        self.join_side()
         order = self._param_order(model)
         state = sd.get("state", {})
         if len(sd.get("param_groups", order)) != len(order):
@@ -460,8 +464,26 @@ class FlatSGD(object):
         self._sgd_region(1)
         self._sgd_region(2)
         if self.early_done:
-            torch.cuda.current_stream().wait_stream(self.side)     # the next forward reads the refreshed weights
+            # the next forward reads the refreshed weights -- but not before its first head GEMM, ~2 ms of backbone
+            # forward away: the wait is handed to the shadows (gemm.Shadow.refresh) instead of blocking the stream here.
+            # (At N > 1 the side stream carries exchange -> update -> refresh back to back after the backward.)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self._head_event = ev
+            for sh in self.shadows:
+                sh.pending = ev
         self.first = False
+
+    _head_event = None
+
+    def join_side(self):
+        """Make the current stream wait for the side stream's update of the head (anything that reads or writes the flat
+        buffers outside the step: schedules, checkpoints)."""
+        if self._head_event is not None:
+            torch.cuda.current_stream().wait_event(self._head_event)
+            self._head_event = None
+            for sh in self.shadows:
+                sh.pending = None
 
 
 def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="hip"):

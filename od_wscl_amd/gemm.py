@@ -114,7 +114,14 @@ class Shadow(object):
         self.version = w._version
         self.mode = P.get_precision()
 
+    # engine.FlatSGD: the event behind which the optimiser's side stream has rewritten this weight's copies; the first
+    # evaluation that reads them waits for it (instead of the whole next forward waiting at the end of the step)
+    pending = None
+
     def refresh(self):
+        if self.pending is not None:
+            torch.cuda.current_stream().wait_event(self.pending)
+            self.pending = None
         mode = P.get_precision()
         if self.managed:
             if self.mode != mode:

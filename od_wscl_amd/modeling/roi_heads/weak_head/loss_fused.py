@@ -388,7 +388,8 @@ class RoIRegLossFused(RoIRegLossComputation):
             col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
             dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
             if (self.early_backward and torch.is_grad_enabled() and clean_pooled_feats.dim() == 2
-                    and clean_pooled_feats.requires_grad and clean_pooled_feats.grad_fn is not None):
+                    and clean_pooled_feats.requires_grad and clean_pooled_feats.grad_fn is not None
+                    and getattr(feature_extractor, "sparse_clean", False)):     # (only then does no other loss reach these nodes)
                 # ---- the backward of the seven dense losses NOW: predictor, the DropBlock half of the stacked fc7 /
                 # fc6 pass (input and weight gradients: ~1.5 ms of large GEMMs at P = 2000) down to the gradient of the
                 # stacked operand.  Nothing on that path depends on the discovery lists, so it is queued before the host

@@ -54,6 +54,8 @@ def save_checkpoint(model, path, optimizer=None, iteration=None, **extra):
     """Checkpointer.save (checkpoint.py:41-63): {"model", "optimizer", "scheduler", "iteration"} in the reference's
     layout, loadable by wetectron.  `optimizer` = engine.FlatSGD (its momenta are written as a torch.optim.SGD
     state_dict, one group per trainable parameter)."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()        # the optimiser may still be rewriting the head on its side stream (engine.FlatSGD.step)
     data = {"model": model.state_dict()}
     if optimizer is not None:
         data["optimizer"] = optimizer.state_dict(model)
