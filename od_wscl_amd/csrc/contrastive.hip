@@ -276,6 +276,10 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
             PwRows q8[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) q8[q] = fetch_item(nb + 4 * q + lrow, lchunk);
+#ifdef ODW_PW_TIMELINE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PW_T(3 + 3 * (int)(it - lo_it));             // (loader wave: its fetches have arrived)
+#endif
 #pragma unroll
             for (int q = 0; q < 8; ++q) park_item(q8[q], slot ^ 1, 4 * q + lrow, lchunk);
         } else {

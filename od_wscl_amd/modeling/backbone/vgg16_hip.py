@@ -478,8 +478,13 @@ class _GraphedBody(object):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
                 net._prep()
+                # (the warm-up doubles as the counting pass: the MFMA work of the two launch sequences, which a replay
+                # reports to the kernel timer as ONE region each -- the launches inside a graph carry no events)
+                kt.tally = 0.0
                 feat = fn.forward(self.ctx, self.img, net)
+                self.flops_fwd, kt.tally = kt.tally, 0.0
                 fn.backward(self.ctx, torch.zeros_like(feat))
+                self.flops_bwd, kt.tally = kt.tally, None
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.g_fwd = torch.cuda.CUDAGraph()
@@ -494,13 +499,15 @@ class _GraphedBody(object):
                 fn.backward(self.ctx, self.dfeat)
         finally:
             kt.active = was
+            kt.tally = None
 
 
 class _GraphedVGGFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, net, graphed, *params):
         graphed.img.copy_(images)
-        graphed.g_fwd.replay()
+        with kernel_timer.region("VGG body forward (HIP graph)", flops=graphed.flops_fwd):
+            graphed.g_fwd.replay()
         net.last_nhwc = graphed.nhwc
         net.last_nhwc_f32 = graphed.nhwc_f32
         ctx.graphed = graphed
@@ -513,5 +520,6 @@ class _GraphedVGGFn(torch.autograd.Function):
     def backward(ctx, dfeat):
         g = ctx.graphed
         g.dfeat.copy_(dfeat)
-        g.g_bwd.replay()
+        with kernel_timer.region("VGG body backward (HIP graph)", flops=g.flops_bwd):
+            g.g_bwd.replay()
         return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

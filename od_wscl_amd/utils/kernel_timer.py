@@ -45,6 +45,7 @@ class KernelTimer(object):
         self.enabled = False      # build-time switch (engine.build_training_step, ODW_NO_TIMER)
         self.active = True        # per-step switch: bench.py times 1 step in `sample_every` (the event pairs cost
         self.layer = None         # ~5 % of the step when every launch of every step carries them)
+        self.tally = None         # a float while a counting pass runs (region() adds its FLOPs and records nothing)
         self.reset()
 
     def reset(self):
@@ -53,6 +54,9 @@ class KernelTimer(object):
 
     def region(self, name, flops=0.0, nbytes=0.0):
         """with kernel_timer.region(symbol, flops=...): <one launch on torch's current stream>"""
+        if self.tally is not None:       # counting pass (a HIP-graph capture's warm-up): FLOPs only, no events
+            self.tally += flops
+            return _NO_REGION
         if not self.enabled or not self.active or name is None:
             return _NO_REGION
         return _Region(self, name, flops, nbytes)
