@@ -2075,6 +2075,236 @@ ODW_EXPORT int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int
     return ODW_OK;
 }
 
+// ---- convolution weight gradient, output-stationary "halo" form (round 3) ---------------------------------------------
+// dW[co][tap][ci] = sum over pixels p of dZ[p][co] X[p + shift(tap)][ci].  gemm_tn_bf16_ring_kernel above treats the nine
+// taps as nine column blocks of one long GEMM: every 64-pixel K step moves 48 KB L2 -> LDS for 4.2 MFLOP, X nine times
+// over (87 FLOP / B: the kernel sat at 18 % MFMA busy, bound by the CU's 64 B/clk of operand delivery).  Here a workgroup
+// OWNS a (64 co) x (9 taps x 64 ci) block of dW in its accumulators -- 9 x 16 registers per lane -- and walks 16 x 16
+// (dilation 2: 8 x 16) spatial tiles: per tile ONE dZ tile (pixels x 64 co) and ONE halo patch of X ((rows + 2 dil) x
+// (16 + 2 dil) pixels x 64 ci) reach LDS, and all nine taps read the SAME patch at shifted pixel rows: 73 KB per
+// 18.9 MFLOP = 258 FLOP / B.  Both operands stay K-major (pixel rows of 128 B, 16-byte chunk c of row r in slot
+// c ^ 4 ((r >> 1) & 1): any four consecutive rows cover all 64 banks) and are read with ds_read_b64_tr_b16 like the
+// ring form; a tile row of 16 pixels is one MFMA K block, and a tap's fragment is the patch at row
+// (y + dy dil) PW + dx dil -- 16 consecutive patch pixels.  Waves: (co half) x (ci half) x (K half: the upper / lower tile
+// rows); the two K halves are summed through LDS at the end.  K is split over workgroups by ranges of spatial tiles
+// (fp32 partials + wgrad_reduce_unpack_kernel, as before).  Double-buffered DMA: tile t + 1 lands while t is computed.
+struct WhGeom {
+    int B, H, W, Cp, ld_dz, tiles_x, tiles_y, tiles_total, tiles_per_split, co_tiles, out_tiles, splits, chunk;
+    long long split_stride;             // floats between the partial sums of consecutive splits
+    int ldw;                            // 9 * Cp
+    const unsigned short* zero;
+};
+
+// tools/exp/wgrad_timeline.hip compiles this file with ODW_WH_TIMELINE: lane 0 of every wave stamps wall_clock64() (100 MHz)
+// at its phase boundaries of the first tiles: 4 t + {0: tile landed (after the barrier), 1: first reads + next DMA issued,
+// 2: K loop done}; 30: before the K-half reduction, 31: exit
+#ifdef ODW_WH_TIMELINE
+__device__ long long g_wh_tl[1024 * 8 * 32];
+#define WH_T(i) do { const int e_ = 4 * (t - t_begin) + (i); if (lane == 0 && e_ < 30) g_wh_tl[(wg * 8 + wave) * 32 + e_] = wall_clock64(); } while (0)
+#define WH_TE(e) do { if (lane == 0) g_wh_tl[(wg * 8 + wave) * 32 + (e)] = wall_clock64(); } while (0)
+#else
+#define WH_T(i) do { } while (0)
+#define WH_TE(e) do { } while (0)
+#endif
+
+template <int TR, int DIL>
+struct WhCfg {
+    static constexpr int PW = 16 + 2 * DIL, PH = TR + 2 * DIL;
+    static constexpr int kARows = TR * 16;
+    static constexpr int kPRows = (PH * PW + 7) / 8 * 8;
+    static constexpr int kStageBytes = (kARows + kPRows) * 128;
+    static constexpr int kLds = 2 * kStageBytes;
+};
+
+template <int TR, int DIL>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_halo_kernel(const unsigned short* __restrict__ dz,
+                                                                 const unsigned short* __restrict__ X,
+                                                                 float* __restrict__ ws, WhGeom g) {
+    using C = WhCfg<TR, DIL>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wh_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave & 1, wi = (wave >> 1) & 1, wk = wave >> 2;
+    // workgroup id -> (split, output tile): consecutive ids land on consecutive XCDs, so XCD k takes the k-th CONTIGUOUS
+    // chunk of the split-major order -- its ~32 co-resident workgroups walk the same spatial tiles (one split, all co
+    // blocks x a few ci blocks) and share them in ITS L2.  With (tile, split) as blockIdx every XCD pulled every dZ / X
+    // tile of every split: 47 % L2 misses, 94 MB of fabric traffic per launch for 12 MB of operands, and the kernel ran
+    // at the pace of those misses (4.1 us per tile against 2.4 us of MFMA time, whatever the LDS side did).
+    const int wg = (int)(blockIdx.x % 8) * g.chunk + (int)(blockIdx.x / 8);
+    if (wg >= g.out_tiles * g.splits) return;
+    const int split = wg / g.out_tiles, ot = wg - split * g.out_tiles;
+    const int co0 = (ot % g.co_tiles) * 64, ci0 = (ot / g.co_tiles) * 64;
+    const int t_begin = split * g.tiles_per_split;
+    const int t_end = t_begin + g.tiles_per_split < g.tiles_total ? t_begin + g.tiles_per_split : g.tiles_total;
+
+    // ---- DMA: 8 rows x 8 chunks per wave instruction; lane -> (row, physical chunk); the swizzle is on the source chunk.
+    // A wave issues NA + NP instructions per tile; everything about them that does not depend on the tile is computed
+    // ONCE here (element offset inside the image, position inside the tile / patch): the first version recomputed rows,
+    // a division by PW, bounds and 64-bit addresses per instruction and spent ~200 cycles on each -- 1 us per tile,
+    // serial with 2.4 us of MFMAs (the same instructions issued by half the waves cost 7 us more per launch).
+    constexpr int NA = C::kARows / 64, NP = (C::kPRows / 8 + 7) / 8;
+    const int drow = lane >> 3, dpc = lane & 7;
+    int a_off[NA], p_off[NP], p_yx[NP];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int r = (i * 8 + wave) * 8 + drow;
+        a_off[i] = ((r >> 4) * g.W + (r & 15)) * g.ld_dz + (dpc ^ (4 * ((r >> 1) & 1))) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int r = (i * 8 + wave) * 8 + drow;
+        const int py = r / C::PW, px = r - py * C::PW;
+        p_off[i] = ((py - DIL) * g.W + (px - DIL)) * g.Cp + (dpc ^ (4 * ((r >> 1) & 1))) * 8;
+        p_yx[i] = r < C::PH * C::PW ? ((py - DIL) & 0xffff) | ((px - DIL) << 16) : 0x7fff7fff;      // rows past the patch: never valid
+    }
+    auto issue = [&](int t, unsigned char* stage) {
+        const int per_img = g.tiles_x * g.tiles_y;
+        const int img = t / per_img, tt = t - img * per_img;
+        const int y0 = (tt / g.tiles_x) * TR, x0 = (tt % g.tiles_x) * 16;
+        const size_t pix0 = (size_t)img * g.H * g.W + (size_t)y0 * g.W + x0;
+        const unsigned short* abase = dz + pix0 * g.ld_dz + co0;
+        const unsigned short* pbase = X + pix0 * g.Cp + ci0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {                        // dZ tile: pixel rows (ty, tx), 64 co
+            const int rbase = (i * 8 + wave) * 8;
+            const int y = y0 + (rbase >> 4), x = x0 + (rbase & 15) + drow;
+            const void* src = (y < g.H && x < g.W) ? static_cast<const void*>(abase + a_off[i]) : static_cast<const void*>(g.zero);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + rbase * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {                        // halo patch of X: (PH x PW) pixel rows, 64 ci
+            const int j = i * 8 + wave;
+            if (j < C::kPRows / 8) {
+                const int y = y0 + (short)(p_yx[i] & 0xffff), x = x0 + (p_yx[i] >> 16);
+                const void* src = ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
+                                      ? static_cast<const void*>(pbase + p_off[i]) : static_cast<const void*>(g.zero);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(stage + (C::kARows + j * 8) * 128), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment addressing (tn_frag: lane supplies row kq (+4) of the 16-pixel K block, 8-byte piece `sub` of chunk cb)
+    const unsigned kq = 8u * (lane >> 5) + ((lane & 15) >> 2);
+    const unsigned cb = 2u * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+    const unsigned sub = 8u * (lane & 1);
+    const unsigned offa = kq * 128u + (((unsigned)(wc * 4) + cb) ^ (4u * ((kq >> 1) & 1))) * 16u + sub;
+    const unsigned cbi = (unsigned)(wi * 4) + cb;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    int stage = 0;
+    if (t_begin < t_end) issue(t_begin, wh_lds);
+    for (int t = t_begin; t < t_end; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t has landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                         // ... everyone's; and everyone is done with the other stage
+        asm volatile("" ::: "memory");
+        WH_T(0);
+        const unsigned char* sa = wh_lds + stage * C::kStageBytes;
+        const unsigned char* sp = sa + C::kARows * 128;
+        // A tap's fragment at tile row y is the patch at pixel row y + dy DIL: the fragments of one patch row serve
+        // three tile rows, so the wave keeps a rolling window of 2 DIL + 1 patch rows x 3 column shifts in registers
+        // and reads THREE new fragments per K block instead of nine (ds_read_b64_tr_b16 runs at half the plain b64
+        // rate: with nine the kernel was LDS-bound at 5.4 us per tile against 2.4 us of MFMA time).
+        if constexpr (DIL == 1) {
+            constexpr int NS = 2 * DIL + 1;
+            bf16x8 win[NS][3];
+            const int y_first = wk * (TR / 2);
+            auto load_row = [&](int prow, bf16x8 (&dst)[3]) {
+    #pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const unsigned row = (unsigned)(prow * C::PW + dx * DIL) + kq;
+                    dst[dx] = tn_frag<128>(sp, row * 128u + ((cbi ^ (4u * ((row >> 1) & 1))) * 16u) + sub);
+                }
+            };
+            bf16x8 fa = tn_frag<128>(sa, offa + (unsigned)y_first * 16u * 128u);
+    #pragma unroll
+            for (int r = 0; r < NS - 1; ++r) load_row(y_first + r, win[r]);
+            // the next tile's DMA is issued HERE, behind this tile's first fragment reads (the other stage: nobody reads it
+            // now).  Its ~10 instructions cost a wave ~0.6 us of issue time per tile (timeline of tools/exp/wgrad_timeline.hip:
+            // tile landed -> issued 0.87 us, K loop 2.65 us = the MFMA time of two waves per SIMD, barrier 0.73 us); moved
+            // between the K-block groups, de-phased between the two waves of a SIMD, the K loop grew by 1.3 us instead.
+            if (t + 1 < t_end) issue(t + 1, wh_lds + (stage ^ 1) * C::kStageBytes);
+            WH_T(1);
+            // (the K blocks in groups of NS: the window slot of a row is static inside a group, and the group loop keeps
+            // the compiler from hoisting the addresses of all TR / 2 blocks at once -- 30 spilled registers when it did)
+    #pragma unroll 1
+            for (int kb0 = 0; kb0 < TR / 2; kb0 += NS) {
+    #pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const int kb = kb0 + j;
+                    if (kb < TR / 2) {
+                        const int y = y_first + kb;
+                        // issue order: this block's new patch row (its taps come last), the NEXT block's dZ fragment; the
+                        // six MFMAs on rows already in registers run while those reads are in flight (LDS returns in order)
+                        load_row(y + NS - 1, win[(j + NS - 1) % NS]);
+                        bf16x8 fa_next = fa;
+                        if (kb + 1 < TR / 2) fa_next = tn_frag<128>(sa, offa + (unsigned)(y + 1) * 16u * 128u);
+    #pragma unroll
+                        for (int tap = 0; tap < 9; ++tap)
+                            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, win[(j + (tap / 3) * DIL) % NS][tap % 3], acc[tap], 0, 0, 0);
+                        fa = fa_next;
+                    }
+                }
+            }
+        } else {
+            // dilation 2 (TR = 8: four K blocks per wave): the window would hold 5 patch rows x 3 shifts = 60 registers on
+            // top of the 144 accumulators; the nine fragments of a K block are read directly instead (same speed here)
+            const int y_first = wk * (TR / 2);
+            if (t + 1 < t_end) issue(t + 1, wh_lds + (stage ^ 1) * C::kStageBytes);
+            WH_T(1);
+#pragma unroll 1
+            for (int kb = 0; kb < TR / 2; ++kb) {
+                const int y = y_first + kb;
+                const bf16x8 fa = tn_frag<128>(sa, offa + (unsigned)y * 16u * 128u);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const unsigned row = (unsigned)((y + (tap / 3) * DIL) * C::PW + (tap % 3) * DIL) + kq;
+                    const bf16x8 fb = tn_frag<128>(sp, row * 128u + ((cbi ^ (4u * ((row >> 1) & 1))) * 16u) + sub);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+        WH_T(2);
+        stage ^= 1;
+    }
+    WH_TE(30);
+
+    // ---- the two K halves summed through LDS, three taps per round (12 KB per wave pair), then the partial sums out:
+    // accumulator register k of lane (half, n) is dW[co0 + 32 wc + crow(k)][tap][ci0 + 32 wi + n]: 128-byte row segments
+    float* red = reinterpret_cast<float*>(wh_lds) + (size_t)(wave & 3) * (3 * 16 * 64);
+    const int half = lane >> 5, l31 = lane & 31;
+    float* out = ws + (size_t)split * g.split_stride + (size_t)(co0 + wc * 32 + 4 * half) * g.ldw + ci0 + wi * 32 + l31;
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wk == 1) {
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) red[(tt * 16 + k) * 64 + lane] = acc[round * 3 + tt][k];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wk == 0) {
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const int tap = round * 3 + tt;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float v = acc[tap][k] + red[(tt * 16 + k) * 64 + lane];
+                    out[(size_t)((k & 3) + 8 * (k >> 2)) * g.ldw + (size_t)tap * g.Cp] = v;
+                }
+            }
+        }
+    }
+    WH_TE(31);
+}
+
 // ---- convolution weight gradient WITHOUT the transposed operands: dW = dZ^T im2col(X) on gemm_tn_bf16_ring_kernel --------
 // dz (n_pix x ld_dz, the masked output gradient, NHWC bf16) and X (n_pix x Cp, the layer input, NHWC bf16) are read as
 // they are: no dZ^T, no 9x transposed im2col.  Needs Cp a power of two >= 128 (one tap per 128-column tile).
@@ -2095,10 +2325,37 @@ TnPlan conv_wgrad_tn_plan(int Co, int Cp, int K) {
 }
 }  // namespace
 
+// the halo form's split of the spatial tiles (see conv_wgrad_halo_kernel): ~256 workgroups, one per CU
+struct WhPlan { int tr, tiles_x, tiles_y, tiles_total, tiles_per_split, splits; };
+static WhPlan conv_wgrad_halo_plan(int Co, int Cp, int B, int H, int W, int dilation) {
+    WhPlan p;
+    p.tr = dilation == 1 ? 16 : 8;
+    p.tiles_x = (W + 15) / 16;
+    p.tiles_y = (H + p.tr - 1) / p.tr;
+    p.tiles_total = B * p.tiles_x * p.tiles_y;
+    const int out_tiles = (Co / 64) * (Cp / 64);
+    int sp = (ODW_NUM_CU + out_tiles - 1) / out_tiles;
+    sp = sp < 1 ? 1 : (sp > p.tiles_total ? p.tiles_total : sp);
+    p.tiles_per_split = (p.tiles_total + sp - 1) / sp;
+    p.splits = (p.tiles_total + p.tiles_per_split - 1) / p.tiles_per_split;
+    return p;
+}
+static bool conv_wgrad_halo_ok(int Co, int Cp, int dilation) {
+    static const bool off = getenv("ODW_WGRAD_HALO") && atoi(getenv("ODW_WGRAD_HALO")) == 0;
+    return !off && Co % 64 == 0 && Cp % 64 == 0 && (dilation == 1 || dilation == 2);
+}
+
+// H, W unknown here: the halo form never needs more than the ring form's plan times 2 (asserted at launch)
 ODW_EXPORT int64_t odw_conv_wgrad_tn_workspace(int Co, int Cp, int n_pix) {
     if (Co <= 0 || Cp < 128 || n_pix <= 0) return 0;
     const TnPlan p = conv_wgrad_tn_plan(Co, Cp, n_pix);
-    return (int64_t)p.splits * Co * 9 * Cp * 4;
+    int64_t splits = p.splits;
+    if (conv_wgrad_halo_ok(Co, Cp, 1)) {
+        const int out_tiles = (Co / 64) * (Cp / 64);
+        const int64_t sp = (ODW_NUM_CU + out_tiles - 1) / out_tiles;
+        splits = sp > splits ? sp : splits;
+    }
+    return splits * Co * 9 * Cp * 4;
 }
 
 ODW_EXPORT int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
@@ -2112,8 +2369,40 @@ ODW_EXPORT int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n
     ODW_REQUIRE(dz && X && dw && zero_page && workspace, "conv_wgrad_tn: null pointer");
     ODW_REQUIRE((((uintptr_t)dz) & 15) == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)zero_page) & 15) == 0 &&
                     (((uintptr_t)workspace) & 15) == 0, "conv_wgrad_tn: 16-byte alignment");
-    const TnPlan plan = conv_wgrad_tn_plan(Co, Cp, n_pix);
     const int N = 9 * Cp;
+    if (conv_wgrad_halo_ok(Co, Cp, dilation)) {
+        const WhPlan hp = conv_wgrad_halo_plan(Co, Cp, n_pix / (H * W), H, W, dilation);
+        if (workspace_bytes >= (int64_t)hp.splits * Co * N * 4) {
+            WhGeom hg;
+            hg.B = n_pix / (H * W); hg.H = H; hg.W = W; hg.Cp = Cp; hg.ld_dz = ld_dz;
+            hg.tiles_x = hp.tiles_x; hg.tiles_y = hp.tiles_y; hg.tiles_total = hp.tiles_total;
+            hg.tiles_per_split = hp.tiles_per_split; hg.co_tiles = Co / 64; hg.out_tiles = (Co / 64) * (Cp / 64);
+            hg.splits = hp.splits; hg.chunk = (hg.out_tiles * hp.splits + 7) / 8;
+            hg.split_stride = (long long)Co * N; hg.ldw = N; hg.zero = (const unsigned short*)zero_page;
+            const dim3 grid((unsigned)(8 * hg.chunk));
+            if (dilation == 1) {
+                static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<16, 1>),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WhCfg<16, 1>::kLds);
+                ODW_CHECK_HIP(a1, "wgrad halo attr");
+                conv_wgrad_halo_kernel<16, 1><<<grid, 512, WhCfg<16, 1>::kLds, stream>>>(
+                    (const unsigned short*)dz, (const unsigned short*)X, (float*)workspace, hg);
+            } else {
+                static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<8, 2>),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WhCfg<8, 2>::kLds);
+                ODW_CHECK_HIP(a2, "wgrad halo attr");
+                conv_wgrad_halo_kernel<8, 2><<<grid, 512, WhCfg<8, 2>::kLds, stream>>>(
+                    (const unsigned short*)dz, (const unsigned short*)X, (float*)workspace, hg);
+            }
+            ODW_CHECK_HIP(hipGetLastError(), "conv_wgrad_halo launch");
+            const long long units = (long long)Co * ((Ci + 63) / 64);
+            const int rblocks = (int)(units < 16384 ? units : 16384);
+            wgrad_reduce_unpack_kernel<<<rblocks, 256, 0, stream>>>((const float*)workspace, hp.splits, (long long)Co * N, Co, Ci,
+                                                                    Cp, N, dw, accumulate);
+            ODW_CHECK_LAUNCH("wgrad_reduce_unpack_kernel");
+            return ODW_OK;
+        }
+    }
+    const TnPlan plan = conv_wgrad_tn_plan(Co, Cp, n_pix);
     ODW_REQUIRE(workspace_bytes >= (int64_t)plan.splits * Co * N * 4, "conv_wgrad_tn: workspace of %lld bytes, need %lld",
                 (long long)workspace_bytes, (long long)plan.splits * Co * N * 4);
     ConvGeom g;
