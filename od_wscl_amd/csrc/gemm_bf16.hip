@@ -1724,7 +1724,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // packed fp32 matrix + wgrad_unpack_kernel).
 __global__ __launch_bounds__(256) void wgrad_reduce_unpack_kernel(const float* __restrict__ ws, int S, long long stride_f,
                                                                   int Co, int Ci, int Cp, int ldw, float* __restrict__ dw,
-                                                                  int accumulate) {
+                                                                  int accumulate, const float* __restrict__ bias_ws = nullptr,
+                                                                  float* __restrict__ db = nullptr) {
+    // (conv_wgrad_halo_kernel's bias workgroups: db[co] += sum over the splits, in split order; block 0 only)
+    if (bias_ws && blockIdx.x == 0)
+        for (int co = threadIdx.x; co < Co; co += 256) {
+            float a = bias_ws[co];
+            for (int sidx = 1; sidx < S; ++sidx) a += bias_ws[(size_t)sidx * Co + co];
+            db[co] += a;
+        }
     // a workgroup = (co, 64 input channels): thread (j = channel, g = tap group) sums taps g, g + 4, g + 8 over the
     // slices in slice order (256-byte coalesced reads, four slices of loads in flight), LDS [j][t], 576 floats out
     __shared__ float sm[64 * 9];
@@ -2093,6 +2101,8 @@ struct WhGeom {
     long long split_stride;             // floats between the partial sums of consecutive splits
     int ldw;                            // 9 * Cp
     const unsigned short* zero;
+    float* bias_ws;                     // [split][Co] partial column sums of dZ (the bias gradient), or null
+    int Co;
 };
 
 // tools/exp/wgrad_timeline.hip compiles this file with ODW_WH_TIMELINE: lane 0 of every wave stamps wall_clock64() (100 MHz)
@@ -2131,9 +2141,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_halo_kernel(const unsigned 
     // tile of every split: 47 % L2 misses, 94 MB of fabric traffic per launch for 12 MB of operands, and the kernel ran
     // at the pace of those misses (4.1 us per tile against 2.4 us of MFMA time, whatever the LDS side did).
     const int wg = (int)(blockIdx.x % 8) * g.chunk + (int)(blockIdx.x / 8);
-    if (wg >= g.out_tiles * g.splits) return;
-    const int split = wg / g.out_tiles, ot = wg - split * g.out_tiles;
-    const int co0 = (ot % g.co_tiles) * 64, ci0 = (ot / g.co_tiles) * 64;
+    const int per_split = g.out_tiles + (g.bias_ws ? g.co_tiles : 0);
+    if (wg >= per_split * g.splits) return;
+    const int split = wg / per_split, ot = wg - split * per_split;
+    const bool bias_wg = ot >= g.out_tiles;          // the last co_tiles workgroups of a split: column sums of dZ only
+    const int co0 = (bias_wg ? ot - g.out_tiles : ot % g.co_tiles) * 64, ci0 = bias_wg ? 0 : (ot / g.co_tiles) * 64;
     const int t_begin = split * g.tiles_per_split;
     const int t_end = t_begin + g.tiles_per_split < g.tiles_total ? t_begin + g.tiles_per_split : g.tiles_total;
 
@@ -2174,7 +2186,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_halo_kernel(const unsigned 
 #pragma unroll
         for (int i = 0; i < NP; ++i) {                        // halo patch of X: (PH x PW) pixel rows, 64 ci
             const int j = i * 8 + wave;
-            if (j < C::kPRows / 8) {
+            if (j < C::kPRows / 8 && !bias_wg) {
                 const int y = y0 + (short)(p_yx[i] & 0xffff), x = x0 + (p_yx[i] >> 16);
                 const void* src = ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W)
                                       ? static_cast<const void*>(pbase + p_off[i]) : static_cast<const void*>(g.zero);
@@ -2189,6 +2201,40 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_halo_kernel(const unsigned 
     const unsigned sub = 8u * (lane & 1);
     const unsigned offa = kq * 128u + (((unsigned)(wc * 4) + cb) ^ (4u * ((kq >> 1) & 1))) * 16u + sub;
     const unsigned cbi = (unsigned)(wi * 4) + cb;
+
+    if (bias_wg) {
+        // ---- the bias gradient db[co] = sum over pixels of dZ[p][co], on the matrix pipe: dZ^T x ones.  Every column of the
+        // 32 x 32 result holds the same 32 sums; wave = (co half) x (quarter of the tile rows).  One summation order
+        // (MFMA K order, tiles in order, row quarters and splits added in index order): identical from run to run.
+        // (Was two launches per layer -- colsum_bf16_part / _finish -- that re-read dZ: 18 launches, ~0.1 ms per step.)
+        f32x16 accb = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+        const int rq = wave >> 1;                          // rows [rq TR / 4, (rq + 1) TR / 4)
+        int bstage = 0;
+        if (t_begin < t_end) issue(t_begin, wh_lds);
+        for (int t = t_begin; t < t_end; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 1 < t_end) issue(t + 1, wh_lds + (bstage ^ 1) * C::kStageBytes);
+            const unsigned char* sa = wh_lds + bstage * C::kStageBytes;
+#pragma unroll
+            for (int kb = 0; kb < TR / 4; ++kb)
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tn_frag<128>(sa, offa + (unsigned)(rq * (TR / 4) + kb) * 16u * 128u),
+                                                               ones, accb, 0, 0, 0);
+            bstage ^= 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float* red = reinterpret_cast<float*>(wh_lds);       // [row quarter][64 co]
+        if ((lane & 31) == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) red[rq * 64 + wc * 32 + (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5)] = accb[k];
+        }
+        __syncthreads();
+        if (tid < 64) g.bias_ws[(size_t)split * g.Co + co0 + tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+        return;
+    }
 
     f32x16 acc[9];
 #pragma unroll
@@ -2358,10 +2404,49 @@ ODW_EXPORT int64_t odw_conv_wgrad_tn_workspace(int Co, int Cp, int n_pix) {
     return splits * Co * 9 * Cp * 4;
 }
 
+ODW_EXPORT int odw_colsum_bf16_ws(const void* X, int ld, int M, int N, float* out, void* workspace, int64_t workspace_bytes,
+                                  void* stream_);
+ODW_EXPORT int64_t odw_colsum_workspace(int M, int N);
+static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
+                              int Co, int Ci, float* dw, float* db, int accumulate, const void* zero_page, void* workspace,
+                              int64_t workspace_bytes, void* stream_);
+
 ODW_EXPORT int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
                                  int Co, int Ci, float* dw, int accumulate, const void* zero_page, void* workspace,
                                  int64_t workspace_bytes, void* stream_) {
+    return conv_wgrad_tn_impl(dz, ld_dz, X, n_pix, H, W, Cp, dilation, Co, Ci, dw, nullptr, accumulate, zero_page, workspace,
+                              workspace_bytes, stream_);
+}
+
+// The same with the layer's BIAS gradient: db[co] += sum over the pixels of dz[p][co] (added onto what db holds, one
+// summation order).  The halo form computes it in extra workgroups of the same launch (dZ^T x ones on the matrix
+// pipe); otherwise the two-launch column sum runs beside the ring form.  Workspace: odw_conv_wgrad_tn_bias_workspace.
+ODW_EXPORT int64_t odw_conv_wgrad_tn_bias_workspace(int Co, int Cp, int n_pix) {
+    const int64_t a = odw_align_up(odw_conv_wgrad_tn_workspace(Co, Cp, n_pix), 256);
+    if (a == 0) return 0;
+    int64_t splits = odw_conv_wgrad_tn_workspace(Co, Cp, n_pix) / ((int64_t)Co * 9 * Cp * 4);
+    int64_t b = splits * Co * 4, c = odw_colsum_workspace(n_pix, Co);
+    return a + odw_align_up(b > c ? b : c, 256);
+}
+ODW_EXPORT int odw_conv_wgrad_tn_bias(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
+                                      int Co, int Ci, float* dw, float* db, int accumulate, const void* zero_page,
+                                      void* workspace, int64_t workspace_bytes, void* stream_) {
+    ODW_REQUIRE(db, "conv_wgrad_tn_bias: null bias gradient");
+    ODW_REQUIRE(workspace_bytes >= odw_conv_wgrad_tn_bias_workspace(Co, Cp, n_pix), "conv_wgrad_tn_bias: workspace of %lld bytes, need %lld",
+                (long long)workspace_bytes, (long long)odw_conv_wgrad_tn_bias_workspace(Co, Cp, n_pix));
+    return conv_wgrad_tn_impl(dz, ld_dz, X, n_pix, H, W, Cp, dilation, Co, Ci, dw, db, accumulate, zero_page, workspace,
+                              workspace_bytes, stream_);
+}
+
+static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
+                              int Co, int Ci, float* dw, float* db, int accumulate, const void* zero_page, void* workspace,
+                              int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    // (with db: the tail of the workspace, behind the weight-gradient partials, holds the bias partials / column-sum scratch)
+    const int64_t main_bytes = db ? odw_align_up(odw_conv_wgrad_tn_workspace(Co, Cp, n_pix), 256) : workspace_bytes;
+    void* tail = db ? (void*)((char*)workspace + main_bytes) : nullptr;
+    const int64_t tail_bytes = db ? workspace_bytes - main_bytes : 0;
+    if (db) workspace_bytes = main_bytes;
     ODW_REQUIRE(n_pix > 0 && H > 0 && W > 0 && n_pix % (H * W) == 0 && Co > 0 && Ci > 0 && Cp >= Ci, "conv_wgrad_tn: bad dims");
     ODW_REQUIRE(Cp >= 128 && (Cp & (Cp - 1)) == 0, "conv_wgrad_tn: Cp=%d must be a power of two >= 128", Cp);
     ODW_REQUIRE(Co % 8 == 0 && ld_dz % 8 == 0 && ld_dz >= Co, "conv_wgrad_tn: Co=%d / ld_dz=%d must be multiples of 8", Co, ld_dz);
@@ -2377,7 +2462,9 @@ ODW_EXPORT int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n
             hg.B = n_pix / (H * W); hg.H = H; hg.W = W; hg.Cp = Cp; hg.ld_dz = ld_dz;
             hg.tiles_x = hp.tiles_x; hg.tiles_y = hp.tiles_y; hg.tiles_total = hp.tiles_total;
             hg.tiles_per_split = hp.tiles_per_split; hg.co_tiles = Co / 64; hg.out_tiles = (Co / 64) * (Cp / 64);
-            hg.splits = hp.splits; hg.chunk = (hg.out_tiles * hp.splits + 7) / 8;
+            hg.splits = hp.splits;
+            hg.bias_ws = db ? (float*)tail : nullptr; hg.Co = Co;
+            hg.chunk = ((hg.out_tiles + (db ? hg.co_tiles : 0)) * hp.splits + 7) / 8;
             hg.split_stride = (long long)Co * N; hg.ldw = N; hg.zero = (const unsigned short*)zero_page;
             const dim3 grid((unsigned)(8 * hg.chunk));
             if (dilation == 1) {
@@ -2397,7 +2484,7 @@ ODW_EXPORT int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n
             const long long units = (long long)Co * ((Ci + 63) / 64);
             const int rblocks = (int)(units < 16384 ? units : 16384);
             wgrad_reduce_unpack_kernel<<<rblocks, 256, 0, stream>>>((const float*)workspace, hp.splits, (long long)Co * N, Co, Ci,
-                                                                    Cp, N, dw, accumulate);
+                                                                    Cp, N, dw, accumulate, db ? (const float*)tail : nullptr, db);
             ODW_CHECK_LAUNCH("wgrad_reduce_unpack_kernel");
             return ODW_OK;
         }
@@ -2426,6 +2513,7 @@ ODW_EXPORT int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n
     wgrad_reduce_unpack_kernel<<<rblocks, 256, 0, stream>>>((const float*)workspace, plan.splits, (long long)Co * N, Co, Ci, Cp,
                                                             N, dw, accumulate);
     ODW_CHECK_LAUNCH("wgrad_reduce_unpack_kernel");
+    if (db) return odw_colsum_bf16_ws(dz, ld_dz, n_pix, Co, db, tail, tail_bytes, stream_);
     return ODW_OK;
 }
 

@@ -149,18 +149,14 @@ def _backward_single_plane(ctx, dfeat):
         if conv.weight.grad is None:
             conv.weight.grad = torch.empty_like(conv.weight)
         if l.cp >= 128 and l.cout % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0":
-            # dZ and the layer input as they are (NHWC rows): K-major operands, transposed fragment reads
-            cs_bytes = lib.odw_colsum_workspace(m, l.cout)
-            if getattr(net, "colsum_ws", None) is None or net.colsum_ws.numel() < cs_bytes:
-                net.colsum_ws = torch.empty(cs_bytes, dtype=torch.uint8, device=dev)
-            L.check(lib.odw_colsum_bf16_ws(L.ptr(dz), l.cout, m, l.cout, L.ptr(conv.bias.grad), L.ptr(net.colsum_ws),
-                                           net.colsum_ws.numel(), st), "conv bias grad")
-            ws_bytes = lib.odw_conv_wgrad_tn_workspace(l.cout, l.cp, m)
+            # dZ and the layer input as they are (NHWC rows): K-major operands, transposed fragment reads; the bias
+            # gradient (column sums of dZ) comes out of the same launch
+            ws_bytes = lib.odw_conv_wgrad_tn_bias_workspace(l.cout, l.cp, m)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             with kernel_timer.region("conv wgrad TN split-K+reduce", flops=2.0 * m * l.cout * 9 * l.cp):
-                L.check(lib.odw_conv_wgrad_tn(L.ptr(dz), l.cout, L.ptr(x_in), m, h, w, l.cp, l.dil, l.cout, l.cin,
-                                              L.ptr(conv.weight.grad), acc, L.ptr(net.zero_page), L.ptr(ws), ws_bytes, st),
-                        "conv_wgrad_tn")
+                L.check(lib.odw_conv_wgrad_tn_bias(L.ptr(dz), l.cout, L.ptr(x_in), m, h, w, l.cp, l.dil, l.cout, l.cin,
+                                                   L.ptr(conv.weight.grad), L.ptr(conv.bias.grad), acc, L.ptr(net.zero_page),
+                                                   L.ptr(ws), ws_bytes, st), "conv_wgrad_tn_bias")
         else:
             dzc = torch.empty((m, _r64(l.cout)), dtype=torch.bfloat16, device=dev)
             dzt = torch.empty((l.cout, m64), dtype=torch.bfloat16, device=dev)

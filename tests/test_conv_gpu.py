@@ -307,6 +307,21 @@ def test_conv_weight_gradient(lib, B, Cin, Cout, H, W, dil):
             outs.append(db3 - 0.5)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
         assert (outs[0] - ref_b).abs().max().item() <= 3e-3 * max(1.0, ref_b.abs().max().item())
+        # weight AND bias gradient from one call (channel counts that are multiples of 64: extra workgroups of the halo
+        # kernel form the column sums on the matrix pipe; otherwise ring form + two-launch column sum): the same dw bits as
+        # odw_conv_wgrad_tn, db added onto what it holds, identical from run to run
+        wsb3 = L.lib().odw_conv_wgrad_tn_bias_workspace(Cout, Cin, m)
+        ws3 = torch.empty(wsb3, dtype=torch.uint8, device="cuda")
+        dbs = []
+        for _ in range(3):
+            dw3 = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+            db4 = torch.full((Cout,), 0.25, device="cuda")
+            L.check(L.lib().odw_conv_wgrad_tn_bias(L.ptr(dyn), dyn.stride(0), L.ptr(xn), m, H, W, Cin, dil, Cout, Cin, L.ptr(dw3),
+                                                   L.ptr(db4), 0, L.ptr(zero), L.ptr(ws3), wsb3, L.stream()), "conv_wgrad_tn_bias")
+            assert torch.equal(dw3, dw2)
+            dbs.append(db4 - 0.25)
+        assert torch.equal(dbs[0], dbs[1]) and torch.equal(dbs[1], dbs[2])
+        assert (dbs[0] - ref_b).abs().max().item() <= 3e-3 * max(1.0, ref_b.abs().max().item())
 
 
 def test_conv_weight_prep_batch_equals_per_layer(lib):
