@@ -2253,63 +2253,23 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_halo_kernel(const unsigned 
         // three tile rows, so the wave keeps a rolling window of 2 DIL + 1 patch rows x 3 column shifts in registers
         // and reads THREE new fragments per K block instead of nine (ds_read_b64_tr_b16 runs at half the plain b64
         // rate: with nine the kernel was LDS-bound at 5.4 us per tile against 2.4 us of MFMA time).
-        if constexpr (DIL == 1) {
-            constexpr int NS = 2 * DIL + 1;
-            bf16x8 win[NS][3];
-            const int y_first = wk * (TR / 2);
-            auto load_row = [&](int prow, bf16x8 (&dst)[3]) {
-    #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const unsigned row = (unsigned)(prow * C::PW + dx * DIL) + kq;
-                    dst[dx] = tn_frag<128>(sp, row * 128u + ((cbi ^ (4u * ((row >> 1) & 1))) * 16u) + sub);
-                }
-            };
-            bf16x8 fa = tn_frag<128>(sa, offa + (unsigned)y_first * 16u * 128u);
-    #pragma unroll
-            for (int r = 0; r < NS - 1; ++r) load_row(y_first + r, win[r]);
-            // the next tile's DMA is issued HERE, behind this tile's first fragment reads (the other stage: nobody reads it
-            // now).  Its ~10 instructions cost a wave ~0.6 us of issue time per tile (timeline of tools/exp/wgrad_timeline.hip:
-            // tile landed -> issued 0.87 us, K loop 2.65 us = the MFMA time of two waves per SIMD, barrier 0.73 us); moved
-            // between the K-block groups, de-phased between the two waves of a SIMD, the K loop grew by 1.3 us instead.
-            if (t + 1 < t_end) issue(t + 1, wh_lds + (stage ^ 1) * C::kStageBytes);
-            WH_T(1);
-            // (the K blocks in groups of NS: the window slot of a row is static inside a group, and the group loop keeps
-            // the compiler from hoisting the addresses of all TR / 2 blocks at once -- 30 spilled registers when it did)
-    #pragma unroll 1
-            for (int kb0 = 0; kb0 < TR / 2; kb0 += NS) {
-    #pragma unroll
-                for (int j = 0; j < NS; ++j) {
-                    const int kb = kb0 + j;
-                    if (kb < TR / 2) {
-                        const int y = y_first + kb;
-                        // issue order: this block's new patch row (its taps come last), the NEXT block's dZ fragment; the
-                        // six MFMAs on rows already in registers run while those reads are in flight (LDS returns in order)
-                        load_row(y + NS - 1, win[(j + NS - 1) % NS]);
-                        bf16x8 fa_next = fa;
-                        if (kb + 1 < TR / 2) fa_next = tn_frag<128>(sa, offa + (unsigned)(y + 1) * 16u * 128u);
-    #pragma unroll
-                        for (int tap = 0; tap < 9; ++tap)
-                            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, win[(j + (tap / 3) * DIL) % NS][tap % 3], acc[tap], 0, 0, 0);
-                        fa = fa_next;
-                    }
-                }
-            }
-        } else {
-            // dilation 2 (TR = 8: four K blocks per wave): the window would hold 5 patch rows x 3 shifts = 60 registers on
-            // top of the 144 accumulators; the nine fragments of a K block are read directly instead (same speed here)
-            const int y_first = wk * (TR / 2);
-            if (t + 1 < t_end) issue(t + 1, wh_lds + (stage ^ 1) * C::kStageBytes);
-            WH_T(1);
+        // Nine fragment reads per K block, straight from the patch.  (A rolling window of three patch rows x three column
+        // shifts in registers -- three new fragments per K block -- ran the same 37 us: the K loop is MFMA-bound either
+        // way.  It cost 50 more registers, and at 241 two waves per SIMD leave no room for a wave of the optimiser's
+        // side-stream kernel, which shares the chip with the backbone's backward: the two kernels took turns on every CU,
+        // 58 / 118 us per launch inside the step against 26-39 us alone.  At 190 (2 x 192 + 64 <= 512) they co-reside.)
+        const int y_first = wk * (TR / 2);
+        if (t + 1 < t_end) issue(t + 1, wh_lds + (stage ^ 1) * C::kStageBytes);
+        WH_T(1);
 #pragma unroll 1
-            for (int kb = 0; kb < TR / 2; ++kb) {
-                const int y = y_first + kb;
-                const bf16x8 fa = tn_frag<128>(sa, offa + (unsigned)y * 16u * 128u);
+        for (int kb = 0; kb < TR / 2; ++kb) {
+            const int y = y_first + kb;
+            const bf16x8 fa = tn_frag<128>(sa, offa + (unsigned)y * 16u * 128u);
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const unsigned row = (unsigned)((y + (tap / 3) * DIL) * C::PW + (tap % 3) * DIL) + kq;
-                    const bf16x8 fb = tn_frag<128>(sp, row * 128u + ((cbi ^ (4u * ((row >> 1) & 1))) * 16u) + sub);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
-                }
+            for (int tap = 0; tap < 9; ++tap) {
+                const unsigned row = (unsigned)((y + (tap / 3) * DIL) * C::PW + (tap % 3) * DIL) + kq;
+                const bf16x8 fb = tn_frag<128>(sp, row * 128u + ((cbi ^ (4u * ((row >> 1) & 1))) * 16u) + sub);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
             }
         }
         WH_T(2);

@@ -408,7 +408,9 @@ class FlatSGD(object):
         HBM-bound pass starves whatever shares the GPU with it (the first backbone weight-gradient GEMM took 400 us
         instead of 43) and the overlap bought nothing; on 192-256 workgroups it stretches over the backbone's backward
         and mostly disappears behind it (8.10 -> 7.96 ms/step, three alternating runs each on one box; 128 and fewer
-        outlast the backward)."""
+        outlast the backward).  Round 3: the next forward no longer waits for this pass at the end of the step (step()),
+        so outlasting the backward costs nothing; 160 workgroups measured 9.42-9.68 ms against 9.57-9.85 at 256 and
+        9.56 unpaced (tools/exp/ab_env.sh, alternating, box drift +-0.15 ms)."""
         start, n, lr, wd = self.regions[i]
         if n == 0:
             return
@@ -431,7 +433,7 @@ class FlatSGD(object):
         with torch.cuda.stream(self.side):
             self.exchange.finish(0, self.n_gemm)       # what the weight-gradient GEMMs did not hand over as they retired
             # (paced only without an exchange in front of it: at N > 1 the all-reduce already takes the window)
-            self._sgd_region(0, paced=int(os.environ.get("ODW_SGD_PACE", "256")) if self.world == 1 else 0)
+            self._sgd_region(0, paced=int(os.environ.get("ODW_SGD_PACE", "160")) if self.world == 1 else 0)
             self._refresh_shadows()
         self.early_done = True
 
