@@ -118,14 +118,17 @@ class GradExchange(object):
             else:
                 self.works.append((dist.all_reduce(piece, async_op=True, group=self.group), a, b))
 
-    def ready(self, lo, hi):
-        """flat[lo:hi) is final: exchange it now (asynchronously)."""
+    def ready(self, lo, hi, stream=None):
+        """flat[lo:hi) is final: exchange it now (asynchronously), behind the producing stream's work, on `stream`
+        (default: the side stream; pieces announced while that stream is busy with the head's update -- the backbone's
+        runs of layers -- name their own)."""
         if self.world <= 1 or hi <= lo:
             return
         self.done.append((lo, hi))
-        if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
+        side = stream if stream is not None else self.side
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
                 self._issue(lo, hi)
         else:
             self._issue(lo, hi)
@@ -524,6 +527,24 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         conv_desc = "od_wscl_amd HIP: 1x1 convs on the MFMA GEMM, implicit-GEMM conv3x3, folded frozen BN (NHWC)"
     opt = FlatSGD(cfg, model, world)
     model.roi_heads.head_grads_ready = opt.head_grads_ready
+    # N > 1: the body's backward in three runs of layers (conv5 / conv4 / conv3 for VGG16), each run's weight gradients
+    # handed to the exchange when its launches are queued -- on a stream of their own: the side stream is busy with the
+    # head's update by then.  What is left for the end of the step is the last run (the smallest) and the biases.
+    if world > 1 and hasattr(hip_body, "bwd_segments") and os.environ.get("ODW_NO_OVERLAP") != "1":
+        from .modeling.backbone.vgg16_hip import backward_segments
+        hip_body.bwd_segments = int(os.environ.get("ODW_BWD_SEGMENTS", "3"))
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        seg_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        ranges = []
+        for hi_li, lo_li in backward_segments(hip_body):
+            offs = [opt.slices[name_of[id(hip_body.layers[li].conv.weight)]] for li in range(lo_li, hi_li + 1)]
+            ranges.append((min(o for o, _ in offs), max(o + k for o, k in offs)))
+
+        def on_segment_done(k, ranges=ranges):
+            if not getattr(opt, "hold", False):
+                opt.exchange.ready(ranges[k][0], ranges[k][1], stream=seg_stream)
+        hip_body.on_segment_done = on_segment_done
+        step_info_segments = ranges
     # the dense losses' backward is queued from inside the loss, before its second host read (loss_fused.early_backward);
     # evaluations of the large Linears that register with their weight-gradient batch after that get reserved columns
     le = getattr(model.roi_heads, "loss_evaluator", None)

@@ -117,20 +117,40 @@ class _VGGFn(torch.autograd.Function):
         return _backward_single_plane(ctx, dfeat)
 
 
-def _backward_single_plane(ctx, dfeat):
+def backward_segments(net):
+    """The trainable layers in backward order, cut into net.bwd_segments runs of consecutive layers [(hi, lo), ...]
+    (inclusive): data-parallel runs hand each run's weight gradients to the exchange as it completes
+    (net.on_segment_done, engine.build_training_step) instead of all of them after the whole backward."""
+    first = min(i for i, l in enumerate(net.layers) if l.trainable)
+    layers = list(range(len(net.layers) - 1, first - 1, -1))
+    n = max(1, min(int(getattr(net, "bwd_segments", 1) or 1), len(layers)))
+    per = -(-len(layers) // n)
+    return [(layers[i], layers[min(i + per, len(layers)) - 1]) for i in range(0, len(layers), per)]
+
+
+def _backward_single_plane(ctx, dfeat, seg=None):
     """Backward of the body with one bf16 plane per operand ("bf16", and "bf16x2f" after its split-precision
     forward): saved layer inputs are NHWC bf16; a pooled layer's saved pre-pool activation is bf16 or ("bf16x2f") the
-    fp32 tensor of the forward, whose first maximum routes the gradient."""
+    fp32 tensor of the forward, whose first maximum routes the gradient.
+    seg = k: only the k-th run of backward_segments(net) (graph capture: one graph per run; the gradient that travels
+    between runs is kept on ctx); seg = None: everything, announcing each completed run to net.on_segment_done."""
     lib = L.lib()
     net, saved, B = ctx.net, ctx.saved_acts, ctx.batch
     st = L.stream()
     dev = dfeat.device
-    _, C, h, w = dfeat.shape
-    dz = torch.empty((B * h * w, C), dtype=torch.bfloat16, device=dev)
-    L.check(lib.odw_nchw_f32_to_nhwc_bf16(L.ptr(dfeat.contiguous()), B, h * w, C, C, L.ptr(dz), st), "nchw_to_nhwc")
-    first = min(i for i, l in enumerate(net.layers) if l.trainable)
+    segs = backward_segments(net)
+    first = segs[-1][1]
+    if seg is None or seg == 0:
+        _, C, h, w = dfeat.shape
+        dz = torch.empty((B * h * w, C), dtype=torch.bfloat16, device=dev)
+        L.check(lib.odw_nchw_f32_to_nhwc_bf16(L.ptr(dfeat.contiguous()), B, h * w, C, C, L.ptr(dz), st), "nchw_to_nhwc")
+    else:
+        dz = ctx._bw_dz
     acc = 1 if getattr(net, "accumulate", False) else 0      # SOLVER.ITER_SIZE: later micro-steps add to the gradients
-    for li in range(len(net.layers) - 1, first - 1, -1):
+    seg_end = {lo: k for k, (hi, lo) in enumerate(segs)}
+    hi_li, lo_li = (segs[0][0], segs[-1][1]) if seg is None else segs[seg]
+    done_cb = getattr(net, "on_segment_done", None) if seg is None else None
+    for li in range(hi_li, lo_li - 1, -1):
         l = net.layers[li]
         x_in, pre, h, w = saved[li]
         if l.pool:       # dz arrives at the pooled resolution: route through the pool (+ ReLU mask of `pre`)
@@ -174,6 +194,9 @@ def _backward_single_plane(ctx, dfeat):
             _conv3x3(lib, dz, m, h, w, l.cout, l.dil, 1, l.wd, l.cin, dx, None, False, mask,
                      l.cin if mask is not None else 0, net.zero_page, st, 2.0 * m * l.cout * 9 * l.cin)
             dz = dx
+        if done_cb is not None and li in seg_end and len(segs) > 1:
+            done_cb(seg_end[li])
+    ctx._bw_dz = dz if seg is not None else None
     return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
@@ -424,9 +447,14 @@ class VGGBackboneHip(nn.Module):
     # per (B, H, W) and replayed: inputs are copied into the graph's static buffers, every tensor the launches touch
     # lives in the graph's memory pool, the gradients land in the parameters' .grad views as in the eager path.
     use_graphs = False
+    # data-parallel runs (engine.build_training_step): the backward in this many runs of layers, each announced to
+    # on_segment_done(k) when its launches are queued -- its weight gradients start their all-reduce under the rest
+    bwd_segments = 1
+    on_segment_done = None
 
     def _graph_for(self, fn, images):
-        key = (fn.__name__, tuple(images.shape), P.get_precision(), bool(getattr(self, "accumulate", False)))
+        key = (fn.__name__, tuple(images.shape), P.get_precision(), bool(getattr(self, "accumulate", False)),
+               int(getattr(self, "bwd_segments", 1)))
         g = self._graphs.get(key)
         if g is None:
             g = self._graphs[key] = _GraphedBody(self, fn, images)
@@ -468,6 +496,7 @@ class _GraphedBody(object):
         self.ctx.needs_input_grad = (False, False) + (False,) * (2 * len(net.layers))
         was = kt.active
         kt.active = False                              # no event records inside a capture
+        seg_cb, net.on_segment_done = getattr(net, "on_segment_done", None), None      # (nor exchanges from the warm-up)
         try:
             # warm-up on a side stream (allocator and lazily-built constants settle), then capture
             side = torch.cuda.Stream(device=dev)
@@ -490,12 +519,22 @@ class _GraphedBody(object):
             self.nhwc = net.last_nhwc
             self.nhwc_f32 = getattr(net, "last_nhwc_f32", None)
             self.dfeat = torch.zeros_like(self.feat)
-            self.g_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()), torch.no_grad():
-                fn.backward(self.ctx, self.dfeat)
+            # the backward as ONE graph, or (data-parallel runs: net.bwd_segments > 1) one per run of layers, so that the
+            # host can start the all-reduce of a run's weight gradients between two replays
+            nseg = len(backward_segments(net)) if (fn is not _VGGSplitFn and getattr(net, "bwd_segments", 1) > 1) else 1
+            self.g_bwd = []
+            for k in range(nseg):
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, pool=self.g_fwd.pool()), torch.no_grad():
+                    if nseg == 1:
+                        fn.backward(self.ctx, self.dfeat)
+                    else:
+                        _backward_single_plane(self.ctx, self.dfeat, seg=k)
+                self.g_bwd.append(gk)
         finally:
             kt.active = was
             kt.tally = None
+            net.on_segment_done = seg_cb
 
 
 class _GraphedVGGFn(torch.autograd.Function):
@@ -517,5 +556,9 @@ class _GraphedVGGFn(torch.autograd.Function):
         g = ctx.graphed
         g.dfeat.copy_(dfeat)
         with kernel_timer.region("VGG body backward (HIP graph)", flops=g.flops_bwd):
-            g.g_bwd.replay()
+            cb = getattr(g.net, "on_segment_done", None)
+            for k, gk in enumerate(g.g_bwd):
+                gk.replay()
+                if cb is not None and len(g.g_bwd) > 1:
+                    cb(k)
         return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

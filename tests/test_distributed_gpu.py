@@ -39,6 +39,9 @@ def _worker(rank, world, port, out_dir, overlap, dtype="bf16"):
     fc6 = step.model.roi_heads.feature_extractor.fc6.weight
     # with the overlap on, the large weight gradients are handed to the exchange from backward, fc6's in row blocks
     assert (getattr(fc6, "_odw_grad_ready", None) is not None) == overlap and (not overlap or 0 < fc6._odw_slice_rows < fc6.shape[0])
+    # ... and the body's backward runs in three runs of layers, each announcing its weight gradients to the exchange
+    body = step.model.hip_body()
+    assert body.bwd_segments == (3 if overlap else 1) and (body.on_segment_done is not None) == overlap
     losses = []
     for it in range(3):
         l, _ = step(images, targets, rois, DeviceRand(cfg.SEED + rank, first_stream=(1 << 20) + (it << 12), device=dev))
