@@ -47,13 +47,15 @@ struct PrepBatch { PrepLayer l[kMaxPrepLayers]; };
 // blockIdx.x walks the layer's work units: first Co units "wk row co" (the row's Ci x 9 floats are one contiguous,
 // coalesced read; through LDS they leave as 9 runs of Cp bf16), then Ci x ceil(Co / 64) units "wd row ci, 64 output
 // channels" (64 reads of 36 contiguous bytes -> 9 runs of 64 bf16).  Zero padding of both layouts included.
-// Tiled form for the layers that matter (Ci a multiple of 64, Co of 32, no padding: every trainable layer of the VGG /
-// ResNet bodies): a workgroup reads a (32 co) x (64 ci) x 9 tile of w ONCE -- 32 contiguous runs of 2304 bytes -- into
-// LDS and writes both copies from it as 16-byte vectors: wk in 128-byte runs (64 ci of one tap and plane block), wd
+// Tiled form for the layers that matter (Ci and Co multiples of 32, no padding: every trainable layer of the VGG /
+// ResNet bodies): a workgroup reads a (32 co) x (32 ci) x 9 tile of w ONCE -- 32 contiguous runs of 1152 bytes -- into
+// LDS and writes both copies from it as 16-byte vectors: wk in 64-byte runs (32 ci of one tap and plane block), wd
 // in 64-byte runs (32 co of one tap).  The row form below read every weight twice, the wd half of it as 36-byte
 // gathers, and stored 2 bytes per lane: 172 us for the nine trainable VGG layers, on the critical path at the head of
-// every step.
-constexpr int kPrepTileCo = 32, kPrepTileCi = 64, kPrepPitch = kPrepTileCi * 9 + 1;
+// every step.  (64-ci tiles, two workgroups per CU: 150 us; 32-ci tiles, four per CU: 121 us; the grid cut from
+// 2048 x layers -- most of them exiting at once -- to one workgroup per tile: 76 us.)
+constexpr int kPrepTileCo = 32, kPrepTileCi = 32, kPrepPitch = kPrepTileCi * 9 + 1;      // 37 KB of LDS: four workgroups per CU
+constexpr int kPrepC8 = kPrepTileCi / 8;
 constexpr int kPrepLds = kPrepTileCo * kPrepPitch * 4;
 
 __device__ __forceinline__ bool prep_tiled(const PrepLayer& L) {
@@ -77,7 +79,7 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int tile, float* s
     if (L.wk) {
         // item = (co, tap, 8 consecutive ci): lanes walk the 8 chunks of a 128-byte run first
         for (int it = tid; it < kPrepTileCo * 9 * (kPrepTileCi / 8); it += 256) {
-            const int c8 = it & 7, t = (it >> 3) % 9, co = it / 72;
+            const int c8 = it % kPrepC8, t = (it / kPrepC8) % 9, co = it / (9 * kPrepC8);
             const float* src = sm + co * kPrepPitch + c8 * 72 + t;
             unsigned pl[3][4];
 #pragma unroll
@@ -582,7 +584,10 @@ ODW_EXPORT int odw_conv_weight_prep_planes_batch(int n, const void* const* w, co
         b.l[i].Co = Co[i]; b.l[i].Ci = Ci[i]; b.l[i].Cp = Cp[i]; b.l[i].ldk = ldk[i]; b.l[i].ldd = ldd[i];
         b.l[i].T = Ti;
         for (int tt = 0; tt < 4; ++tt) b.l[i].pat[tt] = (Ti > 0 && tt < Ti) ? patterns[4 * i + tt] : 3;
-        const size_t e = (wk[i] ? (size_t)Co[i] : 0) + (wd[i] ? (size_t)Ci[i] * ((Co[i] + 63) / 64) : 0);
+        size_t e = (wk[i] ? (size_t)Co[i] : 0) + (wd[i] ? (size_t)Ci[i] * ((Co[i] + 63) / 64) : 0);
+        const bool tiled = Ci[i] % kPrepTileCi == 0 && Co[i] % kPrepTileCo == 0 && Cp[i] == Ci[i] &&
+                           (!wk[i] || ldk[i] == 9 * Cp[i] * (Ti > 0 ? Ti : 1)) && (!wd[i] || ldd[i] == 9 * Co[i]);      // = prep_tiled()
+        if (tiled) e = (size_t)(Co[i] / kPrepTileCo) * (Ci[i] / kPrepTileCi);      // one workgroup per tile, none idle
         most = e > most ? e : most;
     }
     const int gx = (int)(most < 2048 ? most : 2048);
