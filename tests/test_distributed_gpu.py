@@ -47,7 +47,7 @@ def _worker(rank, world, port, out_dir, overlap, dtype="bf16"):
         l, _ = step(images, targets, rois, DeviceRand(cfg.SEED + rank, first_stream=(1 << 20) + (it << 12), device=dev))
         losses.append(float(sum(l.values())))
     torch.cuda.synchronize()
-    opt = step.__closure__ and [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, engine.FlatSGD)][0]
+    opt = step.optimizer
     np.savez(os.path.join(out_dir, "r%d_%d.npz" % (rank, int(overlap))), p=opt.flat_p.cpu().numpy(),
              m=opt.flat_m.cpu().numpy(), losses=np.array(losses), early=np.array(int(opt.early_done)))
     dist.barrier()

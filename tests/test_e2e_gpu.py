@@ -266,7 +266,7 @@ def test_engine_step_fused_predictor_equals_unfused(monkeypatch):
             l, _ = step(images, targets, rois, DeviceRand(cfg.SEED, first_stream=(1 << 20) + (it << 12), device=dev))
             losses.append({k: float(v.detach()) for k, v in l.items()})
         torch.cuda.synchronize()
-        opt = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, engine.FlatSGD)][0]
+        opt = step.optimizer
         pred = {n: opt.flat_p[o:o + k].clone() for n, (o, k) in opt.slices.items() if "predictor" in n}
         mom = {n: opt.flat_m[o:o + k].clone() for n, (o, k) in opt.slices.items() if "predictor" in n}
         out[fuse] = (losses, pred, mom)
@@ -298,7 +298,7 @@ def test_row_sparse_clean_backward_equals_dense(monkeypatch):
         images, targets, rois = bench.synthetic_batch(cfg.SEED, 0, 224, 150, 21, dev)
         l, _ = step(images, targets, rois, DeviceRand(cfg.SEED, first_stream=1 << 20, device=dev))
         torch.cuda.synchronize()
-        opt = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, engine.FlatSGD)][0]
+        opt = step.optimizer
         grads = {n: opt.flat_m[o:o + k].clone() for n, (o, k) in opt.slices.items()}     # momentum after step 1 = d
         out[sparse] = ({k: float(v.detach()) for k, v in l.items()}, grads)
     for k in out[True][0]:
@@ -326,7 +326,7 @@ def test_engine_steps_over_changing_shapes(monkeypatch):
     monkeypatch.setenv("ODW_NO_TIMER", "1")
     cfg = bench.build_cfg(21)
     step, _ = engine.build_training_step(cfg, dev, dtype="bf16", world=1, seed=cfg.SEED, backend="hip")
-    opt = [c.cell_contents for c in step.__closure__ if isinstance(c.cell_contents, engine.FlatSGD)][0]
+    opt = step.optimizer
     p0 = opt.flat_p.clone()
     cases = [(224, 320, 180, [3]), (352, 256, 90, [1, 7, 12]), (224, 320, 180, [3]), (160, 192, 40, [20, 5])]
     for it, (h, w, p, labs) in enumerate(cases):
