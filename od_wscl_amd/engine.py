@@ -544,7 +544,6 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             if not getattr(opt, "hold", False):
                 opt.exchange.ready(ranges[k][0], ranges[k][1], stream=seg_stream)
         hip_body.on_segment_done = on_segment_done
-        step_info_segments = ranges
     # the dense losses' backward is queued from inside the loss, before its second host read (loss_fused.early_backward);
     # evaluations of the large Linears that register with their weight-gradient batch after that get reserved columns
     le = getattr(model.roi_heads, "loss_evaluator", None)
