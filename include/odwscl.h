@@ -397,10 +397,12 @@ int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n_pix, int H
 /* odw_conv_wgrad_tn plus the layer's bias gradient (the .bias half of the same cuDNN backward in the reference,
  * modeling/backbone/vgg16.py:58-83): db[co] += sum over pixels of dz[p][co], one summation order.  Channel counts that are
  * multiples of 64 (dilation 1 / 2) take the output-stationary halo kernel, which forms these sums in extra workgroups of
- * the same launch; otherwise the ring form + the two-launch column sum.  Workspace: odw_conv_wgrad_tn_bias_workspace. */
+ * the same launch; otherwise the ring form + the two-launch column sum.  ldx = row stride of X in elements (the halo
+ * kernel reads the hi plane of a planes operand in place: ldx = T * Cp; the ring form needs ldx == Cp).
+ * Workspace: odw_conv_wgrad_tn_bias_workspace. */
 int64_t odw_conv_wgrad_tn_bias_workspace(int Co, int Cp, int n_pix);
-int odw_conv_wgrad_tn_bias(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation, int Co,
-                           int Ci, float* dw, float* db, int accumulate, const void* zero_page, void* workspace,
+int odw_conv_wgrad_tn_bias(const void* dz, int ld_dz, const void* X, int ldx, int n_pix, int H, int W, int Cp, int dilation,
+                           int Co, int Ci, float* dw, float* db, int accumulate, const void* zero_page, void* workspace,
                            int64_t workspace_bytes, void* stream);
 int odw_im2col_t_bf16(const void* X, int n_pix, int H, int W, int C, int dilation, void* out, int ldm, void* stream);
 /* column-block form: this call owns `cols` (>= n_pix, zero padded) columns of a wider (9*C x ldm) matrix */

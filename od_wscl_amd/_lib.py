@@ -94,7 +94,7 @@ SIGNATURES = {
     "odw_conv_wgrad_tn_workspace": (c_l, [c_i, c_i, c_i]),
     "odw_conv_wgrad_tn": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_l, c_p]),
     "odw_conv_wgrad_tn_bias_workspace": (c_l, [c_i, c_i, c_i]),
-    "odw_conv_wgrad_tn_bias": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_l, c_p]),
+    "odw_conv_wgrad_tn_bias": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_l, c_p]),
     "odw_im2col_t_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "odw_maxpool2x2_nhwc_bf16": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_maxpool2x2_nhwc_bf16_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),

@@ -2097,7 +2097,7 @@ ODW_EXPORT int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int
 // rows); the two K halves are summed through LDS at the end.  K is split over workgroups by ranges of spatial tiles
 // (fp32 partials + wgrad_reduce_unpack_kernel, as before).  Double-buffered DMA: tile t + 1 lands while t is computed.
 struct WhGeom {
-    int B, H, W, Cp, ld_dz, tiles_x, tiles_y, tiles_total, tiles_per_split, co_tiles, out_tiles, splits, chunk;
+    int B, H, W, Cp, ld_dz, ldx, tiles_x, tiles_y, tiles_total, tiles_per_split, co_tiles, out_tiles, splits, chunk;
     long long split_stride;             // floats between the partial sums of consecutive splits
     int ldw;                            // 9 * Cp
     const unsigned short* zero;
@@ -2166,7 +2166,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_halo_kernel(const unsigned 
     for (int i = 0; i < NP; ++i) {
         const int r = (i * 8 + wave) * 8 + drow;
         const int py = r / C::PW, px = r - py * C::PW;
-        p_off[i] = ((py - DIL) * g.W + (px - DIL)) * g.Cp + (dpc ^ (4 * ((r >> 1) & 1))) * 8;
+        p_off[i] = ((py - DIL) * g.W + (px - DIL)) * g.ldx + (dpc ^ (4 * ((r >> 1) & 1))) * 8;
         p_yx[i] = r < C::PH * C::PW ? ((py - DIL) & 0xffff) | ((px - DIL) << 16) : 0x7fff7fff;      // rows past the patch: never valid
     }
     auto issue = [&](int t, unsigned char* stage) {
@@ -2175,7 +2175,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_halo_kernel(const unsigned 
         const int y0 = (tt / g.tiles_x) * TR, x0 = (tt % g.tiles_x) * 16;
         const size_t pix0 = (size_t)img * g.H * g.W + (size_t)y0 * g.W + x0;
         const unsigned short* abase = dz + pix0 * g.ld_dz + co0;
-        const unsigned short* pbase = X + pix0 * g.Cp + ci0;
+        const unsigned short* pbase = X + pix0 * g.ldx + ci0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {                        // dZ tile: pixel rows (ty, tx), 64 co
             const int rbase = (i * 8 + wave) * 8;
@@ -2367,14 +2367,14 @@ ODW_EXPORT int64_t odw_conv_wgrad_tn_workspace(int Co, int Cp, int n_pix) {
 ODW_EXPORT int odw_colsum_bf16_ws(const void* X, int ld, int M, int N, float* out, void* workspace, int64_t workspace_bytes,
                                   void* stream_);
 ODW_EXPORT int64_t odw_colsum_workspace(int M, int N);
-static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
+static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int ldx, int n_pix, int H, int W, int Cp, int dilation,
                               int Co, int Ci, float* dw, float* db, int accumulate, const void* zero_page, void* workspace,
                               int64_t workspace_bytes, void* stream_);
 
 ODW_EXPORT int odw_conv_wgrad_tn(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
                                  int Co, int Ci, float* dw, int accumulate, const void* zero_page, void* workspace,
                                  int64_t workspace_bytes, void* stream_) {
-    return conv_wgrad_tn_impl(dz, ld_dz, X, n_pix, H, W, Cp, dilation, Co, Ci, dw, nullptr, accumulate, zero_page, workspace,
+    return conv_wgrad_tn_impl(dz, ld_dz, X, Cp, n_pix, H, W, Cp, dilation, Co, Ci, dw, nullptr, accumulate, zero_page, workspace,
                               workspace_bytes, stream_);
 }
 
@@ -2388,17 +2388,18 @@ ODW_EXPORT int64_t odw_conv_wgrad_tn_bias_workspace(int Co, int Cp, int n_pix) {
     int64_t b = splits * Co * 4, c = odw_colsum_workspace(n_pix, Co);
     return a + odw_align_up(b > c ? b : c, 256);
 }
-ODW_EXPORT int odw_conv_wgrad_tn_bias(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
-                                      int Co, int Ci, float* dw, float* db, int accumulate, const void* zero_page,
+ODW_EXPORT int odw_conv_wgrad_tn_bias(const void* dz, int ld_dz, const void* X, int ldx, int n_pix, int H, int W, int Cp,
+                                      int dilation, int Co, int Ci, float* dw, float* db, int accumulate, const void* zero_page,
                                       void* workspace, int64_t workspace_bytes, void* stream_) {
     ODW_REQUIRE(db, "conv_wgrad_tn_bias: null bias gradient");
+    ODW_REQUIRE(ldx >= Cp && ldx % 8 == 0, "conv_wgrad_tn_bias: ldx=%d (row stride of X in elements: >= Cp, a multiple of 8)", ldx);
     ODW_REQUIRE(workspace_bytes >= odw_conv_wgrad_tn_bias_workspace(Co, Cp, n_pix), "conv_wgrad_tn_bias: workspace of %lld bytes, need %lld",
                 (long long)workspace_bytes, (long long)odw_conv_wgrad_tn_bias_workspace(Co, Cp, n_pix));
-    return conv_wgrad_tn_impl(dz, ld_dz, X, n_pix, H, W, Cp, dilation, Co, Ci, dw, db, accumulate, zero_page, workspace,
+    return conv_wgrad_tn_impl(dz, ld_dz, X, ldx, n_pix, H, W, Cp, dilation, Co, Ci, dw, db, accumulate, zero_page, workspace,
                               workspace_bytes, stream_);
 }
 
-static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int n_pix, int H, int W, int Cp, int dilation,
+static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int ldx, int n_pix, int H, int W, int Cp, int dilation,
                               int Co, int Ci, float* dw, float* db, int accumulate, const void* zero_page, void* workspace,
                               int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -2419,7 +2420,7 @@ static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int n_pi
         const WhPlan hp = conv_wgrad_halo_plan(Co, Cp, n_pix / (H * W), H, W, dilation);
         if (workspace_bytes >= (int64_t)hp.splits * Co * N * 4) {
             WhGeom hg;
-            hg.B = n_pix / (H * W); hg.H = H; hg.W = W; hg.Cp = Cp; hg.ld_dz = ld_dz;
+            hg.B = n_pix / (H * W); hg.H = H; hg.W = W; hg.Cp = Cp; hg.ld_dz = ld_dz; hg.ldx = ldx;
             hg.tiles_x = hp.tiles_x; hg.tiles_y = hp.tiles_y; hg.tiles_total = hp.tiles_total;
             hg.tiles_per_split = hp.tiles_per_split; hg.co_tiles = Co / 64; hg.out_tiles = (Co / 64) * (Cp / 64);
             hg.splits = hp.splits;
@@ -2449,6 +2450,7 @@ static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int n_pi
             return ODW_OK;
         }
     }
+    ODW_REQUIRE(ldx == Cp, "conv_wgrad_tn: the ring form reads X with row stride Cp (got %d, Cp = %d)", ldx, Cp);
     const TnPlan plan = conv_wgrad_tn_plan(Co, Cp, n_pix);
     ODW_REQUIRE(workspace_bytes >= (int64_t)plan.splits * Co * N * 4, "conv_wgrad_tn: workspace of %lld bytes, need %lld",
                 (long long)workspace_bytes, (long long)plan.splits * Co * N * 4);

@@ -174,7 +174,7 @@ def _backward_single_plane(ctx, dfeat, seg=None):
             ws_bytes = lib.odw_conv_wgrad_tn_bias_workspace(l.cout, l.cp, m)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             with kernel_timer.region("conv wgrad TN split-K+reduce", flops=2.0 * m * l.cout * 9 * l.cp):
-                L.check(lib.odw_conv_wgrad_tn_bias(L.ptr(dz), l.cout, L.ptr(x_in), m, h, w, l.cp, l.dil, l.cout, l.cin,
+                L.check(lib.odw_conv_wgrad_tn_bias(L.ptr(dz), l.cout, L.ptr(x_in), x_in.stride(0), m, h, w, l.cp, l.dil, l.cout, l.cin,
                                                    L.ptr(conv.weight.grad), L.ptr(conv.bias.grad), acc, L.ptr(net.zero_page),
                                                    L.ptr(ws), ws_bytes, st), "conv_wgrad_tn_bias")
         else:
@@ -183,7 +183,7 @@ def _backward_single_plane(ctx, dfeat, seg=None):
             L.check(lib.odw_linear_bwd_prep(L.ptr(dz), 0, l.cout, None, 0, m, l.cout, 1.0, L.ptr(dzc), dzc.stride(0),
                                             L.ptr(dzt), m64, L.ptr(conv.bias.grad), st), "conv bias grad")
             colt = torch.empty((9 * l.cp, m64), dtype=torch.bfloat16, device=dev)
-            L.check(lib.odw_im2col_t_bf16(L.ptr(x_in), m, h, w, l.cp, l.dil, L.ptr(colt), m64, st), "im2col_t")
+            L.check(lib.odw_im2col_t_bf16(L.ptr(x_in.contiguous()), m, h, w, l.cp, l.dil, L.ptr(colt), m64, st), "im2col_t")
             conv_wgrad(lib, dzt, colt, l.cout, l.cin, l.cp, m, conv.weight.grad, st, acc)
         # ---- input gradient (masked by the ReLU of the producing layer unless that layer was pooled:
         #      then the pool backward of the previous iteration applies the mask)
@@ -192,7 +192,7 @@ def _backward_single_plane(ctx, dfeat, seg=None):
             dx = torch.empty((m, l.cin), dtype=torch.bfloat16, device=dev)
             mask = x_in if (prev.relu and not prev.pool) else None
             _conv3x3(lib, dz, m, h, w, l.cout, l.dil, 1, l.wd, l.cin, dx, None, False, mask,
-                     l.cin if mask is not None else 0, net.zero_page, st, 2.0 * m * l.cout * 9 * l.cin)
+                     mask.stride(0) if mask is not None else 0, net.zero_page, st, 2.0 * m * l.cout * 9 * l.cin)
             dz = dx
         if done_cb is not None and li in seg_end and len(segs) > 1:
             done_cb(seg_end[li])
@@ -347,7 +347,10 @@ class _VGGMixedFn(torch.autograd.Function):
                 x16 = None
             else:
                 xs = P.split_rows(x, pa, l.cp)
-                x16 = P.split_rows(x, (0,), l.cp) if l.trainable else None
+                # the backward's operand (weight gradient, ReLU mask) is the hi plane: the FIRST block of the planes, read
+                # in place with row stride T * cp (was: a second split pass per layer writing a contiguous copy)
+                x16 = xs[:, :l.cp] if (l.trainable and pa[0] == 0 and l.cp >= 128 and l.cout % 64 == 0 and l.cp % 64 == 0
+                                       and l.dil in (1, 2)) else (P.split_rows(x, (0,), l.cp) if l.trainable else None)
             y = torch.empty((m, l.cout), dtype=torch.float32, device=dev)
             _conv3x3(lib, xs, m, h, w, T * l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
                      2.0 * m * l.cout * 9 * l.cin * T)

@@ -316,12 +316,21 @@ def test_conv_weight_gradient(lib, B, Cin, Cout, H, W, dil):
         for _ in range(3):
             dw3 = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
             db4 = torch.full((Cout,), 0.25, device="cuda")
-            L.check(L.lib().odw_conv_wgrad_tn_bias(L.ptr(dyn), dyn.stride(0), L.ptr(xn), m, H, W, Cin, dil, Cout, Cin, L.ptr(dw3),
-                                                   L.ptr(db4), 0, L.ptr(zero), L.ptr(ws3), wsb3, L.stream()), "conv_wgrad_tn_bias")
+            L.check(L.lib().odw_conv_wgrad_tn_bias(L.ptr(dyn), dyn.stride(0), L.ptr(xn), xn.stride(0), m, H, W, Cin, dil, Cout, Cin,
+                                                   L.ptr(dw3), L.ptr(db4), 0, L.ptr(zero), L.ptr(ws3), wsb3, L.stream()), "conv_wgrad_tn_bias")
             assert torch.equal(dw3, dw2)
             dbs.append(db4 - 0.25)
         assert torch.equal(dbs[0], dbs[1]) and torch.equal(dbs[1], dbs[2])
         assert (dbs[0] - ref_b).abs().max().item() <= 3e-3 * max(1.0, ref_b.abs().max().item())
+        if Cout % 64 == 0 and Cin % 64 == 0:
+            # X as the first block of a wider planes operand, read in place (row stride 3 Cin): the same bits
+            wide = torch.full((m, 3 * Cin), 9.0, dtype=torch.bfloat16, device="cuda")
+            wide[:, :Cin] = xn
+            dw5 = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+            db5 = torch.zeros(Cout, device="cuda")
+            L.check(L.lib().odw_conv_wgrad_tn_bias(L.ptr(dyn), dyn.stride(0), L.ptr(wide), wide.stride(0), m, H, W, Cin, dil, Cout,
+                                                   Cin, L.ptr(dw5), L.ptr(db5), 0, L.ptr(zero), L.ptr(ws3), wsb3, L.stream()), "strided X")
+            assert torch.equal(dw5, dw2) and torch.equal(db5, dbs[0])
 
 
 def test_conv_weight_prep_batch_equals_per_layer(lib):
