@@ -568,7 +568,11 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
     # with the step's launches dispatched first: 9.39-9.41 against 9.64-9.68 ms per step (tools/exp/ab_env.sh 3 X=1
     # ODW_HP_STREAM=0).  The caller's stream waits for the step's at the end, so nothing changes for code around it.
     hp_stream = [None]
-    use_hp = torch.device(device).type == "cuda" and os.environ.get("ODW_HP_STREAM") != "0"
+    # (One rank only: at N > 1 RCCL's kernels sit on default-priority streams too, and a step that always dispatches first
+    # could keep them off the CUs until its own gaps -- the exchange would slide behind the backward it is meant to hide
+    # under.  Unmeasured here, so data-parallel runs keep equal priorities unless ODW_HP_STREAM=1 asks otherwise.)
+    hp_env = os.environ.get("ODW_HP_STREAM")
+    use_hp = torch.device(device).type == "cuda" and (hp_env == "1" or (hp_env != "0" and world == 1))
 
     def step(images, targets, rois, rand, iteration=None):
         if not use_hp:
