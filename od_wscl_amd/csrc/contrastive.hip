@@ -145,7 +145,9 @@ constexpr int kPwPanel = 32 * kPwCompute;            // rows of S per workgroup 
 constexpr int kPwPitch = 16 * 16 + 16;               // bytes per staged plane row: 128 k x 2 B + 16 B pad (bank spread)
 constexpr int kPwSlot = 3 * 32 * kPwPitch;           // one column block: 3 planes x 32 rows
 constexpr int kPwTrPitch = 36;                       // floats per row of a wave's 32 x 32 transpose scratch
-constexpr int kPwLds = 2 * kPwSlot + kPwCompute * 32 * kPwTrPitch * 4;      // 52224 + 32256 bytes
+constexpr int kPwScratch = kPwCompute * 32 * kPwTrPitch * 4;                // the compute waves' transpose scratch
+constexpr int kPwStage = 4;                          // staging areas of the panel stage: the two block slots + two more behind the scratch
+constexpr int kPwLds = 2 * kPwSlot + kPwScratch + (kPwStage - 2) * kPwSlot;        // 52224 + 32256 + 52224 bytes
 
 // number of 32-column blocks panel p works on: from its first row's block to the last block of S
 __device__ __host__ inline int pw_blocks_of(int p, int nblk32) { const int b = nblk32 - p * (kPwPanel / 32); return b > 0 ? b : 0; }
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
     };
     auto park_item = [&](const PwRows& r, int slot, int row, int chunk) {
         uint4 h, m, l;
-        unsigned char* base = lds + slot * kPwSlot + row * kPwPitch + chunk * 16;
+        unsigned char* base = lds + (slot < 2 ? slot * kPwSlot : kPwScratch + slot * kPwSlot) + row * kPwPitch + chunk * 16;
         ps_split8(r.a0, r.a1, h, m, l);
         *reinterpret_cast<uint4*>(base) = h;
         *reinterpret_cast<uint4*>(base + 32 * kPwPitch) = m;
@@ -235,20 +237,24 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
     for (long long it = lo_it; it < hi_it; ++it) {
         if (panel != have_panel) {
             // ---- this workgroup's 224 rows of E: seven 32-row pieces fetched with coalesced rows by all eight waves (all
-            // fetches issued before the first wait), split, parked in the two block slots two at a time; compute wave w
+            // fetches issued before the first wait), split, parked in four staging areas at a time; compute wave w
             // takes piece w's planes for the whole K into registers (lane: row l31, 8 k at 16 kk + 8 half)
             if (parked) pw_barrier();                    // every wave is done reading the slots
             PwRows pr[kPwCompute];
 #pragma unroll
             for (int q = 0; q < kPwCompute; ++q) pr[q] = fetch_item(panel * kPwPanel + q * 32 + srow, schunk);
             const PwRows first = fetch_item(blk * 32 + srow, schunk);
+            // (four pieces per round -- the two block slots and two more areas behind the scratch -- : two barrier-separated
+            // rounds instead of the four the two slots alone allowed, ~1.1 us each before the first MFMA of a run)
 #pragma unroll
-            for (int hp = 0; hp < (kPwCompute + 1) / 2; ++hp) {
-                park_item(pr[2 * hp], 0, srow, schunk);
-                if (2 * hp + 1 < kPwCompute) park_item(pr[2 * hp + 1 < kPwCompute ? 2 * hp + 1 : 0], 1, srow, schunk);
+            for (int hp = 0; hp < (kPwCompute + kPwStage - 1) / kPwStage; ++hp) {
+#pragma unroll
+                for (int j = 0; j < kPwStage; ++j)
+                    if (kPwStage * hp + j < kPwCompute) park_item(pr[kPwStage * hp + j < kPwCompute ? kPwStage * hp + j : 0], j, srow, schunk);
                 pw_barrier();
-                if (!loader && (wave >> 1) == hp) {
-                    const unsigned char* sa = lds + (wave & 1) * kPwSlot + l31 * kPwPitch + half * 16;
+                if (!loader && wave / kPwStage == hp) {
+                    const int sj = wave % kPwStage;
+                    const unsigned char* sa = lds + (sj < 2 ? sj * kPwSlot : kPwScratch + sj * kPwSlot) + l31 * kPwPitch + half * 16;
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         aH[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + kk * 32));
