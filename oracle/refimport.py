@@ -146,6 +146,15 @@ def reference_cfg(yaml_rel="configs/voc/voc07_contra_db_b8_lr0.01_mcg.yaml", opt
     load_reference()
     from wetectron.config import cfg as global_cfg
     global_cfg.defrost()
+    # the reference reads ONE process-wide cfg (modules import it): restore its defaults first, so that a case built after
+    # another one (R-50 yaml, then the COCO yaml) does not inherit the earlier case's keys
+    if "cfg_defaults" not in _STATE:
+        _STATE["cfg_defaults"] = global_cfg.clone()
+    fresh = _STATE["cfg_defaults"].clone()
+    for k in list(global_cfg.keys()):
+        dict.__delitem__(global_cfg, k)
+    for k, v in fresh.items():
+        dict.__setitem__(global_cfg, k, v)
     global_cfg.merge_from_file(os.path.join(REF_ROOT, yaml_rel))
     global_cfg.merge_from_list(["MODEL.DEVICE", "cpu"] + list(opts))
     return global_cfg

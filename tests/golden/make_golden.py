@@ -1,6 +1,9 @@
 """Generate the committed golden vectors by running the REFERENCE in this container.
 
-Usage (only where /root/reference exists):   python tests/golden/make_golden.py
+Usage (only where /root/reference exists):   python tests/golden/make_golden.py [names]
+                                             python tests/golden/make_golden.py --check [names]
+(--check regenerates into a scratch directory and compares with the committed files bit for bit; the CPU suite runs it:
+tests/test_oracle_vs_reference.py::test_committed_goldens_are_what_the_reference_produces)
 
 The reference Python is imported read-only through oracle/refimport.py (stub
 packages for absent third-party modules, no reference code copied).  What is
@@ -622,28 +625,65 @@ DATA_CASES = {"data_voc": dict(seed=11, shapes=[(60, 80), (75, 50), (64, 64), (4
 INFER_CASES = {"infer_voc_2img": dict(seed=58, images=[(96, 128, 48), (80, 112, 40)], pooler="ROIPool")}
 
 
-if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops"] + list(E2E_CASES)
+def generate(which, out_dir):
+    """Write the golden files named in `which` (all of them when empty) into `out_dir`; returns the paths written."""
+    every = not which
+    which = which or ["ops"] + list(E2E_CASES)
+    written = []
+
+    def run(fn, name, *args):
+        path = os.path.join(out_dir, name + ".npz")
+        fn(*args, path)
+        written.append(path)
+
     if "ops" in which:
-        gen_ops(os.path.join(HERE, "ops_ref.npz"))
+        run(gen_ops, "ops_ref")
     for name, spec in E2E_CASES.items():
         if name in which:
-            gen_e2e(name, spec, os.path.join(HERE, name + ".npz"))
-    for name, spec in INFER_CASES.items():
-        if name in which or not sys.argv[1:]:
-            gen_infer(name, spec, os.path.join(HERE, name + ".npz"))
-    for name, spec in COCO_CASES.items():
-        if name in which or not sys.argv[1:]:
-            gen_coco(name, spec, os.path.join(HERE, name + ".npz"))
-    for name, spec in EVAL_CASES.items():
-        if name in which or not sys.argv[1:]:
-            gen_voc_eval(name, spec, os.path.join(HERE, name + ".npz"))
-    for name, spec in SAMPLER_CASES.items():
-        if name in which or not sys.argv[1:]:
-            gen_sampler(name, spec, os.path.join(HERE, name + ".npz"))
-    for name, spec in TTA_CASES.items():
-        if name in which or not sys.argv[1:]:
-            gen_tta(name, spec, os.path.join(HERE, name + ".npz"))
-    for name, spec in DATA_CASES.items():
-        if name in which or not sys.argv[1:]:
-            gen_data(name, spec, os.path.join(HERE, name + ".npz"))
+            run(gen_e2e, name, name, spec)
+    for cases, fn in ((INFER_CASES, gen_infer), (COCO_CASES, gen_coco), (EVAL_CASES, gen_voc_eval), (SAMPLER_CASES, gen_sampler),
+                      (TTA_CASES, gen_tta), (DATA_CASES, gen_data)):
+        for name, spec in cases.items():
+            if name in which or every:
+                run(fn, name, name, spec)
+    return written
+
+
+def check(which):
+    """Regenerate into a scratch directory and compare with the committed files: the same keys, and every array equal
+    bit for bit (dtype, shape, content).  Returns the list of differences (empty = the committed vectors are what the
+    reference produces from this script today)."""
+    import tempfile
+    problems = []
+    with tempfile.TemporaryDirectory(prefix="odw_golden_") as tmp:
+        for path in generate(which, tmp):
+            name = os.path.basename(path)
+            committed = os.path.join(HERE, name)
+            if not os.path.exists(committed):
+                problems.append("%s: not committed" % name)
+                continue
+            new, old = np.load(path, allow_pickle=False), np.load(committed, allow_pickle=False)
+            for k in sorted(set(new.files) ^ set(old.files)):
+                problems.append("%s: key %r only in the %s file" % (name, k, "regenerated" if k in new.files else "committed"))
+            for k in sorted(set(new.files) & set(old.files)):
+                a, b = new[k], old[k]
+                if a.dtype != b.dtype or a.shape != b.shape:
+                    problems.append("%s[%s]: %s%s regenerated, %s%s committed" % (name, k, a.dtype, a.shape, b.dtype, b.shape))
+                elif a.tobytes() != b.tobytes():
+                    if a.dtype.kind == "f":
+                        d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+                        problems.append("%s[%s]: %d of %d values differ (max abs %.3e)" % (name, k, int((d > 0).sum()), a.size, float(np.nanmax(d)) if a.size else 0.0))
+                    else:
+                        problems.append("%s[%s]: content differs" % (name, k))
+    return problems
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    if args and args[0] == "--check":
+        bad = check(args[1:])
+        for line in bad:
+            print("DIFF", line)
+        print("golden check: %s" % ("%d difference(s)" % len(bad) if bad else "every regenerated file equals the committed one"))
+        sys.exit(1 if bad else 0)
+    generate(args, HERE)

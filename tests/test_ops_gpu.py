@@ -176,6 +176,23 @@ def test_pairwise_sim(C, P):
     np.testing.assert_allclose(C.pairwise_sim(dev(E48)).cpu().numpy(), E48 @ E48.T, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("P", [4000, 4001, 8000])
+def test_pairwise_sim_at_the_benchmarked_sizes(C, P):
+    """The sizes bench.py measures and claims a roofline fraction at (P = 4000: the COCO proposal count, 8000; 4001: a
+    ragged last panel), against float64 (weak_head/loss.py:319: sim_mat = E E^T)."""
+    E = rng.normal(62, P, P * 128).reshape(P, 128)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    S = C.pairwise_sim(dev(E)).cpu().numpy()
+    assert S.shape == (P, P)
+    E64 = E.astype(np.float64)
+    worst = 0.0
+    for r0 in range(0, P, 1000):                                          # fp64 reference in row panels
+        worst = max(worst, float(np.abs(S[r0:r0 + 1000] - E64[r0:r0 + 1000] @ E64.T).max()))
+    assert worst <= 2e-6, worst                                           # exact-fp32 MFMA chain, |S| <= 1
+    assert np.array_equal(S, S.T)
+    assert np.abs(np.diag(S) - 1.0).max() <= 1e-6
+
+
 @pytest.mark.parametrize("name", ["a", "b", "c", "d"])
 def test_supcon_golden(C, ops_golden, name):
     g = ops_golden

@@ -285,3 +285,18 @@ def test_oracle_generator_is_independent_of_and_identical_to_the_product_generat
         np.testing.assert_array_equal(rng_ref.uniform(seed, stream, n, off), rng.uniform(seed, stream, n, off))
         np.testing.assert_array_equal(rng_ref.normal(seed, stream, n, off), rng.normal(seed, stream, n, off))
     assert rng_ref.stream_key(58, 3) == rng.stream_key(58, 3)
+
+
+def test_committed_goldens_are_what_the_reference_produces():
+    """`python tests/golden/make_golden.py --check`: every golden file regenerated from the imported reference (and
+    its compiled CPU operators) into a scratch directory equals the committed file bit for bit -- same keys, same
+    arrays.  Runs only where /root/reference exists (this container); the GPU box sees the committed arrays only."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/wetectron"):
+        pytest.skip("reference tree not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py"), "--check"],
+                       capture_output=True, text=True, timeout=900)
+    diffs = [l for l in r.stdout.splitlines() if l.startswith("DIFF")]
+    assert r.returncode == 0 and not diffs, "\n".join(diffs[:40]) + "\n" + r.stderr[-2000:]

@@ -1,0 +1,200 @@
+"""The step bench.py TIMES, against the oracle (engine/trainer.py:79-120 + solver/build.py:10-24).
+
+tests/test_fullsize_gpu.py drives `model(...)` + `.backward()`; bench.py times `engine.build_training_step(cfg, dev,
+dtype="bf16x2f")` -- HIP graphs of the body, the dense losses' backward queued from inside the loss (early backward),
+the row-sparse clean pass, one weight-gradient GEMM per large Linear, the flat fused SGD on three regions with the head
+stepped on a side stream, the bf16 shadows / forward planes refreshed there.  This file runs THAT step function, built
+by the same call with the same arguments as bench.py's `run()`, at the C2 workload (VGG16, P = 2000 @ 600 px -> 608^2)
+for three consecutive steps, beside the CPU oracle (oracle/hotpath_ref.py forward + autograd backward) stepped by
+`torch.optim.SGD` over the reference's parameter groups (solver/build.py:10-24: one group per parameter, "bias" in the
+name -> lr x BIAS_LR_FACTOR and WEIGHT_DECAY_BIAS, momentum SOLVER.MOMENTUM), and asserts per step
+
+  * the 8 losses within 1e-3 (relative), the 4 accuracies;
+  * every index selection through the margin-gated replay of tests/test_fullsize_gpu.py (`_replay_selections`);
+  * for EVERY trainable parameter the relative L2 error of the gradient TENSOR against the oracle's `.grad` (not its
+    norm: a permuted or mis-scattered gradient with the right norm fails);
+  * the post-step parameters (a) against `torch.optim.SGD` with the reference's groups applied to the product's own
+    gradients -- the optimiser semantics in isolation, tight -- and (b) the parameter UPDATE against the oracle's.
+
+Steps 2 and 3 read the weights the side stream refreshed (bf16 W^T, forward planes, packed convolution weights) and
+carry momentum; the learning rate is chosen so that the losses move by several 1e-3 per step -- a stale shadow or a
+dropped momentum term shows up in the 1e-3 loss bar of the next step, not only in the update check."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from conftest import weights_for  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SEED = 301                      # the C2 seed of tests/test_fullsize_gpu.py (margins scanned by tools/fullsize_seed_scan.py)
+STEPS = 3
+LR = float(os.environ.get("ODW_TEST_STEP_LR", "1e-3"))
+MODE = "bf16x2f"                # bench.py's default dtype
+# relative L2 error of a gradient tensor, product vs oracle.  The backward products of "bf16x2f" read ONE bf16 plane per
+# operand (2^-9 per element, averaged down over the reduction); observed (printed as TIMEDSTEP ... worst gradient):
+GRAD_L2_TOL = 2e-2
+# parameters whose gradient is analytically zero (a softmax over the proposals ignores det_score's bias) hold rounding
+# noise in both implementations
+NOISE_ONLY = ("det_score.bias",)
+
+
+def _reference_groups(cfg, names):
+    """solver/build.py:10-24 restated: one group per trainable parameter in named_parameters() order."""
+    s = cfg.SOLVER
+    groups = []
+    for n in names:
+        bias = "bias" in n
+        groups.append((n, s.BASE_LR * s.BIAS_LR_FACTOR if bias else s.BASE_LR, s.WEIGHT_DECAY_BIAS if bias else s.WEIGHT_DECAY))
+    return groups
+
+
+def _rel_l2(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize("graphs", [True, False])
+def test_the_timed_step_matches_the_oracle_over_three_steps(graphs, monkeypatch):
+    import bench
+    import fullsize_seed_scan as S
+    from oracle import hotpath_ref as H
+    from test_fullsize_gpu import TOL, ORDER_TOL, _replay_selections
+    from od_wscl_amd import engine
+    from od_wscl_amd.structures import BoxList, to_image_list
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("ODW_NO_TIMER", "1")
+    if not graphs:
+        monkeypatch.setenv("ODW_NO_GRAPHS", "1")         # the same step with the body launched eagerly
+    size, p, classes = S.CASES["c2"][:3]
+    assert (size, p, classes) == (600, 2000, 21)         # BASELINE.json configs[1] == bench.py's defaults
+    batch, boxes, lab, _ = S.inputs("c2", SEED)
+    w_np = weights_for("vgg16", classes)
+
+    # ---- the product: the call of bench.py's run() (cfg = bench.build_cfg; only the learning rate differs)
+    cfg = bench.build_cfg(classes)
+    cfg.merge_from_list(["SOLVER.BASE_LR", LR])
+    step, info = engine.build_training_step(cfg, dev, dtype=MODE, world=1, seed=cfg.SEED)
+    model, opt = step.model, step.optimizer
+    assert info["precision"] == MODE
+    assert getattr(model.hip_body(), "use_graphs", False) == graphs
+    assert model.roi_heads.loss_evaluator.early_backward
+    with torch.no_grad():                                # the oracle's weights instead of load_formula_weights(model, 1)
+        for n, q in list(model.named_parameters()) + list(model.named_buffers()):
+            q.copy_(torch.from_numpy(w_np[n]))
+    opt.sync_from_params()
+    images = to_image_list(batch.to(dev))
+    rois = [BoxList(b.to(dev), (size, size), "xyxy") for b in boxes]
+    targets = []
+    for l in lab:
+        t = BoxList(torch.zeros((len(l), 4), device=dev), (size, size), "xyxy")
+        t.add_field("labels", l.to(dev))
+        t.add_field("labels_host", l.tolist())
+        targets.append(t)
+    trainable = [n for n, q in model.named_parameters() if q.requires_grad]
+
+    # ---- the oracle (CPU fp32) and the reference's optimiser over the reference's groups
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd = {}
+    for k, v in w_np.items():
+        t = torch.from_numpy(v.copy())
+        if k in trainable:
+            t.requires_grad_(True)
+        sd[k] = t
+    assert sorted(trainable) == sorted(k for k in sd if sd[k].requires_grad), "the trainable sets differ (FREEZE_CONV_BODY_AT)"
+    groups = _reference_groups(cfg, trainable)
+    ref_opt = torch.optim.SGD([{"params": [sd[n]], "lr": lr, "weight_decay": wd} for n, lr, wd in groups], LR,
+                              momentum=cfg.SOLVER.MOMENTUM)
+    # (a): the same optimiser on the device, fed with the PRODUCT's gradients
+    twin = {n: torch.from_numpy(w_np[n].copy()).to(dev).requires_grad_(True) for n in trainable}
+    twin_opt = torch.optim.SGD([{"params": [twin[n]], "lr": lr, "weight_decay": wd} for n, lr, wd in groups], LR,
+                               momentum=cfg.SOLVER.MOMENTUM)
+    ocfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", sampling_ratio=0, arch="vgg16", scale=0.125)
+
+    first_loss = None
+    for it in range(STEPS):
+        stream0 = (1 << 20) + (it << 12)                 # bench.py's stream numbering of (warm-up + timed) step `it`
+        # -- oracle step
+        tr = {"_decisions": True}
+        ref_losses, ref_accs = H.forward(batch, boxes, lab, sd, H.Rand(SEED, first_stream=stream0), ocfg, tr)
+        ref_opt.zero_grad(set_to_none=True)
+        sum(ref_losses.values()).backward()
+        ref_grad = {n: sd[n].grad.detach().clone() for n in trainable}
+        before = {n: sd[n].detach().clone() for n in trainable}
+        ref_opt.step()
+        ref_delta = {n: sd[n].detach() - before[n] for n in trainable}
+        del before
+        # -- product step
+        trace = {}
+        model.roi_heads.loss_evaluator.trace = trace
+        p_before = opt.flat_p.clone()
+        losses, accs = step(images, targets, rois, DeviceRand(SEED, first_stream=stream0, device=dev))
+        torch.cuda.synchronize()
+        assert getattr(losses, "finish_backward", None) is not None, "the early backward did not run"
+        assert trace.get("dense_loss_kernel"), "the fused dense-loss kernel was not taken"
+        # losses, accuracies
+        report = {k: (float(losses[k].detach()), float(ref_losses[k])) for k in ref_losses}
+        worst_loss = max(abs(g - r) / max(abs(r), 1e-5) for g, r in report.values())
+        flips, lines, score_dev = _replay_selections(H, tr, trace, boxes, lab, classes, TOL[MODE], ORDER_TOL[MODE])
+        # gradients: tensor against tensor
+        worst_grad, worst_name = 0.0, ""
+        for n in trainable:
+            o, k = opt.slices[n]
+            g = opt.flat_g[o:o + k].cpu()
+            r = ref_grad[n].reshape(-1)
+            if n.endswith(NOISE_ONLY) or float(r.double().norm()) < 1e-9:
+                continue
+            e = _rel_l2(g, r)
+            if e > worst_grad:
+                worst_grad, worst_name = e, n
+            if flips == 0:
+                assert e <= GRAD_L2_TOL, ("gradient tensor of %s: relative L2 error %.3e (step %d)" % (n, e, it + 1))
+        # (a) the optimiser: reference groups on the product's gradients
+        for n in trainable:
+            o, k = opt.slices[n]
+            twin[n].grad = opt.flat_g[o:o + k].view_as(twin[n]).clone()
+        twin_opt.step()
+        worst_a, worst_b, name_b = 0.0, 0.0, ""
+        for n in trainable:
+            o, k = opt.slices[n]
+            got = opt.flat_p[o:o + k]
+            want = twin[n].detach().reshape(-1)
+            upd = (want - p_before[o:o + k]).abs().max().item()
+            err = (got - want).abs().max().item()
+            # fp32 rounding of p - lr * (mu * m + g + wd * p): a few ulp of p; a wrong group (bias lr x 2, wd 0) is O(upd)
+            assert err <= 1e-3 * upd + 4e-7 * want.abs().max().item() + 1e-12, ("SGD update of %s: error %.3e, update %.3e (step %d)" % (n, err, upd, it + 1))
+            worst_a = max(worst_a, err / max(upd, 1e-30))
+            # (b) the update against the oracle's
+            if n.endswith(NOISE_ONLY):
+                continue
+            d_got = (got - p_before[o:o + k]).cpu()
+            e = _rel_l2(d_got, ref_delta[n])
+            if e > worst_b:
+                worst_b, name_b = e, n
+            if flips == 0:
+                # the update is a small difference of fp32 parameters: its own rounding (ulp(p) / |update|) is allowed for
+                floor = 2e-7 * float(want.abs().max()) * np.sqrt(k) / max(float(ref_delta[n].double().norm()), 1e-30)
+                assert e <= GRAD_L2_TOL + floor, ("parameter update of %s: relative L2 error %.3e (step %d)" % (n, e, it + 1))
+        moved = None if first_loss is None else max(abs(float(ref_losses[k]) - first_loss[k]) / max(abs(first_loss[k]), 1e-5) for k in ref_losses)
+        if first_loss is None:
+            first_loss = {k: float(v) for k, v in ref_losses.items()}
+        print("TIMEDSTEP graphs=%s step %d: decisions flipped %d %s, score deviation %.2e, worst loss deviation %.2e, worst gradient "
+              "L2 error %.2e (%s), SGD-vs-reference-groups %.2e of the update, update-vs-oracle L2 %.2e (%s), oracle losses moved "
+              "%s since step 1, loss_sim %.4e" % (graphs, it + 1, flips, lines, score_dev, worst_loss, worst_grad, worst_name, worst_a,
+                                                 worst_b, name_b, "-" if moved is None else "%.2e" % moved, float(ref_losses["loss_sim"])))
+        loss_tol = 1e-3 if flips == 0 else 5e-2
+        for k, (got, ref) in report.items():
+            assert abs(got - ref) <= loss_tol * max(abs(ref), 1e-5), (k, got, ref, it + 1)
+        for k in ref_accs:
+            assert abs(float(accs[k]) - float(ref_accs[k])) < 1e-6, (k, it + 1)
+        if it == STEPS - 1:
+            assert moved >= 3e-3, ("the learning rate is too small for steps 2-3 to test the refreshed weights", moved)
+        del ref_grad, ref_delta, p_before

@@ -24,6 +24,10 @@ CASES = {  # name: (size, proposals, classes, labels[, arch]); labels = one list
     "c4s": (688, 4000, 81, [42]),                # another scale of the COCO config's multi-scale training (480-800)
     # the reference's own single-GPU setup: IMS_PER_BATCH 8 on one device (README.md:99-100), VOC shape
     "b8": (600, 2000, 21, [[3, 9], [15], [5, 12], [8], [1, 19], [14], [7], [2, 11]]),
+    # the COCO shape with a NON-ZERO contrastive loss: two images x 4000 proposals x 81 classes, one label each (two
+    # classes in the SupCon set -> loss_sim > 0 and a non-zero SupCon gradient at P = 4000), at 576 px -- a third scale
+    # of the COCO config's multi-scale training (configs/coco/coco14_contra_db_b8_lr0.01_mcg.yaml: 480-800)
+    "c4b": (576, 4000, 81, [[17], [42]]),
 }
 
 
