@@ -119,6 +119,9 @@ def make_defaults():
     # number of row blocks a large Linear's weight gradient is produced AND exchanged in
     c.ODW.GRAD_EXCHANGE = "fp32"
     c.ODW.WGRAD_SLICES = 4
+    # HIP graphs of the body: how many input shapes stay captured at once (least recently used evicted; each holds its
+    # body's activations, ~1 GB at VOC sizes); 0 = always eager
+    c.ODW.GRAPH_CACHE = 4
     c.SEED = -1
     c.min_size = 20                                           # :550
     return c

@@ -124,6 +124,12 @@ class GradExchange(object):
         runs of layers -- name their own)."""
         if self.world <= 1 or hi <= lo:
             return
+        for a, b in self.done:
+            if lo < b and a < hi:
+                # a range announced twice in one step = a producer that wrote into it AFTER its first announcement (e.g. a
+                # weight-gradient batch flushed twice): the first collective summed a partial gradient.  Never silently.
+                raise RuntimeError("GradExchange.ready: [%d, %d) overlaps [%d, %d), already handed to the all-reduce in this "
+                                   "step" % (lo, hi, a, b))
         self.done.append((lo, hi))
         side = stream if stream is not None else self.side
         if side is not None:
@@ -236,6 +242,11 @@ class FlatSGD(object):
         self.first = True
         self.lr_scale = 1.0
         self.total = total
+        # SOLVER.ITER_SIZE bookkeeping, owned by the optimiser like the reference's (engine/trainer.py:86-120): gradients are
+        # zeroed by the optimiser step, not by a position in the iteration count, and the schedule advances by scheduler
+        # steps taken, not by the iteration index (skipped batches and resumed runs keep both consistent)
+        self.grads_clean = True         # nothing accumulated since the last step() / construction / resume()
+        self.sched_steps = 0            # WarmupMultiStepLR.last_epoch: scheduler steps taken so far
         # bf16 shadows of the GEMM weights: one flat buffer the SGD kernel refreshes in the same pass
         self.flat_w16 = None
         self.shadows = []
@@ -314,10 +325,14 @@ class FlatSGD(object):
         mod = model.get_submodule(name.rsplit(".", 1)[0])
         return isinstance(mod, linear_layer.Linear)
 
-    def sync_from_params(self):
+    def sync_from_params(self, model=None):
         """After weights were loaded into the model (utils/checkpoint.load_checkpoint copies into the flat views):
-        rebuild the bf16 shadows the matrix cores read."""
+        rebuild the bf16 shadows the matrix cores read (and, given the model, let its HIP body re-pack the frozen
+        layers' copies, which it otherwise packs once)."""
         self.join_side()
+        body = getattr(model, "backbone_hip", None) if model is not None else None
+        if body is not None and hasattr(body, "invalidate_weights"):
+            body.invalidate_weights()
         if self.shadows:
             self._refresh_shadows(initial=True)
 
@@ -376,15 +391,22 @@ class FlatSGD(object):
         return loaded
 
     def scheduler_state(self, iteration):
-        """WarmupMultiStepLR.state_dict() fields that matter on resume (solver/lr_scheduler.py:14-56)."""
+        """WarmupMultiStepLR.state_dict() fields that matter on resume (solver/lr_scheduler.py:14-56).  `last_epoch` is the
+        number of SCHEDULER steps taken -- one per SOLVER.ITER_SIZE group (engine/trainer.py:86-91), not one per
+        iteration; a caller that never passed iteration numbers to the step gets the group index of `iteration`."""
         s = self.cfg.SOLVER
-        return {"last_epoch": int(iteration), "milestones": tuple(s.STEPS), "gamma": s.GAMMA, "warmup_factor": s.WARMUP_FACTOR,
+        iter_size = max(1, int(s.ITER_SIZE))
+        pos = self.sched_steps if self.sched_steps > 0 else (int(iteration) + iter_size - 1) // iter_size
+        return {"last_epoch": int(pos), "milestones": tuple(s.STEPS), "gamma": s.GAMMA, "warmup_factor": s.WARMUP_FACTOR,
                 "warmup_iters": s.WARMUP_ITERS, "warmup_method": s.WARMUP_METHOD}
 
-    def resume(self, iteration):
-        """Learning-rate factor of a run that has completed `iteration` steps (no momentum rescale: the buffers were
-        saved under that factor)."""
-        self.lr_scale = lr_factor(self.cfg, iteration) if iteration > 0 else 1.0
+    def resume(self, sched_steps):
+        """A run whose scheduler has taken `sched_steps` steps (the checkpoint's scheduler.last_epoch): its learning-rate
+        factor (no momentum rescale: the buffers were saved under that factor), and a FRESH accumulation group -- the
+        partial gradient sum of an interrupted SOLVER.ITER_SIZE group is not part of a checkpoint."""
+        self.sched_steps = max(0, int(sched_steps))
+        self.lr_scale = lr_factor(self.cfg, self.sched_steps) if self.sched_steps > 0 else 1.0
+        self.grads_clean = True
 
     def _on_grad_ready(self, weight, r0, r1):
         """gemm.WgradBatch: rows [r0, r1) of `weight`'s gradient are final (called from backward)."""
@@ -478,6 +500,7 @@ class FlatSGD(object):
             for sh in self.shadows:
                 sh.pending = ev
         self.first = False
+        self.grads_clean = True             # (optimizer.zero_grad() of engine/trainer.py:120: the next backward starts a sum)
 
     _head_event = None
 
@@ -521,6 +544,9 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
     # groups, whose later micro-steps ACCUMULATE into the gradients (different kernel arguments)
     if hasattr(hip_body, "use_graphs") and max(1, int(cfg.SOLVER.ITER_SIZE)) == 1 and os.environ.get("ODW_NO_GRAPHS") != "1":
         hip_body.use_graphs = True
+        # bounded: at most ODW.GRAPH_CACHE shapes stay captured (least recently used evicted), a shape is captured when it
+        # comes back, everything else runs eagerly (vgg16_hip.VGGBackboneHip._graph_for)
+        hip_body.graph_cache_size = int(getattr(getattr(cfg, "ODW", None), "GRAPH_CACHE", hip_body.graph_cache_size))
     if cfg.MODEL.BACKBONE.CONV_BODY.startswith("VGG16"):
         conv_desc = "od_wscl_amd HIP implicit-GEMM conv3x3 (NHWC, MFMA)"
     else:
@@ -548,9 +574,10 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
     # evaluations of the large Linears that register with their weight-gradient batch after that get reserved columns
     le = getattr(model.roi_heads, "loss_evaluator", None)
     if hasattr(le, "early_backward") and os.environ.get("ODW_NO_EARLY_BWD") != "1":
-        from . import gemm as _gemm
         le.early_backward = True
-        _gemm.WgradBatch.reserve = 1024
+        for sh in opt.shadows:                      # (per instance: other models of the process keep reserve = 0)
+            if getattr(sh, "batch", None) is not None:
+                sh.batch.reserve = 1024
         # (measured and rejected, tools/exp/ab_early.sh: the stacked pass's weight gradient as its own GEMM in the early
         # part -- more cover for the host's small launches, but a second read-modify-write of fc6's 411 MB gradient and
         # a 100 MB transposed copy of its own: 10.6-11.2 ms against 9.9-10.1)
@@ -591,16 +618,24 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         return out
 
     def _step(images, targets, rois, rand, iteration=None):
-        k = (iteration - 1) % iter_size if iteration is not None else micro[0] % iter_size      # position in the group
+        # Position in the SOLVER.ITER_SIZE group, by the (1-based) iteration INDEX like the reference (trainer.py:86,118:
+        # the scheduler steps when (iteration - 1) % iter_size == 0, the optimiser when iteration % iter_size == 0) -- a
+        # skipped batch (trainer.py:80-82) moves neither.  Whether this backward starts a gradient sum or adds to one
+        # is the optimiser's state (zeroed by its last step, trainer.py:119-120), not a function of the index: a skipped
+        # first iteration does not leave the previous group's sum in place, a skipped last one keeps accumulating.
+        k = (iteration - 1) % iter_size if iteration is not None else micro[0] % iter_size
         micro[0] += 1
         last = k == iter_size - 1
-        if iteration is not None:           # WarmupMultiStepLR + update_momentum (solver/lr_scheduler.py, trainer.py:38-51)
-            opt.set_iteration((iteration - 1) // iter_size + 1)
-        opt.begin_step(accumulate=k > 0)
+        if iteration is not None and k == 0:        # WarmupMultiStepLR + update_momentum (lr_scheduler.py, trainer.py:38-51)
+            opt.sched_steps += 1
+            opt.set_iteration(opt.sched_steps)
+        accumulate = not opt.grads_clean
+        opt.begin_step(accumulate=accumulate)
+        opt.grads_clean = False
         opt.hold = not last                 # the head's early exchange + update waits for the group's last backward
         hip = getattr(model, "backbone_hip", None)
         if hip is not None:
-            hip.accumulate = k > 0
+            hip.accumulate = accumulate
         losses, accs = model(images, targets, rois, rand=rand)
         mark("forward")
         finish = getattr(losses, "finish_backward", None)

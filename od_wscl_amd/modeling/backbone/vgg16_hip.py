@@ -7,6 +7,8 @@ The parameters stay the nn.Conv2d weights of `VGG_Base.features` (same names, sa
 checkpoints and the optimiser); packed bf16 copies are refreshed from them at the start of each
 forward.  Frozen layers (FREEZE_CONV_BODY_AT=2 -> conv1_x, conv2_x) run forward only, and no input
 gradient is computed below the first trainable convolution."""
+import collections
+import logging
 import os
 
 import torch
@@ -388,7 +390,9 @@ class VGGBackboneHip(nn.Module):
         self.zero_page = None
         self.last_nhwc = None
         self._frozen_ready = False
-        self._graphs = {}
+        self._graphs = collections.OrderedDict()        # least recently used first
+        self._sightings = {}
+        self.graph_stats = {"captures": 0, "replays": 0, "eager": 0, "evictions": 0, "bytes": 0}
 
     def _prep(self):
         lib = L.lib()
@@ -400,8 +404,12 @@ class VGGBackboneHip(nn.Module):
         mixed = P.split_mode() and not P.bwd_split()      # "bf16x2f": split forward operand, single-plane dgrad operand
         todo = []
         for i, l in enumerate(self.layers):
-            if not l.trainable and self._frozen_ready and l.mode == mode:
+            # frozen layers pack their copies once -- until someone writes their weights in place (a checkpoint loaded
+            # after the first forward: copy_ bumps the tensor's version counter)
+            if (not l.trainable and self._frozen_ready and l.mode == mode
+                    and getattr(l, "packed_version", None) == l.conv.weight._version):
                 continue
+            l.packed_version = l.conv.weight._version
             fresh = l.mode != mode
             if P.split_mode() and not mixed:
                 # "bf16x3" / "bf16x2": both packed copies as bf16 planes -- rows (co, tap) x [T blocks of Cp] and rows
@@ -455,12 +463,51 @@ class VGGBackboneHip(nn.Module):
     bwd_segments = 1
     on_segment_done = None
 
+    # The cache of captured shapes is BOUNDED: the reference trains multi-scale (configs/voc/*.yaml:33-34: six MIN_SIZE_TRAIN
+    # values, free aspect ratios, SIZE_DIVISIBILITY 32, two images per GPU -> hundreds of distinct padded shapes), and every
+    # captured pair keeps its whole body's activations in a private pool (~1 GB at VOC sizes).  Policy:
+    #   * at most `graph_cache_size` shapes, least recently used evicted (its graphs and pool are released);
+    #   * a shape is captured only when it comes back (`graph_min_sightings`): the first time it runs eagerly -- a shape
+    #     that never repeats costs nothing beyond its ordinary launches;
+    #   * captures are rate-limited by the replays they buy (one capture = a warm-up forward + backward, two captures and a
+    #     device synchronisation): never more than 2 + replays / 8, so a workload whose shapes cycle faster than the cache
+    #     holds degrades to the eager path instead of re-capturing every step.
+    graph_cache_size = int(os.environ.get("ODW_GRAPH_CACHE", "4"))
+    graph_min_sightings = 2
+
+    def invalidate_weights(self):
+        """The parameters were overwritten from outside the optimiser (a checkpoint): frozen layers re-pack their copies."""
+        self._frozen_ready = False
+
     def _graph_for(self, fn, images):
+        """The captured pair for this (function, shape, mode) or None = run this step eagerly."""
         key = (fn.__name__, tuple(images.shape), P.get_precision(), bool(getattr(self, "accumulate", False)),
                int(getattr(self, "bwd_segments", 1)))
+        st = self.graph_stats
         g = self._graphs.get(key)
-        if g is None:
-            g = self._graphs[key] = _GraphedBody(self, fn, images)
+        if g is not None:
+            self._graphs.move_to_end(key)
+            st["replays"] += 1
+            return g
+        if len(self._sightings) > 8192:
+            self._sightings.clear()
+        seen = self._sightings[key] = self._sightings.get(key, 0) + 1
+        if self.graph_cache_size < 1 or seen < self.graph_min_sightings or st["captures"] >= 2 + st["replays"] // 8:
+            st["eager"] += 1
+            return None
+        while len(self._graphs) >= self.graph_cache_size:
+            torch.cuda.current_stream().synchronize()           # (no replay of the evicted pair may still be in flight)
+            old_key, old = self._graphs.popitem(last=False)
+            st["evictions"] += 1
+            st["bytes"] -= old.bytes
+            del old
+        before = torch.cuda.memory_reserved(images.device)
+        g = self._graphs[key] = _GraphedBody(self, fn, images)
+        g.bytes = max(0, torch.cuda.memory_reserved(images.device) - before)
+        st["captures"] += 1
+        st["bytes"] += g.bytes
+        logging.getLogger("od_wscl_amd").info("HIP graphs of the body captured for %s: %.2f GB reserved (%d shape(s) cached, %.2f GB)",
+                                              tuple(images.shape), g.bytes / 1e9, len(self._graphs), st["bytes"] / 1e9)
         return g
 
     def forward(self, images):
@@ -471,7 +518,14 @@ class VGGBackboneHip(nn.Module):
         if (self.use_graphs and torch.is_grad_enabled() and trainable and fn is not _VGGSplitFn
                 and all(p.grad is not None for l in self.layers if l.trainable for p in (l.conv.weight, l.conv.bias))
                 and getattr(self, "debug", None) is None and os.environ.get("ODW_NO_GRAPHS") != "1"):
-            feat = _GraphedVGGFn.apply(images.float(), self, self._graph_for(fn, images), *params)
+            graphed = self._graph_for(fn, images)
+        else:
+            graphed = None
+        if graphed is not None:
+            if any(getattr(l, "packed_version", None) != l.conv.weight._version for l in self.layers if not l.trainable):
+                with torch.no_grad():       # a frozen layer was rewritten since the capture (which packs trainable layers only):
+                    self._prep()            # re-pack into the same buffers the captured launches read
+            feat = _GraphedVGGFn.apply(images.float(), self, graphed, *params)
         else:
             with torch.no_grad():
                 self._prep()
@@ -492,6 +546,7 @@ class _GraphedBody(object):
     def __init__(self, net, fn, images):
         from ...utils.kernel_timer import kernel_timer as kt
         self.net, self.fn = net, fn
+        self.bytes = 0
         dev = images.device
         self.img = torch.empty(tuple(images.shape), dtype=torch.float32, device=dev)
         self.img.copy_(images)

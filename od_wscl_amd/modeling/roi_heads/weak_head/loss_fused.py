@@ -171,6 +171,26 @@ class _DenseLossFn(torch.autograd.Function):
         return dy * g[col2loss][None, :], None, None, None
 
 
+class _InjectGrad(torch.autograd.Function):
+    """loss_sim with the ALREADY COMPUTED gradient of the dense losses w.r.t. the stacked operand attached: backward hands
+    `dx` to `x` (as it is: the dense losses' backward ran with the unit weight of the reference's plain sum of losses,
+    engine/trainer.py:102, and their parameter gradients are already in place -- a scaled total is not expressible once
+    the early backward is on, and a 200 MB multiply by 1.0 per step is not worth pretending otherwise).  With it every way of
+    starting the backward -- LossDict.finish_backward(), losses.total.backward(), sum(losses.values()).backward() --
+    reaches the pooling node and the body with the dense losses' contribution; without it the last two would silently
+    drop it (the dense losses are detached once their backward has run early)."""
+
+    @staticmethod
+    def forward(ctx, loss_sim, x, dx):
+        ctx.save_for_backward(dx)
+        return loss_sim.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return g, dx, None
+
+
 @registry.ROI_WEAK_LOSS.register("RoIRegLossFused")
 class RoIRegLossFused(RoIRegLossComputation):
     # engine.build_training_step switches this on (the caller must then finish the backward through
@@ -500,13 +520,15 @@ class RoIRegLossFused(RoIRegLossComputation):
         if dense is not None:
             if tr is not None:
                 tr["dense_loss_kernel"] = True
+            if early is not None:
+                loss_sim = _InjectGrad.apply(loss_sim, early[0], early[1])
             losses = LossDict({"loss_img": dense[0], "loss_sim": loss_sim})
             for k in range(1, 7):
                 losses[names[k]] = dense[k]
             losses.total = dense.sum() + loss_sim
             if early is not None:
-                def finish_backward(loss_sim=loss_sim, x=early[0], dx=early[1]):
-                    torch.autograd.backward([loss_sim, x], [None, dx])
+                def finish_backward(loss_sim=loss_sim):
+                    loss_sim.backward()
                 losses.finish_backward = finish_backward
             accs = {"acc_img": tot[7], "acc_ref0": tot[8], "acc_ref1": tot[9], "acc_ref2": tot[10]}
             return losses, accs

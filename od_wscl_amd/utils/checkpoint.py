@@ -90,9 +90,15 @@ def restore_training_state(optimizer, model, rest):
     iteration = int(rest.get("iteration", 0) or 0)
     if rest.get("optimizer") is not None:
         optimizer.load_state_dict(model, rest["optimizer"])
+    # the schedule position is the scheduler's own count (one step per SOLVER.ITER_SIZE group, engine/trainer.py:86-91),
+    # NOT the iteration index: with ITER_SIZE > 1 the two differ, and a learning-rate factor taken from the micro-iteration
+    # count would cross a STEPS milestone early and trigger a spurious momentum correction on the next step
     sched = rest.get("scheduler")
+    iter_size = max(1, int(optimizer.cfg.SOLVER.ITER_SIZE))
     if sched is not None and "last_epoch" in sched:
-        iteration = max(iteration, int(sched["last_epoch"]))
-    optimizer.sync_from_params()
-    optimizer.resume(iteration)
+        position = int(sched["last_epoch"])
+    else:
+        position = (iteration + iter_size - 1) // iter_size
+    optimizer.sync_from_params(model)
+    optimizer.resume(position)
     return iteration

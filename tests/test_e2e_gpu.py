@@ -469,3 +469,115 @@ def test_early_dense_backward_equals_the_ordinary_backward(monkeypatch, fuse):
             continue        # a softmax over the proposals is shift invariant: this gradient is rounding noise around 0
         d = (grads[True][n] - g).abs().max().item()
         assert d <= 1e-6 * g.abs().max().item() + 1e-9, (n, d, g.abs().max().item())
+
+
+def test_graph_cache_stays_bounded_over_many_shapes(monkeypatch):
+    """The reference trains six MIN_SIZE_TRAIN values with free aspect ratios (configs/voc/voc07_contra_db_b8_lr0.01_mcg.yaml:
+    33-34): 12 distinct padded shapes between 480 and 1200 px, cycled three times through the bench's step function.  At most
+    ODW.GRAPH_CACHE shapes stay captured, the allocator's reserve stops growing once the cache is full (an unbounded cache
+    keeps one ~1-4 GB activation pool per shape forever), the rest of the steps run eagerly, losses stay finite."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from od_wscl_amd import engine, synthetic
+    from od_wscl_amd.structures import BoxList, to_image_list
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("ODW_NO_TIMER", "1")
+    cfg = bench.build_cfg(21)
+    cfg.merge_from_list(["ODW.GRAPH_CACHE", 3])
+    step, _ = engine.build_training_step(cfg, dev, dtype="bf16x2f", world=1, seed=cfg.SEED)
+    body = step.model.hip_body()
+    assert body.use_graphs and body.graph_cache_size == 3
+    shapes = [(480, 640), (576, 768), (688, 912), (864, 1152), (1000, 1200), (1200, 900), (640, 480), (768, 576), (912, 688),
+              (1152, 864), (1184, 1000), (800, 1200)]
+    batches = []
+    for k, (h, w) in enumerate(shapes):
+        img = torch.from_numpy(synthetic.make_image(41, k, h, w))[:, :h, :w]
+        boxes = torch.from_numpy(synthetic.make_proposals(41, k, 300, h, w, min_size=20))
+        t = BoxList(torch.zeros((1, 4), device=dev), (w, h), "xyxy")
+        t.add_field("labels", torch.tensor([1 + k % 20], device=dev))
+        t.add_field("labels_host", [1 + k % 20])
+        batches.append((to_image_list([img], 32).to(dev), [t], [BoxList(boxes.to(dev), (w, h), "xyxy")]))
+    reserved, it = [], 0
+    for cycle in range(3):
+        for images, targets, rois in batches:
+            losses, _ = step(images, targets, rois, DeviceRand(41, first_stream=(1 << 20) + (it << 12), device=dev))
+            it += 1
+            assert all(np.isfinite(float(v.detach())) for v in losses.values()), (cycle, it, losses)
+        torch.cuda.synchronize()
+        reserved.append(torch.cuda.memory_reserved(dev))
+    st = body.graph_stats
+    print("GRAPHCACHE", st, [round(r / 1e9, 2) for r in reserved])
+    assert len(body._graphs) <= 3 and st["captures"] <= 2 + st["replays"] // 8 + 1 and st["eager"] >= 24
+    assert reserved[2] <= reserved[1] * 1.10 + (1 << 28), reserved       # no growth once every shape has been seen
+    # the same shape again and again (the bench): captured on its second sighting, replayed from then on
+    images, targets, rois = batches[0]
+    before = st["replays"]
+    for k in range(12):
+        step(images, targets, rois, DeviceRand(41, first_stream=(1 << 20) + ((it + k) << 12), device=dev))
+    torch.cuda.synchronize()
+    assert st["replays"] - before >= 9, st
+
+
+def test_iter_size_follows_the_reference_when_batches_are_skipped(monkeypatch):
+    """SOLVER.ITER_SIZE = 2 with skipped batches (engine/trainer.py:80-82 `continue`s over a batch with an unlabelled
+    image; the optimiser steps when iteration % iter_size == 0 and zeroes the gradients only then, :118-120):
+      * iterations 1, 2 run (step), 3 is skipped, 4 runs: the step after 4 sees the gradient of batch 4 ALONE -- not added
+        to the already-applied sum of the previous group;
+      * iterations 1 runs, 2 is skipped (no step), 3 and 4 run: the step after 4 sees batches 1 + 3 + 4.
+    The momentum buffer after the first optimiser step is the gradient sum itself (weight decay off)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from od_wscl_amd import engine
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("ODW_NO_TIMER", "1")
+    batches = {k: bench.synthetic_batch(1234, k, 224, 150, 21, dev) for k in (1, 2, 3, 4)}
+    rands = lambda it: DeviceRand(1234, first_stream=(1 << 20) + (it << 12), device=dev)
+
+    def build(iter_size, momentum=0.9):
+        cfg = bench.build_cfg(21)
+        cfg.merge_from_list(["SOLVER.ITER_SIZE", iter_size, "SOLVER.WEIGHT_DECAY", 0.0, "SOLVER.WEIGHT_DECAY_BIAS", 0.0,
+                             "SOLVER.BASE_LR", 0.0, "SOLVER.MOMENTUM", momentum])
+        return engine.build_training_step(cfg, dev, dtype="bf16x2f", world=1, seed=cfg.SEED)[0]
+
+    def single(k):                          # the gradient of batch k alone, at the (never changing: lr 0) initial weights
+        one = build(-1)
+        one(*batches[k], rands(k), iteration=1)
+        torch.cuda.synchronize()
+        g = one.optimizer.flat_m.clone()
+        return g, dict(one.optimizer.slices)
+
+    g = {}
+    for k in (1, 3, 4):
+        g[k], slices = single(k)
+
+    def close(a, b, what):
+        for n, (o, k) in slices.items():
+            x, y = a[o:o + k], b[o:o + k]
+            assert (x - y).abs().max().item() <= 2e-3 * y.abs().max().item() + 1e-9, (what, n)
+
+    # case 1: the first iteration of a group is skipped.  momentum 0: the buffer after a step IS that step's gradient sum
+    step = build(2, momentum=0.0)
+    step(*batches[1], rands(1), iteration=1)
+    step(*batches[2], rands(2), iteration=2)          # optimiser step (1 + 2)
+    assert step.optimizer.grads_clean
+    step(*batches[4], rands(4), iteration=4)          # iteration 3 skipped; 4 % 2 == 0: optimiser step
+    torch.cuda.synchronize()
+    assert step.optimizer.grads_clean and step.optimizer.sched_steps == 1      # (the skipped iteration 3 held the scheduler step)
+    close(step.optimizer.flat_m, g[4], "batch 4 alone")
+    del step
+    # case 2: the last iteration of a group is skipped
+    step = build(2, momentum=0.0)
+    p0 = step.optimizer.flat_p.clone()
+    step(*batches[1], rands(1), iteration=1)
+    step(*batches[3], rands(3), iteration=3)          # iteration 2 skipped: no optimiser step, the sum keeps growing
+    torch.cuda.synchronize()
+    assert not step.optimizer.grads_clean and step.optimizer.first, "the optimiser stepped although iteration 2 never ran"
+    step(*batches[4], rands(4), iteration=4)
+    torch.cuda.synchronize()
+    assert step.optimizer.grads_clean and step.optimizer.sched_steps == 2
+    close(step.optimizer.flat_m, g[1] + g[3] + g[4], "batches 1 + 3 + 4")
+    assert torch.equal(step.optimizer.flat_p, p0)     # lr 0

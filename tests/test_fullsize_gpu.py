@@ -46,7 +46,7 @@ ORDER_TOL = {"bf16x3": 1e-5, "bf16x2f": 5e-4}
 GRAD_TOL = {"bf16x3": 1e-3, "bf16x2f": 1e-2}      # observed: 7e-5 / 2.6e-3
 # relative L2 error of every gradient TENSOR against the oracle's (a permuted or mis-scattered gradient keeps its norm;
 # this does not); observed: see the FULLSIZE report lines (profiles/r04/fullsize_report.txt)
-GRAD_L2_TOL = {"bf16x3": 2e-3, "bf16x2f": 2e-2}
+GRAD_L2_TOL = {"bf16x3": 5e-3, "bf16x2f": 2e-2}      # observed: <= 1.74e-3 / <= 7.0e-3
 MAX_UNCERTAIN = 12
 
 

@@ -64,3 +64,131 @@ def test_wgrad_batch_takes_registrations_after_its_first_block():
     finally:
         gemm.WgradBatch.reserve = old
         precision.set_precision(mode)
+
+
+# ---- round 4 ---------------------------------------------------------------------------------------------------------
+def test_graph_cache_policy_is_bounded_and_rate_limited(monkeypatch):
+    """VGGBackboneHip._graph_for without a GPU (the capture itself is stubbed): a shape runs eagerly the first time, is
+    captured when it comes back, at most `graph_cache_size` shapes stay captured (least recently used evicted), and a
+    workload whose shapes cycle faster than the cache holds stops capturing (2 + replays / 8) instead of re-capturing
+    every step (configs/voc/*.yaml:33-34: six training scales x free aspect ratios)."""
+    from od_wscl_amd.modeling.backbone import vgg16_hip as V
+
+    class FakeGraphed(object):
+        def __init__(self, net, fn, images):
+            self.bytes = 0
+
+    monkeypatch.setattr(V, "_GraphedBody", FakeGraphed)
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda dev=None: 0)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: types.SimpleNamespace(synchronize=lambda: None))
+    net = object.__new__(V.VGGBackboneHip)
+    torch.nn.Module.__init__(net)
+    import collections
+    net._graphs, net._sightings = collections.OrderedDict(), {}
+    net.graph_stats = {"captures": 0, "replays": 0, "eager": 0, "evictions": 0, "bytes": 0}
+    net.graph_cache_size = 2
+
+    def fn():
+        pass
+
+    def see(h, w):
+        return net._graph_for(fn, torch.empty(1, 3, h, w))
+
+    assert see(608, 608) is None                                  # first sighting: eager
+    g = see(608, 608)
+    assert g is not None and net.graph_stats["captures"] == 1     # comes back: captured
+    assert all(see(608, 608) is g for _ in range(20))             # the bench's fixed shape: replays from then on
+    assert see(480, 640) is None and see(480, 640) is not None    # a second shape
+    assert len(net._graphs) == 2
+    for _ in range(3):
+        see(608, 608)
+    assert see(800, 1216) is None
+    assert see(800, 1216) is not None                             # third shape: the least recently used one (480 x 640) goes
+    keys = [k[1][2:] for k in net._graphs]
+    assert keys == [(608, 608), (800, 1216)] and net.graph_stats["evictions"] == 1
+    # 40 distinct shapes, each seen twice in a row, with no replays in between: captures stop at the rate limit
+    before = net.graph_stats["captures"]
+    for i in range(40):
+        see(480 + 32 * i, 640)
+        see(480 + 32 * i, 640)
+    st = net.graph_stats
+    assert len(net._graphs) <= 2
+    assert st["captures"] - before <= 2 + st["replays"] // 8
+    assert st["eager"] >= 70
+
+
+def test_grad_exchange_refuses_a_range_announced_twice(monkeypatch):
+    """A flat range handed to the all-reduce twice in one step means its producer wrote into it after the first
+    announcement (a weight-gradient batch flushed twice): the first collective summed a partial gradient."""
+    import pytest
+    from od_wscl_amd import engine
+    ex = engine.GradExchange(torch.zeros(1024), world=2)
+    monkeypatch.setattr(ex, "_issue", lambda lo, hi: None)
+    ex.begin()
+    ex.ready(0, 256)
+    ex.ready(512, 1024)
+    assert ex.pending(0, 1024) == [(256, 512)]
+    with pytest.raises(RuntimeError, match="overlaps"):
+        ex.ready(128, 300)
+    ex.begin()                                                   # a new step starts clean
+    ex.ready(128, 300)
+
+
+def test_schedule_position_is_the_scheduler_step_count_not_the_iteration():
+    """SOLVER.ITER_SIZE = 4: the reference steps its scheduler once per group (engine/trainer.py:86-91) and saves
+    scheduler.last_epoch; the checkpointed `iteration` counts micro-iterations.  Resuming must take the learning-rate
+    factor from the group count -- from the micro count it would cross a STEPS milestone 4x early."""
+    from od_wscl_amd import engine
+    from od_wscl_amd.config import make_defaults
+    from od_wscl_amd.utils import checkpoint as ck
+    cfg = make_defaults()
+    cfg.merge_from_list(["SOLVER.ITER_SIZE", 4, "SOLVER.STEPS", (100, 200), "SOLVER.WARMUP_ITERS", 10, "SOLVER.GAMMA", 0.1])
+    calls = []
+
+    class Opt(engine.FlatSGD):
+        def __init__(self):
+            self.cfg, self.sched_steps, self.lr_scale, self.grads_clean = cfg, 0, 1.0, False
+
+        def sync_from_params(self, model=None):
+            calls.append("sync")
+
+        def load_state_dict(self, model, sd):
+            calls.append("momenta")
+
+    opt = Opt()
+    opt.sched_steps = 60                                          # 240 micro-iterations = 60 groups
+    state = opt.scheduler_state(240)
+    assert state["last_epoch"] == 60
+    fresh = Opt()
+    assert fresh.scheduler_state(240)["last_epoch"] == 60         # a caller that never numbered its steps: ceil(240 / 4)
+    assert fresh.scheduler_state(241)["last_epoch"] == 61
+    it = ck.restore_training_state(fresh, None, {"iteration": 240, "optimizer": {}, "scheduler": state})
+    assert it == 240 and fresh.sched_steps == 60 and fresh.grads_clean and calls == ["momenta", "sync"]
+    assert fresh.lr_scale == engine.lr_factor(cfg, 60) == 1.0     # 60 < 100: before the first milestone
+    assert engine.lr_factor(cfg, 240) == 0.1 * 0.1                # what the micro count would have given
+    legacy = Opt()                                                # a checkpoint without a scheduler entry
+    ck.restore_training_state(legacy, None, {"iteration": 402})
+    assert legacy.sched_steps == 101 and abs(legacy.lr_scale - 0.1) < 1e-12
+
+
+def test_inject_grad_routes_the_early_gradient_through_every_backward_entry():
+    """loss_fused._InjectGrad: once the dense losses' backward has run early, loss_sim carries their gradient w.r.t. the
+    stacked operand, so total.backward() and sum(losses.values()).backward() deliver it like finish_backward()."""
+    from od_wscl_amd.modeling.roi_heads.weak_head.loss_fused import _InjectGrad
+    for entry in ("total", "sum", "loss_sim"):
+        body = torch.randn(5, 3, requires_grad=True)
+        x = body * 1.0                                            # the stacked operand (output of the pooling node)
+        e = torch.randn(4, requires_grad=True)
+        loss_sim = (e ** 2).sum()
+        dx = torch.full((5, 3), 0.25)
+        dense = torch.tensor([1.0, 2.0])                          # detached dense losses
+        ls = _InjectGrad.apply(loss_sim, x, dx)
+        losses = {"loss_img": dense[0], "loss_ref": dense[1], "loss_sim": ls}
+        if entry == "total":
+            (dense.sum() + ls).backward()
+        elif entry == "sum":
+            sum(losses.values()).backward()
+        else:
+            ls.backward()
+        assert torch.equal(body.grad, dx) and torch.allclose(e.grad, 2 * e.detach())
+        assert float(ls) == float(loss_sim)

@@ -103,7 +103,7 @@ def main():
         if resume_from:                             # our own run: momenta, schedule position, iteration
             start_iter = ck.restore_training_state(opt, model, rest)
         else:                                       # pretrained weights: a fresh schedule (trainer.py / train_net.py:75-77)
-            opt.sync_from_params()
+            opt.sync_from_params(model)
         if rank == 0:
             print("loaded %s (%s, iteration %d)" % (weight, "resume" if resume_from else "weights only", start_iter), flush=True)
     elif weight and not (args.synthetic or args.allow_random_init):
