@@ -78,10 +78,24 @@ def parse():
                     help="POOLER_METHOD; every shipped config of the reference uses ROIPool (the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proposals", type=int, default=2000)
+    # ---- data-parallel knobs (N > 1).  The defaults are what `bench.py --gpus N` runs: RCCL, fp32 gradients on the wire,
+    # equal stream priorities
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the gradient exchange: nccl (= RCCL over xGMI, the measured "
+                         "configuration) | gloo (plumbing tests on a box with fewer GPUs than ranks, see --oversubscribe)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="let ranks share GPUs (rank r on device r mod device_count): exercises the launcher, the process "
+                         "group and the exchange on a 1-GPU box; the line is marked \"oversubscribed\" and is NOT a scaling number")
+    ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"],
+                    help="element type of the gradients on the wire (ODW.GRAD_EXCHANGE): fp32 = the reference's DDP; bf16 = "
+                         "half the xGMI bytes, rounded once before the sum, fp32 again in the optimiser")
+    ap.add_argument("--hp-stream", default="auto", choices=["auto", "0", "1"],
+                    help="run the step on a high-priority HIP stream: auto = only at N = 1 (at N > 1 RCCL's kernels sit on "
+                         "default-priority streams and must not be starved of CUs)")
     return ap.parse_args()
 
 
-def build_cfg(classes, arch="vgg16", pooler="ROIPool"):
+def build_cfg(classes, arch="vgg16", pooler="ROIPool", grad_exchange="fp32"):
     from od_wscl_amd.config import make_defaults
     cfg = make_defaults()
     # == configs/voc/voc07_contra_db_b8_lr0.01_mcg.yaml of the reference (voc07_r50_c5_contra_db_b8_lr0.02_ss.yaml for r50)
@@ -94,7 +108,7 @@ def build_cfg(classes, arch="vgg16", pooler="ROIPool"):
                          "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", 7,
                          "MODEL.ROI_WEAK_HEAD.REGRESS_ON", True, "DB.METHOD", "dropblock", "SOLVER.CONTRA", True,
                          "SOLVER.BASE_LR", BENCH_LR, "SOLVER.WEIGHT_DECAY", 0.0001, "SOLVER.IMS_PER_BATCH", 8,
-                         "nms", 0.1, "lmda", 0.03, "temp", 0.2, "SEED", 1234])
+                         "nms", 0.1, "lmda", 0.03, "temp", 0.2, "SEED", 1234, "ODW.GRAD_EXCHANGE", grad_exchange])
     return cfg
 
 
@@ -216,13 +230,32 @@ def pairwise_sim_live(device, sizes=(2000, 4000, 8000), iters=30):
     return out
 
 
-def launch_ranks(n):
+def collective_report(exch, args, world, steps, shared):
+    """The `collective` object of the line: what carried the gradient exchange and how much of it the step WAITED for.
+    exposed_ms_per_step = time the step's own stream spent blocked in GradExchange.finish (HIP events on that stream,
+    around the waits on the outstanding all-reduces: tools/train_net.py:50-55 of the reference is DDP's bucketed
+    all-reduce); side_stream_wait_ms = the same for the optimiser's side stream, where the head's exchange is waited for
+    under the body's backward (hidden unless it outlasts the backward)."""
+    if world <= 1:
+        return {"backend": None, "ranks": 1, "wire_dtype": None, "exposed_ms_per_step": 0.0}
+    tot = {"main": 0.0, "side": 0.0}
+    for tag, e0, e1 in exch.marks:
+        tot[tag] += e0.elapsed_time(e1)
+    nbytes = exch.flat.numel() * (2 if exch.dtype == "bf16" else 4)
+    return {"backend": "rccl" if args.backend == "nccl" else args.backend, "ranks": world, "wire_dtype": exch.dtype,
+            "bytes_per_step": int(nbytes), "exposed_ms_per_step": round(tot["main"] / steps, 4),
+            "side_stream_wait_ms_per_step": round(tot["side"] / steps, 4),
+            "hp_stream": os.environ.get("ODW_HP_STREAM", "auto"), "devices_shared": bool(shared)}
+
+
+def launch_ranks(n, oversubscribe=False):
     """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU over RCCL, the
     reference's torch.distributed.launch flow, tools/train_net.py:286-294) and relay rank 0's JSON line."""
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not oversubscribe:
         raise RuntimeError("bench.py --gpus %d: only %d GPU(s) visible on this node -- refusing to report an "
-                           "n_gpus=%d number from fewer devices" % (n, have, n))
+                           "n_gpus=%d number from fewer devices (--oversubscribe --backend gloo runs the plumbing "
+                           "with shared devices)" % (n, have, n))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -237,8 +270,12 @@ def main():
     args = parse()
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.oversubscribe and args.backend == "nccl" and args.gpus > torch.cuda.device_count():
+        raise RuntimeError("bench.py: RCCL refuses two ranks on one device -- use --backend gloo with --oversubscribe")
+    if args.hp_stream != "auto":
+        os.environ["ODW_HP_STREAM"] = args.hp_stream
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))
+        sys.exit(launch_ranks(args.gpus, args.oversubscribe))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,18 +284,23 @@ def main():
     if args.global_batch and args.global_batch % world:
         raise RuntimeError("bench.py: --global-batch %d is not a multiple of %d ranks" % (args.global_batch, world))
     ipr = args.global_batch // world if args.global_batch else 1            # images per rank
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and not args.oversubscribe:
+        raise RuntimeError("bench.py: rank %d has no GPU of its own (%d visible)" % (local_rank, n_dev))
+    shared = args.oversubscribe and world > n_dev
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")     # nccl == RCCL on ROCm
+        dist.init_process_group(backend=args.backend, init_method="env://")   # nccl == RCCL on ROCm
         assert dist.get_world_size() == args.gpus
     from od_wscl_amd import _lib
     _lib.lib()                                                            # fail loudly if the .so is missing
     from od_wscl_amd import engine
     from od_wscl_amd.utils.device_rand import DeviceRand
 
-    cfg = build_cfg(args.classes, args.arch, args.pooler)
+    cfg = build_cfg(args.classes, args.arch, args.pooler, args.grad_exchange)
     seed = cfg.SEED
     images, targets, rois = synthetic_batch(seed, rank, args.size, args.proposals, args.classes, device, n_images=ipr)
 
@@ -271,11 +313,13 @@ def main():
         """warmup untimed steps, then exactly `steps` timed ones between two barriers; returns (seconds = max over ranks,
         per-step GPU milliseconds from HIP events on the launch stream, info of the step, roofline object of rank 0)."""
         step_fn, info = engine.build_training_step(cfg, device, dtype=dtype, world=world, seed=seed)
+        exch = step_fn.optimizer.exchange
         for it in range(warmup):
             step_fn(images, targets, rois, DeviceRand(seed + rank, first_stream=(1 << 20) + (it << 12), device=device))
         engine.kernel_timer.reset()
         engine.kernel_timer.timed_steps = len([it for it in range(steps) if it % args.time_every == 0])
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        exch.measure, exch.marks = world > 1, []        # event pairs around GradExchange.finish (the waits on the collectives)
         barrier()
         t0 = time.perf_counter()
         for it in range(steps):
@@ -292,6 +336,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        exch.measure = False
+        info = dict(info, collective=collective_report(exch, args, world, steps, shared))
         roof = engine.kernel_timer.roofline(dtype, MFMA_PEAK_TFLOPS, HBM_PEAK_GBPS) if rank == 0 else None
         hbm = engine.kernel_timer.hbm_entries(HBM_PEAK_GBPS) if rank == 0 else None
         flops_step = engine.kernel_timer.flops_per_timed_step() if rank == 0 else None
@@ -352,6 +398,8 @@ def main():
                        "global_batch": world * ipr, "parallelism": "dp%d" % world, "world_size": world, "lr": BENCH_LR, "gemm_backend": info["gemm_backend"],
                        "conv_backend": info["conv_backend"], "optimizer": info["optimizer"]},
             "per_gpu": round(value / world, 1),
+            "collective": info["collective"],
+            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ODW_")},
             "roofline": roof,
         }
     if world == 1 and not args.no_secondary and args.dtype != "bf16":
@@ -363,6 +411,8 @@ def main():
                                          "ms_per_step": round(sdt / n * 1e3, 3), "median_ms_per_step": round(float(np.median(sper)), 3),
                                          "steps": n, "note": DTYPE_NOTE["bf16"]}}
     if rank == 0:
+        if shared:
+            out["oversubscribed"] = "%d ranks on %d device(s): plumbing run, NOT a scaling measurement" % (world, n_dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, seed)
         print(json.dumps(out), flush=True)

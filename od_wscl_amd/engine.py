@@ -103,6 +103,8 @@ class GradExchange(object):
         self.flat, self.world, self.dtype, self.chunk, self.side, self.group = flat, world, dtype, chunk_elems, side, group
         self.stage = torch.empty_like(flat, dtype=torch.bfloat16) if (dtype == "bf16" and world > 1) else None
         self.done, self.works = [], []
+        # bench.py: (stream tag, start event, end event) around every finish() -- the time a stream is blocked on collectives
+        self.measure, self.marks = False, []
 
     def begin(self):
         self.done, self.works = [], []
@@ -158,6 +160,9 @@ class GradExchange(object):
         on the stream that consumes the gradients)."""
         if self.world <= 1:
             return
+        if self.measure:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for a, b in self.pending(lo, hi):
             self.done.append((a, b))
             self._issue(a, b)
@@ -166,6 +171,10 @@ class GradExchange(object):
             if self.stage is not None:
                 self.flat[a:b].copy_(self.stage[a:b])
         self.works = []
+        if self.measure:
+            e1.record()
+            on_side = self.side is not None and torch.cuda.current_stream() == self.side
+            self.marks.append(("side" if on_side else "main", e0, e1))
 
 
 def reduce_loss_dict(loss_dict, world=None, dst=0, group=None):

@@ -119,3 +119,38 @@ def test_rccl_backend_single_rank_step(tmp_path):
     mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     r = np.load(tmp_path / "rccl.npz")
     assert np.isfinite(r["losses"]).all() and float(r["t"][0]) == 1.5
+
+
+def test_bench_launches_two_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` end to end (tools/train_net.py:286-294 of the reference: one process per GPU): bench.py's
+    own launcher (launch_ranks -> python -m torch.distributed.run, the path the driver's multi-GPU run takes when it does
+    not start the ranks itself), the env:// rendezvous, the barrier / MAX-over-ranks timing, the early gradient exchange
+    and the JSON line of rank 0.  One MI355X here, so the two ranks share it (--oversubscribe) and gloo carries the
+    exchange (RCCL refuses two ranks on one device); the line says so and is not a scaling number."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--backend", "gloo",
+           "--oversubscribe", "--proposals", "300", "--size", "224", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["global_batch"] == 2 and out["scaling"] == "weak" and out["steps"] == 3 and out["warmup"] == 2
+    assert out["value"] > 0 and abs(out["value"] - 2 * 300 * 3 / (out["ms_per_step"] * 3e-3)) <= 1e-2 * out["value"]
+    assert abs(out["per_gpu"] * 2 - out["value"]) <= 1.0
+    c = out["collective"]
+    assert c["backend"] == "gloo" and c["ranks"] == 2 and c["wire_dtype"] == "fp32" and c["exposed_ms_per_step"] >= 0.0
+    assert c["devices_shared"] and "oversubscribed" in out
+    assert "secondary" not in out and "cpu_baseline" not in out           # N = 1 only
+    # ... and the same launcher refuses to report an N-GPU number from fewer devices when not asked to share them
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--steps", "1"],
+                        env=env, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "refusing" in r2.stderr
