@@ -25,7 +25,7 @@ def _r64(n):
 
 
 class _Layer(object):
-    __slots__ = ("conv", "cin", "cp", "cout", "dil", "relu", "pool", "trainable", "wk", "wd", "mode")
+    __slots__ = ("conv", "cin", "cp", "cout", "dil", "relu", "pool", "trainable", "wk", "wd", "mode", "packed_version")
 
 
 def _layers_of(features):
@@ -43,7 +43,7 @@ def _layers_of(features):
             j = i + (2 if l.relu else 1)
             l.pool = j < len(mods) and isinstance(mods[j], nn.MaxPool2d)
             l.trainable = m.weight.requires_grad
-            l.wk = l.wd = l.mode = None
+            l.wk = l.wd = l.mode = l.packed_version = None
             out.append(l)
         i += 1
     return out
@@ -501,12 +501,12 @@ class VGGBackboneHip(nn.Module):
             st["evictions"] += 1
             st["bytes"] -= old.bytes
             del old
-        before = torch.cuda.memory_reserved(images.device)
+        before = torch.cuda.memory_allocated(images.device)
         g = self._graphs[key] = _GraphedBody(self, fn, images)
-        g.bytes = max(0, torch.cuda.memory_reserved(images.device) - before)
+        g.bytes = max(0, torch.cuda.memory_allocated(images.device) - before)
         st["captures"] += 1
         st["bytes"] += g.bytes
-        logging.getLogger("od_wscl_amd").info("HIP graphs of the body captured for %s: %.2f GB reserved (%d shape(s) cached, %.2f GB)",
+        logging.getLogger("od_wscl_amd").info("HIP graphs of the body captured for %s: %.2f GB held (%d shape(s) cached, %.2f GB)",
                                               tuple(images.shape), g.bytes / 1e9, len(self._graphs), st["bytes"] / 1e9)
         return g
 

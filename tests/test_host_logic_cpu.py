@@ -79,7 +79,7 @@ def test_graph_cache_policy_is_bounded_and_rate_limited(monkeypatch):
             self.bytes = 0
 
     monkeypatch.setattr(V, "_GraphedBody", FakeGraphed)
-    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda dev=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev=None: 0)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: types.SimpleNamespace(synchronize=lambda: None))
     net = object.__new__(V.VGGBackboneHip)
     torch.nn.Module.__init__(net)
