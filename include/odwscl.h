@@ -147,11 +147,19 @@ int odw_box_iou(const float* a, int N, const float* b, int M, float* iou, void* 
  * replaces `torch.mm(sim_feature, sim_feature.T)` of
  * roi_heads/weak_head/loss.py:319.  E (P,D) fp32, D % 4 == 0 -> S (P,P) fp32. */
 int odw_pairwise_sim(const float* E, int P, int D, float* S, void* stream);
-/* Workspace form (D = 128): E is split once into three bf16 planes (csrc/split.hip arithmetic) and the products run
- * on the bf16 matrix cores, six plane products per fp32-grade product -- the kernel is then bound by the 4 P^2-byte
- * write of S.  odw_pairwise_sim_workspace(P, D) bytes; NULL / too small = the exact-fp32 MFMA chain of the plain entry. */
+/* Workspace form (D = 128): kept for callers of rounds 1-3; the products run on the bf16 matrix cores as six plane
+ * products per fp32-grade product and the kernel is bound by the 4 P^2-byte write of S.  Since round 4 the default is the
+ * ONE-launch kernel whatever the workspace (it splits E in registers; the split-kernel + LDS-DMA form measured 5-7 us
+ * slower, csrc/contrastive.hip); the workspace (odw_pairwise_sim_workspace(P, D) bytes) is used only when
+ * ODW_PAIRWISE_PLANES_MIN selects that form. */
 int64_t odw_pairwise_sim_workspace(int P, int D);
 int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same product from the PLANES of E (round 4): [3 planes][Ppad][128] bf16, Ppad = P rounded up to 32, padding rows
+ * zero, hi + mid + lo == the fp32 value exactly -- odw_pairwise_split_planes writes them (odw_pairwise_sim_workspace(P, 128)
+ * bytes), or the producer of E does.  The planes reach LDS by DMA; results are bit-identical to the one-launch form (and no
+ * faster: this entry exists for callers that already hold the planes).  Reference: roi_heads/weak_head/loss.py:319. */
+int odw_pairwise_split_planes(const float* E, int P, void* planes, void* stream);
+int odw_pairwise_sim_planes(const void* planes, int P, float* S, void* stream);
 
 /* ---- SupConLossV2 ------------------------------------------------------------
  * replaces roi_heads/sim_head/sim_loss.py:49-80 forward + its autograd

@@ -40,6 +40,8 @@ SIGNATURES = {
     "odw_pairwise_sim": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "odw_pairwise_sim_workspace": (c_l, [c_i, c_i]),
     "odw_pairwise_sim_ws": (c_i, [c_p, c_i, c_i, c_p, c_p, c_l, c_p]),
+    "odw_pairwise_split_planes": (c_i, [c_p, c_i, c_p, c_p]),
+    "odw_pairwise_sim_planes": (c_i, [c_p, c_i, c_p, c_p]),
     "odw_supcon_workspace": (c_l, [c_i]),
     "odw_supcon_v2": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_l, c_p]),
     "odw_rng_uniform": (c_i, [c_p, c_l, c_u, c_u, c_u, c_p]),

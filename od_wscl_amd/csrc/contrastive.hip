@@ -152,6 +152,34 @@ constexpr int kPwLds = 2 * kPwSlot + kPwScratch + (kPwStage - 2) * kPwSlot;     
 // number of 32-column blocks panel p works on: from its first row's block to the last block of S
 __device__ __host__ inline int pw_blocks_of(int p, int nblk32) { const int b = nblk32 - p * (kPwPanel / 32); return b > 0 ? b : 0; }
 
+// Work distribution.  Panel p owns pw_blocks_of(p) column blocks and gets ceil(blocks / max_run) workgroups, which cut its
+// blocks into equal runs: no workgroup crosses into another panel.  (Round 3 cut the panel-major list of all blocks into
+// equal runs: every run that straddled two panels -- 18 workgroups at P = 4000, 36 at P = 8000 -- staged a second panel,
+// ~5 us in the middle of its run, and finished that much after everybody else: the kernel's tail.)  pw_max_run picks the
+// smallest run length whose workgroup count fits the chip.
+__device__ __host__ inline int pw_groups(int max_run, int nblk32, int npanel) {
+    int n = 0;
+    for (int p = 0; p < npanel; ++p) n += (pw_blocks_of(p, nblk32) + max_run - 1) / max_run;
+    return n;
+}
+__host__ inline int pw_max_run(int nblk32, int npanel, int max_groups) {
+    int m = 1;
+    while (pw_groups(m, nblk32, npanel) > max_groups) ++m;
+    return m;
+}
+__device__ inline void pw_run_of(int g, int max_run, int nblk32, int npanel, int& panel, int& blk, int& run_len) {
+    panel = 0; blk = 0; run_len = 0;
+    for (int p = 0; p < npanel; ++p) {
+        const int nb = pw_blocks_of(p, nblk32), n = (nb + max_run - 1) / max_run;
+        if (g < n) {
+            const int lo = (int)((long long)nb * g / n), hi = (int)((long long)nb * (g + 1) / n);
+            panel = p; blk = p * (kPwPanel / 32) + lo; run_len = hi - lo;
+            return;
+        }
+        g -= n;
+    }
+}
+
 #ifdef ODW_EXPERIMENTS          // timing studies (WRONG results): 1 no direct stores, 2 no mirror stores, 4 no MFMAs
 #define PW_DBG(bit) (dbg & (bit))
 #else
@@ -176,6 +204,85 @@ __device__ long long g_pw_tl[1024 * 8 * 32];
 // Hence the roles: ONE loader wave per workgroup fetches, splits and parks the next column block and never stores;
 // SEVEN compute waves read fragments, run MFMAs and store, and never wait on vmcnt at all -- their stores drain under
 // the next tile's MFMAs.
+// store flavours of the interior tiles (dbg bits 8 / 16, ODW_PAIRWISE_ST: measurement of what a kernel that leaves no dirty
+// lines behind gains at its boundary): plain, nontemporal, or sc1 (write-through, dropped from L2)
+typedef float pw_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pw_st1(float* p, float v, int dbg) {
+    if (dbg & 8) __builtin_nontemporal_store(v, p);
+    else if (dbg & 16) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+__device__ __forceinline__ void pw_st4(float* p, const float4 v, int dbg) {
+    const pw_f4 x = {v.x, v.y, v.z, v.w};
+    if (dbg & 8) __builtin_nontemporal_store(x, reinterpret_cast<pw_f4*>(p));
+    else if (dbg & 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+    else *reinterpret_cast<pw_f4*>(p) = x;
+}
+
+// The stores of one finished 32 x 32 tile (rows r0.., columns c0.. of S, c0 >= r0): the direct tile as 128-byte row segments,
+// the mirrored tile through the wave's padded LDS scratch so that it leaves as full 128-byte lines too; a diagonal tile
+// writes its upper triangle to both places.  Shared by the panel and the DMA kernel.
+__device__ __forceinline__ void pw_store_tile(const f32x16& acc, float* __restrict__ S, int P, int r0, int c0, int lane, int half,
+                                              int l31, float* scratch, bool small, bool vec, int dbg = 0) {
+    const int col = c0 + l31;
+    const bool full = small && vec && r0 + 32 <= P && c0 + 32 <= P;      // wave-uniform: no per-element predicates
+    if (c0 == r0) {
+        // diagonal tile: (r, c) and (c, r) were accumulated in different term orders -- the upper triangle
+        // goes to both places so that S is exactly symmetric
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int r = crow(k, half);
+            if (r <= l31 && col < P) {
+                S[(size_t)(r0 + r) * P + col] = acc[k];
+                S[(size_t)col * P + r0 + r] = acc[k];
+            }
+        }
+    } else {
+        // mirror S[c0 + n][r0 + m]: the lane holds row n = l31 as 4 runs of 4 consecutive m -- parked in the
+        // wave's scratch as rows of 32 floats, read back 8 lanes per row, stored as full 128-byte lines
+        // (the wave's own LDS traffic is ordered: no barrier)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(scratch + l31 * kPwTrPitch + 8 * q + 4 * half) =
+                make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        if (full) {
+            // interior tile: 32-bit element offsets from the kernel-argument base, no predicates
+            const unsigned dbase = (unsigned)(r0 + 4 * half) * (unsigned)P + (unsigned)col;
+            if (!PW_DBG(1))
+#pragma unroll
+            for (int k = 0; k < 16; ++k)      // direct tile: one 128-byte row segment per half-wave
+                pw_st1(S + (dbase + (unsigned)((k & 3) + 8 * (k >> 2)) * (unsigned)P), acc[k], dbg);
+            const unsigned mbase = (unsigned)(c0 + (lane >> 3)) * (unsigned)P + (unsigned)(r0 + (lane & 7) * 4);
+            if (!PW_DBG(2))
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                pw_st4(S + (mbase + (unsigned)(8 * t) * (unsigned)P),
+                       *reinterpret_cast<const float4*>(scratch + (t * 8 + (lane >> 3)) * kPwTrPitch + (lane & 7) * 4), dbg);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = r0 + crow(k, half);
+                if (r < P && col < P) S[(size_t)r * P + col] = acc[k];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = t * 8 + (lane >> 3), m4 = (lane & 7) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(scratch + n * kPwTrPitch + m4);
+                const int row = c0 + n, cc = r0 + m4;
+                if (row < P) {
+                    float* dst = S + (size_t)row * P + cc;
+                    if (vec && cc + 3 < P) *reinterpret_cast<float4*>(dst) = v;
+                    else {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (cc + u < P) dst[u] = e[u];
+                    }
+                }
+            }
+        }
+    }
+}
+
 struct PwRows { float4 a0, a1; };
 
 // Workgroup barrier that orders LDS traffic ONLY (see above).  The stores of S are never read back inside the kernel.
@@ -186,22 +293,18 @@ __device__ __forceinline__ void pw_barrier() {
 }
 
 __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(const float* __restrict__ E, int P,
-                                                                              float* __restrict__ S, int total_items, int dbg) {
+                                                                              float* __restrict__ S, int max_run, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave == kPwCompute;
     const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
-    // this workgroup's run of (panel, block) items in panel-major order
-    const long long lo_it = (long long)total_items * blockIdx.x / gridDim.x, hi_it = (long long)total_items * (blockIdx.x + 1) / gridDim.x;
-    if (lo_it >= hi_it) return;
+    // this workgroup's run of column blocks INSIDE ONE PANEL (pw_run_of: no run straddles two panels)
+    int panel, blk, run_len;
+    pw_run_of(blockIdx.x, max_run, nblk32, npanel, panel, blk, run_len);
+    const long long lo_it = 0, hi_it = run_len;
+    if (run_len <= 0) return;
     PW_T(0);
-    int panel = 0, blk;
-    {
-        long long rest = lo_it;
-        while (panel < npanel && rest >= pw_blocks_of(panel, nblk32)) { rest -= pw_blocks_of(panel, nblk32); ++panel; }
-        blk = panel * (kPwPanel / 32) + (int)rest;
-    }
     float* const scratch = reinterpret_cast<float*>(lds + 2 * kPwSlot) + (loader ? 0 : wave) * 32 * kPwTrPitch;
     const bool vec = (P & 3) == 0;
     const bool small = (unsigned long long)P * (unsigned long long)P < (1ull << 30);      // 32-bit element offsets
@@ -233,6 +336,10 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
     int p1 = panel, b1 = blk;
     advance(p1, b1);
     bool parked = false;
+    // (Measured and rejected in round 4, tools/pairwise_forms.py with ODW_PAIRWISE_ST: waves 4-6 -- the ones that share a
+    // SIMD's matrix pipe with waves 0-2 -- storing their PREVIOUS tile first and running the current tile's MFMAs afterwards,
+    // so that one wave of a SIMD owns the pipe while the other sits in its stores: 13.7 / 26.7 / 83-85 us -> 14.6 / 27.4-28.9 /
+    // 83 us at P = 2000 / 4000 / 8000.  The block period is set by how fast the chip takes the stores, not by the pipe.)
 
     for (long long it = lo_it; it < hi_it; ++it) {
         if (panel != have_panel) {
@@ -310,63 +417,194 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] += acc1[k];
                 PW_T(3 + 3 * (int)(it - lo_it));
-                const int col = c0 + l31;
-                const bool full = small && vec && r0 + 32 <= P && c0 + 32 <= P;      // wave-uniform: no per-element predicates
-                if (c0 == r0) {
-                    // diagonal tile: (r, c) and (c, r) were accumulated in different term orders -- the upper triangle
-                    // goes to both places so that S is exactly symmetric
+                pw_store_tile(acc, S, P, r0, c0, lane, half, l31, scratch, small, vec, dbg);
+            }
+        }
+        PW_T(4 + 3 * (int)(it - lo_it));
+        slot ^= 1;
+        blk = b1; panel = p1;
+        advance(p1, b1);
+    }
+    PW_T(31);
+}
+
+// ------------------------------------------------------------------ pairwise, planes + LDS-DMA form (round 4)
+// The panel kernel above spends its edges and part of its steady state on the fp32 -> 3-plane split: every workgroup
+// splits its 224 panel rows (two barrier-separated rounds through LDS, ~4.6 us before its first MFMA) and its loader
+// wave splits every 32-row column block again (1.5 us per block, ~9 workgroups splitting the same block) -- the
+// timeline of round 3 (profiles/r03/pairwise_timeline_4000.txt).  Here the planes exist ONCE, in HBM/L2 -- written by
+// pw_split_planes_kernel (P x 128 values: ~1 us) or handed in by the caller (odw_pairwise_sim_planes: the producer of E
+// can emit them) -- as [3 planes][Ppad rows][128] bf16, rows >= P zero, and reach LDS by DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no VALU):
+//   * the loader wave's work per column block is 24 DMA instructions (3 planes x 32 rows x 256 B) instead of 16 loads +
+//     ~350 VALU + 24 LDS stores per lane;
+//   * the panel stage is DMA too: round 1 lands four 32-row pieces (and the first column block) while nothing else runs,
+//     round 2 the other three -- no split, no ds_write pass;
+//   * rows are unpadded 256-byte lines in LDS; the 16-byte chunk c of row r sits at position c ^ (r & 15), applied to the
+//     DMA's SOURCE address (the LDS image of a DMA instruction is lane-linear), so that the 16 lanes ds_read_b128 serves
+//     together (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) hit 16 distinct 4-bank groups.
+// Everything after the fragments -- the six plane products, the direct and the mirrored tile, the diagonal rule -- is
+// the panel kernel's, so the numbers are bit-identical to it.
+// MEASURED (tools/pairwise_forms.py, tools/exp/pairwise_timeline.bin <P> dma; profiles/r04/pairwise_forms.txt): NOT faster.
+// The block period is the same 2.9-3.0 us (it is the compute waves' own chain -- 1.43 us of MFMAs on a pipe two waves share,
+// 0.95 us issuing the tile's stores into a store-bound chip, 0.5 us at the barrier -- and never was the loader), the loader's 24
+// DMA instructions take 1.6 us to land (~15 GB/s for one wave), and the DMA panel stage takes 6.6 us against 4.6 (192 KB per
+// workgroup at the ~30-60 GB/s per CU LDS-DMA sustains).  With the split kernel and its launch boundary in front
+// (odw_pairwise_sim_ws) it is 5-7 us slower than the one-launch form at every size; on caller-provided planes it ties at
+// P <= 6000 and is within box-to-box noise at P = 8000.  It stays as an explicit entry point (odw_pairwise_sim_planes) for a
+// caller that already has the planes; odw_pairwise_sim_ws keeps the one-launch panel kernel (ODW_PAIRWISE_PLANES_MIN=0 forces
+// this form for comparison).
+constexpr int kPwPlanesMinP = 1 << 30;              // rows from which odw_pairwise_sim_ws takes the planes + DMA form: never by default (see below)
+constexpr int kPdSlot = 3 * 32 * 256;                // one 32-row block: 3 planes x 32 rows x 256 B (no padding)
+constexpr int kPdAreas = 3;                          // panel staging areas besides column-block slot 1
+constexpr int kPdLds = 2 * kPdSlot + kPdAreas * kPdSlot;           // 49152 + 73728 (the transpose scratch overlaps area 0/1)
+static_assert(kPwScratch <= 2 * kPdSlot, "the compute waves' transpose scratch must fit in the first two staging areas");
+
+__device__ __forceinline__ int pd_pad(int P) { return (P + 31) / 32 * 32; }
+
+// E (P x 128 fp32) -> planes [3][Ppad][128] bf16 (rows P .. Ppad-1 zero)
+__global__ __launch_bounds__(256) void pw_split_planes_kernel(const float* __restrict__ E, int P, int Ppad,
+                                                              unsigned char* __restrict__ planes) {
+    const size_t plane_bytes = (size_t)Ppad * 256;
+    const int items = Ppad * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < items; i += gridDim.x * blockDim.x) {
+        const int row = i >> 4, chunk = i & 15;
+        uint4 h = make_uint4(0, 0, 0, 0), m = h, l = h;
+        if (row < P) {
+            const float4* src = reinterpret_cast<const float4*>(E + (size_t)row * kD + chunk * 8);
+            ps_split8(src[0], src[1], h, m, l);
+        }
+        unsigned char* dst = planes + (size_t)row * 256 + chunk * 16;
+        *reinterpret_cast<uint4*>(dst) = h;
+        *reinterpret_cast<uint4*>(dst + plane_bytes) = m;
+        *reinterpret_cast<uint4*>(dst + 2 * plane_bytes) = l;
+    }
+}
+
+typedef __attribute__((address_space(3))) void pd_lds_t;
+typedef __attribute__((address_space(1))) const void pd_gbl_t;
+
+// DMA instruction `inst` (0..23) of the 32-row piece starting at plane row `row0` (a multiple of 32, clamped as a whole to
+// the last piece: its rows are then other rows' values, which is fine -- products of rows past P are never stored): plane
+// inst / 8, rows 4 (inst % 8) .. +3.  Lane (lr = lane >> 4, c' = lane & 15) fills LDS position c' of row r = 4 (inst % 8) + lr
+// with logical chunk c' ^ (r & 15) = c' ^ lr ^ 4 (inst & 3): the per-lane part of the source address takes four values
+// (voff[inst & 3]), everything else is wave-uniform.
+__device__ __forceinline__ void pd_dma(const unsigned char* __restrict__ planes, size_t plane_bytes, int row0, int last_piece,
+                                       unsigned char* area, int inst, const unsigned (&voff)[4]) {
+    const int plane = inst >> 3, sub = inst & 7;
+    const int r0 = row0 < last_piece ? row0 : last_piece;
+    const unsigned char* base = planes + plane * plane_bytes + (size_t)(r0 + 4 * sub) * 256;
+    __builtin_amdgcn_global_load_lds((pd_gbl_t*)(base + voff[inst & 3]), (pd_lds_t*)(area + plane * (32 * 256) + sub * 1024), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_dma_kernel(const unsigned char* __restrict__ planes, int P,
+                                                                            float* __restrict__ S, int max_run) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave == kPwCompute;
+    const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
+    const int Ppad = nblk32 * 32;
+    const size_t plane_bytes = (size_t)Ppad * 256;
+    // this workgroup's run of column blocks INSIDE ONE PANEL (pw_run_of: no run straddles two panels)
+    int panel, blk, run_len;
+    pw_run_of(blockIdx.x, max_run, nblk32, npanel, panel, blk, run_len);
+    const long long lo_it = 0, hi_it = run_len;
+    if (run_len <= 0) return;
+    PW_T(0);
+    unsigned char* const slot0 = lds;
+    unsigned char* const slot1 = lds + kPdSlot;
+    unsigned char* const areas = lds + 2 * kPdSlot;
+    float* const scratch = reinterpret_cast<float*>(areas) + (loader ? 0 : wave) * 32 * kPwTrPitch;
+    const bool vec = (P & 3) == 0;
+    const bool small = (unsigned long long)P * (unsigned long long)P < (1ull << 30);
+    // fragment position of this lane inside a piece: row l31, logical chunk 2 kk + half at position (2 kk + half) ^ (l31 & 15)
+    const int frag_row = l31 * 256, frag_x = l31 & 15;
+    unsigned voff[4];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const int r = crow(k, half);
-                        if (r <= l31 && col < P) {
-                            S[(size_t)(r0 + r) * P + col] = acc[k];
-                            S[(size_t)col * P + r0 + r] = acc[k];
-                        }
-                    }
-                } else {
-                    // mirror S[c0 + n][r0 + m]: the lane holds row n = l31 as 4 runs of 4 consecutive m -- parked in the
-                    // wave's scratch as rows of 32 floats, read back 8 lanes per row, stored as full 128-byte lines
-                    // (the wave's own LDS traffic is ordered: no barrier)
+    for (int q = 0; q < 4; ++q) voff[q] = (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ (lane >> 4) ^ (4 * q)) * 16));
+    const int last_piece = Ppad - 32;
+    auto advance = [&](int& pn, int& b) { if (++b >= nblk32) { ++pn; b = pn * (kPwPanel / 32); } };
+    // staging area j of the panel stage: 0 .. kPdAreas-1 behind the slots, kPdAreas = column-block slot 1
+    auto area_of = [&](int j) { return j < kPdAreas ? areas + j * kPdSlot : slot1; };
+    constexpr int kRound = kPdAreas + 1;                 // pieces per round of the panel stage
+
+    bf16x8 aH[8], aM[8], aL[8];
+    int have_panel = -1, slot = 0;
+    int p1 = panel, b1 = blk;
+    advance(p1, b1);
+    bool parked = false;
+
+    for (long long it = lo_it; it < hi_it; ++it) {
+        if (panel != have_panel) {
+            if (parked) pw_barrier();                    // every wave is done reading the slots and its scratch
+            // ---- panel stage: this workgroup's 224 rows as seven 32-row pieces, kRound per round, DMA'd by all eight
+            // waves; the first column block goes to slot 0 with round 1.  (No stores are in flight in a wave that gets
+            // here for the first time; a wave that changes panels waits for its tile stores once per panel.)
+#pragma unroll 1
+            for (int hp = 0; hp < (kPwCompute + kRound - 1) / kRound; ++hp) {
+                const int npieces = min(kRound, kPwCompute - hp * kRound);
+                const int njobs = (npieces + (hp == 0 ? 1 : 0)) * 24;
+                for (int j = wave; j < njobs; j += kPwWaves) {
+                    const int pc = j / 24, inst = j - pc * 24;
+                    if (pc < npieces) pd_dma(planes, plane_bytes, panel * kPwPanel + (hp * kRound + pc) * 32, last_piece, area_of(pc), inst, voff);
+                    else pd_dma(planes, plane_bytes, blk * 32, last_piece, slot0, inst, voff);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pw_barrier();
+                if (!loader && wave / kRound == hp) {
+                    const unsigned char* sa = area_of(wave % kRound) + frag_row;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4*>(scratch + l31 * kPwTrPitch + 8 * q + 4 * half) =
-                            make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-                    if (full) {
-                        // interior tile: 32-bit element offsets from the kernel-argument base, no predicates
-                        const unsigned dbase = (unsigned)(r0 + 4 * half) * (unsigned)P + (unsigned)col;
-                        if (!PW_DBG(1))
-#pragma unroll
-                        for (int k = 0; k < 16; ++k)      // direct tile: one 128-byte row segment per half-wave
-                            S[dbase + (unsigned)((k & 3) + 8 * (k >> 2)) * (unsigned)P] = acc[k];
-                        const unsigned mbase = (unsigned)(c0 + (lane >> 3)) * (unsigned)P + (unsigned)(r0 + (lane & 7) * 4);
-                        if (!PW_DBG(2))
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            *reinterpret_cast<float4*>(S + (mbase + (unsigned)(8 * t) * (unsigned)P)) =
-                                *reinterpret_cast<const float4*>(scratch + (t * 8 + (lane >> 3)) * kPwTrPitch + (lane & 7) * 4);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const int r = r0 + crow(k, half);
-                            if (r < P && col < P) S[(size_t)r * P + col] = acc[k];
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int n = t * 8 + (lane >> 3), m4 = (lane & 7) * 4;
-                            const float4 v = *reinterpret_cast<const float4*>(scratch + n * kPwTrPitch + m4);
-                            const int row = c0 + n, cc = r0 + m4;
-                            if (row < P) {
-                                float* dst = S + (size_t)row * P + cc;
-                                if (vec && cc + 3 < P) *reinterpret_cast<float4*>(dst) = v;
-                                else {
-                                    const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                                    for (int u = 0; u < 4; ++u) if (cc + u < P) dst[u] = e[u];
-                                }
-                            }
-                        }
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int pos = ((2 * kk + half) ^ frag_x) * 16;
+                        aH[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + pos));
+                        aM[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + 32 * 256 + pos));
+                        aL[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + 64 * 256 + pos));
                     }
                 }
+                pw_barrier();
+            }
+            slot = 0;
+            have_panel = panel;
+            parked = true;
+            PW_T(1);
+        } else {
+            pw_barrier();                                // block `blk` has landed in `slot`; the other slot is free
+        }
+        PW_T(2 + 3 * (int)(it - lo_it));
+        unsigned char* const cur = slot ? slot1 : slot0;
+        unsigned char* const nxt = slot ? slot0 : slot1;
+        if (loader) {
+            // ---- the loader wave: the next block's 24 KB by DMA into the other slot (unconditional: past the end of the
+            // run the slot receives rows nobody reads); it waits for them to land before the barrier that publishes them
+            const int nb = min(b1, nblk32 - 1) * 32;
+#pragma unroll 4
+            for (int inst = 0; inst < 24; ++inst) pd_dma(planes, plane_bytes, nb, last_piece, nxt, inst, voff);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PW_T(3 + 3 * (int)(it - lo_it));
+        } else {
+            const int r0 = panel * kPwPanel + wave * 32, c0 = blk * 32;
+            if (c0 >= r0 && r0 < P) {                    // this wave's tile lies on or above the diagonal
+                const unsigned char* sb = cur + frag_row;
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int pos = ((2 * kk + half) ^ frag_x) * 16;
+                    const bf16x8 bH = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + pos));
+                    const bf16x8 bM = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + 32 * 256 + pos));
+                    const bf16x8 bL = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + 64 * 256 + pos));
+                    // (the same term order as the panel kernel: bit-identical results)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aL[kk], bH, acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM[kk], bH, acc1, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH[kk], bL, acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH[kk], bM, acc1, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aM[kk], bM, acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aH[kk], bH, acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] += acc1[k];
+                PW_T(3 + 3 * (int)(it - lo_it));
+                pw_store_tile(acc, S, P, r0, c0, lane, half, l31, scratch, small, vec);
             }
         }
         PW_T(4 + 3 * (int)(it - lo_it));
@@ -570,7 +808,42 @@ int supcon_nsplit(int N) {
 }  // namespace
 
 ODW_EXPORT int64_t odw_pairwise_sim_workspace(int P, int D) {
-    return D == kD && P > 0 ? odw_align_up((int64_t)P * 384 * 2, 256) : 0;
+    // the three bf16 planes of E, rows padded to a multiple of 32 (zero rows): [3][Ppad][128]
+    return D == kD && P > 0 ? odw_align_up((int64_t)((P + 31) / 32 * 32) * 384 * 2, 256) : 0;
+}
+
+
+// E (P x 128 fp32, 16-byte aligned) -> the plane form odw_pairwise_sim_planes reads: [3 planes][Ppad][128] bf16
+// (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): hi + mid + lo == x exactly), Ppad = P rounded up to 32, the
+// padding rows zero.  `planes` holds odw_pairwise_sim_workspace(P, 128) bytes.
+ODW_EXPORT int odw_pairwise_split_planes(const float* E, int P, void* planes, void* stream_) {
+    ODW_REQUIRE(P >= 0, "pairwise_split_planes: bad P=%d", P);
+    if (P == 0) return ODW_OK;
+    ODW_REQUIRE(E && planes, "pairwise_split_planes: null pointer");
+    ODW_REQUIRE((((uintptr_t)E) & 15) == 0 && (((uintptr_t)planes) & 15) == 0, "pairwise_split_planes: buffers must be 16-byte aligned");
+    const int Ppad = (P + 31) / 32 * 32;
+    const int blocks = (Ppad * 16 + 255) / 256;
+    pw_split_planes_kernel<<<blocks < 2048 ? blocks : 2048, 256, 0, (hipStream_t)stream_>>>(E, P, Ppad, (unsigned char*)planes);
+    ODW_CHECK_LAUNCH("pw_split_planes_kernel");
+    return ODW_OK;
+}
+
+// S = E E^T (P x P fp32, fp32-grade: six bf16 plane products of order <= 2 per element) from the PLANES of E -- the form for
+// a caller whose producer of E emits them (the split then costs no launch and no pass over E).  Reference:
+// roi_heads/weak_head/loss.py:319 (sim_mat = torch.mm(sim_feature, sim_feature.T)).  S must be 16-byte aligned.
+ODW_EXPORT int odw_pairwise_sim_planes(const void* planes, int P, float* S, void* stream_) {
+    ODW_REQUIRE(P >= 0, "pairwise_sim_planes: bad P=%d", P);
+    if (P == 0) return ODW_OK;
+    ODW_REQUIRE(planes && S, "pairwise_sim_planes: null pointer");
+    ODW_REQUIRE((((uintptr_t)planes) & 15) == 0 && (((uintptr_t)S) & 15) == 0, "pairwise_sim_planes: buffers must be 16-byte aligned");
+    const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
+    const int max_run = pw_max_run(nblk32, npanel, ODW_NUM_CU), grid = pw_groups(max_run, nblk32, npanel);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_sim_dma_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPdLds);      // once
+    ODW_CHECK_HIP(attr, "pairwise dma attr");
+    pairwise_sim_dma_kernel<<<grid, kPwWaves * 64, kPdLds, (hipStream_t)stream_>>>((const unsigned char*)planes, P, S, max_run);
+    ODW_CHECK_LAUNCH("pairwise_sim_dma_kernel");
+    return ODW_OK;
 }
 
 ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void* workspace, int64_t workspace_bytes,
@@ -581,22 +854,31 @@ ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void*
     ODW_REQUIRE(E && S, "pairwise_sim: null pointer");
     ODW_REQUIRE((((uintptr_t)E) & 15) == 0, "pairwise_sim: E must be 16-byte aligned");
     static const bool fp32_chain = getenv("ODW_PAIRWISE_FP32") != nullptr;      // force the exact-fp32 MFMA form (comparison)
+    // planes + DMA form from this many rows on, when the caller gave the workspace for the planes (ODW_PAIRWISE_PLANES_MIN:
+    // comparison runs; a huge value = always the one-launch panel kernel)
+    static const int planes_min = getenv("ODW_PAIRWISE_PLANES_MIN") ? atoi(getenv("ODW_PAIRWISE_PLANES_MIN")) : kPwPlanesMinP;
+    if (D == kD && !fp32_chain && (((uintptr_t)S) & 15) == 0 && P >= planes_min && workspace &&
+        (((uintptr_t)workspace) & 15) == 0 && workspace_bytes >= odw_pairwise_sim_workspace(P, D)) {
+        const int rc = odw_pairwise_split_planes(E, P, workspace, stream_);
+        if (rc != ODW_OK) return rc;
+        return odw_pairwise_sim_planes(workspace, P, S, stream_);
+    }
     if (D == kD && !fp32_chain && (((uintptr_t)S) & 15) == 0) {
         // split-bf16 panel form: one launch, no workspace (the planes are made in registers)
-        (void)workspace; (void)workspace_bytes;
         const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
-        long long items = 0;
-        for (int pnl = 0; pnl < npanel; ++pnl) items += pw_blocks_of(pnl, nblk32);
-        const int grid = (int)(items < ODW_NUM_CU ? items : ODW_NUM_CU);
+        const int max_run = pw_max_run(nblk32, npanel, ODW_NUM_CU), grid = pw_groups(max_run, nblk32, npanel);
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_sim_panel_kernel),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kPwLds);      // once
         ODW_CHECK_HIP(attr, "pairwise attr");
 #ifdef ODW_EXPERIMENTS
         static const int dbg = getenv("ODW_PAIRWISE_DBG") ? atoi(getenv("ODW_PAIRWISE_DBG")) : 0;
 #else
-        const int dbg = 0;
+        // interior tiles leave as NONTEMPORAL stores (bit 8; ODW_PAIRWISE_ST=0: plain, 16: sc1 write-through): S is written once
+        // and not read back by this kernel -- 27.5 -> 24.5 us at P = 4000, 13.7 -> 12.9 at P = 2000 on the same box
+        // (tools/pairwise_forms.py, alternating runs)
+        static const int dbg = getenv("ODW_PAIRWISE_ST") ? (atoi(getenv("ODW_PAIRWISE_ST")) & 24) : 8;
 #endif
-        pairwise_sim_panel_kernel<<<grid, kPwWaves * 64, kPwLds, stream>>>(E, P, S, (int)items, dbg);
+        pairwise_sim_panel_kernel<<<grid, kPwWaves * 64, kPwLds, stream>>>(E, P, S, max_run, dbg);
         ODW_CHECK_LAUNCH("pairwise_sim_panel_kernel");
     } else if (D == kD) {
         const int nb = (P + 63) / 64;

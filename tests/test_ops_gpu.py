@@ -193,6 +193,32 @@ def test_pairwise_sim_at_the_benchmarked_sizes(C, P):
     assert np.abs(np.diag(S) - 1.0).max() <= 1e-6
 
 
+@pytest.mark.parametrize("P", [1, 31, 33, 224, 225, 1000, 2000, 4001])
+def test_pairwise_planes_form_is_bit_identical_to_the_one_launch_form(P):
+    """odw_pairwise_sim_ws with a workspace (split kernel + planes by LDS-DMA) and the caller-planes entry against the
+    one-launch panel kernel: the same six plane products in the same order -> the same bits; the planes themselves are
+    the exact decomposition hi + mid + lo == x with zero padding rows."""
+    from od_wscl_amd import _lib as L
+    lib = L.lib()
+    E = rng.normal(63, P, P * 128).reshape(P, 128)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    Et = dev(E)
+    S0, S1, S2 = (torch.full((P, P), float("nan"), device="cuda") for _ in range(3))
+    L.check(lib.odw_pairwise_sim(L.ptr(Et), P, 128, L.ptr(S0), L.stream()), "panel")
+    wsb = lib.odw_pairwise_sim_workspace(P, 128)
+    ws = torch.full((wsb,), 0xFF, dtype=torch.uint8, device="cuda")
+    L.check(lib.odw_pairwise_sim_ws(L.ptr(Et), P, 128, L.ptr(S1), L.ptr(ws), wsb, L.stream()), "ws")
+    assert torch.equal(S0, S1) and not torch.isnan(S1).any()
+    ws2 = torch.full((wsb,), 0xFF, dtype=torch.uint8, device="cuda")
+    L.check(lib.odw_pairwise_split_planes(L.ptr(Et), P, L.ptr(ws2), L.stream()), "split")
+    L.check(lib.odw_pairwise_sim_planes(L.ptr(ws2), P, L.ptr(S2), L.stream()), "planes")
+    assert torch.equal(S0, S2)
+    ppad = (P + 31) // 32 * 32
+    pl = ws2[:3 * ppad * 256].view(torch.bfloat16).view(3, ppad, 128).float().cpu().numpy()
+    np.testing.assert_array_equal(pl[0, :P] + pl[1, :P] + pl[2, :P], E)           # exact (each partial sum is representable)
+    assert not pl[:, P:].any()
+
+
 @pytest.mark.parametrize("name", ["a", "b", "c", "d"])
 def test_supcon_golden(C, ops_golden, name):
     g = ops_golden

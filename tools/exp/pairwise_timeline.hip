@@ -14,15 +14,21 @@ int main(int argc, char** argv) {
     std::vector<float> h((size_t)P * 128);
     unsigned s = 12345;
     for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+    const bool dma = argc > 2 && argv[2][0] == 'd';        // "dma": the planes + LDS-DMA kernel (planes split beforehand)
     float *E, *S;
-    hipMalloc(&E, h.size() * 4); hipMalloc(&S, (size_t)P * P * 4);
+    void* ws;
+    const long long wsb = odw_pairwise_sim_workspace(P, 128);
+    hipMalloc(&E, h.size() * 4); hipMalloc(&S, (size_t)P * P * 4); hipMalloc(&ws, wsb);
     hipMemcpy(E, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    for (int r = 0; r < 10; ++r) if (odw_pairwise_sim(E, P, 128, S, nullptr) != 0) { printf("launch failed: %s\n", odw_last_error()); return 1; }
+    odw_pairwise_split_planes(E, P, ws, nullptr);
+    auto launch = [&]() { return dma ? odw_pairwise_sim_planes(ws, P, S, nullptr) : odw_pairwise_sim(E, P, 128, S, nullptr); };
+    for (int r = 0; r < 10; ++r) if (launch() != 0) { printf("launch failed: %s\n", odw_last_error()); return 1; }
     hipDeviceSynchronize();
     std::vector<long long> tl(1024 * 8 * 32, 0);
     hipMemcpyToSymbol(HIP_SYMBOL(g_pw_tl), tl.data(), tl.size() * 8);
-    odw_pairwise_sim(E, P, 128, S, nullptr);
+    launch();
     hipDeviceSynchronize();
+    printf("%s kernel\n", dma ? "planes + DMA" : "panel");
     hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_pw_tl), tl.size() * 8);
     long long t0 = 0;
     for (int w = 0; w < 256 * 8; ++w) if (tl[w * 32] && (!t0 || tl[w * 32] < t0)) t0 = tl[w * 32];
