@@ -185,6 +185,11 @@ int odw_supcon_v2(const float* F, const int32_t* labels, const float* w, int N, 
  *   noise_mul : out = x + N(0,1) * x */
 int odw_rng_uniform(float* out, int64_t n, uint32_t k0, uint32_t k1, uint32_t offset, void* stream);
 int odw_rng_normal(float* out, int64_t n, uint32_t k0, uint32_t k1, void* stream);
+/* DropBlock2D's keep mask (modeling/dropblock/drop_block.py:38-47, :55-71): block centres = (u < gamma) over ONE uniform
+ * draw of n*h*w values from stream (k0, k1) -- element i of odw_rng_uniform --, dilated by a block_size max-pool
+ * (padding block_size / 2, cropped to h x w), inverted; keep (n, h, w) fp32 in {0, 1}, *keep_sum = its sum (exact). */
+int odw_dropblock_keep_mask(int n, int h, int w, int block_size, float gamma, uint32_t k0, uint32_t k1, float* keep,
+                            float* keep_sum, void* stream);
 int odw_dropout(const float* x, float* out, int64_t n, uint32_t k0, uint32_t k1, float p, void* stream);
 int odw_noise_mul(const float* x, float* out, int64_t n, uint32_t k0, uint32_t k1, void* stream);
 

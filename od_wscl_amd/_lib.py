@@ -46,6 +46,7 @@ SIGNATURES = {
     "odw_supcon_v2": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_l, c_p]),
     "odw_rng_uniform": (c_i, [c_p, c_l, c_u, c_u, c_u, c_p]),
     "odw_rng_normal": (c_i, [c_p, c_l, c_u, c_u, c_p]),
+    "odw_dropblock_keep_mask": (c_i, [c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_p, c_p, c_p]),
     "odw_dropout": (c_i, [c_p, c_p, c_l, c_u, c_u, c_f, c_p]),
     "odw_noise_mul": (c_i, [c_p, c_p, c_l, c_u, c_u, c_p]),
     "odw_stack_clean_aug": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),

@@ -278,6 +278,12 @@ class _PoolStackPlanes(torch.autograd.Function):
         return _PoolStack.backward(ctx, dx)
 
 
+def _keep_sum(block):
+    """Sum of a DropBlock keep mask: the value its kernel already produced, else a reduction."""
+    total = getattr(block, "_odw_sum", None)
+    return total if total is not None else block.sum()
+
+
 class TwoFCROIFeatureExtractor(nn.Module):
     Linear = Linear
     fc_index = (1, 4)              # positions of the two Linear layers inside self.classifier
@@ -345,7 +351,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
                 raise RuntimeError("the gradient of the previous step's sampled-row views was parked for the stacked "
                                    "fc6 node, whose backward never ran")
             self._grad_holder = _GradHolder()
-            x = _StackCleanAug.apply(pooled, block.contiguous(), block.sum(), self._grad_holder)
+            x = _StackCleanAug.apply(pooled, block.contiguous(), _keep_sum(block), self._grad_holder)
             h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5])
             return h[:P], h[P:]
         aug = self.forward_dropblock(pooled) if hasattr(self, "dropblock") else pooled
@@ -426,12 +432,12 @@ class TwoFCROIFeatureExtractor(nn.Module):
         self._grad_holder = _GradHolder("extra")
         nhwc = getattr(feat, "_odw_nhwc", None) if os.environ.get("ODW_POOL_NHWC") != "0" else None
         if precision.split_mode():
-            x, planes, pooled32 = _PoolStackPlanes.apply(feat, feat._odw_nhwc_f32, rois5, block.contiguous(), block.sum(),
+            x, planes, pooled32 = _PoolStackPlanes.apply(feat, feat._odw_nhwc_f32, rois5, block.contiguous(), _keep_sum(block),
                                                          self._grad_holder, float(self.pooler.poolers[0].spatial_scale),
                                                          res[0], res[1])
             x._odw_planes, x._odw_pooled32 = planes, pooled32
         else:
-            x = _PoolStack.apply(feat, rois5, block.contiguous(), block.sum(), self._grad_holder,
+            x = _PoolStack.apply(feat, rois5, block.contiguous(), _keep_sum(block), self._grad_holder,
                                  float(self.pooler.poolers[0].spatial_scale), res[0], res[1], nhwc)
         # The clean half feeds only Sim_Net, and the contrastive loss touches a few hundred of its P rows: the stacked
         # evaluation takes part in backward with its DropBlock half only (grad_rows); the clean rows the loss ends

@@ -20,6 +20,17 @@ class DropBlock2D(nn.Module):
         """The (n, h, w) keep mask after dilation (drop_block.py:38-47, :55-71) -- one draw of n*h*w uniforms."""
         gamma = self.drop_prob / (self.block_size ** 2)
         shape = (n, h, w)
+        if rand is not None and hasattr(rand, "key") and torch.device(device).type == "cuda" and n * h * w < (1 << 24):
+            # the counter-based device stream: draw, threshold, dilation, inversion and the sum in ONE kernel
+            # (csrc/rng.hip dropblock_keep_kernel) -- the same draw, the same stream id as rand.uniform(shape)
+            from ... import _lib as L
+            k0, k1 = rand.key()
+            keep = torch.empty(shape, dtype=torch.float32, device=device)
+            total = torch.empty((), dtype=torch.float32, device=device)
+            L.check(L.lib().odw_dropblock_keep_mask(n, h, w, int(self.block_size), float(gamma), k0, k1, L.ptr(keep), L.ptr(total),
+                                                    L.stream()), "dropblock_keep_mask")
+            keep._odw_sum = total           # callers that need block.sum() take this instead of a reduction launch
+            return keep
         u = rand.uniform(shape) if rand is not None else torch.rand(shape, device=device)
         centres = (u < gamma).float()
         block = F.max_pool2d(centres[:, None], kernel_size=self.block_size, stride=1, padding=self.block_size // 2)
@@ -33,4 +44,5 @@ class DropBlock2D(nn.Module):
             return x
         block = self.keep_mask(x.shape[0], x.shape[2], x.shape[3], x.device, rand)
         # (x * block) * numel / sum, evaluated in the reference's order (:49-50)
-        return x * block[:, None, :, :] * block.numel() / block.sum()
+        total = getattr(block, "_odw_sum", None)
+        return x * block[:, None, :, :] * block.numel() / (total if total is not None else block.sum())

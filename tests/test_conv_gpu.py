@@ -217,8 +217,10 @@ def test_vgg16_backbone_forward_backward(lib):
     feat, g = feat.detach().cpu(), g.cpu()
     bb = bb.cpu()
     h = x.bfloat16().float().cpu()
+    from od_wscl_amd.layers.misc import library_reference
     for m in bb.body.features:
-        h = m(h)
+        with library_reference():                  # torch's fp32 convolution on the CPU: the reference, not the product
+            h = m(h)
         if isinstance(m, (torch.nn.ReLU, torch.nn.MaxPool2d)) or m is bb.body.features[-1]:
             h = RoundBF16.apply(h)
     ref = h

@@ -255,3 +255,31 @@ def test_pool_stack_nhwc_equals_plane_form():
         assert torch.equal(outs[0][1], outs[1][1])
         assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
         assert (outs[1][1][0] == -1).all() and (outs[1][0][0] == 0).all()
+
+
+@pytest.mark.parametrize("n,h,w,bs,p", [(2000, 7, 7, 3, 0.3), (333, 7, 7, 1, 0.3), (64, 7, 7, 2, 0.5), (50, 6, 9, 5, 0.4), (1, 7, 7, 3, 0.3), (0, 7, 7, 3, 0.3)])
+def test_dropblock_keep_mask_kernel_equals_the_reference_formula(n, h, w, bs, p):
+    """odw_dropblock_keep_mask (one launch) against drop_block.py:38-47 evaluated with torch on the SAME uniform draw
+    (the counter-based stream, od_wscl_amd/utils/rng.py on the host): centres, max-pool dilation with padding bs // 2 and
+    the even-size crop, inversion, and the sum -- bit for bit."""
+    import torch.nn.functional as F
+    from od_wscl_amd.modeling.dropblock import DropBlock2D
+    from od_wscl_amd.utils import rng
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    db = DropBlock2D(drop_prob=p, block_size=bs)
+    r = DeviceRand(77, first_stream=9, device="cuda")
+    keep = db.keep_mask(n, h, w, torch.device("cuda"), r)
+    assert r.s.next == 10                                                   # one logical draw, like rand.uniform(shape)
+    u = torch.from_numpy(rng.uniform(77, 9, n * h * w).reshape(n, h, w)) if n else torch.zeros((0, h, w))
+    centres = (u < p / (bs ** 2)).float()
+    block = F.max_pool2d(centres[:, None], kernel_size=bs, stride=1, padding=bs // 2) if n else centres[:, None]
+    if bs % 2 == 0 and n:
+        block = block[:, :, :-1, :-1]
+    want = 1 - block.squeeze(1)
+    assert keep.shape == (n, h, w) and torch.equal(keep.cpu(), want)
+    assert float(keep._odw_sum) == float(want.sum())
+    if n:
+        x = torch.randn(n, 4, h, w, device="cuda")
+        got = db.train()(x, rand=DeviceRand(77, first_stream=9, device="cuda"))
+        ref = x.cpu() * want[:, None] * want.numel() / want.sum()
+        assert torch.allclose(got.cpu(), ref, rtol=1e-6, atol=0)

@@ -192,3 +192,20 @@ def test_inject_grad_routes_the_early_gradient_through_every_backward_entry():
             ls.backward()
         assert torch.equal(body.grad, dx) and torch.allclose(e.grad, 2 * e.detach())
         assert float(ls) == float(loss_sim)
+
+
+def test_conv2d_has_no_library_forward_outside_the_reference_context():
+    """layers.Conv2d owns parameters; the bodies' convolutions run in GeneralizedRCNN.hip_body().  A direct call must not
+    reach torch's convolution (MIOpen on the GPU) silently: it raises, unless a test opts in for a reference."""
+    import pytest
+    from od_wscl_amd.layers import Conv2d
+    from od_wscl_amd.layers.misc import library_reference
+    conv = Conv2d(3, 4, kernel_size=3, padding=1)
+    x = torch.randn(1, 3, 8, 8)
+    with pytest.raises(RuntimeError, match="no standalone forward"):
+        conv(x)
+    with library_reference():
+        y = conv(x)
+    assert y.shape == (1, 4, 8, 8)
+    with pytest.raises(RuntimeError):
+        conv(x)

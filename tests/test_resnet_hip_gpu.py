@@ -65,14 +65,16 @@ def test_resnet50_body_matches_torch_fp32():
     body = model.backbone.body
     g = torch.Generator(device="cuda").manual_seed(1)
     images = torch.randn(2, 3, 96, 128, device="cuda", generator=g) * 40
-    ref = body(images)[0]
+    from od_wscl_amd.layers.misc import library_reference
+    with library_reference():                      # torch's own convolutions: the reference, not the product
+        ref = body(images)[0]
     dfeat = torch.randn(ref.shape, device="cuda", generator=g) * (1.0 / ref.shape[1])
     ref.backward(dfeat)
     want = {n: p.grad.clone() for n, p in body.named_parameters() if p.grad is not None}
     for p in body.parameters():
         p.grad = None
     # calibration: the same body under torch's bf16 autocast (MIOpen), against the fp32 gradients
-    with torch.autocast("cuda", dtype=torch.bfloat16):
+    with torch.autocast("cuda", dtype=torch.bfloat16), library_reference():
         amp = body(images)[0].float()
     amp.backward(dfeat)
     amp_cos = {n: _cos(p.grad, want[n]) for n, p in body.named_parameters() if p.grad is not None}
@@ -125,8 +127,10 @@ def test_resnet101_body_forward_matches_torch_fp32():
             else:
                 b.copy_(torch.randn(b.shape, device="cuda", generator=g) * 0.05)
     images = torch.randn(1, 3, 128, 160, device="cuda", generator=g) * 40
+    from od_wscl_amd.layers.misc import library_reference
     with torch.no_grad():
-        ref = body(images)[0]
+        with library_reference():
+            ref = body(images)[0]
         got = ResNetBackboneHip(body)(images)[0]
     assert got.shape == ref.shape == (1, 2048, 8, 10)
     assert _cos(got, ref) > 0.999, _cos(got, ref)

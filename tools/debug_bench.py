@@ -13,7 +13,7 @@ def sync(tag):
     torch.cuda.synchronize(); print("ok", tag, flush=True)
 rand = DeviceRand(1234)
 model.roi_heads.set_rand(rand)
-feats = model.backbone(images.tensors); sync("backbone fwd %s" % (tuple(feats[0].shape),))
+feats = model.hip_body()(images.tensors); sync("backbone fwd %s" % (tuple(feats[0].shape),))
 fe = model.roi_heads.feature_extractor
 cf, cp = fe.forward(feats, rois); sync("fe fwd")
 sim = model.roi_heads.model_sim(cf); sync("sim")

@@ -36,5 +36,5 @@ for k in sorted(g.files):
 sd = {k: torch.from_numpy(v) for k, v in w.items()}
 tr = {}
 H.forward(batch, boxes, labels, sd, H.Rand(seed), cfg, tr)
-feat = model.backbone(batch.cuda())[0]
+feat = model.hip_body()(batch.cuda())[0]
 print("feat max abs diff", (feat.cpu()-tr["feat"]).abs().max().item(), "scale", tr["feat"].abs().max().item())

@@ -22,7 +22,7 @@ for it in range(8):
     torch.cuda.synchronize(); t = time.perf_counter()
     opt.begin_step(); t = tick("begin_step", t)
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        feats = [f.float() for f in model.backbone(images.tensors)]
+        feats = [f.float() for f in model.hip_body()(images.tensors)]
     t = tick("backbone_fwd", t)
     pooled = fe.forward_pooler(feats, rois); t = tick("roipool_fwd", t)
     cf, af = fe.forward_clean_and_aug(pooled); t = tick("fc6fc7_stacked_fwd", t)

@@ -66,7 +66,8 @@ def main():
 
     def step(it):
         rand = DeviceRand(cfg.SEED, first_stream=(1 << 20) + (it << 12), device=dev)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        from od_wscl_amd.layers.misc import library_reference
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp), library_reference():     # MIOpen convolutions: the comparison
             losses, _ = model(images, targets, rois, rand=rand)
         opt.zero_grad(set_to_none=True)
         sum(losses.values()).float().backward()
