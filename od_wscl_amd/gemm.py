@@ -135,6 +135,13 @@ class Shadow(object):
         return self
 
 
+# Set to a list by a caller that wants the input-gradient GEMM of ONE layer (`deferred_weight`: the layer whose input
+# gradient nothing in the backward it is about to run consumes) handed back as a closure instead of launched (see
+# _backward_single_plane.input_gradient); None = launch everything in place.
+deferred_dgrad = None
+deferred_weight = None
+
+
 class WgradBatch(object):
     """One weight-gradient GEMM per step for a Linear that is evaluated several times (fc6: the stacked pass, the
     sampled-row views, the re-evaluated clean rows).  dW = sum_e dZ_e^T X_e = [dZ_1; dZ_2; ...]^T [X_1; X_2; ...]:
@@ -303,9 +310,20 @@ def _backward_single_plane(xb, y, weight, bias, cfg, dy, need_dx):
                 dx_all[:ra].zero_()
                 dx_all[rb:].zero_()
             dx = dx_all[ra:rb]
-        kernel_timer.layer = tag and tag + "_dgrad"
-        gemm_nt(dz, sh.wt, M, K, N, dx)
-        kernel_timer.layer = None
+
+        def launch(dz=dz, dx=dx):
+            kernel_timer.layer = tag and tag + "_dgrad"
+            gemm_nt(dz, sh.wt, M, K, N, dx)
+            kernel_timer.layer = None
+        # A caller that runs this backward EARLY (weak_head/loss_fused.py) may ask for the large input-gradient GEMMs to be
+        # handed back instead of launched: their result is not read before the very end of the step's backward (the ROI
+        # pooling node), and the caller launches them right before it starts the LATE backward -- ~0.3 ms of matrix-core
+        # work under which the host issues the ~100 small launches of the contrastive loss's backward, instead of the GPU
+        # waiting for them one by one (profiles/r03/hip_v8_gaps.csv: 0.35 ms idle in that stretch).
+        if deferred_dgrad is not None and weight is deferred_weight:
+            deferred_dgrad.append(launch)
+        else:
+            launch()
         return dx_all
 
     # a weight whose gradient is exchanged as it retires (N > 1 ranks): its gradient first, so that the collective

@@ -181,14 +181,17 @@ class _InjectGrad(torch.autograd.Function):
     drop it (the dense losses are detached once their backward has run early)."""
 
     @staticmethod
-    def forward(ctx, loss_sim, x, dx):
+    def forward(ctx, loss_sim, x, dx, pending=None):
         ctx.save_for_backward(dx)
+        ctx.pending = pending
         return loss_sim.clone()
 
     @staticmethod
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
-        return g, dx, None
+        while ctx.pending:                      # products that fill `dx` and were handed back by the early backward
+            ctx.pending.pop(0)()                # (finish_backward launches them earlier; any other entry point gets them here)
+        return g, dx, None, None
 
 
 @registry.ROI_WEAK_LOSS.register("RoIRegLossFused")
@@ -422,14 +425,24 @@ class RoIRegLossFused(RoIRegLossComputation):
                 # when the optimiser does not lay them out as one matrix)
                 dsum = dense.sum()
                 leaves = _leaves_between(dsum.grad_fn, clean_pooled_feats.grad_fn)
-                grads = torch.autograd.grad(dsum, [clean_pooled_feats] + leaves, allow_unused=True)
+                # the one product of this stretch whose result nobody reads before the pooling node at the very end --
+                # fc6's input gradient, 0.3 ms -- is handed back and launched in finish_backward, right before the late
+                # backward starts: the host then issues the contrastive loss's ~100 small backward launches under it
+                from .... import gemm as _gemm
+                import os as _os2
+                _gemm.deferred_dgrad = [] if _os2.environ.get("ODW_NO_DEFER_DGRAD") != "1" else None
+                _gemm.deferred_weight = feature_extractor.fc6.weight       # the layer that reads the stacked operand
+                try:
+                    grads = torch.autograd.grad(dsum, [clean_pooled_feats] + leaves, allow_unused=True)
+                finally:
+                    deferred, _gemm.deferred_dgrad, _gemm.deferred_weight = _gemm.deferred_dgrad, None, None
                 for leaf, gl in zip(leaves, grads[1:]):
                     if gl is not None:
                         if leaf.grad is None:
                             leaf.grad = gl.detach().clone()
                         else:
                             leaf.grad.add_(gl)
-                early = (clean_pooled_feats, grads[0])
+                early = (clean_pooled_feats, grads[0], deferred or [])
                 dense = dense.detach()
         host_b = read_b.wait()
         fresh_h = host_b[:nf].reshape(n_img, 3, maxpos)
@@ -521,13 +534,15 @@ class RoIRegLossFused(RoIRegLossComputation):
             if tr is not None:
                 tr["dense_loss_kernel"] = True
             if early is not None:
-                loss_sim = _InjectGrad.apply(loss_sim, early[0], early[1])
+                loss_sim = _InjectGrad.apply(loss_sim, early[0], early[1], early[2])
             losses = LossDict({"loss_img": dense[0], "loss_sim": loss_sim})
             for k in range(1, 7):
                 losses[names[k]] = dense[k]
             losses.total = dense.sum() + loss_sim
             if early is not None:
-                def finish_backward(loss_sim=loss_sim):
+                def finish_backward(loss_sim=loss_sim, pending=early[2]):
+                    while pending:
+                        pending.pop(0)()            # the deferred input-gradient GEMM(s): queued first, cover the launches below
                     loss_sim.backward()
                 losses.finish_backward = finish_backward
             accs = {"acc_img": tot[7], "acc_ref0": tot[8], "acc_ref1": tot[9], "acc_ref2": tot[10]}
