@@ -43,6 +43,9 @@ int odw_version(void);
  * feat (B,C,H,W); out (R,C,PH,PW) fp32; argmax (R,C,PH,PW) int32 (h*W+w or -1).
  * workspace: odw_roi_pool_workspace(R,PH,PW) bytes (per-ROI bin tables). */
 int64_t odw_roi_pool_workspace(int R, int PH, int PW);
+/* Workspace of the faster (ROI, 64-channel) form of odw_roi_pool_forward (round 4: the bin table + an NHWC ordinal image of
+ * the map; C % 8 == 0, PH * PW <= 64).  With only odw_roi_pool_workspace bytes the plane-resident kernels run. */
+int64_t odw_roi_pool_forward_workspace(int B, int C, int H, int W, int R, int PH, int PW);
 int odw_roi_pool_forward(const float* feat, const float* rois, float spatial_scale,
                          int B, int C, int H, int W, int R, int PH, int PW,
                          float* out, int32_t* argmax, void* workspace, int64_t workspace_bytes,

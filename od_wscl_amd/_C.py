@@ -20,10 +20,10 @@ def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
     B, C, H, W = input.shape
     R = rois.shape[0]
     out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device)
-    argmax = torch.zeros((R, C, pooled_height, pooled_width), dtype=torch.int32, device=input.device)
+    argmax = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.int32, device=input.device)     # every entry is written
     if out.numel() == 0:
         return out, argmax
-    nbytes = L.lib().odw_roi_pool_workspace(R, pooled_height, pooled_width)
+    nbytes = L.lib().odw_roi_pool_forward_workspace(B, C, H, W, R, pooled_height, pooled_width)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
     L.check(L.lib().odw_roi_pool_forward(L.ptr(input), L.ptr(rois), float(spatial_scale), B, C, H, W, R,
                                          pooled_height, pooled_width, L.ptr(out), L.ptr(argmax),

@@ -26,6 +26,7 @@ SIGNATURES = {
     "odw_last_error": (ctypes.c_char_p, []),
     "odw_version": (c_i, []),
     "odw_roi_pool_workspace": (c_l, [c_i, c_i, c_i]),
+    "odw_roi_pool_forward_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "odw_roi_pool_forward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_p]),
     "odw_roi_pool_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_roi_pool_backward_det": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),

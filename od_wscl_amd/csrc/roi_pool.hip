@@ -707,6 +707,107 @@ __global__ __launch_bounds__(512) void roi_pool_stack_fwd_nhwc_f32(const unsigne
     }
 }
 
+// ---- the OPERATOR form on the same (ROI, 64-channel) decomposition (round 4) -------------------------------------
+// _C.roi_pool_forward (csrc/ROIPool.h:11-24: NCHW fp32 in, (R, C, PH, PW) fp32 + int32 argmax out) ran on the
+// plane-resident kernel: a workgroup owns 1-4 channel planes and every ROI's output for them -- 196-byte output segments
+// (one (ROI, channel) block of 7 x 7) and a per-cell LDS scan: 590 us at P = 2000 on 76 x 76 x 512, 0.09 of the HBM
+// roofline on its 413 MB.  For a fixed ROI the outputs of 64 consecutive channels are ONE contiguous 12.5 KB block of
+// both arrays, so the decomposition of the fused kernel above fits the operator's layout exactly: a pre-pass turns the
+// NCHW map into the NHWC ordinal image (one tiled transpose, 12 MB), a workgroup pools (ROI n, channels c0 .. c0 + 63)
+// with 16-byte channel-contiguous loads, and the block leaves as full lines.  Same scan order (row-major cells, strictly
+// greater wins) => the same values and first-maximum positions, bit for bit.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_ord_kernel(const float* __restrict__ in, int C, int HW,
+                                                               unsigned* __restrict__ out) {
+    __shared__ unsigned tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;             // 32 x 8
+    const float* src = in + (size_t)b * C * HW;
+    unsigned* dst = out + (size_t)b * HW * C;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int c = c0 + ty + j, p = p0 + tx;
+        unsigned u = 0;
+        if (c < C && p < HW) {
+            u = __float_as_uint(src[(size_t)c * HW + p]);
+            if (u == 0x80000000u) u = 0;                                   // -0.0 == +0.0 in the reference's `>`
+            const bool nan = (u & 0x7fffffffu) > 0x7f800000u;
+            u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+            u = nan ? 0u : u;
+        }
+        tile[ty + j][tx] = u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int p = p0 + ty + j, c = c0 + tx;
+        if (p < HW && c < C) dst[(size_t)p * C + c] = tile[tx][ty + j];
+    }
+}
+
+template <int FLY>
+__global__ __launch_bounds__(512) void roi_pool_fwd_nhwc_op(const unsigned* __restrict__ feat, const int* __restrict__ tab,
+                                                            int C, int H, int W, int PH, int PW, float* __restrict__ out,
+                                                            int* __restrict__ argmax) {
+    __shared__ __attribute__((aligned(16))) float s_val[64 * 64];
+    __shared__ __attribute__((aligned(16))) int s_arg[64 * 64];
+    __shared__ int s_tab[1 + 4 * 64];
+    const int n = blockIdx.x, c0 = blockIdx.y * 64;
+    const int nb = PH * PW, tl = 1 + 2 * PH + 2 * PW;
+    for (int i = threadIdx.x; i < tl; i += blockDim.x) s_tab[i] = tab[(size_t)n * tl + i];
+    __syncthreads();
+    const int bin = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    if (bin < nb && c0 + cg * 8 < C) {
+        const int ph = bin / PW, pw = bin - ph * PW;
+        const int b = s_tab[0], hs = s_tab[1 + ph], he = s_tab[1 + PH + ph], ws = s_tab[1 + 2 * PH + pw], we = s_tab[1 + 2 * PH + PW + pw];
+        unsigned bv[8];
+        int bp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bv[q] = kOrdLowest; bp[q] = -1; }
+        const unsigned* base = feat + ((size_t)b * H * W) * C + c0 + cg * 8;
+        const int nw = we - ws, ncell = (he > hs && nw > 0) ? (he - hs) * nw : 0;
+        int h = hs, w = ws;
+        for (int i = 0; i < ncell; i += FLY) {
+            int cell[FLY];
+#pragma unroll
+            for (int u = 0; u < FLY; ++u) {
+                cell[u] = h * W + w;
+                if (i + u + 1 < ncell) { if (++w == we) { w = ws; ++h; } }
+            }
+            uint4 va[FLY], vb[FLY];
+#pragma unroll
+            for (int u = 0; u < FLY; ++u) {
+                va[u] = *reinterpret_cast<const uint4*>(base + (size_t)cell[u] * C);
+                vb[u] = *reinterpret_cast<const uint4*>(base + (size_t)cell[u] * C + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < FLY; ++u) {
+                const unsigned d[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool up = d[q] > bv[q];
+                    bv[q] = up ? d[q] : bv[q];
+                    bp[q] = up ? cell[u] : bp[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned bits = (bv[q] & 0x80000000u) ? (bv[q] ^ 0x80000000u) : ~bv[q];
+            s_val[(cg * 8 + q) * nb + bin] = ncell ? __uint_as_float(bits) : 0.0f;        // empty bin: 0 (ROIPool_cuda.cu:60)
+            s_arg[(cg * 8 + q) * nb + bin] = bp[q];
+        }
+    }
+    __syncthreads();
+    // channels c0 .. c0 + 63 of ROI n: ONE contiguous block of both arrays (C % 8 == 0: a multiple of 8 values, 32-byte aligned)
+    const int nch = C - c0 < 64 ? C - c0 : 64;
+    const int count4 = nch * nb / 4;
+    const size_t off = ((size_t)n * C + c0) * nb;
+    for (int i = threadIdx.x; i < count4; i += blockDim.x) {
+        reinterpret_cast<float4*>(out + off)[i] = reinterpret_cast<const float4*>(s_val)[i];
+        reinterpret_cast<int4*>(argmax + off)[i] = reinterpret_cast<const int4*>(s_arg)[i];
+    }
+}
+
 template <typename K>
 hipError_t allow_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -717,6 +818,12 @@ hipError_t allow_lds(K kernel, size_t bytes) {
 
 ODW_EXPORT int64_t odw_roi_pool_workspace(int R, int PH, int PW) {
     return odw_align_up((int64_t)(R > 0 ? R : 1) * (1 + 2 * PH + 2 * PW) * 4, 256);
+}
+
+// Workspace of the (ROI, 64-channel) form of odw_roi_pool_forward: the bin table + the NHWC ordinal image of the map.
+// (odw_roi_pool_workspace(R, PH, PW) -- the table alone -- still works: the plane-resident kernels run then.)
+ODW_EXPORT int64_t odw_roi_pool_forward_workspace(int B, int C, int H, int W, int R, int PH, int PW) {
+    return odw_roi_pool_workspace(R, PH, PW) + odw_align_up((int64_t)(B > 0 ? B : 1) * C * H * W * 4, 256);
 }
 
 ODW_EXPORT int odw_roi_pool_forward(const float* feat, const float* rois, float spatial_scale, int B,
@@ -739,6 +846,17 @@ ODW_EXPORT int odw_roi_pool_forward(const float* feat, const float* rois, float 
     ODW_CHECK_LAUNCH("roi_bins_kernel");
 
     const int HW = H * W;
+    static const bool no_nhwc = getenv("ODW_ROI_POOL_PLANE") != nullptr;       // comparison runs: the plane-resident kernels
+    if (!no_nhwc && C % 8 == 0 && PH <= 64 && PW <= 64 && PH * PW <= 64 &&
+        workspace_bytes >= odw_roi_pool_forward_workspace(B, C, H, W, R, PH, PW) && (((uintptr_t)out) & 15) == 0 &&
+        (((uintptr_t)argmax) & 15) == 0 && (long long)B * HW * C < (1ll << 31)) {
+        unsigned* ord = (unsigned*)((char*)workspace + odw_roi_pool_workspace(R, PH, PW));
+        nchw_to_nhwc_ord_kernel<<<dim3((HW + 31) / 32, (C + 31) / 32, B), 256, 0, stream>>>(feat, C, HW, ord);
+        ODW_CHECK_LAUNCH("nchw_to_nhwc_ord_kernel");
+        roi_pool_fwd_nhwc_op<2><<<dim3(R, (C + 63) / 64), 512, 0, stream>>>(ord, tab, C, H, W, PH, PW, out, argmax);
+        ODW_CHECK_LAUNCH("roi_pool_fwd_nhwc_op");
+        return ODW_OK;
+    }
     const int cg = pick_cg(B, C, HW);
     if (cg == 0) {
         size_t total = (size_t)R * C * PH * PW;
