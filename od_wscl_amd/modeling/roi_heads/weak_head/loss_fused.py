@@ -11,6 +11,8 @@ quirks Q1-Q12 kept) as `loss.RoIRegLossComputation`, restructured for the GPU:
   * SupCon features / weights are assembled with one gather each from the concatenated embedding
     matrix; the refinement losses use masked, fixed-shape expressions (no nonzero()).
 """
+import os as _os2
+
 import numpy as np
 import torch
 from torch.nn import functional as F
@@ -429,8 +431,9 @@ class RoIRegLossFused(RoIRegLossComputation):
                 # fc6's input gradient, 0.3 ms -- is handed back and launched in finish_backward, right before the late
                 # backward starts: the host then issues the contrastive loss's ~100 small backward launches under it
                 from .... import gemm as _gemm
-                import os as _os2
-                _gemm.deferred_dgrad = [] if _os2.environ.get("ODW_NO_DEFER_DGRAD") != "1" else None
+                # (OFF by default: 9.08-10.5 / 9.16-9.63 / 9.22-9.39 ms for late / mid / off over four alternating runs each --
+                # no gain outside the run-to-run noise; ODW_DEFER_DGRAD=late|mid switches it on)
+                _gemm.deferred_dgrad = [] if _os2.environ.get("ODW_DEFER_DGRAD") in ("late", "mid") else None
                 _gemm.deferred_weight = feature_extractor.fc6.weight       # the layer that reads the stacked operand
                 try:
                     grads = torch.autograd.grad(dsum, [clean_pooled_feats] + leaves, allow_unused=True)
@@ -445,6 +448,11 @@ class RoIRegLossFused(RoIRegLossComputation):
                 early = (clean_pooled_feats, grads[0], deferred or [])
                 dense = dense.detach()
         host_b = read_b.wait()
+        if early is not None and early[2] and _os2.environ.get("ODW_DEFER_DGRAD") == "mid":
+            # the GPU has drained the early backward by now and the host is about to spend ~0.3 ms assembling index lists and
+            # issuing the contrastive loss's small forward launches: the handed-back input-gradient GEMM goes here
+            while early[2]:
+                early[2].pop(0)()
         fresh_h = host_b[:nf].reshape(n_img, 3, maxpos)
         gt_h = host_b[nf:nf + n_img * 3].reshape(n_img, 3)
         inst_h = host_b[nf + n_img * 3:2 * nf + n_img * 3]
