@@ -1018,7 +1018,10 @@ struct Halo {
     static constexpr size_t kLdsBytes = ((size_t)2 * kBufChunks + 3 * kHaloBStage) * sizeof(uint4);   // 144 / 160 KB
 };
 
-template <bool OUT_BF16, int DIL, int DBG = 0>
+// N64 (round 4): a layer with exactly 64 output channels (conv1_2) -- the 8 waves take 32 pixels x 64 channels each
+// (8 x 1 instead of 4 x 2 waves of 64 x 64): the 4 x 2 form ran its second channel half on clamped weight rows, i.e. half of
+// its MFMAs for nothing (conv1_2 was the slowest forward layer of the body at 0.18 of the peak).
+template <bool OUT_BF16, int DIL, int DBG = 0, bool N64 = false>
 __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
     const unsigned short* __restrict__ X, ConvGeom g, const unsigned short* __restrict__ B, int ldb, int n_img, int N,
     void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_y, int tiles_x, int tiles_n, int splits, int cb_per_split) {
@@ -1047,7 +1050,8 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;            // 4 x 2 waves: 4 tile rows (64 pixels) x 64 channels each
+    constexpr int MI = N64 ? 1 : 2;                     // 32-pixel fragments per wave
+    const int wm = N64 ? wave : wave >> 1, wn = N64 ? 0 : wave & 1;     // 4 x 2 waves of 64 pixels x 64 channels (N64: 8 x 1 of 32 x 64)
     const int half = lane >> 5, l31 = lane & 31;
 
     // this lane's share of a patch: byte offset of (pixel, 16-byte chunk) in X for channel block 0; ~0 = zero page
@@ -1071,15 +1075,15 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
         }
     };
     // halo row of this lane's two fragment rows at the centre tap
-    int hrb[2];
+    int hrb[MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        hrb[i] = (wm * 4 + i * 2 + halo_row_of(l31) + DIL) * HC::HWp + halo_x_of(l31) + DIL;
+    for (int i = 0; i < MI; ++i) {
+        hrb[i] = (wm * (2 * MI) + i * 2 + halo_row_of(l31) + DIL) * HC::HWp + halo_x_of(l31) + DIL;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -1108,9 +1112,9 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
         const uint4* sb = bring + slot * kHaloBStage;
         const int ty_ = (tap * 11) >> 5, tx_ = tap - 3 * ty_;
         const int delta = ((ty_ - 1) * HC::HWp + (tx_ - 1)) * DIL * g.sign;
-        int arow[2], asw[2];
+        int arow[MI], asw[MI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const int hr = hrb[i] + delta;
             arow[i] = hr * kChunksPerRow;
             asw[i] = (hr >> 1) & 7;
@@ -1118,49 +1122,58 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
         if (DBG == 0 || DBG == 8) {
             // the step's 16 fragment reads and 16 MFMAs with the issue order given to the scheduler explicitly: left
             // alone hipcc emits 4 reads -> s_waitcnt lgkmcnt(0) -> 4 MFMAs per slice (1-2 % slower)
-            bf16x8 ga[4][2], gb[4][2];
+            bf16x8 ga[4][MI], gb[4][2];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int c = kk * 2 + half;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) ga[kk][i] = __builtin_bit_cast(bf16x8, sa[arow[i] + (c ^ asw[i])]);
+                for (int i = 0; i < MI; ++i) ga[kk][i] = __builtin_bit_cast(bf16x8, sa[arow[i] + (c ^ asw[i])]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) gb[kk][j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb[kk][j], ga[kk][i], acc[i][j], 0, 0, 0);
-            // issue order for the scheduler: the first slice's 4 reads, then one read of the NEXT slice behind each MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            // issue order for the scheduler: the first slice's reads, then one read of the NEXT slice behind each MFMA
+            if (N64) {                  // 12 reads, 8 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int t = 0; t < 12; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int t = 0; t < 8; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            } else {                    // 16 reads, 16 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         } else
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int c = kk * 2 + half;
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[MI], fb[2];
             if (DBG == 2) {             // timing experiment: no LDS reads
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, make_uint4(arow[i], c, asw[i], st));
+                for (int i = 0; i < MI; ++i) fa[i] = __builtin_bit_cast(bf16x8, make_uint4(arow[i], c, asw[i], st));
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, make_uint4(j, c, lane, st));
             } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[arow[i] + (c ^ asw[i])]);
+            for (int i = 0; i < MI; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[arow[i] + (c ^ asw[i])]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
             }
             if (DBG == 3) {             // timing experiment: no MFMAs (the fragments are still consumed)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const uint4 ua = __builtin_bit_cast(uint4, fa[i]), ub = __builtin_bit_cast(uint4, fb[j]);
@@ -1171,7 +1184,7 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
             // operands swapped: the accumulator holds the TRANSPOSED 32x32 tile (lane & 31 = pixel, 4 consecutive
             // registers = 4 consecutive channels), which is what the staged epilogue wants
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
@@ -1190,10 +1203,10 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                            // every wave is done with the operand tiles
     const int hw = g.H * g.W;
-    band_store<OUT_BF16, 2>(acc, Cv, ldc, N, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds),
+    band_store<OUT_BF16, MI>(acc, Cv, ldc, N, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds),
                             [&](int r) -> long long {
-                                const int prow = wm * 64 + r;
-                                const int y = y0 + wm * 4 + (r >> 5) * 2 + halo_row_of(r & 31), x = x0 + halo_x_of(r & 31);
+                                const int prow = wm * (32 * MI) + r;
+                                const int y = y0 + wm * (2 * MI) + (r >> 5) * 2 + halo_row_of(r & 31), x = x0 + halo_x_of(r & 31);
                                 if (DBG == 7) return (y < g.H && x < g.W) ? (long long)(prow + 256 * (blockIdx.x & 15)) : -1ll;
                                 return (y < g.H && x < g.W) ? (long long)img * hw + (long long)y * g.W + x : -1ll;
                             });
@@ -2739,6 +2752,19 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
 #undef ODW_LAUNCH_HALO_DBG
         } else
 #endif
+        if (N == 64 && hp.tiles_n == 1 && dilation == 1 && !getenv("ODW_CONV_NO_N64")) {
+#define ODW_LAUNCH_HALO64(OUTBF)                                                                                   \
+            do {                                                                                                   \
+                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<OUTBF, 1, 0, true>), \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Halo<1>::kLdsBytes), \
+                              "halo attr");                                                                        \
+                conv3x3_halo_kernel<OUTBF, 1, 0, true><<<grid, kHaloThreads, Halo<1>::kLdsBytes, stream>>>(        \
+                    (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y, \
+                    hp.tiles_x, hp.tiles_n, hp.splits, hp.cb_per_split);                                           \
+            } while (0)
+            if (out_bf16) ODW_LAUNCH_HALO64(true); else ODW_LAUNCH_HALO64(false);
+#undef ODW_LAUNCH_HALO64
+        } else
         if (dilation == 1) { if (out_bf16) ODW_LAUNCH_HALO(true, 1); else ODW_LAUNCH_HALO(false, 1); }
         else { if (out_bf16) ODW_LAUNCH_HALO(true, 2); else ODW_LAUNCH_HALO(false, 2); }
 #undef ODW_LAUNCH_HALO
