@@ -354,7 +354,7 @@ def main():
         if roof is not None:
             # memory-side bytes of the dominant launch from the committed PMC passes (rocprofv3 cannot run inside the
             # timed region): FETCH_SIZE x 2 (gfx950 under-count of 16-B/lane reads) + WRITE_SIZE, per launch
-            for rnd in ("r03", "r02", "r01"):
+            for rnd in ("r04", "r03", "r02", "r01"):
                 tpath = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
                 if os.path.exists(tpath):
                     t = json.load(open(tpath))
