@@ -8,6 +8,7 @@ lib = L.lib()
 LAYERS = {"conv2": (128, 128, 1, 304, 0), "conv3": (256, 256, 1, 152, 0), "conv4": (512, 512, 1, 76, 0),
           "conv5": (512, 512, 2, 76, 0), "conv4_dgrad": (512, 512, 1, 76, 1), "conv3_dgrad": (256, 256, 1, 152, 1)}
 cin, cout, dil, h, mirror = LAYERS[os.environ.get("ODW_CONV_LAYER", "conv4")]
+cin = int(os.environ.get("ODW_CONV_CIN", cin))          # (fixed-overhead fits: time against the K of one layer shape)
 T = int(os.environ.get("ODW_CONV_PLANES", "1"))         # 3 = the forward of the "bf16x2f" mode: three plane blocks, fp32 out
 cin_real = cin
 cin *= T
