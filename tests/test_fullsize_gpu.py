@@ -2,9 +2,10 @@
 
   * one training step of the product (HIP body, fused loss) against the CPU oracle (oracle/hotpath_ref.py) on the same
     formula-generated inputs at P = 500 @ 300 px, P = 2000 @ 600 px (608^2), P = 4000 / 81 classes @ 800 px and @ 688 px
-    (two scales of the COCO config's multi-scale training), the R-50-C5 body at P = 2000 @ 600 px (config 5), and the
-    reference's single-GPU setup -- 8 images of 2000 proposals on one device (README.md:99-100) -- in BOTH parity
-    modes: "bf16x2f" (what bench.py times) and "bf16x3" (fp32-grade);
+    (two scales of the COCO config's multi-scale training), the same shape with SEVERAL images -- 2 x 4000 @ 576 px and
+    3 x 4000 @ 480 px, one label each, so that the contrastive set holds 2-3 classes and loss_sim > 0 --, the R-50-C5 body
+    at P = 2000 @ 600 px (config 5), and the reference's single-GPU setup -- 8 images of 2000 proposals on one device
+    (README.md:99-100) -- in BOTH parity modes: "bf16x2f" (what bench.py times) and "bf16x3" (fp32-grade);
   * the fused pooling kernels of the training step bit-exact against the C oracle's ROIPool at the C2 shape.
 
 How the selections are compared.  At these sizes thousands of threshold decisions are taken per step and the closest one
@@ -31,7 +32,7 @@ from conftest import weights_for  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = {"c1": 303, "c2": 301, "c4": 305, "c5": 300, "c4s": 306, "b8": 302, "c4b": 302}
+SEEDS = {"c1": 303, "c2": 301, "c4": 305, "c5": 300, "c4s": 306, "b8": 302, "c4b": 302, "c4m": 310}
 MODES = ("bf16x2f", "bf16x3")
 # distance from a threshold below which a decision may legitimately differ from the fp32 oracle's: the deviation of the
 # product's similarity values from the oracle's is <= ~2e-7 in "bf16x3" (fp32 re-association) and <= ~2e-5 in "bf16x2f"
@@ -127,7 +128,7 @@ def _same_up_to_score_ties(a, b, score, tol):
     return bool(((sa - sb).abs() <= tol * sa.abs().clamp(min=1e-30)).all())
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c4s", "c5", "b8", "c4b"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c4s", "c5", "b8", "c4b", "c4m"])
 def test_full_size_step_matches_the_oracle(name):
     import fullsize_seed_scan as S
     from oracle import hotpath_ref as H
@@ -208,7 +209,7 @@ def test_full_size_step_matches_the_oracle(name):
         if flips == 0:
             assert worst_grad <= GRAD_TOL[mode], (mode, worst_grad)
             assert worst_l2 <= GRAD_L2_TOL[mode], (mode, worst_l2_name, worst_l2)
-        if name == "c4b":       # the case exists for this: a non-zero contrastive loss (and SupCon gradient) at P = 4000 / 81 classes
+        if name in ("c4b", "c4m"):       # the cases exist for this: a non-zero contrastive loss (and SupCon gradient) at P = 4000 / 81 classes
             assert float(ref_losses["loss_sim"]) > 1e-6 and len(set(int(v) for l in lab for v in l)) >= 2
         del model, losses
         torch.cuda.empty_cache()

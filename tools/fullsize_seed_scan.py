@@ -28,6 +28,8 @@ CASES = {  # name: (size, proposals, classes, labels[, arch]); labels = one list
     # classes in the SupCon set -> loss_sim > 0 and a non-zero SupCon gradient at P = 4000), at 576 px -- a third scale
     # of the COCO config's multi-scale training (configs/coco/coco14_contra_db_b8_lr0.01_mcg.yaml: 480-800)
     "c4b": (576, 4000, 81, [[17], [42]]),
+    # the smallest scale of the COCO config (480 px), three images (one label each: with 80 classes a two-label image makes the same proposal top both classes -- quirk Q3's rounding-dependent comparison, excluded by construction)
+    "c4m": (480, 4000, 81, [[5], [60], [23]]),
 }
 
 
