@@ -116,6 +116,9 @@ int64_t odw_roi_align_backward_workspace(int R, int PH, int PW);
 /* The forward in the same separable form (workspace of odw_roi_align_backward_workspace bytes: the per-ROI axis
  * vectors; they are staged in LDS chunk by chunk): (bin+2)^2 cell reads per bin instead of 4 taps per sample.  The
  * sample coordinates are the reference's, the order of the fp32 additions is not (1e-6 against ROIAlign_cpu.cpp). */
+/* Workspace of the (ROI, 64-channel) form of the forward (round 4: axis vectors + an NHWC copy of the map; C % 8 == 0,
+ * PH * PW <= 64, PH + PW <= 32): ~2x the plane-resident form, the same values. */
+int64_t odw_roi_align_forward_workspace(int B, int C, int H, int W, int R, int PH, int PW);
 int odw_roi_align_forward_ws(const float* feat, const float* rois, float spatial_scale, int B, int C, int H, int W,
                              int R, int PH, int PW, int sampling_ratio, float* out, void* workspace,
                              int64_t workspace_bytes, void* stream);

@@ -63,7 +63,7 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
     out = torch.empty((R, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device)
     if out.numel() == 0:
         return out
-    ws_bytes = L.lib().odw_roi_align_backward_workspace(R, pooled_height, pooled_width)
+    ws_bytes = L.lib().odw_roi_align_forward_workspace(B, C, H, W, R, pooled_height, pooled_width)
     ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=input.device)
     L.check(L.lib().odw_roi_align_forward_ws(L.ptr(input), L.ptr(rois), float(spatial_scale), B, C, H, W, R,
                                              pooled_height, pooled_width, int(sampling_ratio), L.ptr(out), L.ptr(ws),

@@ -34,6 +34,7 @@ SIGNATURES = {
     "odw_roi_align_forward_ws": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "odw_roi_align_backward": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_roi_align_backward_workspace": (c_l, [c_i, c_i, c_i]),
+    "odw_roi_align_forward_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "odw_roi_align_backward_ws": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "odw_nms_workspace": (c_l, [c_i]),
     "odw_nms": (c_i, [c_p, c_p, c_i, c_f, c_i, c_p, c_p, c_p, c_l, c_p]),

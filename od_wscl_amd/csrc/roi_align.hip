@@ -411,6 +411,92 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_sep_plane(
     }
 }
 
+// ---- the forward on the (ROI, 64-channel) decomposition of the pooling kernels (round 4) ----------------------------
+// The plane-resident forward above keeps 1-4 channel planes in LDS and walks every ROI: a lane = one bin reads its
+// (bin + 2)^2 cells one 4-byte LDS word at a time per channel, and writes 196-byte output segments: 0.60 ms at P = 2000 on
+// 76 x 76 x 512.  For a fixed ROI the outputs of 64 consecutive channels are ONE contiguous block of `out`, and in an
+// NHWC copy of the map a cell's 8 consecutive channels are two 16-byte loads: a workgroup takes (ROI n, channels c0 ..
+// c0 + 63), a thread = (bin, 8 channels) forms the same separable sum -- the same axis vectors (roi_align_axis_kernel: the
+// sample coordinates in the reference's fp32 operation order), the same cell order, separate multiply and add -- so the
+// values are the plane kernel's bit for bit, and the block leaves as full lines.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_f32_tile_kernel(const float* __restrict__ in, int C, int HW,
+                                                                    float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + (size_t)b * C * HW;
+    float* dst = out + (size_t)b * HW * C;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int c = c0 + ty + j, p = p0 + tx;
+        tile[ty + j][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int p = p0 + ty + j, c = c0 + tx;
+        if (p < HW && c < C) dst[(size_t)p * C + c] = tile[tx][ty + j];
+    }
+}
+
+constexpr int kOpMaxAxes = 32;          // PH + PW of the (ROI, 64-channel) forward
+
+__global__ __launch_bounds__(512) void roi_align_fwd_nhwc_op(const float* __restrict__ nhwc, const float* __restrict__ nchw,
+                                                             const float* __restrict__ rois, float scale,
+                                                             const float* __restrict__ tab, int C, int H, int W, int PH, int PW,
+                                                             int sr, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_val[64 * 64];
+    __shared__ __attribute__((aligned(16))) float s_tab[kOpMaxAxes * kAxisStride];
+    const int n = blockIdx.x, c0 = blockIdx.y * 64;
+    const int per = PH + PW, nb = PH * PW;
+    {
+        const float4* t4 = reinterpret_cast<const float4*>(tab + (size_t)n * per * kAxisStride);
+        for (int i = threadIdx.x; i < per * kAxisStride / 4; i += blockDim.x) reinterpret_cast<float4*>(s_tab)[i] = t4[i];
+    }
+    __syncthreads();
+    const RoiGeom g = roi_geom(rois + (size_t)n * 5, scale, PH, PW, sr);
+    const int bin = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    if (bin < nb && c0 + cg * 8 < C) {
+        const int ph = bin / PW, pw = bin - ph * PW;
+        const float* ty = s_tab + ph * kAxisStride;
+        const float* tx = s_tab + (PH + pw) * kAxisStride;
+        const int y0 = reinterpret_cast<const int*>(ty)[0], ny = reinterpret_cast<const int*>(ty)[1];
+        const int x0 = reinterpret_cast<const int*>(tx)[0], nx = reinterpret_cast<const int*>(tx)[1];
+        float v[8];
+        if (ny < 0 || nx < 0) {                    // a bin wider than an axis vector (a box far larger than the map): sample form
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = align_one(nchw + ((size_t)g.b * C + c0 + cg * 8 + q) * H * W, g, H, W, ph, pw);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = 0.0f;
+            const float* base = nhwc + ((size_t)g.b * H * W + (size_t)y0 * W + x0) * C + c0 + cg * 8;
+            for (int cy = 0; cy < ny; ++cy) {
+                const float wy = ty[2 + cy];
+                const float* row = base + (size_t)cy * W * C;
+#pragma unroll 2
+                for (int cx = 0; cx < nx; ++cx) {
+                    const float w = wy * tx[2 + cx];
+                    const float4 a = *reinterpret_cast<const float4*>(row + (size_t)cx * C);
+                    const float4 b4 = *reinterpret_cast<const float4*>(row + (size_t)cx * C + 4);
+                    v[0] += w * a.x; v[1] += w * a.y; v[2] += w * a.z; v[3] += w * a.w;
+                    v[4] += w * b4.x; v[5] += w * b4.y; v[6] += w * b4.z; v[7] += w * b4.w;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (ny == 0 || nx == 0) ? 0.0f : v[q] / g.count;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_val[(cg * 8 + q) * nb + bin] = v[q];
+    }
+    __syncthreads();
+    const int nch = C - c0 < 64 ? C - c0 : 64;
+    const int count4 = nch * nb / 4;                  // C % 8 == 0: a multiple of 8 values, 32-byte aligned
+    const size_t off = ((size_t)n * C + c0) * nb;
+    for (int i = threadIdx.x; i < count4; i += blockDim.x)
+        reinterpret_cast<float4*>(out + off)[i] = reinterpret_cast<const float4*>(s_val)[i];
+}
+
 // channel planes per workgroup for the chunk-staged kernels: the planes + one chunk of axis vectors must fit in LDS
 int pick_cg_sep(int B, int C, int HW, int per, int cell_bytes) {
     const int cands[3] = {4, 2, 1};
@@ -522,6 +608,12 @@ int launch_sep(const float* src, const float* rois, float scale, float* tab, int
 
 ODW_EXPORT int64_t odw_roi_align_backward_workspace(int R, int PH, int PW);
 
+// Workspace of the (ROI, 64-channel) forward: the axis vectors + an NHWC copy of the map (C % 8 == 0, PH * PW <= 64,
+// PH + PW <= 32).  With odw_roi_align_backward_workspace bytes only, the plane-resident form runs.
+ODW_EXPORT int64_t odw_roi_align_forward_workspace(int B, int C, int H, int W, int R, int PH, int PW) {
+    return odw_roi_align_backward_workspace(R, PH, PW) + odw_align_up((int64_t)(B > 0 ? B : 1) * C * H * W * 4, 256);
+}
+
 ODW_EXPORT int odw_roi_align_forward_ws(const float* feat, const float* rois, float scale, int B, int C, int H, int W,
                                         int R, int PH, int PW, int sr, float* out, void* workspace,
                                         int64_t workspace_bytes, void* stream_) {
@@ -529,6 +621,21 @@ ODW_EXPORT int odw_roi_align_forward_ws(const float* feat, const float* rois, fl
     ODW_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 0, "roi_align_forward: bad dims");
     if (R == 0 || B == 0) return ODW_OK;
     ODW_REQUIRE(feat && rois && out, "roi_align_forward: null pointer");
+    static const bool no_nhwc = getenv("ODW_ROI_ALIGN_PLANE") != nullptr;          // comparison runs: the plane-resident form
+    if (!no_nhwc && !getenv("ODW_ROI_ALIGN_SAMPLES") && workspace && (((uintptr_t)workspace) & 15) == 0 && C % 8 == 0 &&
+        PH * PW <= 64 && PH + PW <= kOpMaxAxes && (((uintptr_t)out) & 15) == 0 && (long long)B * H * W * C < (1ll << 31) &&
+        workspace_bytes >= odw_roi_align_forward_workspace(B, C, H, W, R, PH, PW)) {
+        float* tab = (float*)workspace;
+        float* nhwc = (float*)((char*)workspace + odw_roi_align_backward_workspace(R, PH, PW));
+        const int items = R * (PH + PW);
+        roi_align_axis_kernel<<<(items + 255) / 256, 256, 0, stream>>>(rois, scale, R, PH, PW, H, W, sr, tab);
+        ODW_CHECK_LAUNCH("roi_align_axis_kernel");
+        nchw_to_nhwc_f32_tile_kernel<<<dim3((H * W + 31) / 32, (C + 31) / 32, B), 256, 0, stream>>>(feat, C, H * W, nhwc);
+        ODW_CHECK_LAUNCH("nchw_to_nhwc_f32_tile_kernel");
+        roi_align_fwd_nhwc_op<<<dim3(R, (C + 63) / 64), 512, 0, stream>>>(nhwc, feat, rois, scale, tab, C, H, W, PH, PW, sr, out);
+        ODW_CHECK_LAUNCH("roi_align_fwd_nhwc_op");
+        return ODW_OK;
+    }
     const int cg = pick_cg_sep(B, C, H * W, PH + PW, 4);
     if (cg == 0 || !workspace || workspace_bytes < odw_roi_align_backward_workspace(R, PH, PW) ||
         (((uintptr_t)workspace) & 15) != 0 || PH * PW > kPlaneThreads || getenv("ODW_ROI_ALIGN_SAMPLES"))
