@@ -12,8 +12,6 @@ NHWC bf16 activations (n_pix x C matrices) end to end:
   * stem (7x7/2 + BN + ReLU, 3x3/2 max pool): csrc/resnet_aux.hip, forward only -- the stem and layer1 are frozen in
     every shipped config (FREEZE_CONV_BODY_AT 2) and nothing below layer2 receives a gradient.
 The parameters stay the nn.Conv2d weights / FrozenBatchNorm2d buffers of the reference-named modules."""
-import collections
-import logging
 import os
 
 import torch
@@ -235,22 +233,6 @@ class _Folded(object):
     __slots__ = ("scale", "shift", "shadow", "key")
 
 
-class _GraphSurface(nn.Module):
-    """What torch.cuda.make_graphed_callables needs to see of the body: a Module whose parameters() are the body's
-    TRAINABLE parameters (the same Parameter objects -- they stay owned by the reference-named modules) and whose forward
-    is the eager body.  Returns (NCHW feature map, the NHWC map the fused ROI pooling reads)."""
-
-    def __init__(self, hip):
-        super().__init__()
-        self.hip = [hip]
-        self.surface = nn.ParameterList([p for p in hip.base[0].parameters() if p.requires_grad])
-
-    def forward(self, images):
-        feat = self.hip[0]._forward_eager(images)[0]
-        nhwc = feat._odw_nhwc_f32 if feat._odw_nhwc_f32 is not None else feat._odw_nhwc
-        return feat, nhwc
-
-
 class ResNetBackboneHip(nn.Module):
     """Drop-in for the ResNet body's forward (model.backbone.body): same parameters and buffers, gfx950 kernels."""
 
@@ -259,58 +241,6 @@ class ResNetBackboneHip(nn.Module):
         self.base = [body]              # not registered: parameters / buffers stay owned by the reference-named modules
         self.cache = {}
         self.zero_page = None
-        self._graphs = collections.OrderedDict()        # least recently used first
-        self._sightings = {}
-        self.graph_stats = {"captures": 0, "replays": 0, "eager": 0, "evictions": 0, "bytes": 0}
-
-    # ---- HIP graphs (engine.build_training_step sets use_graphs; round 4).  The R-50-C5 step issued 819 launches, ~600 of
-    # them the body's (1x1 convolutions as GEMMs with their operand copies, 3x3 convolutions, folds, adds), and was bound by
-    # the HOST issuing them: 7.7 ms of its 26 ms idle under rocprofv3 (profiles/r04/r50_*).  The body -- a chain of this
-    # file's autograd Functions -- is captured as torch.cuda.make_graphed_callables does it (forward graph; backward graph of
-    # torch.autograd.grad w.r.t. the trainable parameters, which come back as static tensors and are accumulated into
-    # .grad by autograd as usual), under the SAME bounded policy as the VGG body's cache (vgg16_hip._graph_for): at most
-    # graph_cache_size shapes, captured when a shape comes back, rate-limited by the replays they buy, eager otherwise.
-    use_graphs = False
-    graph_cache_size = int(os.environ.get("ODW_GRAPH_CACHE", "4"))
-    graph_min_sightings = 2
-
-    def _graph_for(self, images):
-        key = (tuple(images.shape), P.get_precision())
-        st = self.graph_stats
-        g = self._graphs.get(key)
-        if g is not None:
-            self._graphs.move_to_end(key)
-            st["replays"] += 1
-            return g
-        if len(self._sightings) > 8192:
-            self._sightings.clear()
-        seen = self._sightings[key] = self._sightings.get(key, 0) + 1
-        if self.graph_cache_size < 1 or seen < self.graph_min_sightings or st["captures"] >= 2 + st["replays"] // 8:
-            st["eager"] += 1
-            return None
-        while len(self._graphs) >= self.graph_cache_size:
-            torch.cuda.current_stream().synchronize()
-            _, old = self._graphs.popitem(last=False)
-            st["evictions"] += 1
-            st["bytes"] -= old[2]
-            del old
-        before = torch.cuda.memory_allocated(images.device)
-        was_active, kernel_timer.active = kernel_timer.active, False
-        kernel_timer.tally = 0.0                       # counting pass: 3 warm-up iterations + the two captures = 4 x (fwd + bwd)
-        try:
-            surface = _GraphSurface(self)
-            call = torch.cuda.make_graphed_callables(surface, (images.detach().clone(),), allow_unused_input=True)
-            flops = kernel_timer.tally / 4.0
-        finally:
-            kernel_timer.tally = None
-            kernel_timer.active = was_active
-        nbytes = max(0, torch.cuda.memory_allocated(images.device) - before)
-        g = self._graphs[key] = (call, flops, nbytes)
-        st["captures"] += 1
-        st["bytes"] += nbytes
-        logging.getLogger("od_wscl_amd").info("HIP graphs of the ResNet body captured for %s: %.2f GB held (%d shape(s) cached)",
-                                              tuple(images.shape), nbytes / 1e9, len(self._graphs))
-        return g
 
     # ---- constants ------------------------------------------------------------------------------------------
     def _const(self, conv, bn):
@@ -374,21 +304,6 @@ class ResNetBackboneHip(nn.Module):
 
     def forward(self, images):
         L.need_gpu(images)
-        body = self.base[0]
-        if (self.use_graphs and torch.is_grad_enabled() and os.environ.get("ODW_NO_GRAPHS") != "1"
-                and any(p.requires_grad for p in body.parameters())
-                and all(p.grad is not None for p in body.parameters() if p.requires_grad)):
-            g = self._graph_for(images)
-            if g is not None:
-                call, flops, _ = g
-                with kernel_timer.region("ResNet body (HIP graphs; FLOPs of forward + backward, time of the forward replay)", flops=flops):
-                    feat, nhwc = call(images.float().contiguous())
-                feat._odw_nhwc = nhwc if nhwc.dtype == torch.bfloat16 else None
-                feat._odw_nhwc_f32 = nhwc if nhwc.dtype == torch.float32 else None
-                return [feat]
-        return self._forward_eager(images)
-
-    def _forward_eager(self, images):
         body = self.base[0]
         lib, st = L.lib(), L.stream()
         dev = images.device
