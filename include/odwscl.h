@@ -153,6 +153,12 @@ int odw_box_iou(const float* a, int N, const float* b, int M, float* iou, void* 
  * replaces `torch.mm(sim_feature, sim_feature.T)` of
  * roi_heads/weak_head/loss.py:319.  E (P,D) fp32, D % 4 == 0 -> S (P,P) fp32. */
 int odw_pairwise_sim(const float* E, int P, int D, float* S, void* stream);
+/* The same with a row pitch of ldS >= P elements for S (D = 128, S 16-byte aligned; columns P..ldS-1 are not written).
+ * The kernel leaves S as 128-byte row segments: with a pitch that is a multiple of 16 floats they are whole cache lines and
+ * leave as nontemporal stores; otherwise every segment straddles two lines and has to merge in L2 (plain stores), ~15%
+ * slower (P = 5000: 33.9 us dense, 29.5 us with ldS = 5024) -- a caller that may choose the layout of S passes ldS = P
+ * rounded up to 32 and reads the (P, P) view of it. */
+int odw_pairwise_sim_ld(const float* E, int P, int D, float* S, int64_t ldS, void* stream);
 /* Workspace form (D = 128): kept for callers of rounds 1-3; the products run on the bf16 matrix cores as six plane
  * products per fp32-grade product and the kernel is bound by the 4 P^2-byte write of S.  Since round 4 the default is the
  * ONE-launch kernel whatever the workspace (it splits E in registers; the split-kernel + LDS-DMA form measured 5-7 us

@@ -222,7 +222,7 @@ __device__ __forceinline__ void pw_st4(float* p, const float4 v, int dbg) {
 // The stores of one finished 32 x 32 tile (rows r0.., columns c0.. of S, c0 >= r0): the direct tile as 128-byte row segments,
 // the mirrored tile through the wave's padded LDS scratch so that it leaves as full 128-byte lines too; a diagonal tile
 // writes its upper triangle to both places.  Shared by the panel and the DMA kernel.
-__device__ __forceinline__ void pw_store_tile(const f32x16& acc, float* __restrict__ S, int P, int r0, int c0, int lane, int half,
+__device__ __forceinline__ void pw_store_tile(const f32x16& acc, float* __restrict__ S, int P, int ld, int r0, int c0, int lane, int half,
                                               int l31, float* scratch, bool small, bool vec, int dbg = 0) {
     const int col = c0 + l31;
     const bool full = small && vec && r0 + 32 <= P && c0 + 32 <= P;      // wave-uniform: no per-element predicates
@@ -233,8 +233,8 @@ __device__ __forceinline__ void pw_store_tile(const f32x16& acc, float* __restri
         for (int k = 0; k < 16; ++k) {
             const int r = crow(k, half);
             if (r <= l31 && col < P) {
-                S[(size_t)(r0 + r) * P + col] = acc[k];
-                S[(size_t)col * P + r0 + r] = acc[k];
+                S[(size_t)(r0 + r) * ld + col] = acc[k];
+                S[(size_t)col * ld + r0 + r] = acc[k];
             }
         }
     } else {
@@ -247,22 +247,22 @@ __device__ __forceinline__ void pw_store_tile(const f32x16& acc, float* __restri
                 make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
         if (full) {
             // interior tile: 32-bit element offsets from the kernel-argument base, no predicates
-            const unsigned dbase = (unsigned)(r0 + 4 * half) * (unsigned)P + (unsigned)col;
+            const unsigned dbase = (unsigned)(r0 + 4 * half) * (unsigned)ld + (unsigned)col;
             if (!PW_DBG(1))
 #pragma unroll
             for (int k = 0; k < 16; ++k)      // direct tile: one 128-byte row segment per half-wave
-                pw_st1(S + (dbase + (unsigned)((k & 3) + 8 * (k >> 2)) * (unsigned)P), acc[k], dbg);
-            const unsigned mbase = (unsigned)(c0 + (lane >> 3)) * (unsigned)P + (unsigned)(r0 + (lane & 7) * 4);
+                pw_st1(S + (dbase + (unsigned)((k & 3) + 8 * (k >> 2)) * (unsigned)ld), acc[k], dbg);
+            const unsigned mbase = (unsigned)(c0 + (lane >> 3)) * (unsigned)ld + (unsigned)(r0 + (lane & 7) * 4);
             if (!PW_DBG(2))
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                pw_st4(S + (mbase + (unsigned)(8 * t) * (unsigned)P),
+                pw_st4(S + (mbase + (unsigned)(8 * t) * (unsigned)ld),
                        *reinterpret_cast<const float4*>(scratch + (t * 8 + (lane >> 3)) * kPwTrPitch + (lane & 7) * 4), dbg);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int r = r0 + crow(k, half);
-                if (r < P && col < P) S[(size_t)r * P + col] = acc[k];
+                if (r < P && col < P) S[(size_t)r * ld + col] = acc[k];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -270,7 +270,7 @@ __device__ __forceinline__ void pw_store_tile(const f32x16& acc, float* __restri
                 const float4 v = *reinterpret_cast<const float4*>(scratch + n * kPwTrPitch + m4);
                 const int row = c0 + n, cc = r0 + m4;
                 if (row < P) {
-                    float* dst = S + (size_t)row * P + cc;
+                    float* dst = S + (size_t)row * ld + cc;
                     if (vec && cc + 3 < P) *reinterpret_cast<float4*>(dst) = v;
                     else {
                         const float e[4] = {v.x, v.y, v.z, v.w};
@@ -293,7 +293,7 @@ __device__ __forceinline__ void pw_barrier() {
 }
 
 __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(const float* __restrict__ E, int P,
-                                                                              float* __restrict__ S, int max_run, int dbg) {
+                                                                              float* __restrict__ S, int ld, int max_run, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
     if (run_len <= 0) return;
     PW_T(0);
     float* const scratch = reinterpret_cast<float*>(lds + 2 * kPwSlot) + (loader ? 0 : wave) * 32 * kPwTrPitch;
-    const bool vec = (P & 3) == 0;
-    const bool small = (unsigned long long)P * (unsigned long long)P < (1ull << 30);      // 32-bit element offsets
+    const bool vec = (ld & 3) == 0;
+    const bool small = (unsigned long long)P * (unsigned long long)ld < (1ull << 30);      // 32-bit element offsets
 
     // (row, 8-k chunk) items of a 32-row block: rows past the end are clamped to the last row (their products are
     // never stored), so every load is unconditional
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] += acc1[k];
                 PW_T(3 + 3 * (int)(it - lo_it));
-                pw_store_tile(acc, S, P, r0, c0, lane, half, l31, scratch, small, vec, dbg);
+                pw_store_tile(acc, S, P, ld, r0, c0, lane, half, l31, scratch, small, vec, dbg);
             }
         }
         PW_T(4 + 3 * (int)(it - lo_it));
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_dma_kernel(cons
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] += acc1[k];
                 PW_T(3 + 3 * (int)(it - lo_it));
-                pw_store_tile(acc, S, P, r0, c0, lane, half, l31, scratch, small, vec);
+                pw_store_tile(acc, S, P, P, r0, c0, lane, half, l31, scratch, small, vec);
             }
         }
         PW_T(4 + 3 * (int)(it - lo_it));
@@ -846,10 +846,16 @@ ODW_EXPORT int odw_pairwise_sim_planes(const void* planes, int P, float* S, void
     return ODW_OK;
 }
 
-ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void* workspace, int64_t workspace_bytes,
-                                   void* stream_) {
+// S with a row pitch of ldS elements (>= P).  A pitch that is not a multiple of 16 floats makes every 128-byte row segment
+// of a tile straddle two cache lines: the stores then have to merge in L2 (plain stores, below) and the kernel is ~15%
+// slower than with whole-line nontemporal stores (P = 5000: 33.9 us dense, 29.5 us with ldS = 5024;
+// tools/exp/pairwise_psweep.py): callers that may choose the layout pass ldS = P rounded up to 32.
+static int pairwise_sim_impl(const float* E, int P, int D, float* S, int64_t ldS, void* workspace, int64_t workspace_bytes,
+                             void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(P >= 0 && D > 0 && D % 4 == 0, "pairwise_sim: bad dims P=%d D=%d", P, D);
+    ODW_REQUIRE(ldS >= P && ldS <= INT32_MAX, "pairwise_sim: row pitch %lld < P=%d", (long long)ldS, P);
+    ODW_REQUIRE(ldS == P || (D == kD && (((uintptr_t)S) & 15) == 0), "pairwise_sim: a padded row pitch needs D=%d and a 16-byte aligned S", kD);
     if (P == 0) return ODW_OK;
     ODW_REQUIRE(E && S, "pairwise_sim: null pointer");
     ODW_REQUIRE((((uintptr_t)E) & 15) == 0, "pairwise_sim: E must be 16-byte aligned");
@@ -857,13 +863,13 @@ ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void*
     // planes + DMA form from this many rows on, when the caller gave the workspace for the planes (ODW_PAIRWISE_PLANES_MIN:
     // comparison runs; a huge value = always the one-launch panel kernel)
     static const int planes_min = getenv("ODW_PAIRWISE_PLANES_MIN") ? atoi(getenv("ODW_PAIRWISE_PLANES_MIN")) : kPwPlanesMinP;
-    if (D == kD && !fp32_chain && (((uintptr_t)S) & 15) == 0 && P >= planes_min && workspace &&
+    if (D == kD && !fp32_chain && ldS == P && (((uintptr_t)S) & 15) == 0 && P >= planes_min && workspace &&
         (((uintptr_t)workspace) & 15) == 0 && workspace_bytes >= odw_pairwise_sim_workspace(P, D)) {
         const int rc = odw_pairwise_split_planes(E, P, workspace, stream_);
         if (rc != ODW_OK) return rc;
         return odw_pairwise_sim_planes(workspace, P, S, stream_);
     }
-    if (D == kD && !fp32_chain && (((uintptr_t)S) & 15) == 0) {
+    if (D == kD && (ldS != P || (!fp32_chain && (((uintptr_t)S) & 15) == 0))) {
         // split-bf16 panel form: one launch, no workspace (the planes are made in registers)
         const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
         const int max_run = pw_max_run(nblk32, npanel, ODW_NUM_CU), grid = pw_groups(max_run, nblk32, npanel);
@@ -876,9 +882,13 @@ ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void*
         // interior tiles leave as NONTEMPORAL stores (bit 8; ODW_PAIRWISE_ST=0: plain, 16: sc1 write-through): S is written once
         // and not read back by this kernel -- 27.5 -> 24.5 us at P = 4000, 13.7 -> 12.9 at P = 2000 on the same box
         // (tools/pairwise_forms.py, alternating runs)
-        static const int dbg = getenv("ODW_PAIRWISE_ST") ? (atoi(getenv("ODW_PAIRWISE_ST")) & 24) : 8;
+        // Nontemporal stores do not merge in L2: with a row pitch that is not a multiple of 16 floats every 128-byte segment
+        // straddles two lines, the halves go out as partial-line writes and the kernel takes TWICE as long (P = 5000 dense:
+        // 58.3 us nontemporal, 33.9 us plain; rows padded to 5024 floats: 29.5 us nontemporal) -- plain stores there.
+        static const int st = getenv("ODW_PAIRWISE_ST") ? (atoi(getenv("ODW_PAIRWISE_ST")) & 24) : -1;
+        const int dbg = st >= 0 ? st : (ldS % 16 == 0 ? 8 : 0);
 #endif
-        pairwise_sim_panel_kernel<<<grid, kPwWaves * 64, kPwLds, stream>>>(E, P, S, max_run, dbg);
+        pairwise_sim_panel_kernel<<<grid, kPwWaves * 64, kPwLds, stream>>>(E, P, S, (int)ldS, max_run, dbg);
         ODW_CHECK_LAUNCH("pairwise_sim_panel_kernel");
     } else if (D == kD) {
         const int nb = (P + 63) / 64;
@@ -893,8 +903,17 @@ ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void*
     return ODW_OK;
 }
 
+ODW_EXPORT int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void* workspace, int64_t workspace_bytes,
+                                   void* stream_) {
+    return pairwise_sim_impl(E, P, D, S, P, workspace, workspace_bytes, stream_);
+}
+
 ODW_EXPORT int odw_pairwise_sim(const float* E, int P, int D, float* S, void* stream_) {
-    return odw_pairwise_sim_ws(E, P, D, S, nullptr, 0, stream_);          // (the panel kernel needs no workspace)
+    return pairwise_sim_impl(E, P, D, S, P, nullptr, 0, stream_);          // (the panel kernel needs no workspace)
+}
+
+ODW_EXPORT int odw_pairwise_sim_ld(const float* E, int P, int D, float* S, int64_t ldS, void* stream_) {
+    return pairwise_sim_impl(E, P, D, S, ldS, nullptr, 0, stream_);
 }
 
 ODW_EXPORT int64_t odw_supcon_workspace(int N) {

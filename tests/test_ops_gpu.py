@@ -193,6 +193,31 @@ def test_pairwise_sim_at_the_benchmarked_sizes(C, P):
     assert np.abs(np.diag(S) - 1.0).max() <= 1e-6
 
 
+@pytest.mark.parametrize("P", [1, 31, 33, 225, 1000, 3001, 5000])
+def test_pairwise_padded_pitch_is_bit_identical_and_leaves_the_padding_alone(C, P):
+    """odw_pairwise_sim_ld (rows of S padded to 32 floats: C.pairwise_sim(padded=True) returns a view of it) against the dense entry:
+    the same bits in the (P, P) view, and the padding columns are never written."""
+    from od_wscl_amd import _lib as L
+    lib = L.lib()
+    E = rng.normal(64, P, P * 128).reshape(P, 128)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    Et = dev(E)
+    ld = -(-P // 32) * 32
+    S0 = torch.full((P, P), float("nan"), device="cuda")
+    S1 = torch.full((P, ld), float("nan"), device="cuda")
+    L.check(lib.odw_pairwise_sim(L.ptr(Et), P, 128, L.ptr(S0), L.stream()), "dense")
+    L.check(lib.odw_pairwise_sim_ld(L.ptr(Et), P, 128, L.ptr(S1), ld, L.stream()), "padded")
+    assert not torch.isnan(S0).any()
+    assert torch.equal(S0, S1[:, :P])
+    assert torch.isnan(S1[:, P:]).all()
+    V = C.pairwise_sim(Et, padded=True)
+    assert V.shape == (P, P) and V.stride(0) == ld and torch.equal(V, S0)
+    D = C.pairwise_sim(Et)
+    assert D.is_contiguous() and torch.equal(D, S0)
+    with pytest.raises(RuntimeError):
+        L.check(lib.odw_pairwise_sim_ld(L.ptr(Et), P, 128, L.ptr(S1), P - 1, L.stream()), "short pitch")
+
+
 @pytest.mark.parametrize("P", [1, 31, 33, 224, 225, 1000, 2000, 4001])
 def test_pairwise_planes_form_is_bit_identical_to_the_one_launch_form(P):
     """odw_pairwise_sim_ws with a workspace (split kernel + planes by LDS-DMA) and the caller-planes entry against the
