@@ -87,6 +87,14 @@ int odw_roi_pool_stack_forward_nhwc_f32(const float* feat_nhwc, const float* roi
                                         const int* pattern, int T, void* X_planes, int64_t ld, int block,
                                         float* pooled_f32, void* argmax_u16, void* workspace,
                                         int64_t workspace_bytes, void* stream);
+/* ... and (X_cm non-NULL) the clean rows once more as the two CELL-MAJOR planes odw_gemm_nt_cm reads: X_cm (R x ld_cm)
+ * bf16, X_cm[r][bin * C + c] = hi, X_cm[r][cm_mid + bin * C + c] = mid.  With the shared clean + DropBlock fc6 forward
+ * X_planes then only carries what the BACKWARD reads (pattern {0}: the hi plane of both halves). */
+int odw_roi_pool_stack_forward_nhwc_f32_cm(const float* feat_nhwc, const float* rois, float spatial_scale, int B, int C,
+                                           int H, int W, int R, const float* keep, const float* keep_sum,
+                                           const int* pattern, int T, void* X_planes, int64_t ld, int block,
+                                           float* pooled_f32, void* argmax_u16, void* X_cm, int64_t ld_cm, int64_t cm_mid,
+                                           void* workspace, int64_t workspace_bytes, void* stream);
 int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld, const void* argmax_u16, const float* rois,
                                 const float* keep, const float* keep_sum, const float* extra, const int* extra_roi,
                                 int E, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW, float* grad_in,
@@ -277,6 +285,26 @@ int odw_rows_drop_noise_bwd(const void* dX, int dx_is_f32, int ld, int dx_row0, 
 int odw_l2norm_rows(const float* x, int R, int D, float eps, float* y, float* norm, void* stream);
 int odw_l2norm_rows_bwd(const float* g, const float* y, const float* norm, int R, int D, float eps, float* dx,
                         void* stream);
+/* ---- fc6 over CELL-MAJOR planes: clean + DropBlock outputs from one pass (round 4) -------------------------
+ * replaces the two fc6 evaluations of ROIWeakRegHead.forward (roi_heads/weak_head/weak_head.py:107-112: the pooled
+ * features and their DropBlock view, modeling/dropblock/drop_block.py:38-50) in the split precision mode "bf16x2f".
+ * Operands: A (M x lda), B (N x ldb) bf16, each row = two planes [hi at 0 | mid at a_mid / b_mid] of the fp32 values,
+ * laid out k' = s * C + c (cell-major; odw_split_rows_cm writes it, odw_roi_pool_stack_forward_nhwc_f32 can); the three
+ * plane products hi.hi + hi.mid + mid.hi are summed.  keep == NULL: Cout (M x N fp32) = epilogue(A B^T) with the
+ * epilogue arguments of odw_gemm_nt_bf16_ws (workspace: odw_gemm_nt_cm_workspace(M, N, S) bytes lets small M split
+ * the reduction over cells).  keep (M x S floats, 0 = dropped) + keep_sum (device scalar): rows [0, M) of Cout get
+ * the clean result and rows [drop_row0, drop_row0 + M) the result for x * keep * (M S / keep_sum), both from ONE
+ * sweep over A (summation by parts over the cells, csrc/gemm_bf16.hip); dropout then takes two segments
+ * (rows 0 and drop_row0). */
+int64_t odw_gemm_nt_cm_workspace(int M, int N, int S);
+int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, int ldb, int b_mid, int M, int N, int C, int S,
+                   const float* keep, const float* keep_sum, int drop_row0, float* Cout, int ldc, const float* bias,
+                   int relu, float drop_p, int nseg, const int* seg_rows, const uint32_t* seg_keys, const int* row_ids,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+/* fp32 rows (R x C*S, k = c * S + s: the reference's flattening of (C, 7, 7)) -> the two cell-major planes above:
+ * out[r][s * C + c] = hi, out[r][mid_off + s * C + c] = mid.  C % 64 == 0, S <= 64. */
+int odw_split_rows_cm(const float* in, int64_t ld_in, int R, int C, int S, void* out, int64_t ld_out, int64_t mid_off,
+                      void* stream);
 /* Which kernel odw_gemm_nt_bf16 will launch for this product: 0 register-staged 128x128, 1 LDS-DMA 128x128,
  * 2 LDS-DMA 256x128 ring, 3 256x256 (per-kernel timing in bench.py names its roofline entry from this). */
 int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc, int c_is_bf16);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "odw_roi_pool_stack_nhwc_f32_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "odw_roi_pool_stack_forward_nhwc_f32": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_p,
                                                   c_p, c_p, c_l, c_p]),
+    "odw_roi_pool_stack_forward_nhwc_f32_cm": (c_i, [c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_p,
+                                                     c_p, c_p, c_l, c_l, c_p, c_l, c_p]),
     "odw_roi_pool_stack_backward": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                           c_i, c_p, c_p]),
     "odw_roi_pool_stack_backward_ws": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
@@ -69,6 +71,10 @@ SIGNATURES = {
     "odw_l2norm_rows": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
     "odw_l2norm_rows_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     "odw_gemm_nt_bf16_variant": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i]),
+    "odw_gemm_nt_cm_workspace": (c_l, [c_i, c_i, c_i]),
+    "odw_gemm_nt_cm": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_f, c_i, c_p,
+                             c_p, c_p, c_p, c_l, c_p]),
+    "odw_split_rows_cm": (c_i, [c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_p]),
     "odw_gemm_nt_bf16_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "odw_gemm_nt_bf16_ws": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_f, c_f, c_i, c_p, c_p, c_p,
                                   c_i, c_p, c_l, c_p]),

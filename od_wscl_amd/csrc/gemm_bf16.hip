@@ -579,6 +579,135 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
     }
 }
 
+// ---- the first head Linear over CELL-MAJOR planes, clean + DropBlock outputs from ONE pass (round 4) ----------------
+// ROIWeakRegHead evaluates fc6 on the pooled features and on their DropBlock view (weak_head.py:107-112); DropBlock
+// zeroes whole cells of a ROI's 7 x 7 grid for every channel and rescales by a global factor (drop_block.py:38-50):
+//     y_clean[r] =      sum_s  P_s[r],                P_s[r] = sum_c x[r][c][s] W[.][c][s]   (the cell's partial product)
+//     y_drop[r]  = g * sum_s keep[r][s] P_s[r]
+// Rounds 1-3 ran the two as one stacked product (M = 2P): every P_s was computed twice.  Here the reduction walks the
+// cells in order (operands laid out k' = s * C + c: split.hip split_rows_cm_kernel, roi_pool.hip), the wave keeps the
+// RUNNING sum A_s = P_0 + ... + P_s in its MFMA accumulators -- which is y_clean at the end -- and a second register
+// set D that is touched only at the 49 cell boundaries:
+//     sum_s keep_s (A_s - A_{s-1})  =  sum_s A_s (keep_s - keep_{s+1}),   keep_S = 0         (summation by parts)
+// i.e. D += (keep_s - keep_{s+1}) * A after cell s, a coefficient in {-1, 0, 1} per ROI: 64 FMAs per wave and cell
+// against 3 x 8 K tiles of 16 MFMAs.  Half the matrix-core work of the stacked pass, and the DropBlock half of the
+// stacked operand is not read.  The two STORED planes [hi | mid] of each operand meet as the three products of
+// precision.py's "bf16x2f" (hi.hi, hi.mid, mid.hi) through the K-tile map below -- no duplicated hi plane.
+// Tile / ring / DMA as gemm_nt_bf16_ring_kernel (64 x 64 per wave: 64 + 64 accumulator registers).  keep == null: the
+// plain product over the same layout (the sampled-row views of the contrastive loss), optionally split over cells.
+struct CmArgs {
+    int C, S;                   // K = S cells x C channels per plane; C % 64 == 0, S <= 64
+    int a_mid, b_mid;           // element offset of the mid plane inside a row of A / B (the hi plane starts at 0)
+    const float* keep;          // (M x S) DropBlock keep mask, or null
+    const float* keep_sum;      // its sum (device scalar): g = M * S / sum
+    int drop_row0;              // first row of C of the DropBlock half (>= M)
+};
+
+template <bool PAIR>
+__global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_cm_kernel(
+    const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
+    void* __restrict__ Cv, int ldc, Epilogue ep, CmArgs cm, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [stage][A 256 rows | B 128 rows]
+    int cell_lo = 0, cell_hi = cm.S;
+    if (ep.kchunk > 0) {                                              // split over cells (plain mode)
+        cell_lo = blockIdx.y * ep.kchunk;
+        cell_hi = cell_lo + ep.kchunk < cm.S ? cell_lo + ep.kchunk : cm.S;
+        Cv = reinterpret_cast<char*>(Cv) + (long long)blockIdx.y * ep.split_stride;
+    }
+    int tm, tn;
+    tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
+    const int m0 = tm * RM, n0 = tn * RN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;            // 4 x 2 waves, 64 x 64 each
+    const int half = lane >> 5, l31 = lane & 31;
+    const int mw = m0 + wm * 64;
+
+    f32x16 acc[2][2], dacc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            dacc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    // the lane's two ROIs (transposed accumulators: lane & 31 = row) and their keep masks as bit sets
+    unsigned long long kbits[2] = {0ull, 0ull};
+    if (PAIR) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = mw + i * 32 + l31;
+            r = r < M ? r : M - 1;
+            const float* kr = cm.keep + (size_t)r * cm.S;
+            for (int s = 0; s < cm.S; ++s) kbits[i] |= (unsigned long long)(kr[s] != 0.0f) << s;
+        }
+    }
+
+    const int ntc = cm.C / BK, per_cell = 3 * ntc;      // K tiles per plane product of a cell, per cell
+    const int nk = (cell_hi - cell_lo) * per_cell;
+    // K tile kt -> (cell, product p, channel tile): A reads planes [hi hi mid], B reads [hi mid hi]
+    auto issue = [&](int kt, uint4* slot) {
+        const int cell = cell_lo + kt / per_cell, rem = kt % per_cell, p = rem / ntc, ct = rem - p * ntc;
+        const int base = cell * cm.C + ct * BK;
+        dma_rows<32>(A, lda, M, m0, base + (p == 2 ? cm.a_mid : 0), slot, wave, lane);
+        dma_rows<16>(B, ldb, N, n0, base + (p == 1 ? cm.b_mid : 0), slot + RM * kChunksPerRow, wave, lane);
+    };
+    if (nk > 0) issue(0, lds);
+    if (nk > 1) issue(1, lds + kRingStageChunks);
+    int in_cell = 0, cell = cell_lo;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2, lds + (size_t)((kt + 2) % kRingStages) * kRingStageChunks);
+        const uint4* sa = lds + (size_t)(kt % kRingStages) * kRingStageChunks;
+        const uint4* sb = sa + RM * kChunksPerRow;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int c = kk * 2 + half;
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[lds_slot(wm * 64 + i * 32 + l31, c)]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)       // operands swapped: transposed accumulators for band_store
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (++in_cell == per_cell) {              // the cell is complete: summation by parts
+            if (PAIR) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int cur = (int)((kbits[i] >> cell) & 1ull);
+                    const int nxt = cell + 1 < cell_hi ? (int)((kbits[i] >> (cell + 1)) & 1ull) : 0;
+                    const float coef = (float)(cur - nxt);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dacc[i][j][r] = fmaf(coef, acc[i][j][r], dacc[i][j][r]);
+                }
+            }
+            in_cell = 0;
+            ++cell;
+        }
+    }
+    auto rowmap = [&](int r) -> long long { return mw + r < M ? (long long)(mw + r) : -1ll; };
+    auto rowmap_d = [&](int r) -> long long { return mw + r < M ? (long long)(cm.drop_row0 + mw + r) : -1ll; };
+    Epilogue epd = ep;
+    if (PAIR) epd.alpha = ep.alpha * ((float)((double)M * cm.S) / *cm.keep_sum);
+    if (band_store_ok(Cv, ldc, N, 4)) {           // workgroup-uniform
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // every wave is done with the operand tiles
+        band_store<false, 2>(acc, Cv, ldc, N, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds), rowmap);
+        if (PAIR) band_store<false, 2>(dacc, Cv, ldc, N, n0 + wn * 64, wave, lane, epd, reinterpret_cast<char*>(lds), rowmap_d);
+    } else {
+        band_store_scalar<false, 2>(acc, Cv, ldc, N, n0 + wn * 64, lane, ep, rowmap);
+        if (PAIR) band_store_scalar<false, 2>(dacc, Cv, ldc, N, n0 + wn * 64, lane, epd, rowmap_d);
+    }
+}
+
 // ---- 256x256 tile, 8 waves of 128x64 ---------------------------------------------------------
 // The ring kernel is bound by operand delivery, not by MFMA issue (PMC: matrix cores busy 48 %, waves
 // parked on vmcnt/barrier 38 %): a 64x64 wave tile reads 4 KB of LDS per 4 MFMAs and a 256x128 block
@@ -1851,6 +1980,89 @@ int tail_columns(int M, int N, int K, int lda, int ldb, const void* C, int ldc, 
 }
 
 }  // namespace
+
+// ---- cell-major plane GEMM (gemm_nt_cm_kernel) ---------------------------------------------------------------------
+static int cm_cells_per_split(int M, int N, int S, bool allow) {
+    const long tiles = (long)((M + RM - 1) / RM) * ((N + RN - 1) / RN);
+    if (!allow || tiles >= 160) return 0;                      // one pass
+    long want = 384 / tiles;                                   // ~1.5 workgroups per CU over the splits
+    want = want < 1 ? 1 : (want > 16 ? 16 : want);
+    const int kc = (int)((S + want - 1) / want);
+    return (S + kc - 1) / kc > 1 ? kc : 0;
+}
+
+ODW_EXPORT int64_t odw_gemm_nt_cm_workspace(int M, int N, int S) {
+    const int kc = cm_cells_per_split(M, N, S, true);
+    if (kc == 0) return 0;
+    return (int64_t)((S + kc - 1) / kc) * M * ((N + 3) / 4 * 4) * 4;
+}
+
+ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, int ldb, int b_mid, int M, int N, int C, int S,
+                              const float* keep, const float* keep_sum, int drop_row0, float* Cout, int ldc,
+                              const float* bias, int relu, float drop_p, int nseg, const int* seg_rows,
+                              const uint32_t* seg_keys, const int* row_ids, void* workspace, int64_t workspace_bytes,
+                              void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(M >= 0 && N >= 0 && C > 0 && C % BK == 0 && S >= 1 && S <= 64, "gemm_nt_cm: bad dims M=%d N=%d C=%d S=%d", M, N, C, S);
+    if (M == 0 || N == 0) return ODW_OK;
+    const long long K = (long long)C * S;
+    ODW_REQUIRE(A && B && Cout, "gemm_nt_cm: null pointer");
+    ODW_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0 && a_mid % 8 == 0 &&
+                b_mid % 8 == 0 && a_mid >= K && b_mid >= K && (long long)a_mid + K <= lda && (long long)b_mid + K <= ldb,
+                "gemm_nt_cm: planes [hi | mid] of %lld elements each must fit the rows (lda=%d a_mid=%d ldb=%d b_mid=%d)",
+                K, lda, a_mid, ldb, b_mid);
+    ODW_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && nseg >= 0 && nseg <= kMaxSeg, "gemm_nt_cm: bad dropout args");
+    ODW_REQUIRE(!keep || (keep_sum && drop_row0 >= M && !row_ids), "gemm_nt_cm: the pair form needs keep_sum, drop_row0 >= M, no row_ids");
+    Epilogue ep;
+    ep.bias = bias; ep.relu = relu; ep.drop_p = drop_p; ep.nseg = nseg; ep.accumulate = 0; ep.alpha = 1.0f;
+    ep.mask = nullptr; ep.ldmask = 0; ep.kchunk = 0; ep.split_stride = 0; ep.row_ids = row_ids; ep.pm = 0;
+    for (int i = 0; i < kMaxSeg; ++i) {
+        ep.seg_row[i] = (i < nseg && seg_rows) ? seg_rows[i] : 0;
+        ep.seg_k0[i] = (i < nseg && seg_keys) ? seg_keys[2 * i] : 0;
+        ep.seg_k1[i] = (i < nseg && seg_keys) ? seg_keys[2 * i + 1] : 0;
+    }
+    if (drop_p > 0.0f) ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_cm: dropout needs row segments starting at 0");
+    if (keep && drop_p > 0.0f) ODW_REQUIRE(nseg == 2 && seg_rows[1] == drop_row0, "gemm_nt_cm: the pair form takes two dropout segments (clean rows, DropBlock rows)");
+    CmArgs cm;
+    cm.C = C; cm.S = S; cm.a_mid = a_mid; cm.b_mid = b_mid; cm.keep = keep; cm.keep_sum = keep_sum; cm.drop_row0 = drop_row0;
+    const int tiles_m = (M + RM - 1) / RM, tiles_n = (N + RN - 1) / RN;
+    const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
+    if (keep) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds);
+        ODW_CHECK_HIP(attr, "gemm_nt_cm attr");
+        gemm_nt_cm_kernel<true><<<tiles_m * tiles_n, kRingThreads, ring_lds, stream>>>(
+            (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, Cout, ldc, ep, cm, tiles_m, tiles_n);
+        ODW_CHECK_LAUNCH("gemm_nt_cm_kernel<pair>");
+        return ODW_OK;
+    }
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<false>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds);
+    ODW_CHECK_HIP(attr, "gemm_nt_cm attr");
+    const int ldw = (N + 3) / 4 * 4;
+    int kc = cm_cells_per_split(M, N, S, workspace != nullptr);
+    if (kc > 0 && workspace_bytes < (int64_t)((S + kc - 1) / kc) * M * ldw * 4) kc = 0;
+    if (kc > 0) {
+        ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "gemm_nt_cm: workspace must be 16-byte aligned");
+        const int splits = (S + kc - 1) / kc;
+        Epilogue pe = ep;
+        pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.row_ids = nullptr;
+        pe.kchunk = kc; pe.split_stride = (long long)M * ldw * 4;
+        gemm_nt_cm_kernel<false><<<dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), kRingThreads, ring_lds, stream>>>(
+            (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, workspace, ldw, pe, cm, tiles_m, tiles_n);
+        ODW_CHECK_LAUNCH("gemm_nt_cm_kernel<split>");
+        const long long quads = (long long)M * (ldw / 4);
+        const int rblocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+        splitk_reduce_kernel<false><<<rblocks, 256, 0, stream>>>((const float*)workspace, splits, (long long)M * ldw, M, N, ldw,
+                                                                  Cout, ldc, ep);
+        ODW_CHECK_LAUNCH("splitk_reduce_kernel");
+        return ODW_OK;
+    }
+    gemm_nt_cm_kernel<false><<<tiles_m * tiles_n, kRingThreads, ring_lds, stream>>>(
+        (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, Cout, ldc, ep, cm, tiles_m, tiles_n);
+    ODW_CHECK_LAUNCH("gemm_nt_cm_kernel");
+    return ODW_OK;
+}
 
 ODW_EXPORT int odw_gemm_nt_bf16_variant(int M, int N, int K, int lda, int ldb, const void* C, int ldc,
                                         int c_is_bf16) {

@@ -617,7 +617,9 @@ __global__ __launch_bounds__(512) void roi_pool_stack_fwd_nhwc_f32(const unsigne
                                                                    const float* __restrict__ keep_sum, odwpl::Pattern pat,
                                                                    unsigned short* __restrict__ X, long long ld, int block,
                                                                    float* __restrict__ pooled,
-                                                                   unsigned short* __restrict__ argmax) {
+                                                                   unsigned short* __restrict__ argmax,
+                                                                   unsigned short* __restrict__ X_cm, long long ld_cm,
+                                                                   long long cm_mid) {
     __shared__ __attribute__((aligned(16))) float s_val[64 * 49];
     __shared__ __attribute__((aligned(16))) unsigned short s_arg[64 * 49];
     __shared__ float s_keep[49];
@@ -703,6 +705,18 @@ __global__ __launch_bounds__(512) void roi_pool_stack_fwd_nhwc_f32(const unsigne
                               : (p == 2 ? make_uint4(lo[0], lo[1], lo[2], lo[3]) : make_uint4(0, 0, 0, 0)));
                 *reinterpret_cast<uint4*>(dst + (size_t)t * block) = o;
             }
+        }
+        // the clean rows once more as the two CELL-MAJOR planes [hi | mid] (k' = bin * C + c) the shared clean + DropBlock
+        // fc6 forward reads (gemm_bf16.hip: gemm_nt_cm_kernel): 8 lanes = 64 channels of one bin = one 128-byte line
+        if (X_cm) {
+            const int cbin = threadIdx.x >> 3, cg2 = threadIdx.x & 7;
+            unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                odwpl::split2(s_val[(cg2 * 8 + 2 * j) * 49 + cbin], s_val[(cg2 * 8 + 2 * j + 1) * 49 + cbin], false, hi[j], mid[j], lo[j]);
+            unsigned short* dst = X_cm + (size_t)n * ld_cm + (size_t)cbin * C + c0 + cg2 * 8;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(dst + cm_mid) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
         }
     }
 }
@@ -1118,7 +1132,21 @@ ODW_EXPORT int odw_roi_pool_stack_forward_nhwc_f32(const float* feat_nhwc, const
                                                    const int* pattern, int T, void* X_planes, int64_t ld, int block,
                                                    float* pooled_f32, void* argmax_u16, void* workspace,
                                                    int64_t workspace_bytes, void* stream_) {
+    return odw_roi_pool_stack_forward_nhwc_f32_cm(feat_nhwc, rois, spatial_scale, B, C, H, W, R, keep, keep_sum, pattern, T,
+                                                  X_planes, ld, block, pooled_f32, argmax_u16, nullptr, 0, 0, workspace,
+                                                  workspace_bytes, stream_);
+}
+
+ODW_EXPORT int odw_roi_pool_stack_forward_nhwc_f32_cm(const float* feat_nhwc, const float* rois, float spatial_scale, int B,
+                                                      int C, int H, int W, int R, const float* keep, const float* keep_sum,
+                                                      const int* pattern, int T, void* X_planes, int64_t ld, int block,
+                                                      float* pooled_f32, void* argmax_u16, void* X_cm, int64_t ld_cm,
+                                                      int64_t cm_mid, void* workspace, int64_t workspace_bytes,
+                                                      void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(!X_cm || ((((uintptr_t)X_cm) & 15) == 0 && cm_mid % 8 == 0 && cm_mid >= (int64_t)C * 49 && ld_cm % 8 == 0 &&
+                          ld_cm >= cm_mid + (int64_t)C * 49),
+                "roi_pool_stack_forward_nhwc_f32: cell-major planes: alignment / ld / mid offset");
     odwpl::Pattern pat;
     ODW_REQUIRE(odwpl::pattern_ok(pattern, T, pat), "roi_pool_stack_forward_nhwc_f32: pattern = up to %d plane codes in 0..3", odwpl::kMaxTerms);
     ODW_REQUIRE(B >= 1 && C > 0 && C % 64 == 0 && H > 0 && W > 0 && R >= 0, "roi_pool_stack_forward_nhwc_f32: bad dims (C %% 64)");
@@ -1146,13 +1174,16 @@ ODW_EXPORT int odw_roi_pool_stack_forward_nhwc_f32(const float* feat_nhwc, const
     const dim3 grid((unsigned)R, (unsigned)(C / 64));
     if (fly == 4)
         roi_pool_stack_fwd_nhwc_f32<4><<<grid, 512, 0, stream>>>(ordmap, tab, C, H, W, R, keep, keep_sum, pat, (unsigned short*)X_planes,
-                                                                 (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16);
+                                                                 (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16,
+                                                                 (unsigned short*)X_cm, (long long)ld_cm, (long long)cm_mid);
     else if (fly == 1)
         roi_pool_stack_fwd_nhwc_f32<1><<<grid, 512, 0, stream>>>(ordmap, tab, C, H, W, R, keep, keep_sum, pat, (unsigned short*)X_planes,
-                                                                 (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16);
+                                                                 (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16,
+                                                                 (unsigned short*)X_cm, (long long)ld_cm, (long long)cm_mid);
     else
         roi_pool_stack_fwd_nhwc_f32<2><<<grid, 512, 0, stream>>>(ordmap, tab, C, H, W, R, keep, keep_sum, pat, (unsigned short*)X_planes,
-                                                                 (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16);
+                                                                 (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16,
+                                                                 (unsigned short*)X_cm, (long long)ld_cm, (long long)cm_mid);
     ODW_CHECK_LAUNCH("roi_pool_stack_fwd_nhwc_f32");
     return ODW_OK;
 }

@@ -185,6 +185,44 @@ bool pattern_ok(const int* pattern, int T, Pattern& pat) {
     return true;
 }
 
+// ---- cell-major planes of an operand of the first head Linear (round 4) ---------------------------------------------
+// fc6 reduces over k = c * S + s (channel-major: the reference flattens (C, 7, 7), vgg16.py:121).  The shared clean +
+// DropBlock forward (gemm_bf16.hip: gemm_nt_cm_kernel) walks the reduction CELL by cell -- the DropBlock mask zeroes
+// whole cells of a ROI -- so its operands hold k' = s * C + c, as TWO stored planes [hi | mid] (the kernel's K-tile map
+// reads hi twice: the three products hi.hi + hi.mid + mid.hi of precision.py without a duplicated hi plane).
+// One workgroup = (row, 64 channels): 64 * S consecutive floats in (coalesced), S runs of 64 bf16 = 128 bytes out per plane.
+__global__ __launch_bounds__(512) void split_rows_cm_kernel(const float* __restrict__ in, long long ld_in, int C, int S,
+                                                            unsigned short* __restrict__ out, long long ld_out,
+                                                            long long mid_off) {
+    __shared__ __attribute__((aligned(16))) float s_val[64 * 64];
+    const int r = blockIdx.x, c0 = blockIdx.y * 64;
+    const float* src = in + (long long)r * ld_in + (long long)c0 * S;
+    const int n4 = 16 * S;                                 // 64 * S / 4
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        for (int i = threadIdx.x; i < n4; i += 512)
+            reinterpret_cast<float4*>(s_val)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < 64 * S; i += 512) s_val[i] = src[i];
+    }
+    __syncthreads();
+    const int bin = threadIdx.x >> 3, cg = threadIdx.x & 7;
+    if (bin >= S) return;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = s_val[(cg * 8 + j) * S + bin];
+    unsigned hi[4], mid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = pk(v[2 * j], v[2 * j + 1]);
+        const float r0 = finite_or_zero(v[2 * j], v[2 * j] - __uint_as_float(hi[j] << 16));
+        const float r1 = finite_or_zero(v[2 * j + 1], v[2 * j + 1] - __uint_as_float(hi[j] & 0xffff0000u));
+        mid[j] = pk(r0, r1);
+    }
+    unsigned short* dst = out + (long long)r * ld_out + (long long)bin * C + c0 + cg * 8;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(dst + mid_off) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+}
+
 }  // namespace
 
 ODW_EXPORT int odw_split_rows_bf16(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
@@ -201,6 +239,19 @@ ODW_EXPORT int odw_split_rows_bf16(const float* in, int64_t ld_in, int R, int Cc
     split_rows_kernel<<<(int)(blocks > 65536 ? 65536 : blocks), 256, 0, (hipStream_t)stream_>>>(
         in, ld_in, R, Cc, pat, (unsigned short*)out, ld_out, block);
     ODW_CHECK_LAUNCH("split_rows_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_split_rows_cm(const float* in, int64_t ld_in, int R, int C, int S, void* out, int64_t ld_out,
+                                 int64_t mid_off, void* stream_) {
+    ODW_REQUIRE(R >= 0 && C > 0 && C % 64 == 0 && S >= 1 && S <= 64 && ld_in >= (int64_t)C * S && mid_off >= (int64_t)C * S &&
+                mid_off % 8 == 0 && ld_out >= mid_off + (int64_t)C * S && ld_out % 8 == 0,
+                "split_rows_cm: bad dims R=%d C=%d S=%d", R, C, S);
+    if (R == 0) return ODW_OK;
+    ODW_REQUIRE(in && out && (((uintptr_t)out) & 15) == 0, "split_rows_cm: pointers");
+    split_rows_cm_kernel<<<dim3((unsigned)R, (unsigned)(C / 64)), 512, 0, (hipStream_t)stream_>>>(
+        in, ld_in, C, S, (unsigned short*)out, ld_out, mid_off);
+    ODW_CHECK_LAUNCH("split_rows_cm_kernel");
     return ODW_OK;
 }
 

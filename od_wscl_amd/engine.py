@@ -265,8 +265,12 @@ class FlatSGD(object):
             mode = precision.get_precision()
             single_bwd = not precision.bwd_split()      # "bf16" / "bf16x2f": the backward reads one bf16 plane of W
 
-            def managed_shadow(weight, o):
+            def managed_shadow(weight, o, cm=None):
                 sh = gemm.Shadow(weight)
+                if cm is not None and mode == "bf16x2f" and os.environ.get("ODW_NO_PAIR") != "1":
+                    # the first head Linear: also as cell-major planes [hi | mid] for the shared clean + DropBlock forward
+                    sh.cm = tuple(cm)
+                    sh.w_cm = torch.empty((weight.shape[0], 2 * weight.shape[1]), dtype=torch.bfloat16, device=dev)
                 n_out, k_in = weight.shape
                 r64 = lambda v: (v + 63) // 64 * 64
                 if single_bwd:      # W (bf16) is a slice of the flat shadow the SGD kernel rewrites, W^T refreshed in place
@@ -297,7 +301,8 @@ class FlatSGD(object):
             for n, p in gemm_w:
                 if id(p) in pred_ids:
                     continue
-                model.get_submodule(n.rsplit(".", 1)[0])._shadow = managed_shadow(p, self.slices[n][0])
+                mod = model.get_submodule(n.rsplit(".", 1)[0])
+                mod._shadow = managed_shadow(p, self.slices[n][0], getattr(mod, "cm_layout", None))
             if pred_w:
                 ow, nw = self.slices[name_of[id(pred_w[0])]][0], sum(p.numel() for p in pred_w)
                 ob, nb = self.slices[name_of[id(pred_b[0])]][0], sum(p.numel() for p in pred_b)
@@ -326,6 +331,8 @@ class FlatSGD(object):
             else:                           # "bf16x2f": W^T from the refreshed bf16 plane, forward planes from the master
                 gemm.transpose_bf16(sh.w16, n, k, out=sh.wt)
                 precision.split_rows(sh.weight.detach(), precision.patterns("gemm")[1], (k + 63) // 64 * 64, out=sh.w)
+                if sh.cm is not None:
+                    gemm.split_rows_cm(sh.weight.detach(), sh.cm[0], sh.cm[1], out=sh.w_cm)
 
     @staticmethod
     def _is_gemm_weight(model, name, p):

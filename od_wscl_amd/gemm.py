@@ -78,6 +78,45 @@ def transpose_bf16(x, rows, cols, out=None):
     return out
 
 
+def split_rows_cm(x, C, S, out=None):
+    """x (R, C*S) fp32, k = c*S + s (the reference's flattening of (C, 7, 7)) -> (R, 2*C*S) bf16: the two cell-major planes
+    [hi | mid], k' = s*C + c (csrc/split.hip: split_rows_cm_kernel)."""
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] == C * S
+    R, K = x.shape
+    if out is None:
+        out = torch.empty((R, 2 * K), dtype=torch.bfloat16, device=x.device)
+    assert out.shape == (R, 2 * K) and out.dtype == torch.bfloat16 and out.stride(1) == 1
+    L.check(L.lib().odw_split_rows_cm(L.ptr(x), x.stride(0), R, C, S, L.ptr(out), out.stride(0), K, L.stream()), "split_rows_cm")
+    return out
+
+
+def gemm_nt_cm(a_cm, b_cm, M, N, C, S, out, bias=None, relu=False, drop_p=0.0, segs=None, row_ids=None, keep=None,
+               keep_sum=None, drop_row0=0):
+    """out = epilogue(A B^T) over cell-major planes [hi | mid] (three plane products, csrc/gemm_bf16.hip: gemm_nt_cm_kernel).
+    keep (M x S) given: the PAIR form -- rows [0, M) the clean product, rows [drop_row0, drop_row0 + M) the product for
+    x * keep * (M S / keep_sum), from one sweep."""
+    L.need_gpu(a_cm, b_cm, out)
+    K = C * S
+    assert a_cm.dtype == torch.bfloat16 and b_cm.dtype == torch.bfloat16 and out.dtype == torch.float32
+    assert a_cm.shape[1] == 2 * K and b_cm.shape[1] == 2 * K and a_cm.stride(1) == 1 and b_cm.stride(1) == 1 and out.stride(1) == 1
+    nseg = len(segs) if segs else 0
+    assert nseg <= MAX_SEGS
+    rows = (ctypes.c_int * 4)(*([s[0] for s in segs] + [0] * (4 - nseg))) if nseg else None
+    keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
+    pair = keep is not None
+    ws_bytes = 0 if pair else L.lib().odw_gemm_nt_cm_workspace(M, N, S)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device) if ws_bytes else None
+    sym = "gemm_nt_cm_kernel<%s>%s" % ("true" if pair else "false", " split+reduce" if ws_bytes else "")
+    with kernel_timer.region(sym, flops=2.0 * M * N * 3 * K * (2 if pair else 1)):      # (pair: the stacked pass's count)
+        L.check(L.lib().odw_gemm_nt_cm(L.ptr(a_cm), a_cm.stride(0), K, L.ptr(b_cm), b_cm.stride(0), K, M, N, C, S,
+                                       L.ptr(keep), L.ptr(keep_sum), drop_row0, L.ptr(out), out.stride(0), L.ptr(bias),
+                                       1 if relu else 0, float(drop_p), nseg,
+                                       ctypes.cast(rows, ctypes.c_void_p) if nseg else None,
+                                       ctypes.cast(keys, ctypes.c_void_p) if nseg else None, L.ptr(row_ids),
+                                       L.ptr(ws), ws_bytes, L.stream()), "gemm_nt_cm")
+    return out
+
+
 class Shadow(object):
     """bf16 copies of one fp32 weight the matrix cores read: w (N x K) for the forward product and wt (K x r64(N))
     for the input gradient.  In a split precision mode (precision.py) the same matrices as bf16 planes along the
@@ -95,6 +134,8 @@ class Shadow(object):
         self.wt = None
         self.managed = False      # True: the optimiser refreshes w / wt itself (engine.FlatSGD)
         self.batch = None         # gemm.WgradBatch: one weight-gradient GEMM per step over all evaluations
+        self.cm = None            # (C, S): the weight is ALSO kept as cell-major planes w_cm (N x 2K: [hi | mid], k' = s*C + c)
+        self.w_cm = None          # for the shared clean + DropBlock forward of the first head Linear (pair_linear)
 
     def build(self, w_out=None, wt_out=None):
         """(Re)build w / wt from the fp32 master in the current mode (into the given buffers when they fit)."""
@@ -111,6 +152,8 @@ class Shadow(object):
             else:
                 self.w = to_bf16(wd)
                 self.wt = transpose_bf16(wd, n, k, out=wt_out)
+            if self.cm is not None and P.get_precision() == "bf16x2f":
+                self.w_cm = split_rows_cm(wd, self.cm[0], self.cm[1], out=self.w_cm)
         self.version = w._version
         self.mode = P.get_precision()
 
@@ -481,6 +524,59 @@ class _MixedLinear(torch.autograd.Function):
         if dx is not None and x_dtype != torch.float32:
             dx = dx.to(x_dtype)
         return dx, dw, None, None, None, None, None, None, None, None, None, None
+
+
+class _PairLinear(torch.autograd.Function):
+    """fc6 of the clean AND the DropBlock pass of ROIWeakRegHead.forward (weak_head.py:107-112) from ONE sweep over the
+    clean operand ("bf16x2f"; csrc/gemm_bf16.hip: gemm_nt_cm_kernel): y (2P x N) = [clean rows; DropBlock rows], the values
+    of the stacked evaluation it replaces (other summation order).  x is the autograd handle of the stacked (2P x K)
+    operand; planes_cm (P x 2K) the clean rows as cell-major planes, planes_bwd (2P x K) bf16 the hi plane of both
+    halves in the reference's order -- what the single-plane backward reads (= _MixedLinear's)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, shadow, planes_cm, planes_bwd, keep, keep_sum, relu, drop_p, segs, timer_tag, grad_rows,
+                grad_mode):
+        sh = shadow.refresh()
+        if sh.cm is None or sh.w_cm is None:
+            raise RuntimeError("pair_linear: this weight keeps no cell-major planes (gemm.Shadow.cm)")
+        C, S = sh.cm
+        M2, K = x.shape
+        Pn = M2 // 2
+        N = weight.shape[0]
+        assert planes_cm.shape == (Pn, 2 * K) and planes_bwd.shape[0] == M2 and planes_bwd.shape[1] >= K and K == C * S
+        assert keep.numel() == Pn * S and keep.dtype == torch.float32 and keep.is_contiguous()
+        assert segs is None or (len(segs) == 2 and segs[0][0] == 0 and segs[1][0] == Pn)
+        y = torch.empty((M2, N), dtype=torch.float32, device=x.device)
+        kernel_timer.layer = timer_tag and timer_tag + "_fwd"
+        gemm_nt_cm(planes_cm, sh.w_cm, Pn, N, C, S, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs, keep=keep,
+                   keep_sum=keep_sum, drop_row0=Pn)
+        kernel_timer.layer = None
+        ctx.save_for_backward(planes_bwd[:, :K], y if (relu or drop_p > 0) else None, weight, bias)
+        slot = None
+        batch = getattr(sh, "batch", None)
+        if batch is not None and weight.is_leaf and weight.requires_grad and grad_mode:
+            slot = batch.register((grad_rows[1] - grad_rows[0]) if grad_rows is not None else M2)
+        ctx.cfg = (sh, relu, drop_p, x.dtype, timer_tag, grad_rows, slot)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, y, weight, bias = ctx.saved_tensors
+        sh, relu, drop_p, x_dtype, tag, grad_rows, slot = ctx.cfg
+        cfg = (sh, relu, drop_p, torch.float32, tag, grad_rows, slot)
+        dx, dw = _backward_single_plane(x16, y, weight, bias, cfg, dy, ctx.needs_input_grad[0])
+        if dx is not None and x_dtype != torch.float32:
+            dx = dx.to(x_dtype)
+        return (dx, dw) + (None,) * 12
+
+
+def pair_linear(x, weight, bias, shadow, planes_cm, planes_bwd, keep, keep_sum, relu=False, drop_p=0.0, segs=None, tag=None,
+                grad_rows=None):
+    """The clean + DropBlock evaluation of the first head Linear from one sweep (see _PairLinear); "bf16x2f" only."""
+    if P.get_precision() != "bf16x2f":
+        raise RuntimeError("pair_linear: precision mode %r (the shared forward exists for \"bf16x2f\")" % P.get_precision())
+    return _PairLinear.apply(x, weight, bias, shadow, planes_cm, planes_bwd, keep, keep_sum, relu, drop_p, segs, tag, grad_rows,
+                             torch.is_grad_enabled())
 
 
 class _ReuseLinear(torch.autograd.Function):

@@ -28,6 +28,30 @@ class Linear(nn.Linear):
                                  segs=segs if drop_p > 0 else None, out_f32=out_f32, tag=self.tag,
                                  grad_rows=grad_rows, row_ids=row_ids)
 
+    cm_layout = None       # (C, S): this layer reduces over a (C, S-cell) map flattened channel-major (the first head Linear)
+
+    def can_pair(self, C, S):
+        """The shared clean + DropBlock forward applies: the layer reduces over (C, S) and -- when an optimiser keeps its
+        bf16 copies (engine.FlatSGD) -- that optimiser also keeps the cell-major planes."""
+        if self.cm_layout is None or tuple(self.cm_layout) != (C, S) or C % 64 != 0 or S > 64:
+            return False
+        sh = self._shadow
+        return sh is None or sh.weight is not self.weight or not sh.managed or sh.w_cm is not None
+
+    def pair(self, x, planes_cm, planes_bwd, keep, keep_sum, relu=False, drop_p=0.0, segs=None, grad_rows=None):
+        """dropout(relu(.)) of the clean rows AND of their DropBlock view from one sweep over the clean operand
+        (gemm.pair_linear); x = the autograd handle of the stacked (2P x K) operand."""
+        if self._shadow is None or self._shadow.weight is not self.weight:
+            self._shadow = gemm.Shadow(self.weight)
+        if self._shadow.cm is None:
+            if self.cm_layout is None:
+                raise RuntimeError("Linear.pair: the layer has no cm_layout")
+            self._shadow.cm = tuple(self.cm_layout)
+            if not self._shadow.managed:
+                self._shadow.version = -1          # rebuild with the cell-major planes
+        return gemm.pair_linear(x, self.weight, self.bias, self._shadow, planes_cm, planes_bwd, keep, keep_sum, relu=relu,
+                                drop_p=drop_p, segs=segs, tag=self.tag, grad_rows=grad_rows)
+
     def reuse(self, x, y_full, rows, relu=False, drop_p=0.0):
         """Rows `rows` of an earlier no-autograd evaluation `y_full` of this layer, re-attached to the graph with `x` as
         their input (gemm.reuse_linear): backward as usual, no forward GEMM."""

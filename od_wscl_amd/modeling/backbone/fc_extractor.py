@@ -244,16 +244,20 @@ class _PoolStackPlanes(torch.autograd.Function):
     the handle is the autograd stand-in of the (2R x C*49) operand (gemm.planes_handle).  Backward = _PoolStack's."""
 
     @staticmethod
-    def forward(ctx, feat, nhwc32, rois5, keep, keep_sum, holder, scale, ph, pw):
+    def forward(ctx, feat, nhwc32, rois5, keep, keep_sum, holder, scale, ph, pw, pair=False):
+        """pair: the layout of the shared clean + DropBlock forward (gemm.pair_linear) -- `planes` carries only what the
+        backward reads (the hi plane of both halves, 2R x K) and a fourth result holds the clean rows as the two
+        cell-major planes (R x 2K) the forward sweeps: 4 plane-rows per ROI written instead of 6."""
         rois5 = rois5.contiguous().float()
         B, C, H, W = feat.shape
         R, nb = rois5.shape[0], ph * pw
         K = C * nb
-        pa, _ = precision.patterns("gemm")
+        pa = (0,) if pair else precision.patterns("gemm")[0]
         T, blk = len(pa), (K + 63) // 64 * 64
         planes = torch.empty((2 * R, T * blk), dtype=torch.bfloat16, device=feat.device)
         if blk != K:
             planes.zero_()                      # (never for C % 64 == 0 and 7 x 7: C*49 is then a multiple of 64)
+        planes_cm = torch.empty((R, 2 * K), dtype=torch.bfloat16, device=feat.device) if pair else None
         pooled32 = torch.empty((R, C, ph, pw), dtype=torch.float32, device=feat.device)
         argmax = torch.empty((R, K), dtype=torch.int16, device=feat.device)
         lib = L.lib()
@@ -261,21 +265,26 @@ class _PoolStackPlanes(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=feat.device)
         import ctypes
         pat = (ctypes.c_int * T)(*pa)
-        with kernel_timer.region("roi_pool_stack_fwd_nhwc_f32", nbytes=float(B * C * H * W * 4 + 2 * R * T * K * 2 + R * K * 6)):
-            L.check(lib.odw_roi_pool_stack_forward_nhwc_f32(L.ptr(nhwc32), L.ptr(rois5), scale, B, C, H, W, R, L.ptr(keep),
-                                                            L.ptr(keep_sum), ctypes.cast(pat, ctypes.c_void_p), T, L.ptr(planes),
-                                                            planes.stride(0), blk, L.ptr(pooled32), L.ptr(argmax), L.ptr(ws),
-                                                            ws_bytes, L.stream()), "roi_pool_stack_forward_nhwc_f32")
+        with kernel_timer.region("roi_pool_stack_fwd_nhwc_f32",
+                                 nbytes=float(B * C * H * W * 4 + 2 * R * T * K * 2 + (2 * R * K * 2 if pair else 0) + R * K * 6)):
+            L.check(lib.odw_roi_pool_stack_forward_nhwc_f32_cm(L.ptr(nhwc32), L.ptr(rois5), scale, B, C, H, W, R, L.ptr(keep),
+                                                               L.ptr(keep_sum), ctypes.cast(pat, ctypes.c_void_p), T, L.ptr(planes),
+                                                               planes.stride(0), blk, L.ptr(pooled32), L.ptr(argmax),
+                                                               L.ptr(planes_cm), 2 * K if pair else 0, K if pair else 0,
+                                                               L.ptr(ws), ws_bytes, L.stream()), "roi_pool_stack_forward_nhwc_f32")
         ctx.save_for_backward(rois5, keep, keep_sum, argmax)
         ctx.dims = (B, C, H, W, R, ph, pw)
         ctx.holder = holder
-        ctx.mark_non_differentiable(planes, pooled32)
         ctx.set_materialize_grads(False)            # (or autograd hands backward 800 MB of zeros for the two)
+        if pair:
+            ctx.mark_non_differentiable(planes, pooled32, planes_cm)
+            return gemm.planes_handle(feat.device, 2 * R, K), planes, pooled32, planes_cm
+        ctx.mark_non_differentiable(planes, pooled32)
         return gemm.planes_handle(feat.device, 2 * R, K), planes, pooled32
 
     @staticmethod
     def backward(ctx, dx, *unused):
-        return _PoolStack.backward(ctx, dx)
+        return _PoolStack.backward(ctx, dx) + (None,)
 
 
 def _keep_sum(block):
@@ -287,6 +296,7 @@ def _keep_sum(block):
 class TwoFCROIFeatureExtractor(nn.Module):
     Linear = Linear
     fc_index = (1, 4)              # positions of the two Linear layers inside self.classifier
+    pair_min_rois = 1400           # fewer ROIs: the stacked clean + DropBlock pass (measured cross-over)
 
     def __init__(self, config):
         super().__init__()
@@ -316,7 +326,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
     def fc7(self):
         return self.classifier[self.fc_index[1]]
 
-    def _fc(self, x, segs6=None, segs7=None, grad_rows=None, row_ids=None, keep=None):
+    def _fc(self, x, segs6=None, segs7=None, grad_rows=None, row_ids=None, keep=None, pair=None):
         """Linear, ReLU, Dropout, Linear, ReLU, Dropout (vgg16.py:121-127).  With a counter-based `rand`
         the two dropouts are fused into the GEMM epilogues; `segs*` carry per-pass keys when
         several passes are stacked along the row dimension."""
@@ -329,7 +339,10 @@ class TwoFCROIFeatureExtractor(nn.Module):
         if segs6 is None:
             k6, k7 = self.rand.key(), self.rand.key()
             segs6, segs7 = [(0, k6[0], k6[1])], [(0, k7[0], k7[1])]
-        x = fc6.fused(x, relu=True, drop_p=0.5, segs=segs6, grad_rows=grad_rows, row_ids=row_ids)
+        if pair is not None:        # (planes_cm, planes_bwd, DropBlock keep mask, its sum): clean + DropBlock rows from one sweep
+            x = fc6.pair(x, pair[0], pair[1], pair[2], pair[3], relu=True, drop_p=0.5, segs=segs6, grad_rows=grad_rows)
+        else:
+            x = fc6.fused(x, relu=True, drop_p=0.5, segs=segs6, grad_rows=grad_rows, row_ids=row_ids)
         if keep is not None:
             keep["h6"] = x.detach()
         return fc7.fused(x, relu=True, drop_p=0.5, segs=segs7, grad_rows=grad_rows, row_ids=row_ids)
@@ -431,11 +444,19 @@ class TwoFCROIFeatureExtractor(nn.Module):
             raise RuntimeError("the gradient of the previous step's sampled-row views was never folded")
         self._grad_holder = _GradHolder("extra")
         nhwc = getattr(feat, "_odw_nhwc", None) if os.environ.get("ODW_POOL_NHWC") != "0" else None
+        pair = None
         if precision.split_mode():
-            x, planes, pooled32 = _PoolStackPlanes.apply(feat, feat._odw_nhwc_f32, rois5, block.contiguous(), _keep_sum(block),
-                                                         self._grad_holder, float(self.pooler.poolers[0].spatial_scale),
-                                                         res[0], res[1])
+            # the shared clean + DropBlock fc6 forward (gemm.pair_linear): one workgroup per 256 ROIs x 128 outputs walks the
+            # whole reduction, so it pays once the ROIs fill the chip (the stacked pass splits its reduction instead)
+            use_pair = (precision.get_precision() == "bf16x2f" and os.environ.get("ODW_NO_PAIR") != "1"
+                        and P >= self.pair_min_rois and self.fc6.can_pair(feat.shape[1], res[0] * res[1]))
+            block_c, block_sum = block.contiguous(), _keep_sum(block)
+            out = _PoolStackPlanes.apply(feat, feat._odw_nhwc_f32, rois5, block_c, block_sum, self._grad_holder,
+                                         float(self.pooler.poolers[0].spatial_scale), res[0], res[1], use_pair)
+            x, planes, pooled32 = out[0], out[1], out[2]
             x._odw_planes, x._odw_pooled32 = planes, pooled32
+            if use_pair:
+                pair = (out[3], planes, block_c.view(P, -1), block_sum)
         else:
             x = _PoolStack.apply(feat, rois5, block.contiguous(), _keep_sum(block), self._grad_holder,
                                  float(self.pooler.poolers[0].spatial_scale), res[0], res[1], nhwc)
@@ -446,7 +467,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
         self._clean_keys = (k1, k2)
         keep = {} if self.sparse_clean else None
         h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5],
-                     grad_rows=(P, 2 * P, False) if self.sparse_clean else None, keep=keep)   # consumers skip the clean half:
+                     grad_rows=(P, 2 * P, False) if self.sparse_clean else None, keep=keep, pair=pair)   # consumers skip the clean half:
         self._grad_holder.clean_rows = 0 if self.sparse_clean else P                       # fc6's slices it, pooling below
         # the clean half's fc6 / fc7 outputs stay around: the rows the contrastive loss differentiates are re-attached
         # to the graph from them (reuse_clean_rows) instead of being evaluated a second time

@@ -85,6 +85,7 @@ class VGG16FC67ROIFeatureExtractor(TwoFCROIFeatureExtractor):
         self.classifier = nn.Sequential(nn.Identity(), Linear(512 * res * res, 4096), nn.ReLU(inplace=True),
                                         nn.Dropout(), Linear(4096, 4096), nn.ReLU(inplace=True), nn.Dropout())
         self.fc_index = (1, 4)
+        self.fc6.cm_layout = (512, res * res)      # fc6 reduces over (channel, cell): what the shared clean + DropBlock forward walks
         self.out_channels = 4096
         if init_weights:
             self.init_fc()
