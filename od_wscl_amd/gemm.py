@@ -107,7 +107,7 @@ def gemm_nt_cm(a_cm, b_cm, M, N, C, S, out, bias=None, relu=False, drop_p=0.0, s
     ws_bytes = 0 if pair else L.lib().odw_gemm_nt_cm_workspace(M, N, S)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device) if ws_bytes else None
     sym = "gemm_nt_cm_kernel<%s>%s" % ("true" if pair else "false", " split+reduce" if ws_bytes else "")
-    with kernel_timer.region(sym, flops=2.0 * M * N * 3 * K * (2 if pair else 1)):      # (pair: the stacked pass's count)
+    with kernel_timer.region(sym, flops=2.0 * M * N * 3 * K):      # MFMA work ISSUED (the pair form replaces twice that)
         L.check(L.lib().odw_gemm_nt_cm(L.ptr(a_cm), a_cm.stride(0), K, L.ptr(b_cm), b_cm.stride(0), K, M, N, C, S,
                                        L.ptr(keep), L.ptr(keep_sum), drop_row0, L.ptr(out), out.stride(0), L.ptr(bias),
                                        1 if relu else 0, float(drop_p), nseg,

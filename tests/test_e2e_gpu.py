@@ -209,6 +209,34 @@ def test_bf16x2f_mode_meets_the_loss_and_selection_bars(name):
           {k: (float(v.detach()), float(g["loss/" + k])) for k, v in losses.items()})
 
 
+@pytest.mark.parametrize("name", ["e2e_voc_2img", "e2e_voc_1img", "e2e_coco_2img"])
+def test_shared_clean_and_dropblock_fc6_forward_meets_the_same_bars(name, monkeypatch):
+    """The same goldens with the shared clean + DropBlock fc6 forward forced on (gemm.pair_linear: the training step takes
+    it from 1400 ROIs up, tests/test_fullsize_gpu.py; here the goldens' few hundred ROIs): losses within 1e-3, every
+    selected index set the reference's, gradient norms within the mode's tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd import gemm
+    from od_wscl_amd.modeling.backbone.fc_extractor import TwoFCROIFeatureExtractor
+    monkeypatch.setattr(TwoFCROIFeatureExtractor, "pair_min_rois", 0)
+    calls = []
+    real = gemm.pair_linear
+    monkeypatch.setattr(gemm, "pair_linear", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    losses, trace, model, g = _run_golden(name, "bf16x2f")
+    assert calls, "the pair forward did not run"
+    for k, v in losses.items():
+        ref = float(g["loss/" + k])
+        assert abs(float(v.detach()) - ref) <= LOSS_RTOL * max(abs(ref), 1e-6), (k, float(v.detach()), ref)
+    for k in g.files:
+        if k.startswith(("pseudo_", "pgt_instance_")):
+            np.testing.assert_array_equal(trace[k].cpu().numpy(), g[k], err_msg=k)
+    for n, p in model.named_parameters():
+        key = "gradnorm/" + n
+        if key in g.files and float(g[key]) > 1e-5:
+            ref = float(g[key])
+            assert abs(p.grad.double().norm().item() - ref) / ref <= MIXED_GRAD_TOL, n
+
+
 # observed deviation of the single-plane bf16 mode from the reference (profiles/r02/precision_deviation.json, re-measured
 # with the halo-tile convolution, whose K walk -- channel block major -- re-associates the fp32 sums and so moves which
 # near-threshold selections the bf16 rounding flips): worst loss 18 % / 2.2 % / 13 % / 4.6 % / 3.9 %, worst gradient norm

@@ -314,6 +314,20 @@ def test_pool_stack_planes_f32_is_bit_exact_against_the_oracle(P, C, H, W):
     np.testing.assert_array_equal(pl[P:, :K], ahi)
     np.testing.assert_array_equal(pl[P:, K:2 * K], ahi)
     np.testing.assert_array_equal(pl[P:, 2 * K:], amid)
+    # the layout of the shared clean + DropBlock fc6 forward: the hi plane of both halves for the backward, and the clean
+    # rows as the two CELL-MAJOR planes (k' = bin * C + c)
+    hi_only = torch.full((2 * P, K), -1.0, dtype=torch.bfloat16, device="cuda")
+    cm = torch.full((P, 2 * K), -1.0, dtype=torch.bfloat16, device="cuda")
+    pooled2, arg2 = torch.empty_like(pooled), torch.empty_like(arg)
+    cpat1 = (ctypes.c_int * 1)(0)
+    L.check(lib.odw_roi_pool_stack_forward_nhwc_f32_cm(L.ptr(nhwc), L.ptr(r), 0.125, 1, C, H, W, P, L.ptr(keep), L.ptr(ksum),
+                                                       ctypes.cast(cpat1, ctypes.c_void_p), 1, L.ptr(hi_only), K, K, L.ptr(pooled2),
+                                                       L.ptr(arg2), L.ptr(cm), 2 * K, K, L.ptr(ws), ws_bytes, L.stream()), "cm")
+    assert torch.equal(pooled2, pooled) and torch.equal(arg2, arg)
+    np.testing.assert_array_equal(hi_only.float().cpu().numpy(), np.concatenate([hi, ahi]))
+    cmn = cm.float().cpu().numpy()
+    np.testing.assert_array_equal(cmn[:, :K], hi.reshape(P, C, 49).transpose(0, 2, 1).reshape(P, K))
+    np.testing.assert_array_equal(cmn[:, K:], mid.reshape(P, C, 49).transpose(0, 2, 1).reshape(P, K))
 
 
 @pytest.mark.parametrize("dx_f32,skip_clean", [(False, False), (False, True), (True, False)])
