@@ -603,11 +603,11 @@ struct CmArgs {
     int drop_row0;              // first row of C of the DropBlock half (>= M)
 };
 
-template <bool PAIR>
+template <bool PAIR, bool SHARE>
 __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_cm_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     void* __restrict__ Cv, int ldc, Epilogue ep, CmArgs cm, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [stage][A 256 rows | B 128 rows]
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // SHARE: [3 A slots | 4 B slots]; else [stage][A | B]
     int cell_lo = 0, cell_hi = cm.S;
     if (ep.kchunk > 0) {                                              // split over cells (plain mode)
         cell_lo = blockIdx.y * ep.kchunk;
@@ -641,9 +641,86 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_cm_kernel(
             const float* kr = cm.keep + (size_t)r * cm.S;
             for (int s = 0; s < cm.S; ++s) kbits[i] |= (unsigned long long)(kr[s] != 0.0f) << s;
         }
+        // the mask loads are complete HERE: the counted vmcnt waits of the K loop must only ever see operand DMA
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(kbits[0]), "+v"(kbits[1]) : : "memory");
     }
 
     const int ntc = cm.C / BK, per_cell = 3 * ntc;      // K tiles per plane product of a cell, per cell
+    // the D += coef * A step at the end of cell `cell` (summation by parts, see above)
+    auto cell_done = [&](int cell) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cur = (int)((kbits[i] >> cell) & 1ull);
+            const int nxt = cell + 1 < cell_hi ? (int)((kbits[i] >> (cell + 1)) & 1ull) : 0;
+            const float coef = (float)(cur - nxt);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[i][j][r] = fmaf(coef, acc[i][j][r], dacc[i][j][r]);
+        }
+    };
+    auto mfma_step = [&](const uint4* sa, const uint4* sb) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int c = kk * 2 + half;
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[lds_slot(wm * 64 + i * 32 + l31, c)]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)       // operands swapped: transposed accumulators for band_store
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (SHARE) {
+        // The three plane products of one 64-channel group g (columns g * 64 of both planes: cell * C + ct * 64 == g * 64)
+        // read FOUR operand tiles, not six: steps (Ah, Bh), (Ah, Bm), (Am, Bh).  LDS = 3 A slots of 32 KB + 4 B slots of
+        // 16 KB (160 KB); A tiles in the order Ah(0) Am(0) Ah(1) ... cycle through the A slots, B tiles Bh(0) Bm(0) Bh(1)
+        // ... through the B slots.  Issue schedule (each tile three steps before its first use, into a slot whose last
+        // reader finished before the barrier in front of the issue):
+        //     top of step 3g    : Ah(g+1), Bh(g+1)         wait for (Ah, Bh)(g)   = all but the 6 newest loads
+        //     top of step 3g + 1: Bm(g+1)                  wait for Bm(g)         = all but the 10 newest
+        //     top of step 3g + 2: Am(g+1)                  wait for Am(g)         = all but the 8 newest
+        // (4 DMA instructions per wave for an A tile, 2 for a B tile; past the end the last group is fetched again into
+        // the free slots so that the counts stay constant.)  A third less L2 -> LDS traffic than the 48 KB-per-step ring.
+        const int g_lo = cell_lo * ntc, g_hi = cell_hi * ntc;
+        uint4* const a_slots = lds;
+        uint4* const b_slots = lds + 3 * RM * kChunksPerRow;
+        auto a_slot = [&](int t) { return a_slots + (size_t)(t % 3) * (RM * kChunksPerRow); };
+        auto b_slot = [&](int t) { return b_slots + (size_t)(t & 3) * (RN * kChunksPerRow); };
+        auto col = [&](int g) { return (g < g_hi ? g : g_hi - 1) * BK; };
+        if (g_hi > g_lo) {
+            dma_rows<32>(A, lda, M, m0, col(g_lo), a_slot(0), wave, lane);
+            dma_rows<16>(B, ldb, N, n0, col(g_lo), b_slot(0), wave, lane);
+            dma_rows<16>(B, ldb, N, n0, col(g_lo) + cm.b_mid, b_slot(1), wave, lane);
+            dma_rows<32>(A, lda, M, m0, col(g_lo) + cm.a_mid, a_slot(1), wave, lane);
+        }
+        int in_cell = 0, cell = cell_lo;
+        for (int g = g_lo, t = 0; g < g_hi; ++g, t += 2) {          // t = index of Ah(g) / Bh(g) in the tile sequences
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma_rows<32>(A, lda, M, m0, col(g + 1), a_slot(t + 2), wave, lane);
+            dma_rows<16>(B, ldb, N, n0, col(g + 1), b_slot(t + 2), wave, lane);
+            mfma_step(a_slot(t), b_slot(t));
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma_rows<16>(B, ldb, N, n0, col(g + 1) + cm.b_mid, b_slot(t + 3), wave, lane);
+            mfma_step(a_slot(t), b_slot(t + 1));
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma_rows<32>(A, lda, M, m0, col(g + 1) + cm.a_mid, a_slot(t + 3), wave, lane);
+            mfma_step(a_slot(t + 1), b_slot(t));
+            if (++in_cell == ntc) {
+                if (PAIR) cell_done(cell);
+                in_cell = 0;
+                ++cell;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the re-fetched tail tiles land in LDS the epilogue reuses
+    } else {
     const int nk = (cell_hi - cell_lo) * per_cell;
     // K tile kt -> (cell, product p, channel tile): A reads planes [hi hi mid], B reads [hi mid hi]
     auto issue = [&](int kt, uint4* slot) {
@@ -661,37 +738,13 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_cm_kernel(
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < nk) issue(kt + 2, lds + (size_t)((kt + 2) % kRingStages) * kRingStageChunks);
         const uint4* sa = lds + (size_t)(kt % kRingStages) * kRingStageChunks;
-        const uint4* sb = sa + RM * kChunksPerRow;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            const int c = kk * 2 + half;
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = __builtin_bit_cast(bf16x8, sa[lds_slot(wm * 64 + i * 32 + l31, c)]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)       // operands swapped: transposed accumulators for band_store
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-        if (++in_cell == per_cell) {              // the cell is complete: summation by parts
-            if (PAIR) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int cur = (int)((kbits[i] >> cell) & 1ull);
-                    const int nxt = cell + 1 < cell_hi ? (int)((kbits[i] >> (cell + 1)) & 1ull) : 0;
-                    const float coef = (float)(cur - nxt);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dacc[i][j][r] = fmaf(coef, acc[i][j][r], dacc[i][j][r]);
-                }
-            }
+        mfma_step(sa, sa + RM * kChunksPerRow);
+        if (++in_cell == per_cell) {              // the cell is complete
+            if (PAIR) cell_done(cell);
             in_cell = 0;
             ++cell;
         }
+    }
     }
     auto rowmap = [&](int r) -> long long { return mw + r < M ? (long long)(mw + r) : -1ll; };
     auto rowmap_d = [&](int r) -> long long { return mw + r < M ? (long long)(cm.drop_row0 + mw + r) : -1ll; };
@@ -2027,17 +2080,26 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
     cm.C = C; cm.S = S; cm.a_mid = a_mid; cm.b_mid = b_mid; cm.keep = keep; cm.keep_sum = keep_sum; cm.drop_row0 = drop_row0;
     const int tiles_m = (M + RM - 1) / RM, tiles_n = (N + RN - 1) / RN;
     const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
+    const size_t share_lds = (size_t)(3 * RM + 4 * RN) * kChunksPerRow * sizeof(uint4);      // 160 KB
+    static const bool share = getenv("ODW_CM_NOSHARE") == nullptr;      // (comparison: the six-tile ring)
     if (keep) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<true>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<true, true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)share_lds);
         ODW_CHECK_HIP(attr, "gemm_nt_cm attr");
-        gemm_nt_cm_kernel<true><<<tiles_m * tiles_n, kRingThreads, ring_lds, stream>>>(
-            (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, Cout, ldc, ep, cm, tiles_m, tiles_n);
+        static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<true, false>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds);
+        ODW_CHECK_HIP(attr0, "gemm_nt_cm attr");
+        if (share)
+            gemm_nt_cm_kernel<true, true><<<tiles_m * tiles_n, kRingThreads, share_lds, stream>>>(
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, Cout, ldc, ep, cm, tiles_m, tiles_n);
+        else
+            gemm_nt_cm_kernel<true, false><<<tiles_m * tiles_n, kRingThreads, ring_lds, stream>>>(
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, Cout, ldc, ep, cm, tiles_m, tiles_n);
         ODW_CHECK_LAUNCH("gemm_nt_cm_kernel<pair>");
         return ODW_OK;
     }
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<false>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<false, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)share_lds);
     ODW_CHECK_HIP(attr, "gemm_nt_cm attr");
     const int ldw = (N + 3) / 4 * 4;
     int kc = cm_cells_per_split(M, N, S, workspace != nullptr);
@@ -2048,7 +2110,7 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
         Epilogue pe = ep;
         pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.row_ids = nullptr;
         pe.kchunk = kc; pe.split_stride = (long long)M * ldw * 4;
-        gemm_nt_cm_kernel<false><<<dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), kRingThreads, ring_lds, stream>>>(
+        gemm_nt_cm_kernel<false, true><<<dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), kRingThreads, share_lds, stream>>>(
             (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, workspace, ldw, pe, cm, tiles_m, tiles_n);
         ODW_CHECK_LAUNCH("gemm_nt_cm_kernel<split>");
         const long long quads = (long long)M * (ldw / 4);
@@ -2058,7 +2120,7 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
         ODW_CHECK_LAUNCH("splitk_reduce_kernel");
         return ODW_OK;
     }
-    gemm_nt_cm_kernel<false><<<tiles_m * tiles_n, kRingThreads, ring_lds, stream>>>(
+    gemm_nt_cm_kernel<false, true><<<tiles_m * tiles_n, kRingThreads, share_lds, stream>>>(
         (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, Cout, ldc, ep, cm, tiles_m, tiles_n);
     ODW_CHECK_LAUNCH("gemm_nt_cm_kernel");
     return ODW_OK;
