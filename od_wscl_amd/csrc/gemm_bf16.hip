@@ -603,7 +603,7 @@ struct CmArgs {
     int drop_row0;              // first row of C of the DropBlock half (>= M)
 };
 
-template <bool PAIR, bool SHARE>
+template <bool PAIR, int SHARE>
 __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_cm_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     void* __restrict__ Cv, int ldc, Epilogue ep, CmArgs cm, int tiles_m, int tiles_n) {
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_cm_kernel(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     };
-    if (SHARE) {
+    if (SHARE == 1) {
         // The three plane products of one 64-channel group g (columns g * 64 of both planes: cell * C + ct * 64 == g * 64)
         // read FOUR operand tiles, not six: steps (Ah, Bh), (Ah, Bm), (Am, Bh).  LDS = 3 A slots of 32 KB + 4 B slots of
         // 16 KB (160 KB); A tiles in the order Ah(0) Am(0) Ah(1) ... cycle through the A slots, B tiles Bh(0) Bm(0) Bh(1)
@@ -2081,26 +2081,28 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
     const int tiles_m = (M + RM - 1) / RM, tiles_n = (N + RN - 1) / RN;
     const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
     const size_t share_lds = (size_t)(3 * RM + 4 * RN) * kChunksPerRow * sizeof(uint4);      // 160 KB
-    static const bool share = getenv("ODW_CM_NOSHARE") == nullptr;      // (comparison: the six-tile ring)
+    // Four operand tiles per 64-channel group on a 3 A + 4 B slot ring (ODW_CM_VARIANT=0: the six-tile ring, comparison).
+    // Measured at P = 2000 x 4096 x (49 x 512), isolated launch: six-tile ring 1.30 ms, this form 1.08-1.09 ms; with every
+    // operand L2-resident (all workgroups on the same tiles) 1.06-1.08 ms -- cache misses are not the bound; with the loop's
+    // DMA removed 0.86 ms (MFMA floor at the ~1.6 GHz held under load: 0.77 ms).  Tried on top, no gain: 32-channel groups
+    // with all four tiles in one 48 KB stage, one barrier per 24 MFMAs and each fragment read once per K slice (1.18 ms:
+    // 64-byte DMA rows); two barriers per group with (Ah, Bh) + (Ah, Bm) as one block (1.08 ms).
+    static const int share = getenv("ODW_CM_VARIANT") ? atoi(getenv("ODW_CM_VARIANT")) : 1;
     if (keep) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<true, true>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)share_lds);
-        ODW_CHECK_HIP(attr, "gemm_nt_cm attr");
-        static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<true, false>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds);
-        ODW_CHECK_HIP(attr0, "gemm_nt_cm attr");
-        if (share)
-            gemm_nt_cm_kernel<true, true><<<tiles_m * tiles_n, kRingThreads, share_lds, stream>>>(
-                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, Cout, ldc, ep, cm, tiles_m, tiles_n);
-        else
-            gemm_nt_cm_kernel<true, false><<<tiles_m * tiles_n, kRingThreads, ring_lds, stream>>>(
-                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, Cout, ldc, ep, cm, tiles_m, tiles_n);
+#define ODW_CM_LAUNCH(PAIRV, SV, LDSB, GRID, OUT, EP)                                                                   \
+        do {                                                                                                             \
+            static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<PAIRV, SV>), \
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)); \
+            ODW_CHECK_HIP(attr_, "gemm_nt_cm attr");                                                                     \
+            gemm_nt_cm_kernel<PAIRV, SV><<<GRID, kRingThreads, LDSB, stream>>>(                                          \
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, OUT, ldc_, EP, cm, tiles_m, tiles_n); \
+        } while (0)
+        const int ldc_ = ldc;
+        if (share) ODW_CM_LAUNCH(true, 1, share_lds, tiles_m * tiles_n, Cout, ep);
+        else ODW_CM_LAUNCH(true, 0, ring_lds, tiles_m * tiles_n, Cout, ep);
         ODW_CHECK_LAUNCH("gemm_nt_cm_kernel<pair>");
         return ODW_OK;
     }
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<false, true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)share_lds);
-    ODW_CHECK_HIP(attr, "gemm_nt_cm attr");
     const int ldw = (N + 3) / 4 * 4;
     int kc = cm_cells_per_split(M, N, S, workspace != nullptr);
     if (kc > 0 && workspace_bytes < (int64_t)((S + kc - 1) / kc) * M * ldw * 4) kc = 0;
@@ -2110,8 +2112,11 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
         Epilogue pe = ep;
         pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.row_ids = nullptr;
         pe.kchunk = kc; pe.split_stride = (long long)M * ldw * 4;
-        gemm_nt_cm_kernel<false, true><<<dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), kRingThreads, share_lds, stream>>>(
-            (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, workspace, ldw, pe, cm, tiles_m, tiles_n);
+        {
+            const int ldc_ = ldw;
+            const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
+            ODW_CM_LAUNCH(false, 1, share_lds, grid, workspace, pe);
+        }
         ODW_CHECK_LAUNCH("gemm_nt_cm_kernel<split>");
         const long long quads = (long long)M * (ldw / 4);
         const int rblocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
@@ -2120,8 +2125,11 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
         ODW_CHECK_LAUNCH("splitk_reduce_kernel");
         return ODW_OK;
     }
-    gemm_nt_cm_kernel<false, true><<<tiles_m * tiles_n, kRingThreads, share_lds, stream>>>(
-        (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, Cout, ldc, ep, cm, tiles_m, tiles_n);
+    {
+        const int ldc_ = ldc;
+        ODW_CM_LAUNCH(false, 1, share_lds, tiles_m * tiles_n, Cout, ep);
+    }
+#undef ODW_CM_LAUNCH
     ODW_CHECK_LAUNCH("gemm_nt_cm_kernel");
     return ODW_OK;
 }
