@@ -297,6 +297,7 @@ int odw_l2norm_rows_bwd(const float* g, const float* y, const float* norm, int R
  * sweep over A (summation by parts over the cells, csrc/gemm_bf16.hip); dropout then takes two segments
  * (rows 0 and drop_row0). */
 int64_t odw_gemm_nt_cm_workspace(int M, int N, int S);
+int64_t odw_gemm_nt_cm_pair_workspace(int M, int N, int S);      /* the same for the pair form (needs drop_row0 == M) */
 int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, int ldb, int b_mid, int M, int N, int C, int S,
                    const float* keep, const float* keep_sum, int drop_row0, float* Cout, int ldc, const float* bias,
                    int relu, float drop_p, int nseg, const int* seg_rows, const uint32_t* seg_keys, const int* row_ids,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "odw_l2norm_rows_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     "odw_gemm_nt_bf16_variant": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i]),
     "odw_gemm_nt_cm_workspace": (c_l, [c_i, c_i, c_i]),
+    "odw_gemm_nt_cm_pair_workspace": (c_l, [c_i, c_i, c_i]),
     "odw_gemm_nt_cm": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_f, c_i, c_p,
                              c_p, c_p, c_p, c_l, c_p]),
     "odw_split_rows_cm": (c_i, [c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_p]),

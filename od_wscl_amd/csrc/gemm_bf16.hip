@@ -2050,6 +2050,10 @@ ODW_EXPORT int64_t odw_gemm_nt_cm_workspace(int M, int N, int S) {
     return (int64_t)((S + kc - 1) / kc) * M * ((N + 3) / 4 * 4) * 4;
 }
 
+ODW_EXPORT int64_t odw_gemm_nt_cm_pair_workspace(int M, int N, int S) {      // the pair form's partials hold both halves
+    return 2 * odw_gemm_nt_cm_workspace(M, N, S);
+}
+
 ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, int ldb, int b_mid, int M, int N, int C, int S,
                               const float* keep, const float* keep_sum, int drop_row0, float* Cout, int ldc,
                               const float* bias, int relu, float drop_p, int nseg, const int* seg_rows,
@@ -2098,6 +2102,28 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, OUT, ldc_, EP, cm, tiles_m, tiles_n); \
         } while (0)
         const int ldc_ = ldc;
+        // few ROIs: the cells are split over blockIdx.y; a split's partial clean sums land in rows [0, M) of its slice
+        // of the workspace and its partial DropBlock sums (already scaled by g) in rows [M, 2M); one reduction pass adds
+        // the slices and applies the epilogue of both halves (needs the halves adjacent in Cout: drop_row0 == M)
+        const int ldw_p = (N + 3) / 4 * 4;
+        int kcp = drop_row0 == M ? cm_cells_per_split(M, N, S, workspace != nullptr) : 0;
+        if (kcp > 0 && (workspace_bytes < (int64_t)((S + kcp - 1) / kcp) * 2 * M * ldw_p * 4 || (((uintptr_t)workspace) & 15) != 0)) kcp = 0;
+        if (kcp > 0) {
+            const int splits = (S + kcp - 1) / kcp;
+            Epilogue pe = ep;
+            pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0;
+            pe.kchunk = kcp; pe.split_stride = (long long)2 * M * ldw_p * 4;
+            const int ldc_ = ldw_p;
+            const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
+            ODW_CM_LAUNCH(true, 1, share_lds, grid, workspace, pe);
+            ODW_CHECK_LAUNCH("gemm_nt_cm_kernel<pair, split>");
+            const long long quads = (long long)2 * M * (ldw_p / 4);
+            const int rblocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+            splitk_reduce_kernel<false><<<rblocks, 256, 0, stream>>>((const float*)workspace, splits, (long long)2 * M * ldw_p, 2 * M, N,
+                                                                      ldw_p, Cout, ldc, ep);
+            ODW_CHECK_LAUNCH("splitk_reduce_kernel");
+            return ODW_OK;
+        }
         if (share) ODW_CM_LAUNCH(true, 1, share_lds, tiles_m * tiles_n, Cout, ep);
         else ODW_CM_LAUNCH(true, 0, ring_lds, tiles_m * tiles_n, Cout, ep);
         ODW_CHECK_LAUNCH("gemm_nt_cm_kernel<pair>");

@@ -280,7 +280,9 @@ class FlatSGD(object):
                         sh.w = w16
                     else:           # "bf16x2f": the forward operand = the bf16 planes of the fp32 master, re-split in place
                         sh.w16 = w16
-                        sh.w = torch.empty((n_out, len(precision.patterns("gemm")[1]) * r64(k_in)), dtype=torch.bfloat16, device=dev)
+                        # (a weight kept as cell-major planes has no channel-major forward copy: every forward reads w_cm)
+                        sh.w = None if sh.w_cm is not None else torch.empty(
+                            (n_out, len(precision.patterns("gemm")[1]) * r64(k_in)), dtype=torch.bfloat16, device=dev)
                     sh.managed = True
                     sh.mode = mode
                 # ("bf16x3" / "bf16x2": the plane layouts are rebuilt from the fp32 master after each step, Shadow.refresh)
@@ -330,9 +332,10 @@ class FlatSGD(object):
                 gemm.transpose_bf16(sh.w, n, k, out=sh.wt)    # in place: same buffer every step, no allocator traffic
             else:                           # "bf16x2f": W^T from the refreshed bf16 plane, forward planes from the master
                 gemm.transpose_bf16(sh.w16, n, k, out=sh.wt)
-                precision.split_rows(sh.weight.detach(), precision.patterns("gemm")[1], (k + 63) // 64 * 64, out=sh.w)
-                if sh.cm is not None:
+                if sh.w_cm is not None:
                     gemm.split_rows_cm(sh.weight.detach(), sh.cm[0], sh.cm[1], out=sh.w_cm)
+                else:
+                    precision.split_rows(sh.weight.detach(), precision.patterns("gemm")[1], (k + 63) // 64 * 64, out=sh.w)
 
     @staticmethod
     def _is_gemm_weight(model, name, p):

@@ -104,7 +104,7 @@ def gemm_nt_cm(a_cm, b_cm, M, N, C, S, out, bias=None, relu=False, drop_p=0.0, s
     rows = (ctypes.c_int * 4)(*([s[0] for s in segs] + [0] * (4 - nseg))) if nseg else None
     keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
     pair = keep is not None
-    ws_bytes = 0 if pair else L.lib().odw_gemm_nt_cm_workspace(M, N, S)
+    ws_bytes = (L.lib().odw_gemm_nt_cm_pair_workspace(M, N, S) if drop_row0 == M else 0) if pair else L.lib().odw_gemm_nt_cm_workspace(M, N, S)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device) if ws_bytes else None
     sym = "gemm_nt_cm_kernel<%s>%s" % ("true" if pair else "false", " split+reduce" if ws_bytes else "")
     with kernel_timer.region(sym, flops=2.0 * M * N * 3 * K):      # MFMA work ISSUED (the pair form replaces twice that)
@@ -145,15 +145,20 @@ class Shadow(object):
         wd = w.detach()
         wd = wd if wd.stride(1) == 1 else wd.contiguous()
         with torch.no_grad():
-            if P.split_mode():
+            if self.cm is not None and P.get_precision() == "bf16x2f":
+                # the first head Linear in "bf16x2f": every forward reads the cell-major planes (gemm_nt_cm), no other copy
+                self.w_cm = split_rows_cm(wd, self.cm[0], self.cm[1], out=self.w_cm)
+                self.w = None
+                self.wt = transpose_bf16(wd, n, k, out=wt_out)
+            elif P.split_mode():
                 pb = P.patterns("gemm")[1]
                 self.w = P.split_rows(wd, pb, _r64(k), out=w_out)
                 self.wt = P.split_cols(wd, pb, _r64(n), out=wt_out) if P.bwd_split() else transpose_bf16(wd, n, k, out=wt_out)
+                self.w_cm = None
             else:
                 self.w = to_bf16(wd)
                 self.wt = transpose_bf16(wd, n, k, out=wt_out)
-            if self.cm is not None and P.get_precision() == "bf16x2f":
-                self.w_cm = split_rows_cm(wd, self.cm[0], self.cm[1], out=self.w_cm)
+                self.w_cm = None
         self.version = w._version
         self.mode = P.get_precision()
 
@@ -172,7 +177,7 @@ class Shadow(object):
                                    "the process-wide mode is now %r (build a new training step after set_precision)"
                                    % (self.mode, mode))
             return self
-        if self.mode == mode and self.version == self.weight._version and self.w is not None:
+        if self.mode == mode and self.version == self.weight._version and (self.w is not None or self.w_cm is not None):
             return self
         self.build()
         return self
@@ -407,26 +412,46 @@ class _SplitLinear(torch.autograd.Function):
     over K' = T * K with the same fused epilogue (bias, ReLU, counter-based dropout, accumulate)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, shadow, relu, drop_p, segs, timer_tag, grad_rows, row_ids, grad_mode, planes=None):
+    def forward(ctx, x, weight, bias, shadow, relu, drop_p, segs, timer_tag, grad_rows, row_ids, grad_mode, planes=None,
+                planes_cm=None):
         """planes: the operand already laid out as bf16 planes (M x T*r64(K), pattern A of the mode) by its producer
-        (ROI pooling in "bf16x2f"); x is then only the autograd handle of that operand (see planes_handle)."""
+        (ROI pooling in "bf16x2f"); x is then only the autograd handle of that operand (see planes_handle).
+        A weight kept as cell-major planes (Shadow.w_cm: the first head Linear in "bf16x2f") takes its operand the same
+        way -- planes_cm (M x 2K) from the producer, else x is split here -- and `planes` then only carries the hi plane
+        the backward reads."""
         sh = shadow.refresh()
         pa, pb = P.patterns("gemm")
         T = len(pa)
         M, K = x.shape
         N = weight.shape[0]
         kp = _r64(K)
-        if planes is not None:
-            assert planes.shape == (M, T * kp) and planes.dtype == torch.bfloat16 and planes.stride(1) == 1
-            xs, x32 = planes, planes[:, :K]          # backward reads the hi plane (bf16, row stride T*kp)
-        else:
-            x32 = x if x.dtype == torch.float32 else x.float()
-            x32 = x32 if x32.stride(1) == 1 else x32.contiguous()
-            xs = P.split_rows(x32, pa, kp)
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        kernel_timer.layer = timer_tag and timer_tag + "_fwd"
-        gemm_nt(xs, sh.w, M, N, T * kp, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs, row_ids=row_ids)
-        kernel_timer.layer = None
+        if sh.w_cm is not None:
+            C, S = sh.cm
+            if planes_cm is not None:
+                assert planes is not None and planes.shape[0] == M and planes.shape[1] >= K and planes_cm.shape == (M, 2 * K)
+                xs, x32 = planes_cm, planes[:, :K]
+            else:
+                if planes is not None:
+                    raise RuntimeError("fused_linear: this weight is kept as cell-major planes; an operand laid out as "
+                                       "channel-major planes cannot meet it")
+                x32 = x if x.dtype == torch.float32 else x.float()
+                x32 = x32 if x32.stride(1) == 1 else x32.contiguous()
+                xs = split_rows_cm(x32, C, S)
+            kernel_timer.layer = timer_tag and timer_tag + "_fwd"
+            gemm_nt_cm(xs, sh.w_cm, M, N, C, S, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs, row_ids=row_ids)
+            kernel_timer.layer = None
+        else:
+            if planes is not None:
+                assert planes.shape == (M, T * kp) and planes.dtype == torch.bfloat16 and planes.stride(1) == 1
+                xs, x32 = planes, planes[:, :K]          # backward reads the hi plane (bf16, row stride T*kp)
+            else:
+                x32 = x if x.dtype == torch.float32 else x.float()
+                x32 = x32 if x32.stride(1) == 1 else x32.contiguous()
+                xs = P.split_rows(x32, pa, kp)
+            kernel_timer.layer = timer_tag and timer_tag + "_fwd"
+            gemm_nt(xs, sh.w, M, N, T * kp, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs, row_ids=row_ids)
+            kernel_timer.layer = None
         del xs
         ctx.save_for_backward(x32, y if (relu or drop_p > 0) else None, weight, bias)
         slot = None
@@ -505,7 +530,7 @@ class _SplitLinear(torch.autograd.Function):
             kernel_timer.layer = tag and tag + "_wgrad"
             gemm_nt(dzt, xt, N, K, T * m64, target, accumulate=not fresh)
             kernel_timer.layer = None
-        return dx, dw, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _MixedLinear(torch.autograd.Function):
@@ -523,7 +548,7 @@ class _MixedLinear(torch.autograd.Function):
         dx, dw = _backward_single_plane(x32, y, weight, bias, cfg, dy, ctx.needs_input_grad[0])
         if dx is not None and x_dtype != torch.float32:
             dx = dx.to(x_dtype)
-        return dx, dw, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _PairLinear(torch.autograd.Function):
@@ -633,6 +658,6 @@ def fused_linear(x, weight, bias, shadow, relu=False, drop_p=0.0, segs=None, out
     if P.split_mode():
         fn = _SplitLinear if P.bwd_split() else _MixedLinear
         return fn.apply(x, weight, bias, shadow, relu, drop_p, segs, tag, grad_rows, row_ids, torch.is_grad_enabled(),
-                        getattr(x, "_odw_planes", None))
+                        getattr(x, "_odw_planes", None), getattr(x, "_odw_planes_cm", None))
     return _FusedLinear.apply(x, weight, bias, shadow, relu, drop_p, segs, out_f32, tag, grad_rows, row_ids,
                               torch.is_grad_enabled())      # (grad mode is always off INSIDE Function.forward)

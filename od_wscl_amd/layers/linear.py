@@ -5,6 +5,8 @@ with its fused bias / ReLU / dropout epilogue (csrc/gemm_bf16.hip); there is no 
 precision is the process-wide setting of od_wscl_amd.precision: "bf16" (throughput) or "bf16x3" (fp32-grade: the
 reference's DTYPE float32, config/defaults.py:559, on the bf16 matrix cores by operand splitting).
 `tag` names the layer for the bench's per-kernel timing."""
+import os
+
 from torch import nn
 
 from .. import gemm
@@ -20,8 +22,7 @@ class Linear(nn.Linear):
         if not x.is_cuda:
             raise RuntimeError("od_wscl_amd.layers.Linear: tensor is not on the GPU -- the hot path has no CPU "
                                "implementation (the MFMA GEMM of libodwscl.so is the only one)")
-        if self._shadow is None or self._shadow.weight is not self.weight:
-            self._shadow = gemm.Shadow(self.weight)
+        self._get_shadow()
         if drop_p > 0 and segs is None:
             segs = [(0, key[0], key[1])]
         return gemm.fused_linear(x, self.weight, self.bias, self._shadow, relu=relu, drop_p=drop_p,
@@ -30,33 +31,35 @@ class Linear(nn.Linear):
 
     cm_layout = None       # (C, S): this layer reduces over a (C, S-cell) map flattened channel-major (the first head Linear)
 
+    def _get_shadow(self):
+        """The bf16 copies of the weight (gemm.Shadow), created on first use; a layer with a cm_layout keeps its forward
+        operand as cell-major planes in the precision mode "bf16x2f" (ODW_NO_PAIR=1: the channel-major planes of the
+        other layers)."""
+        if self._shadow is None or self._shadow.weight is not self.weight:
+            self._shadow = gemm.Shadow(self.weight)
+            if self.cm_layout is not None and os.environ.get("ODW_NO_PAIR") != "1":
+                self._shadow.cm = tuple(self.cm_layout)
+        return self._shadow
+
     def can_pair(self, C, S):
         """The shared clean + DropBlock forward applies: the layer reduces over (C, S) and -- when an optimiser keeps its
         bf16 copies (engine.FlatSGD) -- that optimiser also keeps the cell-major planes."""
         if self.cm_layout is None or tuple(self.cm_layout) != (C, S) or C % 64 != 0 or S > 64:
             return False
-        sh = self._shadow
-        return sh is None or sh.weight is not self.weight or not sh.managed or sh.w_cm is not None
+        sh = self._get_shadow()
+        return sh.cm is not None and (not sh.managed or sh.w_cm is not None)
 
     def pair(self, x, planes_cm, planes_bwd, keep, keep_sum, relu=False, drop_p=0.0, segs=None, grad_rows=None):
         """dropout(relu(.)) of the clean rows AND of their DropBlock view from one sweep over the clean operand
         (gemm.pair_linear); x = the autograd handle of the stacked (2P x K) operand."""
-        if self._shadow is None or self._shadow.weight is not self.weight:
-            self._shadow = gemm.Shadow(self.weight)
-        if self._shadow.cm is None:
-            if self.cm_layout is None:
-                raise RuntimeError("Linear.pair: the layer has no cm_layout")
-            self._shadow.cm = tuple(self.cm_layout)
-            if not self._shadow.managed:
-                self._shadow.version = -1          # rebuild with the cell-major planes
+        self._get_shadow()
         return gemm.pair_linear(x, self.weight, self.bias, self._shadow, planes_cm, planes_bwd, keep, keep_sum, relu=relu,
                                 drop_p=drop_p, segs=segs, tag=self.tag, grad_rows=grad_rows)
 
     def reuse(self, x, y_full, rows, relu=False, drop_p=0.0):
         """Rows `rows` of an earlier no-autograd evaluation `y_full` of this layer, re-attached to the graph with `x` as
         their input (gemm.reuse_linear): backward as usual, no forward GEMM."""
-        if self._shadow is None or self._shadow.weight is not self.weight:
-            self._shadow = gemm.Shadow(self.weight)
+        self._get_shadow()
         return gemm.reuse_linear(x, self.weight, self.bias, self._shadow, y_full, rows, relu=relu, drop_p=drop_p, tag=self.tag)
 
     def forward(self, x):

@@ -148,15 +148,21 @@ class _RowGather(torch.autograd.Function):
     pooling node (entries [e0, e0+R) of its fp32 side buffer)."""
 
     @staticmethod
-    def forward(ctx, stacked, rows, holder, e0, planes=None):
+    def forward(ctx, stacked, rows, holder, e0, planes=None, planes_cm=None):
         """planes: `stacked` is the handle of a planes operand (_PoolStackPlanes) -- its rows are gathered from the
-        planes and come back as a new handle (the caller attaches the gathered planes, returned second)."""
+        planes and come back as a new handle (the caller attaches the gathered planes, returned second; planes_cm: the
+        cell-major forward planes of the same rows, returned third)."""
         ctx.args = (holder, e0, int(rows.numel()))
         if planes is not None:
             picked = planes.index_select(0, rows)
-            ctx.mark_non_differentiable(picked)
             ctx.set_materialize_grads(False)        # (or autograd hands backward a zero tensor the size of `picked`)
-            return gemm.planes_handle(planes.device, int(rows.numel()), stacked.shape[1]), picked
+            handle = gemm.planes_handle(planes.device, int(rows.numel()), stacked.shape[1])
+            if planes_cm is not None:
+                picked_cm = planes_cm.index_select(0, rows)
+                ctx.mark_non_differentiable(picked, picked_cm)
+                return handle, picked, picked_cm
+            ctx.mark_non_differentiable(picked)
+            return handle, picked
         return stacked.index_select(0, rows)
 
     @staticmethod
@@ -170,7 +176,7 @@ class _RowGather(torch.autograd.Function):
         if holder is None or holder.done:
             raise RuntimeError("_RowGather: the pooling node already ran its backward")
         holder.pending.append(fold)
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class _PoolStack(torch.autograd.Function):
@@ -296,7 +302,6 @@ def _keep_sum(block):
 class TwoFCROIFeatureExtractor(nn.Module):
     Linear = Linear
     fc_index = (1, 4)              # positions of the two Linear layers inside self.classifier
-    pair_min_rois = 1400           # fewer ROIs: the stacked clean + DropBlock pass (measured cross-over)
 
     def __init__(self, config):
         super().__init__()
@@ -446,16 +451,19 @@ class TwoFCROIFeatureExtractor(nn.Module):
         nhwc = getattr(feat, "_odw_nhwc", None) if os.environ.get("ODW_POOL_NHWC") != "0" else None
         pair = None
         if precision.split_mode():
-            # the shared clean + DropBlock fc6 forward (gemm.pair_linear): one workgroup per 256 ROIs x 128 outputs walks the
-            # whole reduction, so it pays once the ROIs fill the chip (the stacked pass splits its reduction instead)
-            use_pair = (precision.get_precision() == "bf16x2f" and os.environ.get("ODW_NO_PAIR") != "1"
-                        and P >= self.pair_min_rois and self.fc6.can_pair(feat.shape[1], res[0] * res[1]))
+            # the shared clean + DropBlock fc6 forward (gemm.pair_linear); fc6 then keeps its weight as cell-major planes only
+            # (ODW_NO_PAIR=1: the stacked pass of rounds 1-3 over channel-major planes, for comparison)
+            use_pair = precision.get_precision() == "bf16x2f" and self.fc6.can_pair(feat.shape[1], res[0] * res[1])
+            if not use_pair and precision.get_precision() == "bf16x2f" and self.fc6._get_shadow().cm is not None:
+                raise RuntimeError("forward_pool_clean_and_aug: fc6 keeps cell-major planes (no channel-major forward copy) "
+                                   "but the shared clean + DropBlock forward does not apply")
             block_c, block_sum = block.contiguous(), _keep_sum(block)
             out = _PoolStackPlanes.apply(feat, feat._odw_nhwc_f32, rois5, block_c, block_sum, self._grad_holder,
                                          float(self.pooler.poolers[0].spatial_scale), res[0], res[1], use_pair)
             x, planes, pooled32 = out[0], out[1], out[2]
             x._odw_planes, x._odw_pooled32 = planes, pooled32
             if use_pair:
+                x._odw_planes_cm = out[3]       # (rows [0, P) only: the clean half)
                 pair = (out[3], planes, block_c.view(P, -1), block_sum)
         else:
             x = _PoolStack.apply(feat, rois5, block.contiguous(), _keep_sum(block), self._grad_holder,
@@ -479,8 +487,11 @@ class TwoFCROIFeatureExtractor(nn.Module):
         with the dropout draws those rows had in the stacked pass; their input gradient is parked as extra rows
         [first_entry, first_entry + len(rows)) of the pooling node's side buffer."""
         k1, k2 = self._clean_keys
-        planes = getattr(stacked, "_odw_planes", None)
-        if planes is not None:
+        planes, planes_cm = getattr(stacked, "_odw_planes", None), getattr(stacked, "_odw_planes_cm", None)
+        if planes is not None and planes_cm is not None:
+            x, picked, picked_cm = _RowGather.apply(stacked, rows, self._grad_holder, first_entry, planes, planes_cm)
+            x._odw_planes, x._odw_planes_cm = picked, picked_cm
+        elif planes is not None:
             x, picked = _RowGather.apply(stacked, rows, self._grad_holder, first_entry, planes)
             x._odw_planes = picked
         else:

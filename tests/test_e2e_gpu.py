@@ -210,20 +210,21 @@ def test_bf16x2f_mode_meets_the_loss_and_selection_bars(name):
 
 
 @pytest.mark.parametrize("name", ["e2e_voc_2img", "e2e_voc_1img", "e2e_coco_2img"])
-def test_shared_clean_and_dropblock_fc6_forward_meets_the_same_bars(name, monkeypatch):
-    """The same goldens with the shared clean + DropBlock fc6 forward forced on (gemm.pair_linear: the training step takes
-    it from 1400 ROIs up, tests/test_fullsize_gpu.py; here the goldens' few hundred ROIs): losses within 1e-3, every
-    selected index set the reference's, gradient norms within the mode's tolerance."""
+@pytest.mark.parametrize("pair", [True, False])
+def test_both_fc6_forward_forms_meet_the_bars(name, pair, monkeypatch):
+    """The shared clean + DropBlock fc6 forward (gemm.pair_linear over cell-major planes: the default in "bf16x2f", here
+    asserted to have run) and the stacked pass of rounds 1-3 (ODW_NO_PAIR=1) on the VGG / ROIPool goldens: losses within
+    1e-3, every selected index set the reference's, gradient norms within the mode's tolerance."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from od_wscl_amd import gemm
-    from od_wscl_amd.modeling.backbone.fc_extractor import TwoFCROIFeatureExtractor
-    monkeypatch.setattr(TwoFCROIFeatureExtractor, "pair_min_rois", 0)
+    if not pair:
+        monkeypatch.setenv("ODW_NO_PAIR", "1")
     calls = []
     real = gemm.pair_linear
     monkeypatch.setattr(gemm, "pair_linear", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     losses, trace, model, g = _run_golden(name, "bf16x2f")
-    assert calls, "the pair forward did not run"
+    assert bool(calls) == pair, "the pair forward %s" % ("did not run" if pair else "ran")
     for k, v in losses.items():
         ref = float(g["loss/" + k])
         assert abs(float(v.detach()) - ref) <= LOSS_RTOL * max(abs(ref), 1e-6), (k, float(v.detach()), ref)

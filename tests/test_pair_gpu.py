@@ -104,6 +104,33 @@ def test_pair_form_is_the_stacked_clean_and_dropblock_evaluation(P, N, C, S):
     assert (out[P + 1][out[P + 1] != 0] - 2.0 * torch.relu(b)[out[P + 1] != 0]).abs().max().item() <= 1e-6      # bias only
 
 
+@pytest.mark.parametrize("P,N,C,S", [(100, 256, 64, 49), (300, 4096, 128, 49)])
+def test_pair_form_split_over_cells_equals_the_single_sweep(P, N, C, S):
+    """Few ROIs: the pair form splits the cells over blockIdx.y (partial clean / DropBlock sums + one reduction pass).  Same
+    results as the unsplit launch up to the re-association of the fp32 sums; identical dropout pattern."""
+    from od_wscl_amd import gemm, _lib as L
+    x, w, b = _operands(P * 3 + N, P, N, C, S)
+    K = C * S
+    g = torch.Generator(device="cuda").manual_seed(P + 1)
+    keep = (torch.rand(P, S, device="cuda", generator=g) > 0.45).float()
+    ksum = keep.sum()
+    xc, wc = gemm.split_rows_cm(x, C, S), gemm.split_rows_cm(w, C, S)
+    segs = [(0, 21, 22), (P, 23, 24)]
+    assert L.lib().odw_gemm_nt_cm_pair_workspace(P, N, S) > 0
+    split = torch.full((2 * P, N), float("nan"), device="cuda")
+    gemm.gemm_nt_cm(xc, wc, P, N, C, S, split, bias=b, relu=True, drop_p=0.5, segs=segs, keep=keep, keep_sum=ksum, drop_row0=P)
+    one = torch.full((2 * P, N), float("nan"), device="cuda")
+    rows = (ctypes.c_int * 4)(0, P, 0, 0)
+    keys = (ctypes.c_uint32 * 8)(21, 22, 23, 24, 0, 0, 0, 0)
+    L.check(L.lib().odw_gemm_nt_cm(L.ptr(xc), 2 * K, K, L.ptr(wc), 2 * K, K, P, N, C, S, L.ptr(keep), L.ptr(ksum), P, L.ptr(one), N,
+                                   L.ptr(b), 1, 0.5, 2, ctypes.cast(rows, ctypes.c_void_p), ctypes.cast(keys, ctypes.c_void_p), None,
+                                   None, 0, L.stream()), "single sweep")
+    assert not torch.isnan(split).any() and not torch.isnan(one).any()
+    differ = (split == 0) != (one == 0)
+    assert differ.float().mean().item() <= 1e-5
+    assert ((split - one).abs() * (~differ)).max().item() <= 3e-5 * max(1.0, one.abs().max().item())
+
+
 def test_pair_form_refuses_what_it_cannot_do():
     from od_wscl_amd import gemm
     x, w, b = _operands(1, 64, 128, 64, 9)
