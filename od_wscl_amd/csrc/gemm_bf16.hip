@@ -2036,12 +2036,22 @@ int tail_columns(int M, int N, int K, int lda, int ldb, const void* C, int ldc, 
 
 // ---- cell-major plane GEMM (gemm_nt_cm_kernel) ---------------------------------------------------------------------
 static int cm_cells_per_split(int M, int N, int S, bool allow) {
+    // One workgroup per CU (160 KB of LDS): a launch of T tiles x s splits takes ceil(T s / 256) rounds of ceil(S / s) cells.
+    // Pick the s with the fewest cells on the critical path (ties: fewer splits = fewer partials); e.g. the sampled-row views
+    // of the contrastive loss, M ~ 450: 64 tiles -> 4 splits of 13 cells in ONE round (6 splits of 9 cells took two: 0.40 ms
+    // against 0.29).
     const long tiles = (long)((M + RM - 1) / RM) * ((N + RN - 1) / RN);
-    if (!allow || tiles >= 160) return 0;                      // one pass
-    long want = 384 / tiles;                                   // ~1.5 workgroups per CU over the splits
-    want = want < 1 ? 1 : (want > 16 ? 16 : want);
-    const int kc = (int)((S + want - 1) / want);
-    return (S + kc - 1) / kc > 1 ? kc : 0;
+    if (!allow || tiles >= 256) return 0;                      // one pass
+    int best_s = 1;
+    long best = (long)S;                                       // rounds(1) = 1
+    for (int sp = 2; sp <= 16 && sp <= S; ++sp) {
+        const int kc = (S + sp - 1) / sp;
+        const int real = (S + kc - 1) / kc;                    // splits that actually get cells
+        const long cost = ((tiles * real + 255) / 256) * kc + 1;      // (+1: the reduction pass is not free)
+        if (cost < best) { best = cost; best_s = real; }
+    }
+    if (best_s <= 1) return 0;
+    return (S + best_s - 1) / best_s;
 }
 
 ODW_EXPORT int64_t odw_gemm_nt_cm_workspace(int M, int N, int S) {

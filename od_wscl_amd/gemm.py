@@ -555,8 +555,9 @@ class _PairLinear(torch.autograd.Function):
     """fc6 of the clean AND the DropBlock pass of ROIWeakRegHead.forward (weak_head.py:107-112) from ONE sweep over the
     clean operand ("bf16x2f"; csrc/gemm_bf16.hip: gemm_nt_cm_kernel): y (2P x N) = [clean rows; DropBlock rows], the values
     of the stacked evaluation it replaces (other summation order).  x is the autograd handle of the stacked (2P x K)
-    operand; planes_cm (P x 2K) the clean rows as cell-major planes, planes_bwd (2P x K) bf16 the hi plane of both
-    halves in the reference's order -- what the single-plane backward reads (= _MixedLinear's)."""
+    operand; planes_cm (P x 2K) the clean rows as cell-major planes, planes_bwd (2P x >= K) what the single-plane backward
+    reads (= _MixedLinear's): the bf16 hi plane of both halves in the reference's order (ROI pooling writes it), or the
+    stacked fp32 operand itself."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, shadow, planes_cm, planes_bwd, keep, keep_sum, relu, drop_p, segs, timer_tag, grad_rows,

@@ -369,8 +369,16 @@ class TwoFCROIFeatureExtractor(nn.Module):
                 raise RuntimeError("the gradient of the previous step's sampled-row views was parked for the stacked "
                                    "fc6 node, whose backward never ran")
             self._grad_holder = _GradHolder()
-            x = _StackCleanAug.apply(pooled, block.contiguous(), _keep_sum(block), self._grad_holder)
-            h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5])
+            block_c, block_sum = block.contiguous(), _keep_sum(block)
+            x = _StackCleanAug.apply(pooled, block_c, block_sum, self._grad_holder)
+            pair = None
+            if precision.get_precision() == "bf16x2f" and self.fc6.can_pair(pooled.shape[1], pooled.shape[2] * pooled.shape[3]):
+                # the shared clean + DropBlock forward reads the CLEAN rows only (as cell-major planes); the stacked fp32
+                # operand stays what the backward reads
+                with torch.no_grad():
+                    planes_cm = gemm.split_rows_cm(pooled.detach().reshape(P, -1), pooled.shape[1], pooled.shape[2] * pooled.shape[3])
+                pair = (planes_cm, x.detach(), block_c.view(P, -1), block_sum)
+            h = self._fc(x, segs6=[(0,) + k1, (P,) + k4], segs7=[(0,) + k2, (P,) + k5], pair=pair)
             return h[:P], h[P:]
         aug = self.forward_dropblock(pooled) if hasattr(self, "dropblock") else pooled
         k4, k5 = self.rand.key(), self.rand.key()
