@@ -364,7 +364,7 @@ def main():
                         roof["traffic"] = hit[0]["traffic_bytes"]
                         roof["traffic_of"] = "%s; algorithmic %d B; %s" % (hit[0]["launch"], hit[0]["algorithmic_bytes"], hit[0]["source"])
                         break
-            if roof["kernel"].startswith("gemm_nt_cm_kernel<true>"):
+            if roof["kernel"].startswith("gemm_nt_cm_kernel<true"):
                 roof["note"] = ("one sweep over the clean fc6 operand yields the clean AND the DropBlock outputs (summation by parts over "
                                 "the 49 cells): `achieved` counts the MFMA work issued; the stacked pass it replaces (rounds 1-3) issued "
                                 "twice that for the same results")

@@ -106,7 +106,8 @@ def gemm_nt_cm(a_cm, b_cm, M, N, C, S, out, bias=None, relu=False, drop_p=0.0, s
     pair = keep is not None
     ws_bytes = (L.lib().odw_gemm_nt_cm_pair_workspace(M, N, S) if drop_row0 == M else 0) if pair else L.lib().odw_gemm_nt_cm_workspace(M, N, S)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device) if ws_bytes else None
-    sym = "gemm_nt_cm_kernel<%s>%s" % ("true" if pair else "false", " split+reduce" if ws_bytes else "")
+    split = bool(ws_bytes) and L.lib().odw_gemm_nt_cm_workspace(M, N, S) > 0
+    sym = "gemm_nt_cm_kernel<%s, 1>%s" % ("true" if pair else "false", " split+reduce" if split else "")      # rocprofv3's name
     with kernel_timer.region(sym, flops=2.0 * M * N * 3 * K):      # MFMA work ISSUED (the pair form replaces twice that)
         L.check(L.lib().odw_gemm_nt_cm(L.ptr(a_cm), a_cm.stride(0), K, L.ptr(b_cm), b_cm.stride(0), K, M, N, C, S,
                                        L.ptr(keep), L.ptr(keep_sum), drop_row0, L.ptr(out), out.stride(0), L.ptr(bias),
