@@ -15,6 +15,6 @@ def t(M, segs, iters=6):
     for _ in range(iters): gemm.gemm_nt(a, b, M, N, K, out, bias=bias, relu=True, drop_p=0.5, segs=segs)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    return ms, 2.0 * M * N * K / ms / 1e12
+    return ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12
 which = os.environ.get("ODW_GEMM_VARIANT", "auto")
 print("variant %-5s  M=4000: %.3f ms %.0f TF   M=2000: %.3f ms %.0f TF" % ((which,) + t(2 * P, [(0, 1, 2), (P, 3, 4)]) + t(P, [(0, 1, 2)])), flush=True)
