@@ -14,6 +14,7 @@ the flow: one process per GPU, IMS_PER_BATCH split over the ranks).  Inputs are 
 the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -72,8 +73,9 @@ def parse():
     ap.add_argument("--arch", default="vgg16", choices=["vgg16", "r50"],
                     help="vgg16 = the headline workload (BASELINE.json configs[1]); r50 = the R-50-C5 config "
                          "(configs/voc/voc07_r50_c5_*.yaml), a secondary line")
-    ap.add_argument("--time-every", type=int, default=4,
-                    help="bracket the GEMM / conv launches of 1 timed step in N with HIP events (roofline object)")
+    ap.add_argument("--time-every", type=int, default=10,
+                    help="bracket the GEMM / conv launches of 1 timed step in N with HIP events (roofline object); such a step "
+                         "carries ~220 event records and takes ~1.1 ms longer (`per_step_ms`), inside the timed region")
     ap.add_argument("--pooler", default="ROIPool", choices=["ROIPool", "ROIAlign"],
                     help="POOLER_METHOD; every shipped config of the reference uses ROIPool (the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -316,10 +318,15 @@ def main():
         exch = step_fn.optimizer.exchange
         for it in range(warmup):
             step_fn(images, targets, rois, DeviceRand(seed + rank, first_stream=(1 << 20) + (it << 12), device=device))
-        engine.kernel_timer.reset()
-        engine.kernel_timer.timed_steps = len([it for it in range(steps) if it % args.time_every == 0])
+        n_timed = len([it for it in range(steps) if it % args.time_every == 0])
+        engine.kernel_timer.reset(prealloc=2 * 160 * n_timed if engine.kernel_timer.enabled else 0)
+        engine.kernel_timer.timed_steps = n_timed
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         exch.measure, exch.marks = world > 1, []        # event pairs around GradExchange.finish (the waits on the collectives)
+        # the model, the optimiser and the captured graphs are long-lived: keep the cyclic collector from walking them in the
+        # middle of a step (a full collection over ~1e6 objects showed up as a single 17 ms step in `per_step_ms`)
+        gc.collect()
+        gc.freeze()
         barrier()
         t0 = time.perf_counter()
         for it in range(steps):
@@ -335,6 +342,7 @@ def main():
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        gc.unfreeze()
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         exch.measure = False
         info = dict(info, collective=collective_report(exch, args, world, steps, shared))
@@ -395,6 +403,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "dtype_note": DTYPE_NOTE[args.dtype], "data": "synthetic",
             "median_ms_per_step": round(med, 3),
             "value_at_median_step": round(world * ipr * args.proposals / (med * 1e-3), 1),
+            "per_step_ms": [round(float(v), 2) for v in per_step],      # rank 0's HIP-event time of each timed step
             "config": {"workload": "%s + %d MCG-like proposals, batch %d/GPU, %dpx (padded %d), %s 7x7, "
                                    "OD-WSCL loss (CONTRA), SGD step, %d classes"
                                    % ("VGG16-OICR" if args.arch == "vgg16" else "R-50-C5", args.proposals, ipr, args.size,

@@ -6,6 +6,7 @@ forward product and W^T (K x N8) for the input gradient.  Shadows are refreshed 
 parameter's version counter moves (after every optimiser step).
 """
 import ctypes
+import os
 
 import torch
 
@@ -28,6 +29,8 @@ def _r64(n):
 
 
 _VARIANT_SYMBOL = {0: "", 1: "glds_", 2: "ring_", 3: "big_"}      # names as rocprofv3's kernel trace prints them
+_ENV = os.environ.get
+_PLAN_CACHE = {}      # (M, N, K, lda, ldb, ldc, out_bf16, alignment of C) -> (split-K workspace bytes, kernel variant)
 
 
 def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, segs=None, accumulate=False, row_ids=None):
@@ -41,10 +44,20 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
     out_bf16 = out.dtype == torch.bfloat16
     # per-symbol timing for bench.py's roofline object (same names as rocprofv3's kernel trace)
-    var = ctypes.c_int(0)
-    ws_bytes = L.lib().odw_gemm_nt_bf16_workspace(M, N, K, a.stride(0), b.stride(0), L.ptr(out), out.stride(0),
-                                                  1 if out_bf16 else 0, ctypes.byref(var))
-    var = var.value
+    # the planner's answer depends on the shape, the strides and the alignment of C only: asked once per distinct product
+    # (a ctypes round trip per launch otherwise, ~70 launches per step)
+    out_ptr = L.ptr(out)
+    key = (M, N, K, a.stride(0), b.stride(0), out.stride(0), out_bf16, out.data_ptr() & 15, _ENV("ODW_GEMM_VARIANT"),
+           _ENV("ODW_GEMM_SPLITK"))
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        var = ctypes.c_int(0)
+        ws_bytes = L.lib().odw_gemm_nt_bf16_workspace(M, N, K, a.stride(0), b.stride(0), out_ptr, out.stride(0),
+                                                      1 if out_bf16 else 0, ctypes.byref(var))
+        if len(_PLAN_CACHE) > 4096:
+            _PLAN_CACHE.clear()
+        plan = _PLAN_CACHE[key] = (ws_bytes, var.value)
+    ws_bytes, var = plan
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None     # split-K partials
     split = ws is not None
     sym = "gemm_nt_bf16_%skernel<%s>%s" % (_VARIANT_SYMBOL[var], ("false" if split or not out_bf16 else "true")

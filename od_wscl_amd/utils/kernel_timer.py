@@ -15,12 +15,12 @@ class _Region(object):
         self.layer = timer.layer
 
     def __enter__(self):
-        self.start = torch.cuda.Event(enable_timing=True)
+        self.start = self.timer.event()
         self.start.record()
         return self
 
     def __exit__(self, *exc):
-        end = torch.cuda.Event(enable_timing=True)
+        end = self.timer.event()
         end.record()
         rec = (self.start, end, self.flops, self.nbytes)
         self.timer.records.setdefault(self.name, []).append(rec)
@@ -48,9 +48,21 @@ class KernelTimer(object):
         self.tally = None         # a float while a counting pass runs (region() adds its FLOPs and records nothing)
         self.reset()
 
-    def reset(self):
+    def reset(self, prealloc=0):
+        """prealloc: HIP events created (and recorded once, which is what creates them) ahead of the timed region -- a
+        timed step brackets ~110 launches, and creating its 220 events on the fly cost it about half a millisecond."""
         self.records = {}       # name -> list of (start_event, end_event, flops, bytes)
         self.timed_steps = 0    # steps whose launches carried events (set by the caller: flops_per_timed_step)
+        self.pool = []
+        if prealloc and torch.cuda.is_available():
+            for _ in range(int(prealloc)):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self.pool.append(e)
+            torch.cuda.synchronize()
+
+    def event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
 
     def region(self, name, flops=0.0, nbytes=0.0):
         """with kernel_timer.region(symbol, flops=...): <one launch on torch's current stream>"""

@@ -439,7 +439,9 @@ def test_iter_size_accumulates_gradients_over_a_group(monkeypatch):
     want = singles[0] + singles[1]
     for n, (o, k) in slices.items():
         a, b = m_group[o:o + k], want[o:o + k]
-        assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item() + 1e-9, n
+        # (absolute floor: the det_score bias gradient is analytically zero -- a softmax over the proposals is shift
+        # invariant -- and what is left of it, ~1e-8, is the rounding of sums whose terms are ~1e-3)
+        assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item() + 2e-8, n
 
 
 def test_mixed_batch_with_an_unlabelled_image_gets_background_labels():

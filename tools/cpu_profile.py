@@ -10,6 +10,11 @@ images, targets, rois = bench.synthetic_batch(1234, 0, 600, 2000, 21, dev)
 for it in range(5):
     step(images, targets, rois, DeviceRand(1234, first_stream=(1 << 20) + (it << 12), device=dev))
 torch.cuda.synchronize()
+if os.environ.get("ODW_PROFILE_BACKWARD") == "1":      # run autograd on THIS thread, so that cProfile sees the backward functions
+    torch.autograd.set_multithreading_enabled(False)
+    for it in range(3):
+        step(images, targets, rois, DeviceRand(1234, first_stream=(1 << 20) + ((20 + it) << 12), device=dev))
+    torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
 for it in range(5, 15):
     step(images, targets, rois, DeviceRand(1234, first_stream=(1 << 20) + (it << 12), device=dev))
