@@ -328,6 +328,7 @@ def main():
         gc.collect()
         gc.freeze()
         barrier()
+        allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
         t0 = time.perf_counter()
         for it in range(steps):
             engine.kernel_timer.active = it % args.time_every == 0
@@ -343,6 +344,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         gc.unfreeze()
+        info = dict(info, device_allocs=int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0))
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         exch.measure = False
         info = dict(info, collective=collective_report(exch, args, world, steps, shared))
@@ -404,6 +406,7 @@ def main():
             "median_ms_per_step": round(med, 3),
             "value_at_median_step": round(world * ipr * args.proposals / (med * 1e-3), 1),
             "per_step_ms": [round(float(v), 2) for v in per_step],      # rank 0's HIP-event time of each timed step
+            "device_allocs_in_timed_region": info.get("device_allocs"),   # hipMalloc calls of the caching allocator (a spike in per_step_ms)
             "config": {"workload": "%s + %d MCG-like proposals, batch %d/GPU, %dpx (padded %d), %s 7x7, "
                                    "OD-WSCL loss (CONTRA), SGD step, %d classes"
                                    % ("VGG16-OICR" if args.arch == "vgg16" else "R-50-C5", args.proposals, ipr, args.size,
