@@ -838,8 +838,8 @@ ODW_EXPORT int odw_pairwise_sim_planes(const void* planes, int P, float* S, void
     ODW_REQUIRE((((uintptr_t)planes) & 15) == 0 && (((uintptr_t)S) & 15) == 0, "pairwise_sim_planes: buffers must be 16-byte aligned");
     const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
     const int max_run = pw_max_run(nblk32, npanel, ODW_NUM_CU), grid = pw_groups(max_run, nblk32, npanel);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_sim_dma_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPdLds);      // once
+    static const hipError_t attr = odw_set_max_lds(reinterpret_cast<const void*>(pairwise_sim_dma_kernel),
+                                                       kPdLds);      // once
     ODW_CHECK_HIP(attr, "pairwise dma attr");
     pairwise_sim_dma_kernel<<<grid, kPwWaves * 64, kPdLds, (hipStream_t)stream_>>>((const unsigned char*)planes, P, S, max_run);
     ODW_CHECK_LAUNCH("pairwise_sim_dma_kernel");
@@ -873,8 +873,8 @@ static int pairwise_sim_impl(const float* E, int P, int D, float* S, int64_t ldS
         // split-bf16 panel form: one launch, no workspace (the planes are made in registers)
         const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
         const int max_run = pw_max_run(nblk32, npanel, ODW_NUM_CU), grid = pw_groups(max_run, nblk32, npanel);
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_sim_panel_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPwLds);      // once
+        static const hipError_t attr = odw_set_max_lds(reinterpret_cast<const void*>(pairwise_sim_panel_kernel),
+                                                           kPwLds);      // once
         ODW_CHECK_HIP(attr, "pairwise attr");
 #ifdef ODW_EXPERIMENTS
         static const int dbg = getenv("ODW_PAIRWISE_DBG") ? atoi(getenv("ODW_PAIRWISE_DBG")) : 0;

@@ -217,8 +217,8 @@ int pow2_at_least(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 int launch_detect(DetArgs a, int n_img, int max_p, void* stream_) {
     const int ppow2 = pow2_at_least(max_p);
     const size_t lds = (size_t)ppow2 * (16 + 16 + 4 + 4 + 1) + 64;
-    ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(detect_classes_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "detect attr");
+    ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(detect_classes_kernel),
+                                      (int)lds), "detect attr");
     detect_classes_kernel<<<dim3((unsigned)n_img, (unsigned)(a.C - 1)), kThreads, lds, (hipStream_t)stream_>>>(a, ppow2);
     ODW_CHECK_LAUNCH("detect_classes_kernel");
     return ODW_OK;

@@ -519,8 +519,8 @@ ODW_EXPORT int odw_discover_sim(const float* E, const float* s0, const float* s1
                  (size_t)ppow2 + 64;
     const int sbox_off = (int)((lds + 15) / 16 * 16);
     lds = (size_t)sbox_off + (size_t)ppow2 * 16;
-    ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(discover_sim_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "discover_sim attr");
+    ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(discover_sim_kernel),
+                                      (int)lds), "discover_sim attr");
     discover_sim_kernel<<<dim3(n_img, 3 * maxpos), kThreads, lds, (hipStream_t)stream_>>>(a, ppow2, sbox_off);
     ODW_CHECK_LAUNCH("discover_sim_kernel");
     const size_t lds2 = kThreads * sizeof(ArgMax) + (size_t)a.W32 * 4 * 2 + (size_t)(a.W32 + 1) * 4;

@@ -2105,8 +2105,8 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
     if (keep) {
 #define ODW_CM_LAUNCH(PAIRV, SV, LDSB, GRID, OUT, EP)                                                                   \
         do {                                                                                                             \
-            static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_cm_kernel<PAIRV, SV>), \
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)); \
+            static const hipError_t attr_ = odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_cm_kernel<PAIRV, SV>), \
+                                                                (int)(LDSB)); \
             ODW_CHECK_HIP(attr_, "gemm_nt_cm attr");                                                                     \
             gemm_nt_cm_kernel<PAIRV, SV><<<GRID, kRingThreads, LDSB, stream>>>(                                          \
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, OUT, ldc_, EP, cm, tiles_m, tiles_n); \
@@ -2251,15 +2251,15 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
         const dim3 grid_b((unsigned)(((M + GM - 1) / GM) * ((N + GN - 1) / GN)), (unsigned)plan.splits);
         if (plan.variant == 3) {
             const size_t big_lds = (size_t)5 * GM * kChunksPerRow * sizeof(uint4);      // three-slot B ring
-            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr");
+            ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
+                                              (int)big_lds), "big attr");
             gemm_nt_bf16_big_kernel<false, 7><<<grid_b, kBigThreads, big_lds, stream>>>(
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, workspace, ldw, pe,
                 (M + GM - 1) / GM, (N + GN - 1) / GN);
         } else {
             const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
-            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "ring attr");
+            ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
+                                              (int)ring_lds), "ring attr");
             gemm_nt_bf16_ring_kernel<false><<<grid_r, kRingThreads, ring_lds, stream>>>(
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, workspace, ldw, pe,
                 (M + RM - 1) / RM, (N + RN - 1) / RN);
@@ -2286,13 +2286,13 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
         if (ring3) {                      // the default: three-slot B ring, 160 KB of LDS (ODW_GEMM_EXP=0: two slots)
             const size_t lds7 = (size_t)5 * GM * kChunksPerRow * sizeof(uint4);
             if (c_is_bf16) {
-                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<true, 7>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7), "big7 attr");
+                ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<true, 7>),
+                                                  (int)lds7), "big7 attr");
                 gemm_nt_bf16_big_kernel<true, 7><<<btiles_m * btiles_n, kBigThreads, lds7, stream>>>(
                     (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n);
             } else {
-                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7), "big7 attr");
+                ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
+                                                  (int)lds7), "big7 attr");
                 gemm_nt_bf16_big_kernel<false, 7><<<btiles_m * btiles_n, kBigThreads, lds7, stream>>>(
                     (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n);
             }
@@ -2300,8 +2300,8 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
             return 0;
         }
         if (c_is_bf16) {
-            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr");
+            ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<true>),
+                                              (int)big_lds), "big attr");
             gemm_nt_bf16_big_kernel<true><<<btiles_m * btiles_n, kBigThreads, big_lds, stream>>>(
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n);
         } else {
@@ -2313,8 +2313,8 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
 #endif
 #define ODW_BIG_X(XV)                                                                                            \
             do {                                                                                                 \
-                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, XV>), \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr"); \
+                ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, XV>), \
+                                                  (int)big_lds), "big attr"); \
                 gemm_nt_bf16_big_kernel<false, XV><<<btiles_m * btiles_n, kBigThreads, big_lds, stream>>>(       \
                     (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, btiles_m, btiles_n); \
             } while (0)
@@ -2327,21 +2327,21 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
     }
 #define ODW_LAUNCH_GEMM(KERNEL, OUTBF)                                                                          \
     do {                                                                                                        \
-        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<OUTBF>),                         \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "gemm attr"); \
+        ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(KERNEL<OUTBF>),                         \
+                                          (int)lds_bytes), "gemm attr"); \
         KERNEL<OUTBF><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(                                      \
             (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, tiles_m, tiles_n); \
     } while (0)
     if (use_ring) {
         const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);   // 144 KB
         if (c_is_bf16) {
-            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "ring attr");
+            ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<true>),
+                                              (int)ring_lds), "ring attr");
             gemm_nt_bf16_ring_kernel<true><<<rtiles_m * rtiles_n, kRingThreads, ring_lds, stream>>>(
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, rtiles_m, rtiles_n);
         } else {
-            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "ring attr");
+            ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
+                                              (int)ring_lds), "ring attr");
             gemm_nt_bf16_ring_kernel<false><<<rtiles_m * rtiles_n, kRingThreads, ring_lds, stream>>>(
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, C, ldc, ep, rtiles_m, rtiles_n);
         }
@@ -2386,16 +2386,16 @@ ODW_EXPORT int odw_conv_wgrad_nt(const void* dzt, int lda, const void* colt, int
         if (plan.variant == 3) {
             const size_t big_lds = (size_t)5 * GM * kChunksPerRow * sizeof(uint4);
             const dim3 grid((unsigned)(((Co + GM - 1) / GM) * ((N + GN - 1) / GN)), (unsigned)S);
-            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds), "big attr");
+            ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<false, 7>),
+                                              (int)big_lds), "big attr");
             gemm_nt_bf16_big_kernel<false, 7><<<grid, kBigThreads, big_lds, stream>>>(
                 (const unsigned short*)dzt, lda, (const unsigned short*)colt, ldb, Co, N, K, workspace, ldw, pe,
                 (Co + GM - 1) / GM, (N + GN - 1) / GN);
         } else {
             const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
             const dim3 grid((unsigned)(((Co + RM - 1) / RM) * ((N + RN - 1) / RN)), (unsigned)S);
-            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "ring attr");
+            ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_bf16_ring_kernel<false>),
+                                              (int)ring_lds), "ring attr");
             gemm_nt_bf16_ring_kernel<false><<<grid, kRingThreads, ring_lds, stream>>>(
                 (const unsigned short*)dzt, lda, (const unsigned short*)colt, ldb, Co, N, K, workspace, ldw, pe,
                 (Co + RM - 1) / RM, (N + RN - 1) / RN);
@@ -2760,14 +2760,14 @@ static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int ldx,
             hg.split_stride = (long long)Co * N; hg.ldw = N; hg.zero = (const unsigned short*)zero_page;
             const dim3 grid((unsigned)(8 * hg.chunk));
             if (dilation == 1) {
-                static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<16, 1>),
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WhCfg<16, 1>::kLds);
+                static const hipError_t a1 = odw_set_max_lds(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<16, 1>),
+                                                                 WhCfg<16, 1>::kLds);
                 ODW_CHECK_HIP(a1, "wgrad halo attr");
                 conv_wgrad_halo_kernel<16, 1><<<grid, 512, WhCfg<16, 1>::kLds, stream>>>(
                     (const unsigned short*)dz, (const unsigned short*)X, (float*)workspace, hg);
             } else {
-                static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<8, 2>),
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WhCfg<8, 2>::kLds);
+                static const hipError_t a2 = odw_set_max_lds(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<8, 2>),
+                                                                 WhCfg<8, 2>::kLds);
                 ODW_CHECK_HIP(a2, "wgrad halo attr");
                 conv_wgrad_halo_kernel<8, 2><<<grid, 512, WhCfg<8, 2>::kLds, stream>>>(
                     (const unsigned short*)dz, (const unsigned short*)X, (float*)workspace, hg);
@@ -2795,8 +2795,8 @@ static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int ldx,
     for (int i = 0; i < kMaxSeg; ++i) { pe.seg_row[i] = 0; pe.seg_k0[i] = 0; pe.seg_k1[i] = 0; }
     pe.kchunk = plan.kchunk; pe.split_stride = (long long)Co * N * 4;
     const size_t ring_lds = (size_t)kRingStages * kRingStageChunks * sizeof(uint4);
-    ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_ring_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds), "tn attr");
+    ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(gemm_tn_bf16_ring_kernel<true>),
+                                      (int)ring_lds), "tn attr");
     gemm_tn_bf16_ring_kernel<true><<<dim3((unsigned)(plan.tiles_m * plan.tiles_n), (unsigned)plan.splits), kRingThreads,
                                      ring_lds, stream>>>((const unsigned short*)dz, ld_dz, (const unsigned short*)X, Cp, Co, N,
                                                          n_pix, workspace, N, pe, plan.tiles_m, plan.tiles_n, g);
@@ -3045,8 +3045,8 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
         }
 #define ODW_LAUNCH_HALO(OUTBF, D)                                                                                  \
         do {                                                                                                       \
-            ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<OUTBF, D>),        \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Halo<D>::kLdsBytes), \
+            ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(conv3x3_halo_kernel<OUTBF, D>),        \
+                                              (int)Halo<D>::kLdsBytes), \
                           "halo attr");                                                                            \
             conv3x3_halo_kernel<OUTBF, D><<<grid, kHaloThreads, Halo<D>::kLdsBytes, stream>>>(                      \
                 (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y,    \
@@ -3058,8 +3058,8 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
         if (dbg > 0 && out_bf16 && dilation == 1) {
 #define ODW_LAUNCH_HALO_DBG(X_)                                                                                    \
             do {                                                                                                   \
-                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<true, 1, X_>), \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Halo<1>::kLdsBytes), \
+                ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(conv3x3_halo_kernel<true, 1, X_>), \
+                                                  (int)Halo<1>::kLdsBytes), \
                               "halo attr");                                                                        \
                 conv3x3_halo_kernel<true, 1, X_><<<grid, kHaloThreads, Halo<1>::kLdsBytes, stream>>>(              \
                     (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y, \
@@ -3073,8 +3073,8 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
         if (N == 64 && hp.tiles_n == 1 && dilation == 1 && !getenv("ODW_CONV_NO_N64")) {
 #define ODW_LAUNCH_HALO64(OUTBF)                                                                                   \
             do {                                                                                                   \
-                ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<OUTBF, 1, 0, true>), \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Halo<1>::kLdsBytes), \
+                ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(conv3x3_halo_kernel<OUTBF, 1, 0, true>), \
+                                                  (int)Halo<1>::kLdsBytes), \
                               "halo attr");                                                                        \
                 conv3x3_halo_kernel<OUTBF, 1, 0, true><<<grid, kHaloThreads, Halo<1>::kLdsBytes, stream>>>(        \
                     (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y, \
@@ -3109,8 +3109,8 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
         pe.split_stride = (long long)n_pix * N * 4;
         const int tm_ = (n_pix + BM - 1) / BM, tn_ = (N + BN - 1) / BN;
         const size_t lds_b = (size_t)2 * 2 * kTileChunks * sizeof(uint4);
-        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_glds_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b), "conv attr");
+        ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(conv3x3_glds_kernel<false>),
+                                          (int)lds_b), "conv attr");
         conv3x3_glds_kernel<false><<<dim3((unsigned)(tm_ * tn_), (unsigned)sp), kThreads, lds_b, stream>>>(
             (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_pix, N, workspace, N, pe, tm_, tn_);
         ODW_CHECK_HIP(hipGetLastError(), "conv3x3 split launch");
@@ -3128,13 +3128,13 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
     const int tiles_m = (n_pix + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);
     if (y_is_bf16) {
-        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_glds_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "conv attr");
+        ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(conv3x3_glds_kernel<true>),
+                                          (int)lds_bytes), "conv attr");
         conv3x3_glds_kernel<true><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(
             (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_pix, N, Y, ldy, ep, tiles_m, tiles_n);
     } else {
-        ODW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_glds_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "conv attr");
+        ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(conv3x3_glds_kernel<false>),
+                                          (int)lds_bytes), "conv attr");
         conv3x3_glds_kernel<false><<<tiles_m * tiles_n, kThreads, lds_bytes, stream>>>(
             (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_pix, N, Y, ldy, ep, tiles_m, tiles_n);
     }

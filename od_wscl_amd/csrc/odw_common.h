@@ -8,7 +8,7 @@
 
 #define ODW_EXPORT extern "C" __attribute__((visibility("default")))
 
-// thread-local last-error message (the only mutable state in the library)
+// thread-local last-error message (with the per-kernel LDS-size cache below: the only mutable state in the library)
 void odw_set_error(const char* fmt, ...);
 
 #define ODW_REQUIRE(cond, ...)                    \
@@ -27,6 +27,21 @@ void odw_set_error(const char* fmt, ...);
             return ODW_ELAUNCH;                                                  \
         }                                                                        \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver call on the launch path of every kernel that asks for more
+// than 64 KB of LDS -- ~26 GEMM launches per step.  Remember the largest size set per kernel and only go to the driver for more.
+#include <mutex>
+#include <unordered_map>
+static inline hipError_t odw_set_max_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = seen.find(fn);
+    if (it != seen.end() && it->second >= bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) seen[fn] = bytes;
+    return e;
+}
 
 #define ODW_CHECK_HIP(expr, name)                                        \
     do {                                                                 \

@@ -525,8 +525,8 @@ int pick_cg(int B, int C, int HW) {
 
 template <typename K>
 hipError_t allow_lds(K kernel, size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return odw_set_max_lds(reinterpret_cast<const void*>(kernel),
+                               (int)bytes);
 }
 
 }  // namespace

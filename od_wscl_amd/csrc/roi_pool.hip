@@ -824,8 +824,8 @@ __global__ __launch_bounds__(512) void roi_pool_fwd_nhwc_op(const unsigned* __re
 
 template <typename K>
 hipError_t allow_lds(K kernel, size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return odw_set_max_lds(reinterpret_cast<const void*>(kernel),
+                               (int)bytes);
 }
 
 }  // namespace

@@ -6,7 +6,6 @@ forward product and W^T (K x N8) for the input gradient.  Shadows are refreshed 
 parameter's version counter moves (after every optimiser step).
 """
 import ctypes
-import os
 
 import torch
 
@@ -29,7 +28,6 @@ def _r64(n):
 
 
 _VARIANT_SYMBOL = {0: "", 1: "glds_", 2: "ring_", 3: "big_"}      # names as rocprofv3's kernel trace prints them
-_ENV = os.environ.get
 _PLAN_CACHE = {}      # (M, N, K, lda, ldb, ldc, out_bf16, alignment of C) -> (split-K workspace bytes, kernel variant)
 
 
@@ -47,8 +45,9 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     # the planner's answer depends on the shape, the strides and the alignment of C only: asked once per distinct product
     # (a ctypes round trip per launch otherwise, ~70 launches per step)
     out_ptr = L.ptr(out)
-    key = (M, N, K, a.stride(0), b.stride(0), out.stride(0), out_bf16, out.data_ptr() & 15, _ENV("ODW_GEMM_VARIANT"),
-           _ENV("ODW_GEMM_SPLITK"))
+    # (ODW_GEMM_VARIANT / ODW_GEMM_SPLITK changed mid-process: the launch itself re-plans in C; a stale entry here only means
+    # an unused or missing split-K workspace and a stale timing label)
+    key = (M, N, K, a.stride(0), b.stride(0), out.stride(0), out_bf16, out.data_ptr() & 15)
     plan = _PLAN_CACHE.get(key)
     if plan is None:
         var = ctypes.c_int(0)
