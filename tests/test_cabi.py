@@ -37,6 +37,23 @@ def test_error_reporting_without_gpu():
     assert lib.odw_roi_pool_workspace(2000, 7, 7) >= 2000 * 29 * 4
 
 
+def test_cell_split_of_the_cell_major_product_fills_whole_rounds():
+    """odw_gemm_nt_cm_workspace (host logic, no launch): one workgroup per CU, so T tiles x s splits take ceil(T s / 256)
+    rounds of ceil(49 / s) cells -- the split count is the one with the fewest cells on the critical path; a product that
+    fills the chip by itself is not split; the pair form's partials hold both halves."""
+    lib = _lib.lib()
+    N, S, ldw = 4096, 49, 4096
+    splits = lambda M: lib.odw_gemm_nt_cm_workspace(M, N, S) // (M * ldw * 4)
+    assert splits(2000) == 0 and splits(4000) == 0                   # 256 / 512 tiles of 256 x 128
+    for M in (100, 300, 446, 892, 1400):
+        s = splits(M)
+        tiles = -(-M // 256) * (N // 128)
+        cost = lambda k: -(-tiles * k // 256) * -(-S // k)
+        assert s >= 2 and cost(s) <= min(cost(k) for k in range(1, 17)) + 1, (M, s)
+        assert lib.odw_gemm_nt_cm_pair_workspace(M, N, S) == 2 * lib.odw_gemm_nt_cm_workspace(M, N, S)
+    assert splits(446) == 4                                           # the sampled-row views of the bench step: one round
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "od_wscl_amd")
     for dp, _, files in os.walk(pkg):
