@@ -131,6 +131,35 @@ def test_pair_form_split_over_cells_equals_the_single_sweep(P, N, C, S):
     assert ((split - one).abs() * (~differ)).max().item() <= 3e-5 * max(1.0, one.abs().max().item())
 
 
+def test_c_abi_binding_of_integration_5a_gives_the_references_two_fc6_evaluations():
+    """INTEGRATION.md 5a, as a maintainer of the reference would call it: raw C-ABI entry points on (P, 512, 7, 7) pooled
+    features and DropBlock2D's block mask, against `relu(fc6(x))` and `relu(fc6(x * mask * mask.numel() / mask.sum()))`
+    (vgg16.py:121, drop_block.py:49-50) evaluated by torch in fp64."""
+    from od_wscl_amd import _lib as L
+    lib = L.lib()
+    P, C, S, N = 96, 512, 49, 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pooled = torch.relu(torch.randn(P, C, 7, 7, device="cuda", generator=g))
+    weight = torch.randn(N, C * S, device="cuda", generator=g) * 0.01
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    keep = (torch.rand(P, 7, 7, device="cuda", generator=g) > 0.4).float()
+    x_cm = torch.empty((P, 2 * C * S), dtype=torch.bfloat16, device="cuda")
+    w_cm = torch.empty((N, 2 * C * S), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.odw_split_rows_cm(L.ptr(pooled.reshape(P, -1)), C * S, P, C, S, L.ptr(x_cm), 2 * C * S, C * S, L.stream()), "x")
+    L.check(lib.odw_split_rows_cm(L.ptr(weight), C * S, N, C, S, L.ptr(w_cm), 2 * C * S, C * S, L.stream()), "w")
+    out = torch.full((2 * P, N), float("nan"), device="cuda")
+    ksum = keep.sum()
+    L.check(lib.odw_gemm_nt_cm(L.ptr(x_cm), 2 * C * S, C * S, L.ptr(w_cm), 2 * C * S, C * S, P, N, C, S, L.ptr(keep), L.ptr(ksum), P,
+                               L.ptr(out), N, L.ptr(bias), 1, 0.0, 0, None, None, None, None, 0, L.stream()), "pair")
+    x64, w64, b64 = pooled.double(), weight.double(), bias.double()
+    clean = torch.relu(x64.reshape(P, -1) @ w64.T + b64)
+    xd = x64 * keep.double()[:, None] * keep.numel() / keep.double().sum()
+    drop = torch.relu(xd.reshape(P, -1) @ w64.T + b64)
+    scale = max(1.0, clean.abs().max().item(), drop.abs().max().item())
+    assert (out[:P].double() - clean).abs().max().item() <= 3e-5 * scale
+    assert (out[P:].double() - drop).abs().max().item() <= 3e-5 * scale
+
+
 def test_pair_form_refuses_what_it_cannot_do():
     from od_wscl_amd import gemm
     x, w, b = _operands(1, 64, 128, 64, 9)
