@@ -57,7 +57,8 @@ __global__ __launch_bounds__(512, 2) void stream_dma(const char* __restrict__ sr
 // PFD > 0: waves 0-3 touch the 256 lines of the A tile PFD steps ahead, waves 4-5 the 128 lines of the B tile, with one
 // global_load_dword each (lane -> line), issued BEHIND the step's DMA so that only later DMA waits behind it in the queue.
 template <bool LOCK, int PFD = 0>
-__global__ __launch_bounds__(512, 2) void stream_gemm(const char* __restrict__ src, size_t stream_bytes, int steps, int* sink) {
+__global__ __launch_bounds__(512, 2) void stream_gemm(const char* __restrict__ src, size_t stream_bytes, int steps, int* sink,
+                                                      int stagger_ns = 0) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     char* my = lds + wave * 18 * 1024;                          // 3 stages x 6 pieces
@@ -65,6 +66,14 @@ __global__ __launch_bounds__(512, 2) void stream_gemm(const char* __restrict__ s
     const char* A = src + (size_t)(xcd * 4 + (j >> 3)) * stream_bytes;
     const char* Bp = src + (size_t)(32 + xcd * 8 + (j & 7)) * stream_bytes;
     size_t oa = (size_t)wave * 4096, ob = (size_t)wave * 2048;   // per step: A 32 KB (4 KB per wave), B 16 KB (2 KB per wave)
+    if (stagger_ns > 0) {
+        // start the workgroups that share a stream one after the other: rank ((c - 2 r) mod 8) in units of stagger_ns -- every A
+        // stream (fixed r) and every B stream (fixed c) then has ONE leader whose misses the others find in L2
+        const int r = j >> 3, c = j & 7;
+        const long long wait = (long long)(((c - 2 * r) & 7)) * stagger_ns / 10;      // wall_clock64: 100 MHz
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     auto issue = [&](int stage) {
         char* dst = my + stage * 6 * 1024;
 #pragma unroll
@@ -93,6 +102,39 @@ __global__ __launch_bounds__(512, 2) void stream_gemm(const char* __restrict__ s
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((my[lane] == 123 && lane == 77) || pf == 0x12345678u) *sink = 1;
+}
+
+// The same pattern with the kernels' REAL addressing: a tile is 256 (A) / 128 (B) rows of a row-major matrix with `pitch` bytes
+// per row, a K step takes 128 bytes of every row, one DMA instruction = 8 rows x 128 B.  Do the rows of a tile spread over the
+// L2 channels?  (fc6's cell-major planes: pitch = 2 x 25088 x 2 = 100352 B = 392 x 256.)
+__global__ __launch_bounds__(512, 2) void stream_rows(const char* __restrict__ src, size_t pitch, int steps, int* sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    char* my = lds + wave * 18 * 1024;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const char* A = src + (size_t)(xcd * 4 + (j >> 3)) * 256 * pitch;                  // A tile rows
+    const char* Bp = src + (size_t)(32 * 256) * pitch + (size_t)(xcd * 8 + (j & 7)) * 128 * pitch;
+    const char* la = A + (size_t)(wave * 32 + (lane >> 3)) * pitch + (lane & 7) * 16;
+    const char* lb = Bp + (size_t)(wave * 16 + (lane >> 3)) * pitch + (lane & 7) * 16;
+    size_t k = 0;
+    auto issue = [&](int stage) {
+        char* dst = my + stage * 6 * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(la + (size_t)i * 8 * pitch + k), (lds_void_t*)(dst + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(lb + (size_t)i * 8 * pitch + k), (lds_void_t*)(dst + (4 + i) * 1024), 16, 0, 0);
+        k += 128;
+    };
+    issue(0); issue(1);
+    for (int s = 0; s < steps; ++s) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue((s + 2) % 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (my[lane] == 123 && lane == 77) *sink = 1;
 }
 
 template <int DEPTH>
@@ -191,7 +233,7 @@ int main() {
         const int steps = 1176;                                  // the fc6 sweep: 1176 K steps of 48 KB per workgroup
         const size_t sb = (size_t)40 << 20;                      // >= 1178 x 32 KB per stream
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-        for (int lock = 0; lock < 5; ++lock) {
+        for (int lock = 0; lock < 9; ++lock) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
@@ -200,7 +242,8 @@ int main() {
             float best = 1e9f;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(a);
-                if (lock == 1) stream_gemm<true><<<grid, 512, 144 * 1024>>>(src, sb, steps, sink);
+                if (lock >= 5) stream_gemm<true><<<grid, 512, 144 * 1024>>>(src, sb, steps, sink, lock == 5 ? 500 : lock == 6 ? 1000 : lock == 7 ? 2000 : 4000);
+                else if (lock == 1) stream_gemm<true><<<grid, 512, 144 * 1024>>>(src, sb, steps, sink);
                 else if (lock == 2) stream_gemm<true, 4><<<grid, 512, 144 * 1024>>>(src, sb, steps, sink);
                 else if (lock == 3) stream_gemm<true, 8><<<grid, 512, 144 * 1024>>>(src, sb, steps, sink);
                 else if (lock == 4) stream_gemm<true, 16><<<grid, 512, 144 * 1024>>>(src, sb, steps, sink);
@@ -209,7 +252,24 @@ int main() {
                 float ms; hipEventElapsedTime(&ms, a, b); best = ms < best ? ms : best;
             }
             printf("GEMM pattern (4 A + 8 B streams per XCD, 48 KB per step, 96 KB in flight)%s: %7.1f GB/s per CU, %.3f ms for %d steps (%.2f us per step)\n",
-                   lock == 0 ? "" : lock == 1 ? " + barrier per step" : lock == 2 ? " + barrier + L2 prefetch 4 steps ahead" : lock == 3 ? " + barrier + L2 prefetch 8 ahead" : " + barrier + L2 prefetch 16 ahead", 48.0 * 1024 * steps / (best * 1e-3) / 1e9, best, steps, best * 1e3 / steps);
+                   lock == 0 ? "" : lock == 1 ? " + barrier per step" : lock == 2 ? " + barrier + L2 prefetch 4 steps ahead" : lock == 3 ? " + barrier + L2 prefetch 8 ahead" : lock == 4 ? " + barrier + L2 prefetch 16 ahead" : lock == 5 ? " + barrier + sharers staggered 0.5 us" : lock == 6 ? " + barrier + staggered 1 us" : lock == 7 ? " + barrier + staggered 2 us" : " + barrier + staggered 4 us", 48.0 * 1024 * steps / (best * 1e-3) / 1e9, best, steps, best * 1e3 / steps);
+        }
+    }
+    {
+        const int steps = 784;                                   // 784 x 128 B = the 100352-byte rows of fc6's planes
+        hipFuncSetAttribute(reinterpret_cast<const void*>(stream_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        const size_t pitches[] = {100352, 100352 + 128, 100352 + 256, 100352 + 512, 100352 + 1024, 100352 + 2048 + 256, 131072, 131072 + 256};
+        for (size_t pitch : pitches) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(a);
+                stream_rows<<<grid, 512, 144 * 1024>>>(src, pitch, steps, sink);
+                hipEventRecord(b); hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b); best = ms < best ? ms : best;
+            }
+            printf("row tiles, pitch %7zu B (%5zu x 256 + %3zu): %7.1f GB/s per CU, %.2f us per step\n", pitch, pitch / 256, pitch % 256,
+                   48.0 * 1024 * steps / (best * 1e-3) / 1e9, best * 1e3 / steps);
         }
     }
     return 0;
