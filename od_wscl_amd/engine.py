@@ -267,7 +267,8 @@ class FlatSGD(object):
 
             def managed_shadow(weight, o, cm=None):
                 sh = gemm.Shadow(weight)
-                if cm is not None and mode == "bf16x2f" and os.environ.get("ODW_NO_PAIR") != "1":
+                if (cm is not None and mode == "bf16x2f" and os.environ.get("ODW_NO_PAIR") != "1"
+                        and cm[0] % 64 == 0 and 1 <= cm[1] <= 64):
                     # the first head Linear: also as cell-major planes [hi | mid] for the shared clean + DropBlock forward
                     sh.cm = tuple(cm)
                     sh.w_cm = torch.empty((weight.shape[0], 2 * weight.shape[1]), dtype=torch.bfloat16, device=dev)

@@ -37,7 +37,8 @@ class Linear(nn.Linear):
         other layers)."""
         if self._shadow is None or self._shadow.weight is not self.weight:
             self._shadow = gemm.Shadow(self.weight)
-            if self.cm_layout is not None and os.environ.get("ODW_NO_PAIR") != "1":
+            if (self.cm_layout is not None and os.environ.get("ODW_NO_PAIR") != "1"
+                    and self.cm_layout[0] % 64 == 0 and 1 <= self.cm_layout[1] <= 64):      # (what gemm_nt_cm_kernel walks)
                 self._shadow.cm = tuple(self.cm_layout)
         return self._shadow
 

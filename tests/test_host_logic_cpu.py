@@ -209,3 +209,23 @@ def test_conv2d_has_no_library_forward_outside_the_reference_context():
     assert y.shape == (1, 4, 8, 8)
     with pytest.raises(RuntimeError):
         conv(x)
+
+
+def test_cell_major_layout_is_kept_only_for_shapes_the_kernel_walks(monkeypatch):
+    """layers.Linear.cm_layout -> gemm.Shadow.cm (the cell-major forward planes of the first head Linear): only
+    for channel counts that are multiples of the 64-wide K tile and at most 64 cells (the keep mask is a 64-bit set); any other
+    pooler resolution keeps the channel-major planes, and ODW_NO_PAIR=1 switches the form off altogether."""
+    from od_wscl_amd.layers.linear import Linear
+    ok = Linear(512 * 49, 8)
+    ok.cm_layout = (512, 49)
+    assert ok._get_shadow().cm == (512, 49) and ok.can_pair(512, 49) and not ok.can_pair(512, 36)
+    big = Linear(64 * 196, 8)
+    big.cm_layout = (64, 196)                      # a 14 x 14 pooler: more cells than the mask holds
+    assert big._get_shadow().cm is None and not big.can_pair(64, 196)
+    odd = Linear(48 * 49, 8)
+    odd.cm_layout = (48, 49)
+    assert odd._get_shadow().cm is None
+    monkeypatch.setenv("ODW_NO_PAIR", "1")
+    off = Linear(512 * 49, 8)
+    off.cm_layout = (512, 49)
+    assert off._get_shadow().cm is None and not off.can_pair(512, 49)
