@@ -341,6 +341,33 @@ def test_row_sparse_clean_backward_equals_dense(monkeypatch):
         assert rel <= 3e-2, (n, rel)          # bf16 GEMMs over different row sets: re-association + bf16 rounding
 
 
+@pytest.mark.parametrize("name", ["e2e_voc_2img", "e2e_coco_2img"])
+def test_reevaluated_clean_rows_equal_the_reattached_ones_in_the_bench_mode(name, monkeypatch):
+    """"bf16x2f", the shared clean + DropBlock fc6 forward: the clean rows the contrastive loss differentiates are re-attached
+    from the stacked pass's outputs (default) or RE-EVALUATED from the gathered planes (ODW_RECOMPUTE_CLEAN=1: the channel-major
+    hi plane for the backward, the cell-major planes for the forward product, with the dropout draws of their original rows).
+    Same losses, same gradients -- on goldens whose contrastive loss is not zero."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = {}
+    for recompute in (False, True):
+        monkeypatch.setenv("ODW_RECOMPUTE_CLEAN", "1" if recompute else "0")
+        losses, trace, model, g = _run_golden(name, "bf16x2f")
+        out[recompute] = ({k: float(v.detach()) for k, v in losses.items()},
+                          {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        del model
+    assert out[True][0]["loss_sim"] > 1e-6
+    for k in out[True][0]:
+        a, b = out[True][0][k], out[False][0][k]
+        assert abs(a - b) <= 1e-5 * max(abs(b), 1e-3), (k, a, b)
+    for n in out[True][1]:
+        ga, gb = out[True][1][n], out[False][1][n]
+        # (the re-evaluated rows' forward values come from other launches -- other tiling, other fp32 summation order --, so
+        # the single-plane bf16 backward rounds slightly different operands: per tensor, relative L2 within the mode's
+        # gradient tolerance, tests/test_fullsize_gpu.py GRAD_L2_TOL["bf16x2f"])
+        assert (ga - gb).double().norm().item() <= 2e-2 * gb.double().norm().item() + 1e-7, n
+
+
 def test_engine_steps_over_changing_shapes(monkeypatch):
     """Consecutive training steps on images of different sizes, proposal counts and label sets (the reference trains
     multi-scale: INPUT.MIN_SIZE_TRAIN has six sizes): every per-step buffer, index upload, split-K plan and
