@@ -78,6 +78,11 @@ def parse():
                          "carries ~220 event records and takes ~1.1 ms longer (`per_step_ms`), inside the timed region")
     ap.add_argument("--pooler", default="ROIPool", choices=["ROIPool", "ROIAlign"],
                     help="POOLER_METHOD; every shipped config of the reference uses ROIPool (the default)")
+    ap.add_argument("--rotate", type=int, default=8,
+                    help="the timed steps rotate over this many synthetic images per rank (image = rank + step mod n; 1-3 labels "
+                         "each, `config.labels_per_image`): the loss's loop work is proportional to 3 x the image's positive "
+                         "classes (weak_head/loss.py:281-345), and image 0 alone has ONE.  Capped at the warm-up step count, so "
+                         "that every image of the timed region has been through the step (allocator, planner caches) before")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proposals", type=int, default=2000)
     # ---- data-parallel knobs (N > 1).  The defaults are what `bench.py --gpus N` runs: RCCL, fp32 gradients on the wire,
@@ -141,13 +146,17 @@ def cpu_baseline(args, seed):
     from oracle import hotpath_ref as H
     p = args.cpu_proposals
     sd = H.make_state(1, args.classes, arch=args.arch)
-    img = torch.from_numpy(synthetic.make_image(seed, 0, args.size, args.size))[None]
-    boxes = [torch.from_numpy(synthetic.make_proposals(seed, 0, p, args.size, args.size))]
-    labels = [torch.from_numpy(synthetic.make_labels(seed, 0, args.classes))]
+    # three of the images the GPU line rotates over: 1, 2 and 3 labels (mean 2.0 = that of the default rotation 0..4)
+    sample = [(torch.from_numpy(synthetic.make_image(seed, i, args.size, args.size))[None],
+               [torch.from_numpy(synthetic.make_proposals(seed, i, p, args.size, args.size))],
+               [torch.from_numpy(synthetic.make_labels(seed, i, args.classes))]) for i in range(3)]
     cfg = dict(nms=0.1, lmda=0.03, thres=0.5, temp=0.2, pooler="ROIPool", arch=args.arch,
                scale=0.125 if args.arch == "vgg16" else 0.0625)
+    turn = [0]
 
     def one():
+        img, boxes, labels = sample[turn[0] % len(sample)]
+        turn[0] += 1
         for v in sd.values():
             if getattr(v, "grad", None) is not None:
                 v.grad = None
@@ -166,8 +175,9 @@ def cpu_baseline(args, seed):
         if cores > logical or cores in runs:
             continue
         torch.set_num_threads(cores)
+        turn[0] = 2
         one()                                                   # warm-up (thread pool, allocator, first-touch pages)
-        runs[cores] = sorted(one() for _ in range(3))[1]        # median of 3
+        runs[cores] = sum(one() for _ in range(3)) / 3.0        # mean over images 0, 1, 2 (1, 2 and 3 labels)
     if physical not in runs and physical > 32 and min(runs.values()) < 8.0:
         torch.set_num_threads(physical)
         first = one()
@@ -183,8 +193,9 @@ def cpu_baseline(args, seed):
     except OSError:
         pass
     return {"value": round(p / dt, 2), "unit": "proposals/s", "cores": best, "kind": "port",
-            "sample": "median of 3 steps after 1 warm-up, fwd+bwd (no optimizer), %s %dpx, %d of the %d proposals, torch-CPU "
-                      "fp32 oracle (C ROIPool single-threaded); `value` = the fastest thread count tried"
+            "sample": "mean of 3 steps (synthetic images 0, 1, 2: 1, 2 and 3 labels) after 1 warm-up, fwd+bwd (no optimizer), "
+                      "%s %dpx, %d of the %d proposals, torch-CPU fp32 oracle (C ROIPool single-threaded); `value` = the "
+                      "fastest thread count tried"
                       % (ARCH_NAME[args.arch], args.size, p, args.proposals),
             "seconds": round(dt, 2), "cpu_model": model, "host_logical_cpus": logical,
             "by_threads": {str(c): round(p / t, 2) for c, t in sorted(runs.items())}}
@@ -304,7 +315,14 @@ def main():
 
     cfg = build_cfg(args.classes, args.arch, args.pooler, args.grad_exchange)
     seed = cfg.SEED
-    images, targets, rois = synthetic_batch(seed, rank, args.size, args.proposals, args.classes, device, n_images=ipr)
+    # The timed steps rotate over `n_rot` batches of this rank (batch j = images (rank + j) * ipr ...): the synthetic images
+    # carry 1-3 labels and the loss's loops run 3 x n_pos chains per image (weak_head/loss.py:281-345) -- image 0 alone (one
+    # label, loss_sim == 0) is the lightest case the workload allows.  Never more batches than warm-up steps: every batch of
+    # the timed region has been through the step once before the clock starts.
+    n_rot = max(1, min(args.rotate, args.warmup if args.warmup > 0 else 1))
+    batches = [synthetic_batch(seed, rank + j, args.size, args.proposals, args.classes, device, n_images=ipr) for j in range(n_rot)]
+    images, targets, rois = batches[0]
+    labels_per_image = [[len(t.get_field("labels_host")) for t in b[1]] for b in batches]
 
     def barrier():
         if world > 1:
@@ -317,7 +335,8 @@ def main():
         step_fn, info = engine.build_training_step(cfg, device, dtype=dtype, world=world, seed=seed)
         exch = step_fn.optimizer.exchange
         for it in range(warmup):
-            step_fn(images, targets, rois, DeviceRand(seed + rank, first_stream=(1 << 20) + (it << 12), device=device))
+            bi, bt, br = batches[it % n_rot]
+            step_fn(bi, bt, br, DeviceRand(seed + rank, first_stream=(1 << 20) + (it << 12), device=device))
         n_timed = len([it for it in range(steps) if it % args.time_every == 0])
         engine.kernel_timer.reset(prealloc=2 * 160 * n_timed if engine.kernel_timer.enabled else 0)
         engine.kernel_timer.timed_steps = n_timed
@@ -333,8 +352,8 @@ def main():
         for it in range(steps):
             engine.kernel_timer.active = it % args.time_every == 0
             marks[it].record()
-            step_fn(images, targets, rois,
-                    DeviceRand(seed + rank, first_stream=(1 << 20) + ((warmup + it) << 12), device=device))
+            bi, bt, br = batches[(warmup + it) % n_rot]
+            step_fn(bi, bt, br, DeviceRand(seed + rank, first_stream=(1 << 20) + ((warmup + it) << 12), device=device))
         marks[steps].record()
         barrier()
         dt = time.perf_counter() - t0
@@ -362,29 +381,25 @@ def main():
 
     if rank == 0:
         if roof is not None:
-            # memory-side bytes of the dominant launch from the committed PMC passes (rocprofv3 cannot run inside the
-            # timed region): FETCH_SIZE x 2 (gfx950 under-count of 16-B/lane reads) + WRITE_SIZE, per launch
-            for rnd in ("r04", "r03", "r02", "r01"):
+            # memory-side bytes of the dominant symbol's heaviest launch shape from the committed PMC passes (rocprofv3 cannot
+            # run inside the timed region): FETCH_SIZE x 2 (gfx950 under-count of 16-B/lane reads) + WRITE_SIZE, per launch.
+            # Keyed on (kernel, dtype, launch shape): a run at another size reports null instead of another shape's bytes.
+            for rnd in ("r05", "r04", "r03", "r02", "r01"):
                 tpath = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
                 if os.path.exists(tpath):
                     t = json.load(open(tpath))
                     entries = t if isinstance(t, list) else [t]
-                    hit = [e for e in entries if e.get("kernel") == roof["kernel"] and e.get("dtype", "bf16") == args.dtype]
+                    hit = [e for e in entries if e.get("kernel") == roof["kernel"] and e.get("dtype", "bf16") == args.dtype
+                           and e.get("shape") == roof.get("top_shape")]
                     if hit:
                         roof["traffic"] = hit[0]["traffic_bytes"]
-                        roof["traffic_of"] = "%s; algorithmic %d B; %s" % (hit[0]["launch"], hit[0]["algorithmic_bytes"], hit[0]["source"])
+                        roof["traffic_of"] = "%s [%s]; algorithmic %d B; %s" % (hit[0]["launch"], hit[0]["shape"],
+                                                                               hit[0]["algorithmic_bytes"], hit[0]["source"])
                         break
-            if roof["kernel"].startswith("gemm_nt_cm_kernel<true"):
-                # the same launch against the reference's arithmetic: two fp32 fc6 evaluations (clean + DropBlock) = 2 x 2 P N K,
-                # i.e. 2/3 of the three plane products one sweep issues (the stacked pass of rounds 1-3: 1/3 of what it issued)
-                roof["algorithmic"] = {"flops_per_launch": roof["flops_per_launch"] * 2.0 / 3.0,
-                                       "achieved": round(roof["achieved"] * 2.0 / 3.0, 2), "unit": "TFLOP/s",
-                                       "frac": round(roof["frac"] * 2.0 / 3.0, 4),
-                                       "note": "the reference's two fp32 fc6 products per launch / launch duration; the stacked pass "
-                                               "this kernel replaced reached 0.18 on this scale (0.54 of issued work / 3)"}
-                roof["note"] = ("one sweep over the clean fc6 operand yields the clean AND the DropBlock outputs (summation by parts over "
-                                "the 49 cells): `achieved` counts the MFMA work issued; the stacked pass it replaces (rounds 1-3) issued "
-                                "twice that for the same results")
+            roof["note"] = ("dominant = the kernel SYMBOL with the largest total time over the timed steps, split-K launches "
+                            "included; frac = FLOPs of the reference's fp32 arithmetic for what its launches deliver / their time / "
+                            "peak; frac_issued counts every bf16 plane product issued (3 per fp32-grade forward product). "
+                            "gemm_nt_cm_kernel<true, 1> delivers TWO fc6 evaluations (clean + DropBlock) per sweep.")
             roof["timed_steps"] = "HIP events around every GEMM/conv launch of 1 timed step in %d" % args.time_every
             # ---- the whole step against the MFMA roofline: algorithmic work (1.36 GFLOP per proposal as
             # executed, single-precision semantics) and the MFMA work actually issued (every plane product counted)
@@ -415,9 +430,13 @@ def main():
             "per_step_ms": [round(float(v), 2) for v in per_step],      # rank 0's HIP-event time of each timed step
             "device_allocs_in_timed_region": info.get("device_allocs"),   # hipMalloc calls of the caching allocator (a spike in per_step_ms)
             "config": {"workload": "%s + %d MCG-like proposals, batch %d/GPU, %dpx (padded %d), %s 7x7, "
-                                   "OD-WSCL loss (CONTRA), SGD step, %d classes"
+                                   "OD-WSCL loss (CONTRA), SGD step, %d classes; timed steps rotate over %d synthetic image(s) "
+                                   "with labels_per_image %s (mean %.2f)"
                                    % ("VGG16-OICR" if args.arch == "vgg16" else "R-50-C5", args.proposals, ipr, args.size,
-                                      images.tensors.shape[-1], args.pooler, args.classes),
+                                      images.tensors.shape[-1], args.pooler, args.classes, n_rot,
+                                      [n for b in labels_per_image for n in b],
+                                      float(np.mean([n for b in labels_per_image for n in b]))),
+                       "labels_per_image": labels_per_image, "rotate": n_rot,
                        "global_batch": world * ipr, "parallelism": "dp%d" % world, "world_size": world, "lr": BENCH_LR, "gemm_backend": info["gemm_backend"],
                        "conv_backend": info["conv_backend"], "optimizer": info["optimizer"]},
             "per_gpu": round(value / world, 1),
@@ -427,12 +446,22 @@ def main():
         }
     if world == 1 and not args.no_secondary and args.dtype != "bf16":
         # the single-plane mode, for reference only: same workload, a short run (it misses the parity bar)
-        sdt, sper, _, _, _, _ = run("bf16", max(5, args.steps // 2), 3)
+        n = max(5, args.steps // 2)
+        sdt, sper, _, _, _, _ = run("bf16", n, max(3, n_rot))
         if rank == 0:
-            n = max(5, args.steps // 2)
             out["secondary"] = {"bf16": {"value": round(args.proposals * ipr * n / sdt, 1), "unit": "proposals/s",
                                          "ms_per_step": round(sdt / n * 1e3, 3), "median_ms_per_step": round(float(np.median(sper)), 3),
                                          "steps": n, "note": DTYPE_NOTE["bf16"]}}
+        if args.dtype != "bf16x3":
+            # the fp32-GRADE mode (the reference computes in fp32, config/defaults.py:559): every product, forward and
+            # backward, on three bf16 planes per operand = six plane products.  A short run of the same workload.
+            n3 = max(5, args.steps // 4)
+            sdt, sper, _, _, _, _ = run("bf16x3", n3, max(2, n_rot))
+            if rank == 0:
+                out["secondary"]["bf16x3"] = {"value": round(args.proposals * ipr * n3 / sdt, 1), "unit": "proposals/s",
+                                              "ms_per_step": round(sdt / n3 * 1e3, 3),
+                                              "median_ms_per_step": round(float(np.median(sper)), 3), "steps": n3,
+                                              "note": DTYPE_NOTE["bf16x3"]}
     if rank == 0:
         if shared:
             out["oversubscribed"] = "%d ranks on %d device(s): plumbing run, NOT a scaling measurement" % (world, n_dev)

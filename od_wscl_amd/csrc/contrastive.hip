@@ -163,8 +163,11 @@ __device__ __host__ inline int pw_groups(int max_run, int nblk32, int npanel) {
     return n;
 }
 __host__ inline int pw_max_run(int nblk32, int npanel, int max_groups) {
+    // every panel contributes at least one group: with more panels than `max_groups` (P > 224 * 256 rows) no run length
+    // fits the chip, and a run of all nblk32 blocks -- one workgroup per panel -- is the fewest groups there are
+    if (max_groups < npanel) max_groups = npanel;
     int m = 1;
-    while (pw_groups(m, nblk32, npanel) > max_groups) ++m;
+    while (m < nblk32 && pw_groups(m, nblk32, npanel) > max_groups) ++m;
     return m;
 }
 __device__ inline void pw_run_of(int g, int max_run, int nblk32, int npanel, int& panel, int& blk, int& run_len) {
@@ -838,7 +841,7 @@ ODW_EXPORT int odw_pairwise_sim_planes(const void* planes, int P, float* S, void
     ODW_REQUIRE((((uintptr_t)planes) & 15) == 0 && (((uintptr_t)S) & 15) == 0, "pairwise_sim_planes: buffers must be 16-byte aligned");
     const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
     const int max_run = pw_max_run(nblk32, npanel, ODW_NUM_CU), grid = pw_groups(max_run, nblk32, npanel);
-    static const hipError_t attr = odw_set_max_lds(reinterpret_cast<const void*>(pairwise_sim_dma_kernel),
+    const hipError_t attr = odw_set_max_lds(reinterpret_cast<const void*>(pairwise_sim_dma_kernel),
                                                        kPdLds);      // once
     ODW_CHECK_HIP(attr, "pairwise dma attr");
     pairwise_sim_dma_kernel<<<grid, kPwWaves * 64, kPdLds, (hipStream_t)stream_>>>((const unsigned char*)planes, P, S, max_run);
@@ -873,7 +876,7 @@ static int pairwise_sim_impl(const float* E, int P, int D, float* S, int64_t ldS
         // split-bf16 panel form: one launch, no workspace (the planes are made in registers)
         const int nblk32 = (P + 31) / 32, npanel = (P + kPwPanel - 1) / kPwPanel;
         const int max_run = pw_max_run(nblk32, npanel, ODW_NUM_CU), grid = pw_groups(max_run, nblk32, npanel);
-        static const hipError_t attr = odw_set_max_lds(reinterpret_cast<const void*>(pairwise_sim_panel_kernel),
+        const hipError_t attr = odw_set_max_lds(reinterpret_cast<const void*>(pairwise_sim_panel_kernel),
                                                            kPwLds);      // once
         ODW_CHECK_HIP(attr, "pairwise attr");
 #ifdef ODW_EXPERIMENTS

@@ -591,7 +591,7 @@ ODW_EXPORT int odw_conv_weight_prep_planes_batch(int n, const void* const* w, co
         most = e > most ? e : most;
     }
     const int gx = (int)(most < 2048 ? most : 2048);
-    static const hipError_t attr = odw_set_max_lds(reinterpret_cast<const void*>(weight_prep_batch_kernel),
+    const hipError_t attr = odw_set_max_lds(reinterpret_cast<const void*>(weight_prep_batch_kernel),
                                                        kPrepLds);      // once
     ODW_CHECK_HIP(attr, "weight_prep attr");
     weight_prep_batch_kernel<<<dim3(gx, n), 256, kPrepLds, (hipStream_t)stream_>>>(b);

@@ -2105,7 +2105,7 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
     if (keep) {
 #define ODW_CM_LAUNCH(PAIRV, SV, LDSB, GRID, OUT, EP)                                                                   \
         do {                                                                                                             \
-            static const hipError_t attr_ = odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_cm_kernel<PAIRV, SV>), \
+            const hipError_t attr_ = odw_set_max_lds(reinterpret_cast<const void*>(gemm_nt_cm_kernel<PAIRV, SV>), \
                                                                 (int)(LDSB)); \
             ODW_CHECK_HIP(attr_, "gemm_nt_cm attr");                                                                     \
             gemm_nt_cm_kernel<PAIRV, SV><<<GRID, kRingThreads, LDSB, stream>>>(                                          \
@@ -2760,13 +2760,13 @@ static int conv_wgrad_tn_impl(const void* dz, int ld_dz, const void* X, int ldx,
             hg.split_stride = (long long)Co * N; hg.ldw = N; hg.zero = (const unsigned short*)zero_page;
             const dim3 grid((unsigned)(8 * hg.chunk));
             if (dilation == 1) {
-                static const hipError_t a1 = odw_set_max_lds(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<16, 1>),
+                const hipError_t a1 = odw_set_max_lds(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<16, 1>),
                                                                  WhCfg<16, 1>::kLds);
                 ODW_CHECK_HIP(a1, "wgrad halo attr");
                 conv_wgrad_halo_kernel<16, 1><<<grid, 512, WhCfg<16, 1>::kLds, stream>>>(
                     (const unsigned short*)dz, (const unsigned short*)X, (float*)workspace, hg);
             } else {
-                static const hipError_t a2 = odw_set_max_lds(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<8, 2>),
+                const hipError_t a2 = odw_set_max_lds(reinterpret_cast<const void*>(conv_wgrad_halo_kernel<8, 2>),
                                                                  WhCfg<8, 2>::kLds);
                 ODW_CHECK_HIP(a2, "wgrad halo attr");
                 conv_wgrad_halo_kernel<8, 2><<<grid, 512, WhCfg<8, 2>::kLds, stream>>>(

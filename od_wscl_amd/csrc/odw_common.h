@@ -29,17 +29,22 @@ void odw_set_error(const char* fmt, ...);
     } while (0)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver call on the launch path of every kernel that asks for more
-// than 64 KB of LDS -- ~26 GEMM launches per step.  Remember the largest size set per kernel and only go to the driver for more.
+// than 64 KB of LDS -- ~26 GEMM launches per step.  Remember the largest size set per (device, kernel) -- the attribute is a
+// per-device property of the function -- and only go to the driver for more.  Callers evaluate this on EVERY launch (no
+// function-local `static` results: a process that later launches on a second GPU must set the attribute there too).
 #include <mutex>
 #include <unordered_map>
 static inline hipError_t odw_set_max_lds(const void* fn, int bytes) {
     static std::mutex mu;
-    static std::unordered_map<const void*, int> seen;
+    static std::unordered_map<uint64_t, int> seen;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t key = (uint64_t)(uintptr_t)fn ^ ((uint64_t)(unsigned)dev << 56);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = seen.find(fn);
+    auto it = seen.find(key);
     if (it != seen.end() && it->second >= bytes) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) seen[fn] = bytes;
+    if (e == hipSuccess) seen[key] = bytes;
     return e;
 }
 

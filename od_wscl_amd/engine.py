@@ -417,7 +417,9 @@ class FlatSGD(object):
         s = self.cfg.SOLVER
         iter_size = max(1, int(s.ITER_SIZE))
         pos = self.sched_steps if self.sched_steps > 0 else (int(iteration) + iter_size - 1) // iter_size
-        return {"last_epoch": int(pos), "milestones": tuple(s.STEPS), "gamma": s.GAMMA, "warmup_factor": s.WARMUP_FACTOR,
+        # "unit": what last_epoch counts.  Checkpoints of earlier revisions stored the micro-ITERATION index there (no marker);
+        # utils/checkpoint.restore_training_state reconciles those against the iteration count.
+        return {"unit": "sched_steps", "last_epoch": int(pos), "milestones": tuple(s.STEPS), "gamma": s.GAMMA, "warmup_factor": s.WARMUP_FACTOR,
                 "warmup_iters": s.WARMUP_ITERS, "warmup_method": s.WARMUP_METHOD}
 
     def resume(self, sched_steps):
@@ -566,7 +568,9 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         hip_body.use_graphs = True
         # bounded: at most ODW.GRAPH_CACHE shapes stay captured (least recently used evicted), a shape is captured when it
         # comes back, everything else runs eagerly (vgg16_hip.VGGBackboneHip._graph_for)
-        hip_body.graph_cache_size = int(getattr(getattr(cfg, "ODW", None), "GRAPH_CACHE", hip_body.graph_cache_size))
+        # (the ODW_GRAPH_CACHE environment knob documented in vgg16_hip.py wins over the config default)
+        hip_body.graph_cache_size = int(os.environ.get("ODW_GRAPH_CACHE") or
+                                        getattr(getattr(cfg, "ODW", None), "GRAPH_CACHE", hip_body.graph_cache_size))
     if cfg.MODEL.BACKBONE.CONV_BODY.startswith("VGG16"):
         conv_desc = "od_wscl_amd HIP implicit-GEMM conv3x3 (NHWC, MFMA)"
     else:
@@ -656,16 +660,30 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         hip = getattr(model, "backbone_hip", None)
         if hip is not None:
             hip.accumulate = accumulate
-        losses, accs = model(images, targets, rois, rand=rand)
-        mark("forward")
-        finish = getattr(losses, "finish_backward", None)
-        if finish is not None:              # the dense losses' backward already ran inside the loss (early_backward)
-            finish()
-        else:
-            loss = getattr(losses, "total", None)
-            if loss is None:
-                loss = sum(losses.values())
-            loss.backward()
+        try:
+            losses, accs = model(images, targets, rois, rand=rand)
+            mark("forward")
+            finish = getattr(losses, "finish_backward", None)
+            if finish is not None:          # the dense losses' backward already ran inside the loss (early_backward)
+                finish()
+            else:
+                loss = getattr(losses, "total", None)
+                if loss is None:
+                    loss = sum(losses.values())
+                loss.backward()
+        except BaseException:
+            # A step that dies mid-way (out of memory, the > 2048 pseudo-GT error of the fused loss after its early backward
+            # has already written gradients) must not leave a half-built sum behind: a caller that skips the batch or retries
+            # (engine/trainer.py:80-82 skips bad batches) would otherwise ADD its next backward to the partial gradients.
+            # An ITER_SIZE == 1 step starts fresh again; inside a group the sum so far is lost with the failed micro-step,
+            # so the group restarts.
+            opt.grads_clean = True
+            opt.hold = False
+            for sh in opt.shadows:
+                b = getattr(sh, "batch", None)
+                if b is not None:
+                    b.reset()
+            raise
         mark("backward")
         if last:
             opt.all_reduce()

@@ -31,8 +31,11 @@ _VARIANT_SYMBOL = {0: "", 1: "glds_", 2: "ring_", 3: "big_"}      # names as roc
 _PLAN_CACHE = {}      # (M, N, K, lda, ldb, ldc, out_bf16, alignment of C) -> (split-K workspace bytes, kernel variant)
 
 
-def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, segs=None, accumulate=False, row_ids=None):
-    """out[M,N] (+)= epilogue(alpha * a[M,K] @ b[N,K]^T); a, b bf16 2-D tensors (row stride % 8 == 0)."""
+def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, segs=None, accumulate=False, row_ids=None,
+            planes=1):
+    """out[M,N] (+)= epilogue(alpha * a[M,K] @ b[N,K]^T); a, b bf16 2-D tensors (row stride % 8 == 0).
+    planes: K spans this many bf16 plane products of ONE fp32-grade product (split precision modes) -- only the timer's
+    bookkeeping uses it (algorithmic FLOPs = issued / planes)."""
     L.need_gpu(a, b, out)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
@@ -61,7 +64,7 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     split = ws is not None
     sym = "gemm_nt_bf16_%skernel<%s>%s" % (_VARIANT_SYMBOL[var], ("false" if split or not out_bf16 else "true")
                                            + (", 7" if var == 3 else ""), " split-K+reduce" if split else "")
-    with kernel_timer.region(sym, flops=2.0 * M * N * K):
+    with kernel_timer.region(sym, flops=2.0 * M * N * K, alg=2.0 * M * N * K / planes, shape="M=%d,N=%d,K=%d" % (M, N, K)):
         L.check(L.lib().odw_gemm_nt_bf16_ws(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out),
                                             out.stride(0), 1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0,
                                             float(alpha), float(drop_p), nseg,
@@ -120,7 +123,10 @@ def gemm_nt_cm(a_cm, b_cm, M, N, C, S, out, bias=None, relu=False, drop_p=0.0, s
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device) if ws_bytes else None
     split = bool(ws_bytes) and L.lib().odw_gemm_nt_cm_workspace(M, N, S) > 0
     sym = "gemm_nt_cm_kernel<%s, 1>%s" % ("true" if pair else "false", " split+reduce" if split else "")      # rocprofv3's name
-    with kernel_timer.region(sym, flops=2.0 * M * N * 3 * K):      # MFMA work ISSUED (the pair form replaces twice that)
+    # flops = MFMA work ISSUED (three plane products of one sweep); alg = the reference's arithmetic for what the launch
+    # delivers: one fp32 fc6 product, or -- pair form -- two (the clean and the DropBlock evaluation, weak_head.py:107-112)
+    with kernel_timer.region(sym, flops=2.0 * M * N * 3 * K, alg=2.0 * M * N * K * (2 if pair else 1),
+                             shape="M=%d,N=%d,C=%d,S=%d%s" % (M, N, C, S, ",pair" if pair else "")):
         L.check(L.lib().odw_gemm_nt_cm(L.ptr(a_cm), a_cm.stride(0), K, L.ptr(b_cm), b_cm.stride(0), K, M, N, C, S,
                                        L.ptr(keep), L.ptr(keep_sum), drop_row0, L.ptr(out), out.stride(0), L.ptr(bias),
                                        1 if relu else 0, float(drop_p), nseg,
@@ -272,14 +278,15 @@ class WgradBatch(object):
         # all-reduce of fc6's 411 MB runs under the rest of this GEMM and of the backward instead of after it
         ready = getattr(weight, "_odw_grad_ready", None)
         rows = int(getattr(weight, "_odw_slice_rows", 0)) if ready is not None else 0
+        tp = len(P.patterns("gemm")[0]) if P.bwd_split() else 1
         if rows <= 0 or rows >= n_out:
-            gemm_nt(self.dzt, self.xt, n_out, k_in, self.kpad, weight.grad, accumulate=not fresh)
+            gemm_nt(self.dzt, self.xt, n_out, k_in, self.kpad, weight.grad, accumulate=not fresh, planes=tp)
             if ready is not None:
                 ready(weight, 0, n_out)
         else:
             for r0 in range(0, n_out, rows):
                 r1 = min(n_out, r0 + rows)
-                gemm_nt(self.dzt[r0:r1], self.xt, r1 - r0, k_in, self.kpad, weight.grad[r0:r1], accumulate=not fresh)
+                gemm_nt(self.dzt[r0:r1], self.xt, r1 - r0, k_in, self.kpad, weight.grad[r0:r1], accumulate=not fresh, planes=tp)
                 ready(weight, r0, r1)
         kernel_timer.layer = None
         self.reset()
@@ -463,7 +470,7 @@ class _SplitLinear(torch.autograd.Function):
                 x32 = x32 if x32.stride(1) == 1 else x32.contiguous()
                 xs = P.split_rows(x32, pa, kp)
             kernel_timer.layer = timer_tag and timer_tag + "_fwd"
-            gemm_nt(xs, sh.w, M, N, T * kp, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs, row_ids=row_ids)
+            gemm_nt(xs, sh.w, M, N, T * kp, y, bias=bias, relu=relu, drop_p=drop_p, segs=segs, row_ids=row_ids, planes=T)
             kernel_timer.layer = None
         del xs
         ctx.save_for_backward(x32, y if (relu or drop_p > 0) else None, weight, bias)
@@ -513,7 +520,7 @@ class _SplitLinear(torch.autograd.Function):
                 dx = dx_all[ra:rb]
             dzs = P.split_rows(dz, pa, np_)
             kernel_timer.layer = tag and tag + "_dgrad"
-            gemm_nt(dzs, sh.wt, M, K, T * np_, dx)
+            gemm_nt(dzs, sh.wt, M, K, T * np_, dx, planes=T)
             kernel_timer.layer = None
             del dzs
             dx = dx_all if x_dtype == torch.float32 else dx_all.to(x_dtype)
@@ -541,7 +548,7 @@ class _SplitLinear(torch.autograd.Function):
                 fresh = True
                 target = dw = torch.empty_like(weight)
             kernel_timer.layer = tag and tag + "_wgrad"
-            gemm_nt(dzt, xt, N, K, T * m64, target, accumulate=not fresh)
+            gemm_nt(dzt, xt, N, K, T * m64, target, accumulate=not fresh, planes=T)
             kernel_timer.layer = None
         return dx, dw, None, None, None, None, None, None, None, None, None, None, None
 

@@ -199,7 +199,9 @@ class _PoolStack(torch.autograd.Function):
             # the backbone's own NHWC bf16 map (`feat` is its fp32 NCHW copy): (ROI, 64-channel) workgroups
             ws_bytes = lib.odw_roi_pool_stack_nhwc_workspace(R, B, C, H, W)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=feat.device)
-            with kernel_timer.region("roi_pool_stack_fwd_nhwc", nbytes=float(B * C * H * W * 2 + 2 * R * C * nb * 2 + R * C * nb * 2)):
+            # alg = SURVEY 8(d)'s bytes of the reference operator this replaces (fp32 out + int32 argmax written, map read once)
+            with kernel_timer.region("roi_pool_stack_fwd_nhwc", nbytes=float(B * C * H * W * 2 + 2 * R * C * nb * 2 + R * C * nb * 2),
+                                     alg=float(2 * R * C * nb * 4 + B * C * H * W * 4)):
                 L.check(lib.odw_roi_pool_stack_forward_nhwc(L.ptr(nhwc), L.ptr(rois5), scale, B, C, H, W, R, L.ptr(keep),
                                                             L.ptr(keep_sum), L.ptr(x), x.stride(0), L.ptr(argmax), L.ptr(ws),
                                                             ws_bytes, L.stream()), "roi_pool_stack_forward_nhwc")
@@ -235,7 +237,7 @@ class _PoolStack(torch.autograd.Function):
         ws = torch.empty(64, dtype=torch.uint8, device=dx.device)       # the launch's fixed-point scale (odw_fixed.h)
         K = C * ph * pw
         nbytes = float((R if skip_clean else 2 * R) * K * dx.element_size() + R * K * 2 + E * K * 4 + B * C * H * W * 4)
-        with kernel_timer.region("roi_pool_stack_backward", nbytes=nbytes):
+        with kernel_timer.region("roi_pool_stack_backward", nbytes=nbytes, alg=float(2 * R * K * 4 + B * C * H * W * 4)):
             L.check(L.lib().odw_roi_pool_stack_backward_ws(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
                                                            L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
                                                            L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph, pw,
@@ -272,7 +274,8 @@ class _PoolStackPlanes(torch.autograd.Function):
         import ctypes
         pat = (ctypes.c_int * T)(*pa)
         with kernel_timer.region("roi_pool_stack_fwd_nhwc_f32",
-                                 nbytes=float(B * C * H * W * 4 + 2 * R * T * K * 2 + (2 * R * K * 2 if pair else 0) + R * K * 6)):
+                                 nbytes=float(B * C * H * W * 4 + 2 * R * T * K * 2 + (2 * R * K * 2 if pair else 0) + R * K * 6),
+                                 alg=float(2 * R * K * 4 + B * C * H * W * 4)):
             L.check(lib.odw_roi_pool_stack_forward_nhwc_f32_cm(L.ptr(nhwc32), L.ptr(rois5), scale, B, C, H, W, R, L.ptr(keep),
                                                                L.ptr(keep_sum), ctypes.cast(pat, ctypes.c_void_p), T, L.ptr(planes),
                                                                planes.stride(0), blk, L.ptr(pooled32), L.ptr(argmax),

@@ -49,14 +49,14 @@ def _layers_of(features):
     return out
 
 
-def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask, zero_page, st, flops):
+def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask, zero_page, st, flops, alg=None):
     """One implicit-GEMM convolution (y bf16 or fp32); the launcher's split-K workspace (deep layers) comes from
-    torch's allocator."""
+    torch's allocator.  flops = MFMA work issued (plane products counted), alg = the one fp32 product they stand for."""
     ws_bytes = lib.odw_conv3x3_workspace_hw(m, h, w, c, n, dil)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=y.device) if ws_bytes else None
     out_bf16 = y.dtype == torch.bfloat16
     sym = "conv3x3 split-K+reduce" if ws_bytes else ("conv3x3<%s>" % ("bf16" if out_bf16 else "f32"))
-    with kernel_timer.region(sym, flops=flops):
+    with kernel_timer.region(sym, flops=flops, alg=alg, shape="m=%d,hw=%dx%d,c=%d,n=%d,dil=%d" % (m, h, w, c, n, dil)):
         L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, w, c, dil, mirror, L.ptr(wk), wk.stride(0), n, L.ptr(y), n,
                                              1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0, L.ptr(mask), ldmask,
                                              L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv3x3")
@@ -227,7 +227,7 @@ class _VGGSplitFn(torch.autograd.Function):
             xs = P.split_rows(x, pa, l.cp)
             y = torch.empty((m, l.cout), dtype=torch.float32, device=dev)
             _conv3x3(lib, xs, m, h, w, T * l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
-                     2.0 * m * l.cout * 9 * l.cin * T)
+                     2.0 * m * l.cout * 9 * l.cin * T, alg=2.0 * m * l.cout * 9 * l.cin)
             del xs
             pre = None
             if l.pool:
@@ -293,7 +293,8 @@ class _VGGSplitFn(torch.autograd.Function):
                 dx = torch.empty((m, l.cin), dtype=torch.float32, device=dev)
                 mask = planes[0] if (prev.relu and not prev.pool) else None     # hi plane: zero exactly where x_in is
                 _conv3x3(lib, dzs, m, h, w, T * l.cout, l.dil, 1, l.wd, l.cin, dx, None, False, mask,
-                         l.cp if mask is not None else 0, net.zero_page, st, 2.0 * m * l.cout * 9 * l.cin * T)
+                         l.cp if mask is not None else 0, net.zero_page, st, 2.0 * m * l.cout * 9 * l.cin * T,
+                         alg=2.0 * m * l.cout * 9 * l.cin)
                 dz = dx
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
@@ -355,7 +356,7 @@ class _VGGMixedFn(torch.autograd.Function):
                                        and l.dil in (1, 2)) else (P.split_rows(x, (0,), l.cp) if l.trainable else None)
             y = torch.empty((m, l.cout), dtype=torch.float32, device=dev)
             _conv3x3(lib, xs, m, h, w, T * l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
-                     2.0 * m * l.cout * 9 * l.cin * T)
+                     2.0 * m * l.cout * 9 * l.cin * T, alg=2.0 * m * l.cout * 9 * l.cin)
             del xs
             pre = None
             if l.pool:
@@ -563,11 +564,11 @@ class _GraphedBody(object):
                 net._prep()
                 # (the warm-up doubles as the counting pass: the MFMA work of the two launch sequences, which a replay
                 # reports to the kernel timer as ONE region each -- the launches inside a graph carry no events)
-                kt.tally = 0.0
+                kt.tally, kt.tally_alg = 0.0, 0.0
                 feat = fn.forward(self.ctx, self.img, net)
-                self.flops_fwd, kt.tally = kt.tally, 0.0
+                self.flops_fwd, self.alg_fwd, kt.tally, kt.tally_alg = kt.tally, kt.tally_alg, 0.0, 0.0
                 fn.backward(self.ctx, torch.zeros_like(feat))
-                self.flops_bwd, kt.tally = kt.tally, None
+                self.flops_bwd, self.alg_bwd, kt.tally = kt.tally, kt.tally_alg, None
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.g_fwd = torch.cuda.CUDAGraph()
@@ -599,7 +600,7 @@ class _GraphedVGGFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, images, net, graphed, *params):
         graphed.img.copy_(images)
-        with kernel_timer.region("VGG body forward (HIP graph)", flops=graphed.flops_fwd):
+        with kernel_timer.region("VGG body forward (HIP graph)", flops=graphed.flops_fwd, alg=graphed.alg_fwd):
             graphed.g_fwd.replay()
         net.last_nhwc = graphed.nhwc
         net.last_nhwc_f32 = graphed.nhwc_f32
@@ -613,7 +614,7 @@ class _GraphedVGGFn(torch.autograd.Function):
     def backward(ctx, dfeat):
         g = ctx.graphed
         g.dfeat.copy_(dfeat)
-        with kernel_timer.region("VGG body backward (HIP graph)", flops=g.flops_bwd):
+        with kernel_timer.region("VGG body backward (HIP graph)", flops=g.flops_bwd, alg=g.alg_bwd):
             cb = getattr(g.net, "on_segment_done", None)
             for k, gk in enumerate(g.g_bwd):
                 gk.replay()

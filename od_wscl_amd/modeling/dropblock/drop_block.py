@@ -20,7 +20,9 @@ class DropBlock2D(nn.Module):
         """The (n, h, w) keep mask after dilation (drop_block.py:38-47, :55-71) -- one draw of n*h*w uniforms."""
         gamma = self.drop_prob / (self.block_size ** 2)
         shape = (n, h, w)
-        if rand is not None and hasattr(rand, "key") and torch.device(device).type == "cuda" and n * h * w < (1 << 24):
+        if (rand is not None and hasattr(rand, "key") and torch.device(device).type == "cuda" and n * h * w < (1 << 24)
+                and self.block_size <= 15):         # (the kernel re-derives a cell's block_size^2 draws: <= 15 x 15; larger blocks
+                                                    # take the torch expression below, any size)
             # the counter-based device stream: draw, threshold, dilation, inversion and the sum in ONE kernel
             # (csrc/rng.hip dropblock_keep_kernel) -- the same draw, the same stream id as rand.uniform(shape)
             from ... import _lib as L

@@ -95,10 +95,20 @@ def restore_training_state(optimizer, model, rest):
     # count would cross a STEPS milestone early and trigger a spurious momentum correction on the next step
     sched = rest.get("scheduler")
     iter_size = max(1, int(optimizer.cfg.SOLVER.ITER_SIZE))
+    derived = (iteration + iter_size - 1) // iter_size
     if sched is not None and "last_epoch" in sched:
         position = int(sched["last_epoch"])
+        # Checkpoints written before the "unit" marker existed stored the micro-iteration index in last_epoch.  With
+        # ITER_SIZE > 1 that places the schedule ITER_SIZE times too far (an early STEPS milestone, a spurious momentum
+        # correction): a position no run of `iteration` iterations can have reached falls back to the derived one.
+        if sched.get("unit") != "sched_steps" and iteration > 0 and position > derived:
+            import logging
+            logging.getLogger("od_wscl_amd").warning(
+                "checkpoint: scheduler.last_epoch = %d is not a scheduler-step count for iteration %d with ITER_SIZE %d "
+                "(an older checkpoint format); resuming the schedule at %d", position, iteration, iter_size, derived)
+            position = derived
     else:
-        position = (iteration + iter_size - 1) // iter_size
+        position = derived
     optimizer.sync_from_params(model)
     optimizer.resume(position)
     return iteration
