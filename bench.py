@@ -83,6 +83,8 @@ def parse():
                          "each, `config.labels_per_image`): the loss's loop work is proportional to 3 x the image's positive "
                          "classes (weak_head/loss.py:281-345), and image 0 alone has ONE.  Capped at the warm-up step count, so "
                          "that every image of the timed region has been through the step (allocator, planner caches) before")
+    ap.add_argument("--first-image", type=int, default=0,
+                    help="index of the first synthetic image of rank 0's rotation (--first-image 2 --rotate 1: the 3-label image alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-proposals", type=int, default=2000)
     # ---- data-parallel knobs (N > 1).  The defaults are what `bench.py --gpus N` runs: RCCL, fp32 gradients on the wire,
@@ -320,7 +322,8 @@ def main():
     # label, loss_sim == 0) is the lightest case the workload allows.  Never more batches than warm-up steps: every batch of
     # the timed region has been through the step once before the clock starts.
     n_rot = max(1, min(args.rotate, args.warmup if args.warmup > 0 else 1))
-    batches = [synthetic_batch(seed, rank + j, args.size, args.proposals, args.classes, device, n_images=ipr) for j in range(n_rot)]
+    batches = [synthetic_batch(seed, args.first_image + rank + j, args.size, args.proposals, args.classes, device, n_images=ipr)
+               for j in range(n_rot)]
     images, targets, rois = batches[0]
     labels_per_image = [[len(t.get_field("labels_host")) for t in b[1]] for b in batches]
 

@@ -246,7 +246,7 @@ int odw_od_assign_indexed_dev(const float* boxes, int P, const int* gt_index, co
  *   C        : bf16 (c_is_bf16) or fp32, row stride ldc; accumulate (fp32 only): C += result
  *   epilogue : + bias[N] (nullable), ReLU, dropout(drop_p) with counter-based keys:
  *              nseg row segments (seg_rows[i] = first row, seg_keys[2i..2i+1] = key); element
- *              (m,n) of segment s uses index (m - seg_rows[s]) * N + n   (HOST arrays, <= 4)
+ *              (m,n) of segment s uses index (m - seg_rows[s]) * N + n   (HOST arrays, <= 8)
  * odw_linear_bwd_prep: dZ = dY * [Y != 0] * scale (Y = saved output, nullable), emitted
  *   row-major (ld_z) and transposed (N x ld_t), both zero padded; db[n] += column sums.
  *   dy_is_f32 is a bit set: bit 0 = dY is fp32 (else bf16), bit 1 = Y is fp32 (else bf16; the saved
@@ -418,6 +418,22 @@ int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, int C, int 
                              int ldw, int N, void* Y, int ldy, int y_is_bf16, const float* bias, int relu,
                              const void* mask, int ldmask, const void* zero_page, void* workspace,
                              int64_t workspace_bytes, void* stream);
+/* The forward convolution of the precision mode "bf16x2f" on TWO stored planes (round 5; conv3x3_halo2_kernel): the same
+ * cuDNN convolution of modeling/backbone/vgg16.py:34-36,58-83 as the sum of the three bf16 plane products
+ * x_hi w_hi + x_hi w_mid + x_mid w_hi, fp32 accumulation.
+ *   X  : (n_pix x ldx) bf16, a pixel row = [hi plane: C channels | mid plane: C channels | padding], C % 32 == 0
+ *   Wk : (N x ldw) bf16 packed by odw_conv_weight_prep_planes_batch with T = -2: per tap, per block of 32 channels,
+ *        [hi 32 | mid 32]; ldw >= 18 C
+ *   Y  : y_planes == 0: fp32 (n_pix x ldy);  y_planes != 0: the next layer's operand, bf16 planes [hi N | mid N] per pixel
+ *        (ldy bf16 elements per row, the mid plane ldy / 2 elements in) -- bias and ReLU applied before the split
+ *   N % 64 == 0, dilation 1 or 2; the workspace (odw_conv3x3_planes2_workspace bytes; 0 = none) holds the fp32 partials
+ *   of the K slices small maps are cut into. */
+int64_t odw_conv3x3_planes2_workspace(int n_pix, int H, int W, int C, int N);
+int odw_conv3x3_planes2_ws(const void* X, int ldx, int n_pix, int H, int W, int C, int dilation, const void* Wk, int ldw, int N,
+                           void* Y, int ldy, int y_planes, const float* bias, int relu, const void* zero_page, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+/* 2x2 / 2 max pooling of an fp32 NHWC activation written as that operand (planes [hi C | mid C], row stride ldy) */
+int odw_maxpool2x2_nhwc_f32_planes2(const float* X, int B, int H, int W, int C, void* Y, int ldy, void* stream);
 int odw_conv_weight_prep(const float* w, int Co, int Ci, int Cp, void* wk, int ldk, void* wd, int ldd, void* stream);
 int odw_conv_wgrad_unpack(const float* dwk, int ld, int Co, int Ci, int Cp, float* dw, void* stream);
 /* every layer of a body in one launch: host arrays of length n (<= 32) of the arguments of odw_conv_weight_prep */

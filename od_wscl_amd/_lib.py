@@ -90,6 +90,9 @@ SIGNATURES = {
     "odw_discover_iou": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p]),
     "odw_discover_sim": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_i,
                                c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "odw_conv3x3_planes2_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
+    "odw_conv3x3_planes2_ws": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_l, c_p]),
+    "odw_maxpool2x2_nhwc_f32_planes2": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "odw_conv3x3_workspace": (c_l, [c_i, c_i, c_i]),
     "odw_conv3x3_workspace_hw": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "odw_conv3x3_nhwc_bf16_ws": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p,

@@ -6,6 +6,7 @@
 //   * 2x2 max pooling forward / backward (first maximum wins, like torch) with the ReLU mask folded in
 //   * NCHW fp32 <-> NHWC bf16 at the two ends of the backbone
 #include "odw_common.h"
+#include "odw_planes.h"
 
 namespace {
 
@@ -59,7 +60,8 @@ constexpr int kPrepC8 = kPrepTileCi / 8;
 constexpr int kPrepLds = kPrepTileCo * kPrepPitch * 4;
 
 __device__ __forceinline__ bool prep_tiled(const PrepLayer& L) {
-    return L.Ci % kPrepTileCi == 0 && L.Co % kPrepTileCo == 0 && L.Cp == L.Ci && (!L.wk || L.ldk == 9 * L.Cp * (L.T > 0 ? L.T : 1)) &&
+    return L.Ci % kPrepTileCi == 0 && L.Co % kPrepTileCo == 0 && L.Cp == L.Ci &&
+           (!L.wk || L.ldk == 9 * L.Cp * (L.T > 0 ? L.T : (L.T == -2 ? 2 : 1))) &&
            (!L.wd || L.ldd == 9 * L.Co);
 }
 
@@ -96,6 +98,14 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int tile, float* s
                 pl[0][j] = h[0] | ((unsigned)h[1] << 16);
                 pl[1][j] = m[0] | ((unsigned)m[1] << 16);
                 pl[2][j] = l[0] | ((unsigned)l[1] << 16);
+            }
+            if (L.T == -2) {
+                // conv3x3_halo2_kernel's layout: per tap, per block of 32 channels, [hi 32 | mid 32] (T = -2)
+                const int ci = ci0 + c8 * 8;
+                unsigned short* d = L.wk + (size_t)(co0 + co) * L.ldk + (size_t)t * 2 * L.Cp + (ci >> 5) * 64 + (ci & 31);
+                *reinterpret_cast<uint4*>(d) = make_uint4(pl[0][0], pl[0][1], pl[0][2], pl[0][3]);
+                *reinterpret_cast<uint4*>(d + 32) = make_uint4(pl[1][0], pl[1][1], pl[1][2], pl[1][3]);
+                continue;
             }
             unsigned short* row = L.wk + (size_t)(co0 + co) * L.ldk + ci0 + c8 * 8;
             for (int tt = 0; tt < T; ++tt) {
@@ -141,7 +151,17 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(PrepBatch b) {
                 for (int k = threadIdx.x; k < nc * 9; k += 256) sm[k] = src[k];
                 __syncthreads();
                 const int np = L.Cp - c0 < 512 ? L.Cp - c0 : 512;
-                if (L.T > 0) {
+                if (L.T == -2) {
+                    for (int k = threadIdx.x; k < 9 * np; k += 256) {
+                        const int t = k / np, ci = k - t * np;
+                        const float x = ci < nc ? sm[ci * 9 + t] : 0.0f;
+                        const unsigned short hi = f2bf(x);
+                        const int cc = c0 + ci;
+                        unsigned short* d = row + (size_t)t * 2 * L.Cp + (cc >> 5) * 64 + (cc & 31);
+                        d[0] = hi;
+                        d[32] = f2bf(x - bf2f(hi));
+                    }
+                } else if (L.T > 0) {
                     for (int k = threadIdx.x; k < 9 * np; k += 256) {
                         const int t = k / np, ci = k - t * np;
                         const float x = ci < nc ? sm[ci * 9 + t] : 0.0f;
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(PrepBatch b) {
                 }
                 __syncthreads();
             }
-            for (int k = 9 * L.Cp * (L.T > 0 ? L.T : 1) + threadIdx.x; k < L.ldk; k += 256) row[k] = 0;
+            for (int k = 9 * L.Cp * (L.T > 0 ? L.T : (L.T == -2 ? 2 : 1)) + threadIdx.x; k < L.ldk; k += 256) row[k] = 0;
         } else {
             const int v = u - nk, ci = v / cochunks, co0 = (v - ci * cochunks) * 64;
             const int nco = L.Co - co0 < 64 ? L.Co - co0 : 64;
@@ -446,6 +466,39 @@ __global__ void maxpool_f32_fwd_kernel(const float* __restrict__ X, int B, int H
     }
 }
 
+// 2x2 max pooling of an fp32 NHWC activation written straight as the next convolution's operand: the two bf16 planes
+// [hi (C) | mid (C)] per pooled pixel (row stride ldy bf16 elements, mid plane ldy / 2 further) -- what
+// maxpool_f32_fwd_kernel + split_rows_kernel produced in two passes (conv3x3_halo2_kernel, "bf16x2f").  4 channels per thread.
+__global__ __launch_bounds__(256) void maxpool_f32_planes2_kernel(const float* __restrict__ X, int B, int H, int W, int C,
+                                                                  unsigned short* __restrict__ Y, int ldy) {
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        size_t q = i / C4;
+        const size_t opix = q;
+        const int xo = (int)(q % Wo); q /= Wo;
+        const int yo = (int)(q % Ho);
+        const int b = (int)(q / Ho);
+        const size_t base = (((size_t)b * H + 2 * yo) * W + 2 * xo) * C + c;
+        const float4 v0 = *reinterpret_cast<const float4*>(X + base), v1 = *reinterpret_cast<const float4*>(X + base + C);
+        const float4 v2 = *reinterpret_cast<const float4*>(X + base + (size_t)W * C);
+        const float4 v3 = *reinterpret_cast<const float4*>(X + base + (size_t)W * C + C);
+        float m[4] = {v0.x, v0.y, v0.z, v0.w};
+        const float o[3][4] = {{v1.x, v1.y, v1.z, v1.w}, {v2.x, v2.y, v2.z, v2.w}, {v3.x, v3.y, v3.z, v3.w}};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = o[k][e] > m[e] ? o[k][e] : m[e];      // the same comparisons as maxpool_f32_fwd_kernel
+        unsigned h0, m0, h1, m1, lo_;
+        odwpl::split2(m[0], m[1], false, h0, m0, lo_);
+        odwpl::split2(m[2], m[3], false, h1, m1, lo_);
+        unsigned short* row = Y + opix * ldy + c;
+        *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(row + (ldy >> 1)) = make_uint2(m0, m1);
+    }
+}
+
 __global__ void maxpool_f32_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dY, int B, int H, int W,
                                        int C, float* __restrict__ dX) {
     const int Ho = H / 2, Wo = W / 2;
@@ -566,6 +619,7 @@ ODW_EXPORT int odw_conv_weight_prep_batch(int n, const void* const* w, const int
 // The same with wk written as bf16 PLANES of the fp32 weights (split-precision forward operand, csrc/split.hip):
 // T[i] (0 = plain bf16, else 1..4) blocks of Cp[i] channels per tap, block tt = plane patterns[4 i + tt] (0 hi, 1 mid,
 // 2 lo, 3 zeros); ldk[i] >= 9 * T[i] * Cp[i].  wd (the input-gradient copy) stays single-plane bf16.  T == NULL: plain.
+// T[i] == -2: hi and mid interleaved per block of 32 channels -- row = per tap, per block, [hi 32 | mid 32] (ldk >= 18 Cp).
 ODW_EXPORT int odw_conv_weight_prep_planes_batch(int n, const void* const* w, const int* Co, const int* Ci, const int* Cp,
                                                  void* const* wk, const int* ldk, void* const* wd, const int* ldd,
                                                  const int* T, const int* patterns, void* stream_) {
@@ -577,8 +631,11 @@ ODW_EXPORT int odw_conv_weight_prep_planes_batch(int n, const void* const* w, co
     for (int i = 0; i < n; ++i) {
         ODW_REQUIRE(Co[i] > 0 && Ci[i] > 0 && Cp[i] >= Ci[i] && w[i] && (wk[i] || wd[i]), "conv_weight_prep_batch: layer %d", i);
         const int Ti = T ? T[i] : 0;
-        ODW_REQUIRE(Ti >= 0 && Ti <= 4 && (Ti == 0 || patterns), "conv_weight_prep_batch: layer %d: T = %d (0..4)", i, Ti);
-        ODW_REQUIRE((!wk[i] || ldk[i] >= 9 * Cp[i] * (Ti > 0 ? Ti : 1)) && (!wd[i] || ldd[i] >= 9 * Co[i]),
+        // T = -2: the two planes interleaved per block of 32 channels, [hi 32 | mid 32] (conv3x3_halo2_kernel's operand)
+        ODW_REQUIRE((Ti >= 0 && Ti <= 4 && (Ti == 0 || patterns)) || (Ti == -2 && Cp[i] % 32 == 0),
+                    "conv_weight_prep_batch: layer %d: T = %d (0..4, or -2 with Cp a multiple of 32)", i, Ti);
+        const int planes_i = Ti > 0 ? Ti : (Ti == -2 ? 2 : 1);
+        ODW_REQUIRE((!wk[i] || ldk[i] >= 9 * Cp[i] * planes_i) && (!wd[i] || ldd[i] >= 9 * Co[i]),
                     "conv_weight_prep_batch: leading dimensions of layer %d too small", i);
         b.l[i].w = (const float*)w[i]; b.l[i].wk = (unsigned short*)wk[i]; b.l[i].wd = (unsigned short*)wd[i];
         b.l[i].Co = Co[i]; b.l[i].Ci = Ci[i]; b.l[i].Cp = Cp[i]; b.l[i].ldk = ldk[i]; b.l[i].ldd = ldd[i];
@@ -586,7 +643,7 @@ ODW_EXPORT int odw_conv_weight_prep_planes_batch(int n, const void* const* w, co
         for (int tt = 0; tt < 4; ++tt) b.l[i].pat[tt] = (Ti > 0 && tt < Ti) ? patterns[4 * i + tt] : 3;
         size_t e = (wk[i] ? (size_t)Co[i] : 0) + (wd[i] ? (size_t)Ci[i] * ((Co[i] + 63) / 64) : 0);
         const bool tiled = Ci[i] % kPrepTileCi == 0 && Co[i] % kPrepTileCo == 0 && Cp[i] == Ci[i] &&
-                           (!wk[i] || ldk[i] == 9 * Cp[i] * (Ti > 0 ? Ti : 1)) && (!wd[i] || ldd[i] == 9 * Co[i]);      // = prep_tiled()
+                           (!wk[i] || ldk[i] == 9 * Cp[i] * planes_i) && (!wd[i] || ldd[i] == 9 * Co[i]);      // = prep_tiled()
         if (tiled) e = (size_t)(Co[i] / kPrepTileCo) * (Ci[i] / kPrepTileCi);      // one workgroup per tile, none idle
         most = e > most ? e : most;
     }
@@ -706,6 +763,16 @@ ODW_EXPORT int odw_maxpool2x2_nhwc_f32(const float* X, int B, int H, int W, int 
     ODW_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && X && Y, "maxpool2x2_f32: bad arguments");
     maxpool_f32_fwd_kernel<<<blocks_for((size_t)B * (H / 2) * (W / 2) * C), 256, 0, (hipStream_t)stream_>>>(X, B, H, W, C, Y);
     ODW_CHECK_LAUNCH("maxpool_f32_fwd_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_maxpool2x2_nhwc_f32_planes2(const float* X, int B, int H, int W, int C, void* Y, int ldy, void* stream_) {
+    ODW_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0 && X && Y, "maxpool2x2_f32_planes2: bad arguments");
+    ODW_REQUIRE(ldy >= 2 * C && ldy % 8 == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 7) == 0,
+                "maxpool2x2_f32_planes2: row stride %d (>= 2 C, multiple of 8), aligned buffers", ldy);
+    maxpool_f32_planes2_kernel<<<blocks_for((size_t)B * (H / 2) * (W / 2) * (C / 4)), 256, 0, (hipStream_t)stream_>>>(
+        X, B, H, W, C, (unsigned short*)Y, ldy);
+    ODW_CHECK_LAUNCH("maxpool_f32_planes2_kernel");
     return ODW_OK;
 }
 

@@ -21,6 +21,7 @@
 // optional accumulate (C += ...) for weight gradients shared by several passes.
 #include "odw_common.h"
 #include "odw_rng.h"
+#include "odw_planes.h"
 #include <stdlib.h>
 
 namespace {
@@ -30,18 +31,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kThreads = 256;
-constexpr int kMaxSeg = 4;      // stacked logical passes per launch (each has its own dropout key); more = more launches
+#ifndef ODW_MAX_SEG
+#define ODW_MAX_SEG 8
+#endif
+constexpr int kMaxSeg = ODW_MAX_SEG;      // stacked logical passes per launch (each has its own dropout key); more = more launches.  (4 until
+                                // round 5: an image with three positive classes stacks 6 sampled-row views -- drop + noise per class,
+                                // loss.py:292-305 -- and needed two launches of every Linear, each streaming the weight again)
 constexpr int kChunksPerRow = BK / 8;                 // 16-byte chunks per LDS row
 constexpr int kTileChunks = BM * kChunksPerRow;       // 1024 uint4 per operand tile
 constexpr int kLoadsPerThread = kTileChunks / kThreads;  // 4
 
-struct Epilogue {
+template <int NSEG>
+struct EpilogueT {
+    static constexpr int kSegs = NSEG;
     const float* bias;     // (N) or null
     int relu;
     float drop_p;          // 0 = no dropout
     int nseg;              // dropout row segments (each logical draw has its own key)
-    int seg_row[kMaxSeg];
-    uint32_t seg_k0[kMaxSeg], seg_k1[kMaxSeg];
+    int seg_row[NSEG];
+    uint32_t seg_k0[NSEG], seg_k1[NSEG];
     int accumulate;        // fp32 output only: C += result
     float alpha;           // scales the product before bias
     const unsigned short* mask;   // optional bf16 (M x ldmask): result forced to 0 where mask == 0 (ReLU backward)
@@ -51,6 +59,22 @@ struct Epilogue {
     int kchunk;            // split-K: > 0 = this launch's blockIdx.y owns K range [y*kchunk, (y+1)*kchunk) and writes
     long long split_stride;  //          its partial product split_stride bytes further into C (an fp32 workspace)
 };
+typedef EpilogueT<kMaxSeg> Epilogue;
+// The pair form of gemm_nt_cm_kernel (two accumulator sets, 256 VGPRs, counted vmcnt waits) takes the two segments it
+// needs and no more: with the eight-entry table the compiler spilled 16 SGPRs and one more VGPR INSIDE its main loop,
+// and a scratch reload sits in the same vmcnt queue as the operand DMA the loop's counted waits are written for --
+// four rows of the DropBlock half came out wrong (tests/test_pair_gpu.py caught it).
+typedef EpilogueT<2> EpilogueS;
+
+template <int NSEG>
+inline EpilogueT<NSEG> epilogue_narrow(const Epilogue& e) {
+    EpilogueT<NSEG> o;
+    o.bias = e.bias; o.relu = e.relu; o.drop_p = e.drop_p; o.nseg = e.nseg < NSEG ? e.nseg : NSEG;
+    for (int i = 0; i < NSEG; ++i) { o.seg_row[i] = e.seg_row[i]; o.seg_k0[i] = e.seg_k0[i]; o.seg_k1[i] = e.seg_k1[i]; }
+    o.accumulate = e.accumulate; o.alpha = e.alpha; o.mask = e.mask; o.ldmask = e.ldmask; o.pm = e.pm; o.row_ids = e.row_ids;
+    o.kchunk = e.kchunk; o.split_stride = e.split_stride;
+    return o;
+}
 
 // split-K entry of a DMA kernel: narrow the operands / output to this workgroup's K range
 #define ODW_SPLITK_ENTER()                                                                 \
@@ -134,9 +158,9 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[MI][NJ], void
                 if (ep.drop_p > 0.0f) {
                     int srow = ep.seg_row[0];
                     uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
-                    if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
-                    if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
-                    if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+                    #pragma unroll
+                    for (int sg = 1; sg < kMaxSeg; ++sg)
+                        if (ep.nseg > sg && m >= ep.seg_row[sg]) { srow = ep.seg_row[sg]; k0 = ep.seg_k0[sg]; k1 = ep.seg_k1[sg]; }
                     const uint32_t lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
                     const uint32_t idx = lrow * (uint32_t)N + (uint32_t)n;
                     v = odw_uniform(idx, k0, k1) >= ep.drop_p ? v * (1.0f / (1.0f - ep.drop_p)) : 0.0f;
@@ -320,7 +344,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_glds_kernel(
 // once per wave (band_store), the mask comes as one 8-byte load per column group and band.
 // mask words of one row for the lane's 8 column groups: bit test "(bf16 & 0x7fff) != 0" per element.  vec = rows and
 // columns of the mask allow one 8-byte load per group (ldmask % 4 == 0, 8-byte aligned base, N % 4 == 0).
-__device__ __forceinline__ void epi_load_mask(const Epilogue& ep, bool vec, long long m, int nw, int N, int half,
+template <class EP>
+__device__ __forceinline__ void epi_load_mask(const EP& ep, bool vec, long long m, int nw, int N, int half,
                                               uint2 (&mk)[2][4]) {
     const unsigned short* row = ep.mask + (size_t)(m > 0 ? m : 0) * ep.ldmask;
 #pragma unroll
@@ -351,9 +376,9 @@ __device__ __forceinline__ bool epi_mask_zero(const uint2& w, int q) {
 // parks the band in its private LDS region as 8-byte (bf16) / 16-byte (fp32) pieces (padded rows, conflict-free) and
 // streams it out with one 16-byte store per lane: full 128-byte (bf16) / 256-byte (fp32) row segments instead of
 // 2-byte scatters.  Rows of C must be 16-byte aligned and ldc >= N rounded up to the 16-byte chunk.
-template <bool OUT_BF16, int NI, class RowMap>
+template <bool OUT_BF16, int NI, class RowMap, class EP>
 __device__ __forceinline__ void band_store(const f32x16 (&acc)[NI][2], void* __restrict__ Cv, int ldc, int N, int nw,
-                                           int wave, int lane, const Epilogue& ep, char* lds, RowMap rowmap) {
+                                           int wave, int lane, const EP& ep, char* lds, RowMap rowmap) {
     constexpr int kEl = OUT_BF16 ? 2 : 4;
     constexpr int kRowBytes = 64 * kEl + (OUT_BF16 ? 8 : 16);       // padded: conflict-free b64 / b128 writes
     char* region = lds + wave * (32 * kRowBytes);
@@ -376,9 +401,9 @@ __device__ __forceinline__ void band_store(const f32x16 (&acc)[NI][2], void* __r
         uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
         uint32_t lrow = 0;
         if (ep.drop_p > 0.0f) {
-            if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
-            if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
-            if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+            #pragma unroll
+            for (int sg = 1; sg < EP::kSegs; ++sg)
+                if (ep.nseg > sg && m >= ep.seg_row[sg]) { srow = ep.seg_row[sg]; k0 = ep.seg_k0[sg]; k1 = ep.seg_k1[sg]; }
             lrow = (ep.row_ids && m >= 0) ? (uint32_t)ep.row_ids[m] : (uint32_t)((int)m - srow);
         }
 #pragma unroll
@@ -434,9 +459,9 @@ __device__ __forceinline__ void band_store(const f32x16 (&acc)[NI][2], void* __r
 
 // The same block without the 16-byte-alignment conditions (any N, any ldc): element stores straight from the
 // transposed accumulators.  Only odd-shaped outputs take it (the 357-column predictor written in place).
-template <bool OUT_BF16, int NI, class RowMap>
+template <bool OUT_BF16, int NI, class RowMap, class EP>
 __device__ __forceinline__ void band_store_scalar(const f32x16 (&acc)[NI][2], void* __restrict__ Cv, int ldc, int N, int nw,
-                                                  int lane, const Epilogue& ep, RowMap rowmap) {
+                                                  int lane, const EP& ep, RowMap rowmap) {
     const int half = lane >> 5, l31 = lane & 31;
     const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
 #pragma unroll
@@ -447,9 +472,9 @@ __device__ __forceinline__ void band_store_scalar(const f32x16 (&acc)[NI][2], vo
         uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
         uint32_t lrow = 0;
         if (ep.drop_p > 0.0f) {
-            if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
-            if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
-            if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+            #pragma unroll
+            for (int sg = 1; sg < EP::kSegs; ++sg)
+                if (ep.nseg > sg && m >= ep.seg_row[sg]) { srow = ep.seg_row[sg]; k0 = ep.seg_k0[sg]; k1 = ep.seg_k1[sg]; }
             lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)((int)m - srow);
         }
 #pragma unroll
@@ -603,10 +628,13 @@ struct CmArgs {
     int drop_row0;              // first row of C of the DropBlock half (>= M)
 };
 
+template <bool PAIR> struct CmEp { typedef Epilogue type; };
+template <> struct CmEp<true> { typedef EpilogueS type; };      // (see EpilogueS)
+
 template <bool PAIR, int SHARE>
 __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_cm_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
-    void* __restrict__ Cv, int ldc, Epilogue ep, CmArgs cm, int tiles_m, int tiles_n) {
+    void* __restrict__ Cv, int ldc, typename CmEp<PAIR>::type ep, CmArgs cm, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // SHARE: [3 A slots | 4 B slots]; else [stage][A | B]
     int cell_lo = 0, cell_hi = cm.S;
     if (ep.kchunk > 0) {                                              // split over cells (plain mode)
@@ -748,7 +776,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_cm_kernel(
     }
     auto rowmap = [&](int r) -> long long { return mw + r < M ? (long long)(mw + r) : -1ll; };
     auto rowmap_d = [&](int r) -> long long { return mw + r < M ? (long long)(cm.drop_row0 + mw + r) : -1ll; };
-    Epilogue epd = ep;
+    typename CmEp<PAIR>::type epd = ep;
     if (PAIR) epd.alpha = ep.alpha * ((float)((double)M * cm.S) / *cm.keep_sum);
     if (band_store_ok(Cv, ldc, N, 4)) {           // workgroup-uniform
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1394,6 +1422,216 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo_kernel(
                             });
 }
 
+// ---- round 5: the halo-tile convolution of the "bf16x2f" FORWARD on TWO stored planes ----------------------------------
+// The forward of the timed mode is the sum of three bf16 plane products per layer, x_hi w_hi + x_hi w_mid + x_mid w_hi
+// (od_wscl_amd/precision.py).  Rounds 3-4 ran them as THREE passes of the kernel above over an operand stored as the
+// channel blocks [hi | hi | mid] against weights [hi | mid | hi]: the hi patch of every 64-channel block was staged
+// twice, the hi weight tile of every (block, tap) streamed twice, 6 bytes per activation element stored, and a K step
+// (one barrier, one weight tile, 16 fragment reads) fed 16 MFMAs per wave.
+// Here the operand is stored as the two planes it consists of, [hi (C) | mid (C)] per pixel, and a K step covers 32
+// CHANNELS of both: the patch row of a pixel in LDS is [hi 32 | mid 32] (128 B: the DMA gathers two 64-byte pieces),
+// the weight tile row of (output channel, tap, block) is [hi 32 | mid 32] as well (packed that way by
+// weight_prep_batch_kernel, T = -2), and the step's 16 fragment reads feed the 24 MFMAs of ALL THREE products:
+//     chunk pairs  a0 a1 = x_hi, a2 a3 = x_mid;  b0 b1 = w_hi, b2 b3 = w_mid
+//     acc += b0 a0 + b1 a1  (hi hi)  + b2 a0 + b3 a1  (x_hi w_mid)  + b0 a2 + b1 a3  (x_mid w_hi)
+// Two thirds of the K steps (barriers, weight DMA pieces, patch stagings) of the three-pass form for the same MFMAs,
+// 4 instead of 6 bytes per stored activation, and the hi plane -- the first C columns of a pixel row -- is what the
+// single-plane backward reads (weight gradient operand, ReLU mask), in place.
+// OUTM: 0 = fp32 rows (ldc floats; a pooled layer's pre-pool activation, the feature map, split-K partials),
+//       1 = the next layer's operand itself: bf16 planes [hi (N) | mid (N)] per pixel, ldc bf16 elements per row --
+//           the epilogue splits in registers (odw_planes.h: split2), no fp32 activation, no split_rows pass.
+template <int NI, class RowMap>
+__device__ __forceinline__ void band_store_planes2(const f32x16 (&acc)[NI][2], unsigned short* __restrict__ Cv, int ldc, int N,
+                                                   int nw, int wave, int lane, const Epilogue& ep, char* lds, RowMap rowmap) {
+    constexpr int kRowBytes = 256 + 16;                 // [hi 64 x 2 B | mid 64 x 2 B] + pad: conflict-free b64 writes
+    char* region = lds + wave * (32 * kRowBytes);
+    const int half = lane >> 5, l31 = lane & 31;
+    float* const bias_s = reinterpret_cast<float*>(lds + 8 * 32 * kRowBytes) + wave * 64;
+    {
+        const int n = nw + lane;
+        bias_s[lane] = ep.bias ? ep.bias[n < N ? n : N - 1] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cw = j * 32 + 8 * g + 4 * half;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_s + cw);
+                float v[4] = {acc[i][j][4 * g] + b4.x, acc[i][j][4 * g + 1] + b4.y, acc[i][j][4 * g + 2] + b4.z,
+                              acc[i][j][4 * g + 3] + b4.w};
+                if (ep.relu) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.0f);
+                }
+                unsigned h0, m0, h1, m1, lo_;
+                odwpl::split2(v[0], v[1], false, h0, m0, lo_);
+                odwpl::split2(v[2], v[3], false, h1, m1, lo_);
+                *reinterpret_cast<uint2*>(region + l31 * kRowBytes + cw * 2) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(region + l31 * kRowBytes + 128 + cw * 2) = make_uint2(m0, m1);
+            }
+        }
+        // read the band back row-major: 16 lanes per pixel row (8 x 16 B of the hi plane, 8 x 16 B of the mid plane)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int r = t * 4 + (lane >> 4), cchunk = lane & 15;
+            const uint4 d = *reinterpret_cast<const uint4*>(region + r * kRowBytes + cchunk * 16);
+            const long long gm = rowmap(i * 32 + r);
+            const int gn = nw + (cchunk & 7) * 8;
+            if (gm < 0 || gn >= N) continue;
+            *reinterpret_cast<uint4*>(Cv + (size_t)gm * ldc + (cchunk >> 3) * (ldc >> 1) + gn) = d;      // mid plane: ldc / 2 further
+        }
+    }
+}
+
+template <int OUTM, int DIL, bool N64 = false>
+__global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo2_kernel(
+    const unsigned short* __restrict__ X, int ldx, ConvGeom g, const unsigned short* __restrict__ B, int ldb, int n_img, int N,
+    void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_y, int tiles_x, int tiles_n, int splits, int cb_per_split) {
+    using HC = Halo<DIL>;
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];     // [patch 0 | patch 1 | weight ring of 3]
+    uint4* const bring = lds + 2 * HC::kBufChunks;
+    const int nsp = n_img * tiles_y * tiles_x;
+    const int nblk = nsp * tiles_n * splits;
+    int t;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk / 8, r = nblk % 8, xcd = b % 8, j = b / 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int combo = t / nsp, sp = t - combo * nsp;
+    const int tn = combo % tiles_n, split = combo / tiles_n;
+    const int img = sp / (tiles_y * tiles_x), rem = sp - img * (tiles_y * tiles_x);
+    const int y0 = (rem / tiles_x) * HT, x0 = (rem % tiles_x) * HT, n0 = tn * RN;
+    const int cb0 = split * cb_per_split;
+    const int ncb_all = g.C >> 5;                         // blocks of 32 channels (g.C = channels of ONE plane)
+    const int cb1 = cb0 + cb_per_split < ncb_all ? cb0 + cb_per_split : ncb_all;
+    if (splits > 1) Cv = reinterpret_cast<char*>(Cv) + (long long)split * ep.split_stride;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int MI = N64 ? 1 : 2;
+    const int wm = N64 ? wave : wave >> 1, wn = N64 ? 0 : wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // this lane's share of a patch: byte offset of (pixel, 16-byte chunk) in X for channel block 0; ~0 = zero page.
+    // LDS chunk c of a pixel row: c < 4 = channels 8c .. 8c+7 of the hi plane, c >= 4 = the same of the mid plane
+    unsigned voff[HC::NA];
+#pragma unroll
+    for (int i = 0; i < HC::NA; ++i) {
+        const int hr = (i * 8 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((hr >> 1) & 7);
+        const int hy = hr / HC::HWp, hx = hr - hy * HC::HWp;
+        const int y = y0 - DIL + hy, x = x0 - DIL + hx;
+        const bool ok = hr < HC::kRows && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+        voff[i] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)ldx) * 2u + (unsigned)(c & 3) * 16u +
+                           (c >= 4 ? (unsigned)g.C * 2u : 0u)
+                     : 0xffffffffu;
+    }
+    auto dma_patch = [&](int cb, uint4* buf) {
+        const char* base = reinterpret_cast<const char*>(X) + (size_t)cb * 64;
+#pragma unroll
+        for (int i = 0; i < HC::NA; ++i) {
+            const void* src = voff[i] != 0xffffffffu ? static_cast<const void*>(base + voff[i])
+                                                     : static_cast<const void*>(g.zero);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(buf + (i * 8 + wave) * 64), 16, 0, 0);
+        }
+    };
+    int hrb[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) hrb[i] = (wm * (2 * MI) + i * 2 + halo_row_of(l31) + DIL) * HC::HWp + halo_x_of(l31) + DIL;
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int ktap = 2 * g.C;                            // weight row: per tap the blocks [hi 32 | mid 32] of all channels
+    const int nsteps = (cb1 - cb0) * 9;
+    dma_patch(cb0, lds);
+    dma_rows<16>(B, ldb, N, n0, cb0 * 64, bring, wave, lane);
+    if (nsteps > 1) dma_rows<16>(B, ldb, N, n0, ktap + cb0 * 64, bring + kHaloBStage, wave, lane);
+    int tap = 0, cb = cb0, slot = 0;
+    int tap2 = 2, cb2 = cb0;
+    for (int st = 0; st < nsteps; ++st) {
+        if (st + 2 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if ((tap == 1 || tap == 2) && cb + 1 < cb1) {
+            if (HC::NA == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < nsteps) {
+            const int s2 = slot + 2 >= 3 ? slot - 1 : slot + 2;
+            dma_rows<16>(B, ldb, N, n0, tap2 * ktap + cb2 * 64, bring + s2 * kHaloBStage, wave, lane);
+        }
+        if (tap == 0 && cb + 1 < cb1) dma_patch(cb + 1, lds + (((cb - cb0) + 1) & 1) * HC::kBufChunks);
+        const uint4* sa = lds + ((cb - cb0) & 1) * HC::kBufChunks;
+        const uint4* sb = bring + slot * kHaloBStage;
+        const int ty_ = (tap * 11) >> 5, tx_ = tap - 3 * ty_;
+        const int delta = ((ty_ - 1) * HC::HWp + (tx_ - 1)) * DIL * g.sign;
+        int arow[MI], asw[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int hr = hrb[i] + delta;
+            arow[i] = hr * kChunksPerRow;
+            asw[i] = (hr >> 1) & 7;
+        }
+        bf16x8 ga[4][MI], gb[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = kk * 2 + half;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) ga[kk][i] = __builtin_bit_cast(bf16x8, sa[arow[i] + (c ^ asw[i])]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gb[kk][j] = __builtin_bit_cast(bf16x8, sb[lds_slot(wn * 64 + j * 32 + l31, c)]);
+        }
+        // (ka, kb): hi hi over both 16-channel halves, x_hi w_mid, x_mid w_hi -- in the order the fragments arrive
+        constexpr int KA[6] = {0, 1, 0, 1, 2, 3}, KB[6] = {0, 1, 2, 3, 0, 1};
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb[KB[p]][j], ga[KA[p]][i], acc[i][j], 0, 0, 0);
+        if (N64) {                  // 12 reads, 12 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        } else {                    // 16 reads, 24 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+        if (++tap == 9) { tap = 0; ++cb; }
+        if (++tap2 == 9) { tap2 = 0; ++cb2; }
+    }
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int hw = g.H * g.W;
+    auto rowmap = [&](int r) -> long long {
+        const int y = y0 + wm * (2 * MI) + (r >> 5) * 2 + halo_row_of(r & 31), x = x0 + halo_x_of(r & 31);
+        return (y < g.H && x < g.W) ? (long long)img * hw + (long long)y * g.W + x : -1ll;
+    };
+    if (OUTM == 1)
+        band_store_planes2<MI>(acc, reinterpret_cast<unsigned short*>(Cv), ldc, N, n0 + wn * 64, wave, lane, ep,
+                               reinterpret_cast<char*>(lds), rowmap);
+    else
+        band_store<false, MI>(acc, Cv, ldc, N, n0 + wn * 64, wave, lane, ep, reinterpret_cast<char*>(lds), rowmap);
+}
+
 // ---- "TN" product on the ring pipeline: C[M,N] = sum_k A[k][m] * B[k][n], BOTH operands K-major ----------------------
 // A weight gradient is dW = dZ^T X with dZ (rows x N_out) and X (rows x K_in) stored row-major: the reduction index is
 // the ROW of both operands.  The NT kernels above want it contiguous, which costs a transposed copy of each operand
@@ -1868,9 +2106,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         int srow = ep.seg_row[0];
         uint32_t k0 = ep.seg_k0[0], k1 = ep.seg_k1[0];
         if (ep.drop_p > 0.0f) {
-            if (ep.nseg > 1 && m >= ep.seg_row[1]) { srow = ep.seg_row[1]; k0 = ep.seg_k0[1]; k1 = ep.seg_k1[1]; }
-            if (ep.nseg > 2 && m >= ep.seg_row[2]) { srow = ep.seg_row[2]; k0 = ep.seg_k0[2]; k1 = ep.seg_k1[2]; }
-            if (ep.nseg > 3 && m >= ep.seg_row[3]) { srow = ep.seg_row[3]; k0 = ep.seg_k0[3]; k1 = ep.seg_k1[3]; }
+            #pragma unroll
+            for (int sg = 1; sg < kMaxSeg; ++sg)
+                if (ep.nseg > sg && m >= ep.seg_row[sg]) { srow = ep.seg_row[sg]; k0 = ep.seg_k0[sg]; k1 = ep.seg_k1[sg]; }
         }
         // bias and mask of the four columns as one batch of independent loads (clamped; per-element "if (ep.bias) x +=
         // ep.bias[n]" compiles to a conditional load + s_waitcnt per element)
@@ -1911,6 +2149,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (n + q < N) c[q] = ep.accumulate ? c[q] + v[q] : v[q];
         }
+    }
+}
+
+// The same second pass when the consumer is the next convolution of the "bf16x2f" forward (conv3x3_halo2_kernel): the sum of
+// the K slices + bias, ReLU, written as the two bf16 planes [hi (N) | mid (N)] per row (ldc bf16 elements per row).
+__global__ __launch_bounds__(256) void splitk_reduce_planes2_kernel(const float* __restrict__ ws, int S, long long stride_f,
+                                                                    int M, int N, unsigned short* __restrict__ C, int ldc,
+                                                                    const float* __restrict__ bias, int relu) {
+    const int n4 = N / 4;
+    const long long total = (long long)M * n4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
+        const float* p = ws + (size_t)m * N + n;
+        float4 a = *reinterpret_cast<const float4*>(p);
+        for (int sidx = 1; sidx < S; ++sidx) {
+            const float4 b = *reinterpret_cast<const float4*>(p + (size_t)sidx * stride_f);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + n);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (relu) { a.x = fmaxf(a.x, 0.0f); a.y = fmaxf(a.y, 0.0f); a.z = fmaxf(a.z, 0.0f); a.w = fmaxf(a.w, 0.0f); }
+        unsigned h0, m0, h1, m1, lo_;
+        odwpl::split2(a.x, a.y, false, h0, m0, lo_);
+        odwpl::split2(a.z, a.w, false, h1, m1, lo_);
+        unsigned short* row = C + (size_t)m * ldc + n;
+        *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(row + (ldc >> 1)) = make_uint2(m0, m1);
     }
 }
 
@@ -2109,7 +2376,8 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
                                                                 (int)(LDSB)); \
             ODW_CHECK_HIP(attr_, "gemm_nt_cm attr");                                                                     \
             gemm_nt_cm_kernel<PAIRV, SV><<<GRID, kRingThreads, LDSB, stream>>>(                                          \
-                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, OUT, ldc_, EP, cm, tiles_m, tiles_n); \
+                (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, OUT, ldc_,                           \
+                epilogue_narrow<CmEp<PAIRV>::type::kSegs>(EP), cm, tiles_m, tiles_n);                                    \
         } while (0)
         const int ldc_ = ldc;
         // few ROIs: the cells are split over blockIdx.y; a split's partial clean sums land in rows [0, M) of its slice
@@ -3139,5 +3407,93 @@ ODW_EXPORT int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, 
             (const unsigned short*)X, g, (const unsigned short*)Wk, ldw, n_pix, N, Y, ldy, ep, tiles_m, tiles_n);
     }
     ODW_CHECK_LAUNCH("conv3x3_glds_kernel");
+    return ODW_OK;
+}
+
+// ---- the two-plane forward convolution of the "bf16x2f" mode (conv3x3_halo2_kernel) ---------------------------------------
+namespace {
+HaloPlan halo2_plan(int n_pix, int H, int W, int C, int N) {
+    HaloPlan p = {true, (H + HT - 1) / HT, (W + HT - 1) / HT, (N + RN - 1) / RN, 1, 0};
+    const int ncb = C / 32;
+    const long tiles = (long)(n_pix / (H * W)) * p.tiles_y * p.tiles_x * p.tiles_n;
+    int sp = (int)(256 / (tiles > 0 ? tiles : 1));
+    if (sp > 4) sp = 4;
+    if (sp > ncb) sp = ncb;
+    if (sp < 1) sp = 1;
+    const char* f = getenv("ODW_CONV_SPLITK");
+    if (f) { sp = atoi(f); if (sp > ncb) sp = ncb; if (sp < 1) sp = 1; }
+    p.cb_per_split = (ncb + sp - 1) / sp;
+    p.splits = (ncb + p.cb_per_split - 1) / p.cb_per_split;
+    return p;
+}
+}  // namespace
+
+ODW_EXPORT int64_t odw_conv3x3_planes2_workspace(int n_pix, int H, int W, int C, int N) {
+    if (H <= 0 || W <= 0 || n_pix <= 0 || C < 32 || C % 32 != 0) return 0;
+    const HaloPlan hp = halo2_plan(n_pix, H, W, C, N);
+    return hp.splits > 1 ? (int64_t)hp.splits * n_pix * N * 4 : 0;
+}
+
+ODW_EXPORT int odw_conv3x3_planes2_ws(const void* X, int ldx, int n_pix, int H, int W, int C, int dilation, const void* Wk, int ldw,
+                                      int N, void* Y, int ldy, int y_planes, const float* bias, int relu, const void* zero_page,
+                                      void* workspace, int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(n_pix >= 0 && H > 0 && W > 0 && N > 0 && n_pix % (H * W) == 0, "conv3x3_planes2: bad dims");
+    ODW_REQUIRE(dilation == 1 || dilation == 2, "conv3x3_planes2: dilation %d", dilation);
+    if (n_pix == 0) return ODW_OK;
+    ODW_REQUIRE(X && Wk && Y && zero_page, "conv3x3_planes2: null pointer");
+    ODW_REQUIRE(C >= 32 && C % 32 == 0 && ldx >= 2 * C && ldx % 8 == 0, "conv3x3_planes2: C=%d channels per plane (multiple of 32), "
+                "row stride %d >= 2 C", C, ldx);
+    ODW_REQUIRE(N % 64 == 0, "conv3x3_planes2: N=%d output channels must be a multiple of 64", N);
+    ODW_REQUIRE(ldw >= 18 * C && ldw % 8 == 0, "conv3x3_planes2: weight rows hold 9 x 2 x %d values (ldw=%d)", C, ldw);
+    ODW_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Wk) & 15) == 0 && (((uintptr_t)zero_page) & 15) == 0 &&
+                (((uintptr_t)Y) & 15) == 0, "conv3x3_planes2: 16-byte alignment");
+    ODW_REQUIRE(y_planes ? (ldy >= 2 * N && ldy % 16 == 0) : (ldy >= N && ldy % 4 == 0), "conv3x3_planes2: output row stride %d", ldy);
+    ODW_REQUIRE((unsigned long long)n_pix * (unsigned long long)ldx * 2ull < (1ull << 32), "conv3x3_planes2: operand too large for 32-bit offsets");
+    ConvGeom g;
+    g.H = H; g.W = W; g.C = C; g.dil = dilation; g.sign = 1; g.zero = (const unsigned short*)zero_page; g.logC = 0;
+    Epilogue ep;
+    ep.bias = bias; ep.relu = relu; ep.drop_p = 0.0f; ep.nseg = 0; ep.accumulate = 0; ep.alpha = 1.0f;
+    ep.mask = nullptr; ep.ldmask = 0; ep.pm = 0; ep.kchunk = 0; ep.split_stride = 0; ep.row_ids = nullptr;
+    for (int i = 0; i < kMaxSeg; ++i) { ep.seg_row[i] = 0; ep.seg_k0[i] = 0; ep.seg_k1[i] = 0; }
+    HaloPlan hp = halo2_plan(n_pix, H, W, C, N);
+    if (hp.splits > 1 && (!workspace || workspace_bytes < (int64_t)hp.splits * n_pix * N * 4 || (((uintptr_t)workspace) & 15) != 0)) {
+        hp.splits = 1; hp.cb_per_split = C / 32;
+    }
+    const int n_img = n_pix / (H * W);
+    const unsigned grid = (unsigned)(n_img * hp.tiles_y * hp.tiles_x * hp.tiles_n * hp.splits);
+    Epilogue pe = ep;
+    void* out = Y;
+    int ldo = ldy;
+    int outm = y_planes ? 1 : 0;
+    if (hp.splits > 1) {
+        pe.bias = nullptr; pe.relu = 0;
+        pe.split_stride = (long long)n_pix * N * 4;
+        out = workspace; ldo = N; outm = 0;
+    }
+#define ODW_LAUNCH_HALO2(OM, D, N64V)                                                                              \
+    do {                                                                                                           \
+        ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_kernel<OM, D, N64V>),            \
+                                      (int)Halo<D>::kLdsBytes), "halo2 attr");                                     \
+        conv3x3_halo2_kernel<OM, D, N64V><<<grid, kHaloThreads, Halo<D>::kLdsBytes, stream>>>(                      \
+            (const unsigned short*)X, ldx, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y,   \
+            hp.tiles_x, hp.tiles_n, hp.splits, hp.cb_per_split);                                                   \
+    } while (0)
+    if (N == 64 && dilation == 1) { if (outm) ODW_LAUNCH_HALO2(1, 1, true); else ODW_LAUNCH_HALO2(0, 1, true); }
+    else if (dilation == 1) { if (outm) ODW_LAUNCH_HALO2(1, 1, false); else ODW_LAUNCH_HALO2(0, 1, false); }
+    else { if (outm) ODW_LAUNCH_HALO2(1, 2, false); else ODW_LAUNCH_HALO2(0, 2, false); }
+#undef ODW_LAUNCH_HALO2
+    ODW_CHECK_HIP(hipGetLastError(), "conv3x3_planes2 launch");
+    if (hp.splits > 1) {
+        const long long quads = (long long)n_pix * (N / 4);
+        const int rblocks = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+        if (y_planes)
+            splitk_reduce_planes2_kernel<<<rblocks, 256, 0, stream>>>((const float*)workspace, hp.splits, (long long)n_pix * N,
+                                                                       n_pix, N, (unsigned short*)Y, ldy, bias, relu);
+        else
+            splitk_reduce_kernel<false><<<rblocks, 256, 0, stream>>>((const float*)workspace, hp.splits, (long long)n_pix * N,
+                                                                      n_pix, N, N, Y, ldy, ep);
+    }
+    ODW_CHECK_LAUNCH("conv3x3_halo2_kernel");
     return ODW_OK;
 }

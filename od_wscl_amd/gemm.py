@@ -14,7 +14,7 @@ from . import precision as P
 from .utils.kernel_timer import kernel_timer
 
 
-MAX_SEGS = 4      # dropout row segments one GEMM launch carries keys for (kMaxSeg in csrc/gemm_bf16.hip)
+MAX_SEGS = 8      # dropout row segments one GEMM launch carries keys for (kMaxSeg in csrc/gemm_bf16.hip)
 
 
 def _r8(n):
@@ -41,8 +41,8 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
     nseg = len(segs) if segs else 0
     assert nseg <= MAX_SEGS, "at most %d stacked passes per GEMM launch" % MAX_SEGS
-    rows = (ctypes.c_int * 4)(*([s[0] for s in segs] + [0] * (4 - nseg))) if nseg else None
-    keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
+    rows = (ctypes.c_int * MAX_SEGS)(*([s[0] for s in segs] + [0] * (MAX_SEGS - nseg))) if nseg else None
+    keys = (ctypes.c_uint32 * (2 * MAX_SEGS))(*([k for s in segs for k in (s[1], s[2])] + [0] * (2 * (MAX_SEGS - nseg)))) if nseg else None
     out_bf16 = out.dtype == torch.bfloat16
     # per-symbol timing for bench.py's roofline object (same names as rocprofv3's kernel trace)
     # the planner's answer depends on the shape, the strides and the alignment of C only: asked once per distinct product
@@ -116,8 +116,8 @@ def gemm_nt_cm(a_cm, b_cm, M, N, C, S, out, bias=None, relu=False, drop_p=0.0, s
     assert a_cm.shape[1] == 2 * K and b_cm.shape[1] == 2 * K and a_cm.stride(1) == 1 and b_cm.stride(1) == 1 and out.stride(1) == 1
     nseg = len(segs) if segs else 0
     assert nseg <= MAX_SEGS
-    rows = (ctypes.c_int * 4)(*([s[0] for s in segs] + [0] * (4 - nseg))) if nseg else None
-    keys = (ctypes.c_uint32 * 8)(*([k for s in segs for k in (s[1], s[2])] + [0] * (8 - 2 * nseg))) if nseg else None
+    rows = (ctypes.c_int * MAX_SEGS)(*([s[0] for s in segs] + [0] * (MAX_SEGS - nseg))) if nseg else None
+    keys = (ctypes.c_uint32 * (2 * MAX_SEGS))(*([k for s in segs for k in (s[1], s[2])] + [0] * (2 * (MAX_SEGS - nseg)))) if nseg else None
     pair = keep is not None
     ws_bytes = (L.lib().odw_gemm_nt_cm_pair_workspace(M, N, S) if drop_row0 == M else 0) if pair else L.lib().odw_gemm_nt_cm_workspace(M, N, S)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device) if ws_bytes else None

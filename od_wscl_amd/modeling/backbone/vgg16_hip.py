@@ -25,7 +25,7 @@ def _r64(n):
 
 
 class _Layer(object):
-    __slots__ = ("conv", "cin", "cp", "cout", "dil", "relu", "pool", "trainable", "wk", "wd", "mode", "packed_version")
+    __slots__ = ("conv", "cin", "cp", "cout", "dil", "relu", "pool", "trainable", "wk", "wd", "mode", "packed_version", "p2")
 
 
 def _layers_of(features):
@@ -43,7 +43,7 @@ def _layers_of(features):
             j = i + (2 if l.relu else 1)
             l.pool = j < len(mods) and isinstance(mods[j], nn.MaxPool2d)
             l.trainable = m.weight.requires_grad
-            l.wk = l.wd = l.mode = l.packed_version = None
+            l.wk = l.wd = l.mode = l.packed_version = l.p2 = None
             out.append(l)
         i += 1
     return out
@@ -60,6 +60,33 @@ def _conv3x3(lib, x, m, h, w, c, dil, mirror, wk, n, y, bias, relu, mask, ldmask
         L.check(lib.odw_conv3x3_nhwc_bf16_ws(L.ptr(x), m, h, w, c, dil, mirror, L.ptr(wk), wk.stride(0), n, L.ptr(y), n,
                                              1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0, L.ptr(mask), ldmask,
                                              L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv3x3")
+
+
+def planes2_layer(l):
+    """True when the "bf16x2f" forward of this layer runs on the two stored planes [hi | mid] of its input
+    (csrc/gemm_bf16.hip: conv3x3_halo2_kernel) instead of three passes over the blocks [hi | hi | mid]."""
+    return l.cp == l.cin and l.cp % 32 == 0 and l.cout % 64 == 0 and l.dil in (1, 2)
+
+
+def planes2_body(net):
+    """The whole body takes the two-plane path: a direct stem that writes planes, every later layer eligible
+    (ODW_CONV_PLANES2=0: the three-pass form of rounds 3-4, for comparison runs)."""
+    l0 = net.layers[0]
+    return (os.environ.get("ODW_CONV_PLANES2") != "0" and len(net.layers) > 1 and not l0.trainable and l0.cin == 3 and l0.dil == 1
+            and l0.relu and not l0.pool and l0.cout % 32 == 0 and os.environ.get("ODW_NO_STEM") != "1"
+            and all(planes2_layer(l) for l in net.layers[1:]))
+
+
+def _conv3x3_planes2(lib, xs, m, h, w, l, y, y_planes, zero_page, st):
+    """One forward convolution over the two-plane operand xs (m, >= 2 cp) -> y fp32 (m, cout) or planes (m, 2 cout)."""
+    ws_bytes = lib.odw_conv3x3_planes2_workspace(m, h, w, l.cp, l.cout)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=y.device) if ws_bytes else None
+    sym = "conv3x3_planes2<%s>%s" % ("planes" if y_planes else "f32", " split-K+reduce" if ws_bytes else "")
+    issued = 2.0 * m * l.cout * 9 * l.cin * 3
+    with kernel_timer.region(sym, flops=issued, alg=issued / 3.0, shape="m=%d,hw=%dx%d,c=%d,n=%d,dil=%d" % (m, h, w, l.cp, l.cout, l.dil)):
+        L.check(lib.odw_conv3x3_planes2_ws(L.ptr(xs), xs.stride(0), m, h, w, l.cp, l.dil, L.ptr(l.wk), l.wk.stride(0), l.cout,
+                                           L.ptr(y), y.stride(0), 1 if y_planes else 0, L.ptr(l.conv.bias), 1 if l.relu else 0,
+                                           L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv3x3_planes2")
 
 
 def conv_wgrad(lib, dzt, colt, cout, cin, cp, k, dw, st, accumulate=0):
@@ -319,6 +346,8 @@ class _VGGMixedFn(torch.autograd.Function):
         # MFMA pass, no fp32 activation + split pass
         direct0 = (not l0.trainable and l0.cin == 3 and l0.dil == 1 and l0.relu and not l0.pool and l0.cout % 8 == 0
                    and len(net.layers) > 1 and os.environ.get("ODW_NO_STEM") != "1")
+        if planes2_body(net):
+            return _VGGMixedFn._forward_planes2(ctx, images, net)
         x = None
         if not direct0:
             cp0 = l0.cp
@@ -377,6 +406,64 @@ class _VGGMixedFn(torch.autograd.Function):
         return feat
 
     @staticmethod
+    def _forward_planes2(ctx, images, net):
+        """Round 5: every activation between two convolutions exists ONLY as the next layer's operand -- the two bf16 planes
+        [hi (C) | mid (C)] per pixel, written by the producing kernel itself: the stem, the convolution epilogue
+        (conv3x3_halo2_kernel, OUTM = 1), or the pooling kernel behind a pooled layer.  No fp32 activation and no
+        split_rows pass per layer (12 launches and 6 + 4 bytes per element moved in rounds 3-4); fp32 only where something
+        else reads it: a pooled layer's pre-pool activation (its first maximum routes the gradient) and the feature map.
+        The hi plane -- the first C columns of a row -- is the backward's operand in place (weight gradient, ReLU mask)."""
+        import ctypes
+        lib = L.lib()
+        B, C, H, W = images.shape
+        dev = images.device
+        st = L.stream()
+        l0, l1 = net.layers[0], net.layers[1]
+        m = B * H * W
+        xs = torch.empty((m, 2 * l1.cp), dtype=torch.bfloat16, device=dev)
+        cpat = (ctypes.c_int * 2)(0, 1)
+        L.check(lib.odw_stem_conv3x3_bias_relu_planes(L.ptr(images.contiguous()), L.ptr(l0.conv.weight.detach()),
+                                                      L.ptr(l0.conv.bias.detach()), B, H, W, l0.cout,
+                                                      ctypes.cast(cpat, ctypes.c_void_p), 2, L.ptr(xs), xs.stride(0), l1.cp, st),
+                "stem_conv3x3_planes")
+        saved = [(None, None, H, W)]
+        h, w = H, W
+        last = len(net.layers) - 1
+        x = None
+        for li in range(1, len(net.layers)):
+            l = net.layers[li]
+            m = B * h * w
+            to_planes = not l.pool and li != last
+            y = torch.empty((m, 2 * l.cout), dtype=torch.bfloat16, device=dev) if to_planes else \
+                torch.empty((m, l.cout), dtype=torch.float32, device=dev)
+            _conv3x3_planes2(lib, xs, m, h, w, l, y, to_planes, net.zero_page, st)
+            x16 = None
+            if l.trainable:
+                # the TN / halo weight-gradient kernels read the hi plane in place (row stride 2 cp); the others want it dense
+                x16 = xs[:, :l.cp] if (l.cp >= 128 and l.cout % 64 == 0 and l.cp % 64 == 0) else xs[:, :l.cp].contiguous()
+            pre = None
+            if l.pool:
+                pre = y if l.trainable else None
+                nxt = torch.empty((B * (h // 2) * (w // 2), 2 * l.cout), dtype=torch.bfloat16, device=dev)
+                L.check(lib.odw_maxpool2x2_nhwc_f32_planes2(L.ptr(y), B, h, w, l.cout, L.ptr(nxt), nxt.stride(0), st), "maxpool_planes2")
+                xs = nxt
+            elif to_planes:
+                xs = y
+            else:
+                x = y
+            saved.append((x16, pre, h, w))
+            if l.pool:
+                h, w = h // 2, w // 2
+        assert x is not None, "the body's last layer must not be pooled"
+        cl = net.layers[-1].cout
+        feat = torch.empty((B, cl, h, w), dtype=torch.float32, device=dev)
+        L.check(lib.odw_nhwc_f32_to_nchw_f32(L.ptr(x), B, h * w, cl, cl, L.ptr(feat), st), "nhwc_to_nchw_f32")
+        ctx.net, ctx.saved_acts, ctx.batch = net, saved, B
+        net.last_nhwc = None
+        net.last_nhwc_f32 = x
+        return feat
+
+    @staticmethod
     def backward(ctx, dfeat):
         return _backward_single_plane(ctx, dfeat)
 
@@ -404,10 +491,11 @@ class VGGBackboneHip(nn.Module):
         mode = P.get_precision()
         mixed = P.split_mode() and not P.bwd_split()      # "bf16x2f": split forward operand, single-plane dgrad operand
         todo = []
+        body_p2 = mixed and planes2_body(self)
         for i, l in enumerate(self.layers):
             # frozen layers pack their copies once -- until someone writes their weights in place (a checkpoint loaded
             # after the first forward: copy_ bumps the tensor's version counter)
-            if (not l.trainable and self._frozen_ready and l.mode == mode
+            if (not l.trainable and self._frozen_ready and l.mode == mode and (l.p2 is None or l.p2 == (body_p2 and i > 0))
                     and getattr(l, "packed_version", None) == l.conv.weight._version):
                 continue
             l.packed_version = l.conv.weight._version
@@ -430,7 +518,10 @@ class VGGBackboneHip(nn.Module):
             # bf16 -- every layer's copies in ONE launch (weight_prep_batch_kernel; the per-layer torch passes of the
             # parity modes -- fill, permuted copy, split, pad -- were 36 launches and 0.5 ms of launch gaps at the head of
             # every step)
-            t_blocks = len(P.conv_patterns(l.cp)[1]) if mixed else 1
+            p2 = body_p2 and i > 0        # [hi 32 | mid 32] per tap and 32-channel block (T = -2)
+            t_blocks = 2 if p2 else (len(P.conv_patterns(l.cp)[1]) if mixed else 1)
+            if getattr(l, "p2", None) != p2:
+                l.p2, l.wk = p2, None
             if l.wk is None or fresh:
                 l.wk = torch.empty((l.cout, _r64(9 * t_blocks * l.cp)), dtype=torch.bfloat16, device=dev)
                 l.wd = None
@@ -441,14 +532,16 @@ class VGGBackboneHip(nn.Module):
         if todo:
             import ctypes
             n = len(todo)
-            key = (mode,) + tuple((l.conv.weight.data_ptr(), l.wk.data_ptr(), l.wd.data_ptr() if l.wd is not None else 0) for l in todo)
+            key = (mode, tuple(bool(getattr(l, "p2", False)) for l in todo)) + \
+                tuple((l.conv.weight.data_ptr(), l.wk.data_ptr(), l.wd.data_ptr() if l.wd is not None else 0) for l in todo)
             if getattr(self, "_prep_key", None) != key:      # the argument arrays change only when a buffer moves
                 vp, ia = ctypes.c_void_p * n, ctypes.c_int * n
                 pats = [list(P.conv_patterns(l.cp)[1]) if mixed else [] for l in todo]
-                args = (vp(*[k[0] for k in key[1:]]), ia(*[l.cout for l in todo]), ia(*[l.cin for l in todo]),
-                        ia(*[l.cp for l in todo]), vp(*[k[1] for k in key[1:]]), ia(*[l.wk.stride(0) for l in todo]),
-                        vp(*[k[2] or None for k in key[1:]]), ia(*[l.wd.stride(0) if l.wd is not None else 0 for l in todo]),
-                        ia(*[len(pt) for pt in pats]), (ctypes.c_int * (4 * n))(*[v for pt in pats for v in (pt + [3] * 4)[:4]]))
+                args = (vp(*[k[0] for k in key[2:]]), ia(*[l.cout for l in todo]), ia(*[l.cin for l in todo]),
+                        ia(*[l.cp for l in todo]), vp(*[k[1] for k in key[2:]]), ia(*[l.wk.stride(0) for l in todo]),
+                        vp(*[k[2] or None for k in key[2:]]), ia(*[l.wd.stride(0) if l.wd is not None else 0 for l in todo]),
+                        ia(*[-2 if getattr(l, "p2", False) else len(pt) for l, pt in zip(todo, pats)]),
+                        (ctypes.c_int * (4 * n))(*[v for pt in pats for v in (pt + [3] * 4)[:4]]))
                 self._prep_key, self._prep_args = key, (args, [ctypes.cast(a, ctypes.c_void_p) for a in args])
             L.check(lib.odw_conv_weight_prep_planes_batch(n, *self._prep_args[1], L.stream()), "conv_weight_prep_batch")
         self._frozen_ready = True

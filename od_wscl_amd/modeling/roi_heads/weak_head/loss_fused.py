@@ -18,6 +18,7 @@ import torch
 from torch.nn import functional as F
 
 from .... import _C
+from .... import gemm
 from .... import _lib as L
 from ....layers import smooth_l1_loss
 from ... import registry
@@ -328,11 +329,12 @@ class RoIRegLossFused(RoIRegLossComputation):
         if views is not None:       # production path: gather + both views + bf16 cast = two launches per class
             x, segs6, segs7 = views
             embs = []
-            for s0 in range(0, len(segs6), 4):          # a GEMM launch carries the dropout keys of 4 stacked passes
+            ms = gemm.MAX_SEGS
+            for s0 in range(0, len(segs6), ms):         # a GEMM launch carries the dropout keys of MAX_SEGS stacked passes
                 a = segs6[s0][0]
-                b = segs6[s0 + 4][0] if s0 + 4 < len(segs6) else x.shape[0]
-                s6 = [(r - a, k0, k1) for (r, k0, k1) in segs6[s0:s0 + 4]]
-                s7 = [(r - a, k0, k1) for (r, k0, k1) in segs7[s0:s0 + 4]]
+                b = segs6[s0 + ms][0] if s0 + ms < len(segs6) else x.shape[0]
+                s6 = [(r - a, k0, k1) for (r, k0, k1) in segs6[s0:s0 + ms]]
+                s7 = [(r - a, k0, k1) for (r, k0, k1) in segs7[s0:s0 + ms]]
                 embs.append(model_sim(feature_extractor._fc(x[a:b], segs6=s6, segs7=s7)).float())
             emb = embs[0] if len(embs) == 1 else torch.cat(embs, dim=0)
         else:
@@ -346,7 +348,7 @@ class RoIRegLossFused(RoIRegLossComputation):
                 parts += [drop.reshape(k, -1), noisy.reshape(k, -1)]
                 segs6 += [(m[4],) + k6d, (m[4] + k,) + k6n]
                 segs7 += [(m[4],) + k7d, (m[4] + k,) + k7n]
-            if len(segs6) > 4:       # more stacked passes than one launch carries dropout keys for: split
+            if len(segs6) > gemm.MAX_SEGS:       # more stacked passes than one launch carries dropout keys for: split
                 emb = self._embed_in_chunks(feature_extractor, model_sim, parts, segs6, segs7)
             else:
                 x = torch.cat(parts, dim=0)
@@ -609,7 +611,8 @@ class RoIRegLossFused(RoIRegLossComputation):
         return cls._col2loss_cache[key]
 
     @staticmethod
-    def _embed_in_chunks(fe, model_sim, parts, segs6, segs7, max_segs=4):
+    def _embed_in_chunks(fe, model_sim, parts, segs6, segs7, max_segs=None):
+        max_segs = max_segs or gemm.MAX_SEGS
         out = []
         for s in range(0, len(parts), max_segs):
             chunk = parts[s:s + max_segs]

@@ -108,6 +108,30 @@ def test_gemm_epilogue_bias_relu_dropout_accumulate(G):
     assert (acc - (1 + a.float() @ b.float().T)).abs().max().item() <= 1e-3
 
 
+@pytest.mark.parametrize("variant", ["", "big", "ring"])
+def test_gemm_carries_eight_dropout_segments(G, variant, monkeypatch):
+    """One launch carries the keys of up to gemm.MAX_SEGS = 8 stacked passes (4 until round 5: an image with three positive
+    classes stacks six sampled-row views, loss.py:292-305, and every Linear ran twice): every segment draws from its OWN
+    stream, numbered from its first row -- against the generator itself, in every kernel variant (direct and split-K)."""
+    if variant:
+        monkeypatch.setenv("ODW_GEMM_VARIANT", variant)
+    assert G.MAX_SEGS == 8
+    M, N, K = 1100, 264, 512
+    a, b = rnd(51, (M, K)).bfloat16(), rnd(52, (N, K)).bfloat16()
+    bias = rnd(53, (N,))
+    starts = [0, 37, 300, 301, 555, 800, 801, 1000]
+    segs = [(r,) + rng.stream_key(13, 40 + i) for i, r in enumerate(starts)]
+    out = torch.empty(M, N, device="cuda")
+    G.gemm_nt(a, b, M, N, K, out, bias=bias, relu=True, drop_p=0.5, segs=segs)
+    keep = np.concatenate([rng.uniform(13, 40 + i, (e - r) * N).reshape(e - r, N)
+                           for i, (r, e) in enumerate(zip(starts, starts[1:] + [M]))]) >= 0.5
+    exp = torch.relu(a.float() @ b.float().T + bias) * torch.from_numpy(keep).cuda() * 2.0
+    assert ((out == 0) == (exp == 0)).all()                     # the zero pattern IS the draw
+    assert (out - exp).abs().max().item() <= 1e-3 * max(1.0, exp.abs().max().item())
+    with pytest.raises(AssertionError):
+        G.gemm_nt(a, b, M, N, K, out, drop_p=0.5, segs=segs + [(1050,) + rng.stream_key(13, 99)])
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (700, 520, 320), (4000, 1032, 512), (130, 72, 25088), (257, 8, 64)])
 def test_gemm_256x256_variant(G, M, N, K, monkeypatch):
     """The 256x256-tile kernel (asm-scheduled slices, skewed barrier, LDS-staged coalesced epilogue) forced on

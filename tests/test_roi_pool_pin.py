@@ -123,7 +123,16 @@ def test_hip_operator_equals_the_numpy_restatement(case):
     out_np, arg_np = RP.roi_pool_forward(feat, rois, scale, ph, pw)
     out, arg = _C.roi_pool_forward(torch.from_numpy(feat).cuda(), torch.from_numpy(rois).cuda(), scale, ph, pw)
     np.testing.assert_array_equal(arg.cpu().numpy(), arg_np)
-    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), out_np.view(np.uint32))
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got, out_np)                   # every value equal ...
+    # ... and bit for bit, with ONE documented exception: the kernels pool on an order-preserving integer image of the
+    # map in which -0.0 is folded onto +0.0 (the reference's '>' treats them as equal, so the first cell wins either
+    # way: the POSITIONS above are exact); where the winning cell holds -0.0 the kernel returns +0.0
+    diff = got.view(np.uint32) != out_np.view(np.uint32)
+    assert not diff.any() or ((out_np[diff] == 0).all() and (got.view(np.uint32)[diff] == 0).all()
+                              and (out_np.view(np.uint32)[diff] == 0x80000000).all())
+    if kind != "zeros":
+        assert not diff.any()
     g = _rng(200 + seed).standard_normal(out_np.shape).astype(np.float32)
     gin = _C.roi_pool_backward(torch.from_numpy(g).cuda(), None, torch.from_numpy(rois).cuda(), arg, scale, ph, pw, B, C, H, W)
     gin_np = RP.roi_pool_backward(g, arg_np, rois, feat.shape)
