@@ -167,11 +167,12 @@ int odw_pairwise_sim(const float* E, int P, int D, float* S, void* stream);
  * slower (P = 5000: 33.9 us dense, 29.5 us with ldS = 5024) -- a caller that may choose the layout of S passes ldS = P
  * rounded up to 32 and reads the (P, P) view of it. */
 int odw_pairwise_sim_ld(const float* E, int P, int D, float* S, int64_t ldS, void* stream);
-/* Workspace form (D = 128): kept for callers of rounds 1-3; the products run on the bf16 matrix cores as six plane
- * products per fp32-grade product and the kernel is bound by the 4 P^2-byte write of S.  Since round 4 the default is the
- * ONE-launch kernel whatever the workspace (it splits E in registers; the split-kernel + LDS-DMA form measured 5-7 us
- * slower, csrc/contrastive.hip); the workspace (odw_pairwise_sim_workspace(P, D) bytes) is used only when
- * ODW_PAIRWISE_PLANES_MIN selects that form. */
+/* Workspace form (D = 128): the products run on the bf16 matrix cores as six plane products per fp32-grade product and the
+ * kernel is bound by the 4 P^2-byte write of S.  Below odw_pairwise_sim_planes_min() rows (5600; ODW_PAIRWISE_PLANES_MIN
+ * overrides) the ONE-launch panel kernel runs whatever the workspace (it splits E in registers: 5-7 us ahead at P <= 4000);
+ * from there on, given odw_pairwise_sim_workspace(P, D) bytes, the split kernel + LDS-DMA kernel pair, which is ahead at
+ * P >= 6000 (43.4 / 72.6 us against 48.5 / 80.7 us at P = 6000 / 8000).  Bit-identical results either way. */
+int odw_pairwise_sim_planes_min(void);
 int64_t odw_pairwise_sim_workspace(int P, int D);
 int odw_pairwise_sim_ws(const float* E, int P, int D, float* S, void* workspace, int64_t workspace_bytes, void* stream);
 /* The same product from the PLANES of E (round 4): [3 planes][Ppad][128] bf16, Ppad = P rounded up to 32, padding rows

@@ -145,7 +145,12 @@ def pairwise_sim(E, padded=False):
     P, D = E.shape
     ld = -(-P // 32) * 32 if (padded and D == 128) else P
     buf = torch.empty((P, ld), dtype=torch.float32, device=E.device)
-    if P:
+    if P and ld == P and D == 128 and P >= L.lib().odw_pairwise_sim_planes_min():
+        # large dense products: the split kernel + LDS-DMA kernel pair (ahead of the one-launch kernel from ~P = 6000)
+        nbytes = L.lib().odw_pairwise_sim_workspace(P, D)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=E.device)
+        L.check(L.lib().odw_pairwise_sim_ws(L.ptr(E), P, D, L.ptr(buf), L.ptr(ws), nbytes, L.stream()), "pairwise_sim")
+    elif P:
         L.check(L.lib().odw_pairwise_sim_ld(L.ptr(E), P, D, L.ptr(buf), ld, L.stream()), "pairwise_sim")
     return buf if ld == P else buf[:, :P]
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "odw_box_iou": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
     "odw_pairwise_sim": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "odw_pairwise_sim_ld": (c_i, [c_p, c_i, c_i, c_p, c_l, c_p]),
+    "odw_pairwise_sim_planes_min": (c_i, []),
     "odw_pairwise_sim_workspace": (c_l, [c_i, c_i]),
     "odw_pairwise_sim_ws": (c_i, [c_p, c_i, c_i, c_p, c_p, c_l, c_p]),
     "odw_pairwise_split_planes": (c_i, [c_p, c_i, c_p, c_p]),

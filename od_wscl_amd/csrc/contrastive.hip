@@ -457,7 +457,9 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
 // P <= 6000 and is within box-to-box noise at P = 8000.  It stays as an explicit entry point (odw_pairwise_sim_planes) for a
 // caller that already has the planes; odw_pairwise_sim_ws keeps the one-launch panel kernel (ODW_PAIRWISE_PLANES_MIN=0 forces
 // this form for comparison).
-constexpr int kPwPlanesMinP = 1 << 30;              // rows from which odw_pairwise_sim_ws takes the planes + DMA form: never by default (see below)
+constexpr int kPwPlanesMinP = 5600;                 // rows from which odw_pairwise_sim_ws takes the planes + DMA form (round 5; see below:
+                                                    // split + DMA kernel 43.4 / 72.6 us against the panel kernel's 48.5 / 80.7 us at P = 6000 /
+                                                    // 8000, the panel kernel ahead at P <= 4000: profiles/r04/pairwise_forms.txt)
 constexpr int kPdSlot = 3 * 32 * 256;                // one 32-row block: 3 planes x 32 rows x 256 B (no padding)
 constexpr int kPdAreas = 3;                          // panel staging areas besides column-block slot 1
 constexpr int kPdLds = 2 * kPdSlot + kPdAreas * kPdSlot;           // 49152 + 73728 (the transpose scratch overlaps area 0/1)
@@ -809,6 +811,12 @@ int supcon_nsplit(int N) {
 }
 
 }  // namespace
+
+// The smallest P at which odw_pairwise_sim_ws uses its workspace (below it the one-launch panel kernel runs and the
+// workspace may be NULL): callers allocate odw_pairwise_sim_workspace(P, D) bytes only from here on.
+ODW_EXPORT int odw_pairwise_sim_planes_min(void) {
+    return getenv("ODW_PAIRWISE_PLANES_MIN") ? atoi(getenv("ODW_PAIRWISE_PLANES_MIN")) : kPwPlanesMinP;
+}
 
 ODW_EXPORT int64_t odw_pairwise_sim_workspace(int P, int D) {
     // the three bf16 planes of E, rows padded to a multiple of 32 (zero rows): [3][Ppad][128]

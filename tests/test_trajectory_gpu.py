@@ -1,4 +1,4 @@
-"""Trajectory-level parity (VERDICT r04 missing #4 / next #7): 50 FREE-RUNNING training steps of the product beside the oracle.
+"""Trajectory-level parity (VERDICT r04 missing #4 / next #7): FREE-RUNNING training steps of the product beside the oracle.
 
 tests/test_timed_step_gpu.py checks three steps and re-synchronises the oracle's weights to the product's before each;
 nothing there shows what the gradient error of the headline mode ("bf16x2f": backward products on ONE bf16 plane per
@@ -9,16 +9,25 @@ formula weights and then run on their own for STEPS steps -- the product through
 torch.optim.SGD over the reference's parameter groups (solver/build.py:10-24) -- with identical inputs and identical
 injected randomness per step, and NO weight transfer between them after step 0.
 
-Asserted (bars chosen from the report this test prints, profiles/r05/trajectory_report.txt):
-  * every step: the 8 losses of the product within LOSS_TOL (1 %) of the oracle's at that step, wherever the two sides
-    made the same selections in that step; a step whose selections differ (two near-tied NMS candidates swapping, an
-    IoU-sampled set gaining a member) is counted, not compared -- the loss is discontinuous in the selection;
-  * no selection set diverges permanently: every traced set (pseudo-GT instances, pseudo labels, IoU samples) agrees
-    again after its last disagreement, at the latest in the final step, and at most MAX_DIVERGED_STEPS steps disagree;
-  * the run does something: the oracle's total loss moves by >= 5 % over the run (a learning rate that leaves the weights
-    in place would pass everything above trivially);
-  * the distance between the two weight trajectories stays a small fraction of the distance travelled (printed per
-    tensor group; asserted for the whole parameter vector).
+What the first runs showed (profiles/r05/trajectory_report_lr*.txt, 50 steps): from random-init weights this workload is
+CHAOTIC at any learning rate that moves the loss -- the predictor's scores are near-tied (Q10: ties in NMS order, arg-max
+proposals 1e-3 apart), and once one pseudo-GT set differs the refinement losses and every later step differ.  Two runs of
+the ORACLE ITSELF whose start weights differ by one fp32 rounding (x (1 +- 2^-22)) keep identical selections for 12 steps
+and then part for good (37 of 50 steps differ, weights 6.8 % of the distance travelled apart at lr 1e-5).  The bar asked
+for -- losses within 1 % over 50 steps, no selection set diverging permanently -- is therefore not one the reference meets
+against itself; what CAN be asserted is that the product is no further from the oracle than the oracle's twin is:
+
+  * CONTROL: a second oracle started 2^-22 away runs beside the first (same inputs, same draws);
+  * while the product's selections equal the oracle's (the first ~10 steps) the 8 losses agree within LOSS_TOL = 1 %
+    (measured <= 3e-3 before the first differing step);
+  * the product's selections first differ no earlier than FIRST_DIV_SLACK steps before the control's do, the number of
+    differing steps is at most the control's + 20 % of the run, and the distance between the weight trajectories
+    |w_product - w_oracle| / |w_oracle - w_0| is at most 1.5 x the control's (measured: 6.2e-2 vs 6.8e-2 at lr 1e-5,
+    3.3e-2 vs 4.0e-2 at lr 5e-6) -- the single-plane bf16 backward's 0.5 % gradient error adds nothing measurable to
+    what fp32 rounding already does to this run;
+  * the run moves the loss by >= 5 %, and every loss stays finite.
+ODW_TRAJ_STEPS / ODW_TRAJ_LR / ODW_TRAJ_REPORT=1 (print only) run other settings; the default (24 steps at bench.py's
+learning rate) keeps the GPU suite's time in bounds -- two CPU oracles are stepped per product step.
 """
 import os
 import sys
@@ -34,14 +43,14 @@ from conftest import weights_for  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-STEPS = int(os.environ.get("ODW_TRAJ_STEPS", "50"))
-LR = float(os.environ.get("ODW_TRAJ_LR", "2e-4"))
+STEPS = int(os.environ.get("ODW_TRAJ_STEPS", "24"))
+LR = float(os.environ.get("ODW_TRAJ_LR", "1e-5"))          # == bench.BENCH_LR
 SEED = int(os.environ.get("ODW_TRAJ_SEED", "41"))
 SIZE_H, SIZE_W, PROPOSALS, CLASSES = 160, 192, 128, 21
 IMAGE_INDEX = 1                  # synthetic image 1 carries two labels: loss_sim > 0, the multi-class branch (Q3) runs
 MODE = "bf16x2f"
 LOSS_TOL = 1e-2
-MAX_DIVERGED_STEPS = STEPS // 5
+FIRST_DIV_SLACK = 3
 SELECTION_KEYS = ("pgt_instance_", "pseudo_", "iou_samples_")
 
 
@@ -227,8 +236,14 @@ def _run(bench, H, engine, synthetic, BoxList, to_image_list, DeviceRand, dev):
     if os.environ.get("ODW_TRAJ_REPORT") == "1":
         return
     assert moved >= 0.05, ("the run does not move the loss: the learning rate is too small to test anything", moved)
-    assert len(diverged_steps) <= MAX_DIVERGED_STEPS, ("selections differed in too many steps", diverged_steps)
-    for k, s_ in last_disagree.items():
-        assert s_ < STEPS - 1, ("selection set %s still differs in the final step: diverged for good?" % k, s_ + 1)
-    assert worst_loss <= LOSS_TOL, ("losses left the oracle's by more than %.0e on a step with identical selections" % LOSS_TOL, worst_loss)
-    assert ratio <= 0.05, ("the weight trajectories drift apart", ratio)
+    assert control, "the assertions below compare against the control run (ODW_TRAJ_CONTROL=0 is report-only)"
+    first = diverged_steps[0] if diverged_steps else STEPS
+    first_ctl = control_diverged[0] if control_diverged else STEPS
+    # 1. while the product follows the oracle's selections, the losses agree (every step before the first differing one)
+    head = devs_same[:first]
+    assert head and max(head) <= LOSS_TOL, ("losses left the oracle's before any selection differed", max(head) if head else None)
+    # 2. the product parts from the oracle no earlier, no more often and no further than the oracle's own twin does
+    assert first >= first_ctl - FIRST_DIV_SLACK, ("selections differed %d steps before the control's did" % (first_ctl - first),
+                                                  first + 1, first_ctl + 1)
+    assert len(diverged_steps) <= len(control_diverged) + max(2, STEPS // 5), (len(diverged_steps), len(control_diverged))
+    assert ratio <= 1.5 * ratio2 + 5e-3, ("the product drifts from the oracle faster than fp32 rounding noise does", ratio, ratio2)
