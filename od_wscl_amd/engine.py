@@ -276,7 +276,9 @@ class FlatSGD(object):
                 r64 = lambda v: (v + 63) // 64 * 64
                 if single_bwd:      # W (bf16) is a slice of the flat shadow the SGD kernel rewrites, W^T refreshed in place
                     w16 = self.flat_w16[o:o + weight.numel()].view(weight.shape)
-                    sh.wt = torch.empty((k_in, r64(n_out)), dtype=torch.bfloat16, device=dev)
+                    sh.bwd2 = gemm.bwd2_layer(weight)       # (ODW_BWD2=1, a measurement mode: small-K layers' backward on two planes)
+                    t_bwd = len(precision.patterns("gemm")[1]) if sh.bwd2 else 1
+                    sh.wt = torch.empty((k_in, t_bwd * r64(n_out)), dtype=torch.bfloat16, device=dev)
                     if mode == "bf16":
                         sh.w = w16
                     else:           # "bf16x2f": the forward operand = the bf16 planes of the fp32 master, re-split in place
@@ -290,6 +292,8 @@ class FlatSGD(object):
                 # Linears whose gradient is large enough for its read-modify-write to matter get ONE weight-gradient
                 # GEMM per step over all their evaluations (gemm.WgradBatch)
                 sh.batch = gemm.WgradBatch() if (weight.numel() >= (8 << 20) and os.environ.get("ODW_NO_WGRAD_BATCH") != "1") else None
+                if sh.batch is not None:
+                    sh.batch.split = bool(sh.bwd2)
                 if sh.batch is not None and self.world > 1 and os.environ.get("ODW_NO_OVERLAP") != "1":
                     # its gradient is produced by ONE GEMM per step (the batch): hand it to the exchange as it retires,
                     # the largest ones (fc6: 411 MB) in row blocks
@@ -332,7 +336,10 @@ class FlatSGD(object):
             if sh.mode == "bf16":
                 gemm.transpose_bf16(sh.w, n, k, out=sh.wt)    # in place: same buffer every step, no allocator traffic
             else:                           # "bf16x2f": W^T from the refreshed bf16 plane, forward planes from the master
-                gemm.transpose_bf16(sh.w16, n, k, out=sh.wt)
+                if sh.bwd2:                 # (ODW_BWD2: the planes of W^T, from the master)
+                    precision.split_cols(sh.weight.detach(), precision.patterns("gemm")[1], (n + 63) // 64 * 64, out=sh.wt)
+                else:
+                    gemm.transpose_bf16(sh.w16, n, k, out=sh.wt)
                 if sh.w_cm is not None:
                     gemm.split_rows_cm(sh.weight.detach(), sh.cm[0], sh.cm[1], out=sh.w_cm)
                 else:

@@ -153,6 +153,8 @@ class Shadow(object):
         self.wt = None
         self.managed = False      # True: the optimiser refreshes w / wt itself (engine.FlatSGD)
         self.batch = None         # gemm.WgradBatch: one weight-gradient GEMM per step over all evaluations
+        self.bwd2 = False         # "bf16x2f" with ODW_BWD2=1 (a measurement mode): THIS layer's backward products run on two
+                                  # planes per operand as well (wt = planes of W^T); see bwd2_layer()
         self.cm = None            # (C, S): the weight is ALSO kept as cell-major planes w_cm (N x 2K: [hi | mid], k' = s*C + c)
         self.w_cm = None          # for the shared clean + DropBlock forward of the first head Linear (pair_linear)
 
@@ -172,7 +174,7 @@ class Shadow(object):
             elif P.split_mode():
                 pb = P.patterns("gemm")[1]
                 self.w = P.split_rows(wd, pb, _r64(k), out=w_out)
-                self.wt = P.split_cols(wd, pb, _r64(n), out=wt_out) if P.bwd_split() else transpose_bf16(wd, n, k, out=wt_out)
+                self.wt = P.split_cols(wd, pb, _r64(n), out=wt_out) if (P.bwd_split() or self.bwd2) else transpose_bf16(wd, n, k, out=wt_out)
                 self.w_cm = None
             else:
                 self.w = to_bf16(wd)
@@ -202,6 +204,15 @@ class Shadow(object):
         return self
 
 
+def bwd2_layer(weight):
+    """ODW_BWD2=1 (measurement): in "bf16x2f" the backward products of the SMALL-K Linears -- fc7, Sim_Net,
+    the predictor: in_features <= 4096 -- run on two bf16 planes per operand (three plane products) like the forward,
+    instead of one.  fc6 (K = 25088) and the convolutions keep the single-plane backward.  profiles/r05/bwd2_report.txt
+    holds the step time and the per-tensor gradient error with and without."""
+    import os
+    return os.environ.get("ODW_BWD2") == "1" and P.get_precision() == "bf16x2f" and weight.dim() == 2 and weight.shape[1] <= 4096
+
+
 # Set to a list by a caller that wants the input-gradient GEMM of ONE layer (`deferred_weight`: the layer whose input
 # gradient nothing in the backward it is about to run consumes) handed back as a closure instead of launched (see
 # _backward_single_plane.input_gradient); None = launch everything in place.
@@ -221,13 +232,14 @@ class WgradBatch(object):
     # for the discovery lists, weak_head/loss_fused.py: early_backward; the clean rows re-attached afterwards are a
     # few hundred).  Beyond the reserve the buffers are re-allocated and the filled blocks copied.
     reserve = 0
+    split = False     # this layer's backward runs on split planes although the process-wide mode's does not (Shadow.bwd2)
 
     def __init__(self):
         self.rows, self.filled, self.dzt, self.xt, self.kpad, self.done = [], 0, None, None, 0, []
 
     def register(self, m):
         """Reserve the column block of an evaluation over m rows (split precision: one block per plane product)."""
-        self.rows.append(_r64(m) * (len(P.patterns("gemm")[0]) if P.bwd_split() else 1))
+        self.rows.append(_r64(m) * (len(P.patterns("gemm")[0]) if (P.bwd_split() or self.split) else 1))
         if self.dzt is not None:
             self.done.append(False)
             need = sum(self.rows)
@@ -278,7 +290,7 @@ class WgradBatch(object):
         # all-reduce of fc6's 411 MB runs under the rest of this GEMM and of the backward instead of after it
         ready = getattr(weight, "_odw_grad_ready", None)
         rows = int(getattr(weight, "_odw_slice_rows", 0)) if ready is not None else 0
-        tp = len(P.patterns("gemm")[0]) if P.bwd_split() else 1
+        tp = len(P.patterns("gemm")[0]) if (P.bwd_split() or self.split) else 1
         if rows <= 0 or rows >= n_out:
             gemm_nt(self.dzt, self.xt, n_out, k_in, self.kpad, weight.grad, accumulate=not fresh, planes=tp)
             if ready is not None:
@@ -484,9 +496,17 @@ class _SplitLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x32, y, weight, bias = ctx.saved_tensors
+        dx, dw = _backward_split(x32, y, weight, bias, ctx.cfg, dy, ctx.needs_input_grad[0])
+        return dx, dw, None, None, None, None, None, None, None, None, None, None, None
+
+
+def _backward_split(x32, y, weight, bias, cfg, dy, need_dx):
+    """Backward of a fused Linear with every product on split planes (modes "bf16x3" / "bf16x2"; Shadow.bwd2 layers of
+    "bf16x2f"): x32 / y are the saved fp32 input / output."""
+    if True:
         if x32.dtype != torch.float32:
             raise RuntimeError("_SplitLinear: a pre-split operand is only supported by the single-plane backward (bf16x2f)")
-        sh, relu, drop_p, x_dtype, tag, grad_rows, slot = ctx.cfg
+        sh, relu, drop_p, x_dtype, tag, grad_rows, slot = cfg
         pa, pb = P.patterns("gemm")
         T = len(pa)
         M_all, K = x32.shape
@@ -510,7 +530,7 @@ class _SplitLinear(torch.autograd.Function):
         scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
         dz = P.bwd_mask(dy, y, scale, db)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             dx_all = torch.empty((M_all, K), dtype=torch.float32, device=dy.device)
             dx = dx_all
             if grad_rows is not None:
@@ -550,7 +570,7 @@ class _SplitLinear(torch.autograd.Function):
             kernel_timer.layer = tag and tag + "_wgrad"
             gemm_nt(dzt, xt, N, K, T * m64, target, accumulate=not fresh, planes=T)
             kernel_timer.layer = None
-        return dx, dw, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw
 
 
 class _MixedLinear(torch.autograd.Function):
@@ -564,6 +584,9 @@ class _MixedLinear(torch.autograd.Function):
     def backward(ctx, dy):
         x32, y, weight, bias = ctx.saved_tensors
         sh, relu, drop_p, x_dtype, tag, grad_rows, slot = ctx.cfg
+        if sh.bwd2 and x32.dtype == torch.float32:      # (measurement mode ODW_BWD2: this layer's backward on two planes)
+            dx, dw = _backward_split(x32, y, weight, bias, ctx.cfg, dy, ctx.needs_input_grad[0])
+            return dx, dw, None, None, None, None, None, None, None, None, None, None, None
         cfg = (sh, relu, drop_p, torch.float32, tag, grad_rows, slot)
         dx, dw = _backward_single_plane(x32, y, weight, bias, cfg, dy, ctx.needs_input_grad[0])
         if dx is not None and x_dtype != torch.float32:
@@ -652,7 +675,10 @@ class _ReuseLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xb, y, weight, bias = ctx.saved_tensors
-        dx, dw = _backward_single_plane(xb, y, weight, bias, ctx.cfg, dy, ctx.needs_input_grad[0])
+        if ctx.cfg[0].bwd2 and xb.dtype == torch.float32:      # (measurement mode ODW_BWD2: this layer's backward on two planes)
+            dx, dw = _backward_split(xb, y, weight, bias, ctx.cfg, dy, ctx.needs_input_grad[0])
+        else:
+            dx, dw = _backward_single_plane(xb, y, weight, bias, ctx.cfg, dy, ctx.needs_input_grad[0])
         return dx, dw, None, None, None, None, None, None, None, None
 
 
@@ -661,6 +687,8 @@ def reuse_linear(x, weight, bias, shadow, y_full, rows, relu=False, drop_p=0.0, 
     _ReuseLinear).  Single-plane backward only ("bf16", "bf16x2f")."""
     if P.bwd_split():
         raise RuntimeError("reuse_linear: the split-precision backward keeps no single-plane operands")
+    if shadow.bwd2 and x.dtype != torch.float32:
+        raise RuntimeError("reuse_linear: a two-plane backward (ODW_BWD2) needs the fp32 input of the re-attached rows")
     return _ReuseLinear.apply(x, weight, bias, shadow, y_full, rows, relu, drop_p, tag, getattr(x, "_odw_planes", None))
 
 
