@@ -1525,12 +1525,13 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo2_kernel(
         const int hy = hr / HC::HWp, hx = hr - hy * HC::HWp;
         const int y = y0 - DIL + hy, x = x0 - DIL + hx;
         const bool ok = hr < HC::kRows && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-        voff[i] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)ldx) * 2u + (unsigned)(c & 3) * 16u +
-                           (c >= 4 ? (unsigned)g.C * 2u : 0u)
+        // (offsets inside THIS image: 32 bits; the image's base is added as a 64-bit pointer below -- any batch size)
+        voff[i] = ok ? ((unsigned)(y * g.W + x) * (unsigned)ldx) * 2u + (unsigned)(c & 3) * 16u + (c >= 4 ? (unsigned)g.C * 2u : 0u)
                      : 0xffffffffu;
     }
+    const char* const ximg = reinterpret_cast<const char*>(X) + (size_t)img * g.H * g.W * (size_t)ldx * 2;
     auto dma_patch = [&](int cb, uint4* buf) {
-        const char* base = reinterpret_cast<const char*>(X) + (size_t)cb * 64;
+        const char* base = ximg + (size_t)cb * 64;
 #pragma unroll
         for (int i = 0; i < HC::NA; ++i) {
             const void* src = voff[i] != 0xffffffffu ? static_cast<const void*>(base + voff[i])
@@ -3449,7 +3450,8 @@ ODW_EXPORT int odw_conv3x3_planes2_ws(const void* X, int ldx, int n_pix, int H, 
     ODW_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Wk) & 15) == 0 && (((uintptr_t)zero_page) & 15) == 0 &&
                 (((uintptr_t)Y) & 15) == 0, "conv3x3_planes2: 16-byte alignment");
     ODW_REQUIRE(y_planes ? (ldy >= 2 * N && ldy % 16 == 0) : (ldy >= N && ldy % 4 == 0), "conv3x3_planes2: output row stride %d", ldy);
-    ODW_REQUIRE((unsigned long long)n_pix * (unsigned long long)ldx * 2ull < (1ull << 32), "conv3x3_planes2: operand too large for 32-bit offsets");
+    ODW_REQUIRE((unsigned long long)H * W * (unsigned long long)ldx * 2ull < (1ull << 32), "conv3x3_planes2: one image of the operand "
+                "must stay below 4 GB (32-bit offsets inside an image)");
     ConvGeom g;
     g.H = H; g.W = W; g.C = C; g.dil = dilation; g.sign = 1; g.zero = (const unsigned short*)zero_page; g.logC = 0;
     Epilogue ep;
