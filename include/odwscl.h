@@ -425,8 +425,10 @@ int odw_conv3x3_nhwc_bf16_ws(const void* X, int n_pix, int H, int W, int C, int 
  *   X  : (n_pix x ldx) bf16, a pixel row = [hi plane: C channels | mid plane: C channels | padding], C % 32 == 0
  *   Wk : (N x ldw) bf16 packed by odw_conv_weight_prep_planes_batch with T = -2: per tap, per block of 32 channels,
  *        [hi 32 | mid 32]; ldw >= 18 C
- *   Y  : y_planes == 0: fp32 (n_pix x ldy);  y_planes != 0: the next layer's operand, bf16 planes [hi N | mid N] per pixel
- *        (ldy bf16 elements per row, the mid plane ldy / 2 elements in) -- bias and ReLU applied before the split
+ *   Y  : y_planes == 0: fp32 (n_pix x ldy);  y_planes == 1: the next layer's operand, bf16 planes [hi N | mid N] per pixel
+ *        (ldy bf16 elements per row, the mid plane ldy / 2 elements in) -- bias and ReLU applied before the split;
+ *        y_planes == 2: the same planes of the 2 x 2 / 2 max-pooled result (n_pix / 4 rows; H and W even): bias, ReLU, pool and
+ *        split all in the epilogue, no fp32 activation (a pooled layer without a backward: the frozen conv1_2 / conv2_2)
  *   N % 64 == 0, dilation 1 or 2; the workspace (odw_conv3x3_planes2_workspace bytes; 0 = none) holds the fp32 partials
  *   of the K slices small maps are cut into. */
 int64_t odw_conv3x3_planes2_workspace(int n_pix, int H, int W, int C, int N);

@@ -1485,6 +1485,68 @@ __device__ __forceinline__ void band_store_planes2(const f32x16 (&acc)[NI][2], u
     }
 }
 
+// OUTM = 2: bias + ReLU, the 2 x 2 / 2 max pool AND the split in the epilogue -- a pooled layer whose pre-pool activation nobody
+// reads again (the frozen conv1_2 / conv2_2 of VGG16: no backward) writes the next layer's operand at a quarter of the pixels
+// and no fp32 activation at all (94.6 MB at 608^2 x 64, written and read back by the pooling pass before).  A wave's 32-pixel
+// fragment is two tile rows x 16 pixels (halo_row_of / halo_x_of) = eight complete 2 x 2 windows: the fragment is staged in the
+// wave's LDS region like the fp32 epilogue's, then lane = (window q, 8 channels) takes the maximum of its four pixels, splits it
+// and stores 16 bytes of each plane.  poolmap(i, q) = pooled pixel row of C for window q of fragment i, or -1.
+template <int NI, class PoolMap>
+__device__ __forceinline__ void band_store_pool_planes2(const f32x16 (&acc)[NI][2], unsigned short* __restrict__ Cv, int ldc, int N,
+                                                        int nw, int wave, int lane, const Epilogue& ep, char* lds, PoolMap poolmap) {
+    constexpr int kRowBytes = 256 + 16;
+    char* region = lds + wave * (32 * kRowBytes);
+    const int half = lane >> 5, l31 = lane & 31;
+    float* const bias_s = reinterpret_cast<float*>(lds + 8 * 32 * kRowBytes) + wave * 64;
+    {
+        const int n = nw + lane;
+        bias_s[lane] = ep.bias ? ep.bias[n < N ? n : N - 1] : 0.0f;
+    }
+    // fragment row of pixel (tile row 0 / 1, x): the inverse of halo_row_of / halo_x_of
+    const int q = lane >> 3, c8 = (lane & 7) * 8;
+    const int xa = 2 * q, xb = 2 * q + 1;
+    auto r_top = [](int x) { return x < 4 ? x : x < 8 ? x + 8 : x + 12; };
+    auto r_bot = [](int x) { return x < 8 ? x + 4 : x < 12 ? x + 8 : x + 16; };
+    const int rr[4] = {r_top(xa), r_top(xb), r_bot(xa), r_bot(xb)};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cw = j * 32 + 8 * g + 4 * half;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_s + cw);
+                float v[4] = {acc[i][j][4 * g] + b4.x, acc[i][j][4 * g + 1] + b4.y, acc[i][j][4 * g + 2] + b4.z,
+                              acc[i][j][4 * g + 3] + b4.w};
+                if (ep.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                }
+                *reinterpret_cast<float4*>(region + l31 * kRowBytes + cw * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(region + rr[k] * kRowBytes + c8 * 4);
+            const float4 b = *reinterpret_cast<const float4*>(region + rr[k] * kRowBytes + c8 * 4 + 16);
+            const float e[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m[u] = (k == 0 || e[u] > m[u]) ? e[u] : m[u];      // maxpool_f32_planes2_kernel's comparisons
+        }
+        unsigned h[4], md[4], lo_;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) odwpl::split2(m[2 * u], m[2 * u + 1], false, h[u], md[u], lo_);
+        const long long gm = poolmap(i, q);
+        const int gn = nw + c8;
+        if (gm >= 0 && gn < N) {
+            unsigned short* dst = Cv + (size_t)gm * ldc + gn;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(dst + (ldc >> 1)) = make_uint4(md[0], md[1], md[2], md[3]);
+        }
+    }
+}
+
 template <int OUTM, int DIL, bool N64 = false>
 __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo2_kernel(
     const unsigned short* __restrict__ X, int ldx, ConvGeom g, const unsigned short* __restrict__ B, int ldb, int n_img, int N,
@@ -1626,7 +1688,15 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo2_kernel(
         const int y = y0 + wm * (2 * MI) + (r >> 5) * 2 + halo_row_of(r & 31), x = x0 + halo_x_of(r & 31);
         return (y < g.H && x < g.W) ? (long long)img * hw + (long long)y * g.W + x : -1ll;
     };
-    if (OUTM == 1)
+    if (OUTM == 2) {
+        const int hw2 = (g.H >> 1) * (g.W >> 1);
+        band_store_pool_planes2<MI>(acc, reinterpret_cast<unsigned short*>(Cv), ldc, N, n0 + wn * 64, wave, lane, ep,
+                                    reinterpret_cast<char*>(lds), [&](int i, int q) -> long long {
+                                        const int y = y0 + wm * (2 * MI) + i * 2, x = x0 + 2 * q;       // top-left pixel of the window
+                                        return (y + 1 < g.H && x + 1 < g.W)
+                                                   ? (long long)img * hw2 + (long long)(y >> 1) * (g.W >> 1) + (x >> 1) : -1ll;
+                                    });
+    } else if (OUTM == 1)
         band_store_planes2<MI>(acc, reinterpret_cast<unsigned short*>(Cv), ldc, N, n0 + wn * 64, wave, lane, ep,
                                reinterpret_cast<char*>(lds), rowmap);
     else
@@ -3450,6 +3520,8 @@ ODW_EXPORT int odw_conv3x3_planes2_ws(const void* X, int ldx, int n_pix, int H, 
     ODW_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Wk) & 15) == 0 && (((uintptr_t)zero_page) & 15) == 0 &&
                 (((uintptr_t)Y) & 15) == 0, "conv3x3_planes2: 16-byte alignment");
     ODW_REQUIRE(y_planes ? (ldy >= 2 * N && ldy % 16 == 0) : (ldy >= N && ldy % 4 == 0), "conv3x3_planes2: output row stride %d", ldy);
+    ODW_REQUIRE(y_planes >= 0 && y_planes <= 2 && (y_planes != 2 || (H % 2 == 0 && W % 2 == 0)),
+                "conv3x3_planes2: y_planes = 0 (fp32) | 1 (planes) | 2 (2 x 2 max pool + planes: even H and W)");
     ODW_REQUIRE((unsigned long long)H * W * (unsigned long long)ldx * 2ull < (1ull << 32), "conv3x3_planes2: one image of the operand "
                 "must stay below 4 GB (32-bit offsets inside an image)");
     ConvGeom g;
@@ -3462,12 +3534,13 @@ ODW_EXPORT int odw_conv3x3_planes2_ws(const void* X, int ldx, int n_pix, int H, 
     if (hp.splits > 1 && (!workspace || workspace_bytes < (int64_t)hp.splits * n_pix * N * 4 || (((uintptr_t)workspace) & 15) != 0)) {
         hp.splits = 1; hp.cb_per_split = C / 32;
     }
+    if (y_planes == 2) { hp.splits = 1; hp.cb_per_split = C / 32; }      // (the pooled epilogue takes whole sums: no K slices)
     const int n_img = n_pix / (H * W);
     const unsigned grid = (unsigned)(n_img * hp.tiles_y * hp.tiles_x * hp.tiles_n * hp.splits);
     Epilogue pe = ep;
     void* out = Y;
     int ldo = ldy;
-    int outm = y_planes ? 1 : 0;
+    int outm = y_planes;
     if (hp.splits > 1) {
         pe.bias = nullptr; pe.relu = 0;
         pe.split_stride = (long long)n_pix * N * 4;
@@ -3481,9 +3554,13 @@ ODW_EXPORT int odw_conv3x3_planes2_ws(const void* X, int ldx, int n_pix, int H, 
             (const unsigned short*)X, ldx, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y,   \
             hp.tiles_x, hp.tiles_n, hp.splits, hp.cb_per_split);                                                   \
     } while (0)
-    if (N == 64 && dilation == 1) { if (outm) ODW_LAUNCH_HALO2(1, 1, true); else ODW_LAUNCH_HALO2(0, 1, true); }
-    else if (dilation == 1) { if (outm) ODW_LAUNCH_HALO2(1, 1, false); else ODW_LAUNCH_HALO2(0, 1, false); }
-    else { if (outm) ODW_LAUNCH_HALO2(1, 2, false); else ODW_LAUNCH_HALO2(0, 2, false); }
+    if (N == 64 && dilation == 1) {
+        if (outm == 2) ODW_LAUNCH_HALO2(2, 1, true); else if (outm) ODW_LAUNCH_HALO2(1, 1, true); else ODW_LAUNCH_HALO2(0, 1, true);
+    } else if (dilation == 1) {
+        if (outm == 2) ODW_LAUNCH_HALO2(2, 1, false); else if (outm) ODW_LAUNCH_HALO2(1, 1, false); else ODW_LAUNCH_HALO2(0, 1, false);
+    } else {
+        if (outm == 2) ODW_LAUNCH_HALO2(2, 2, false); else if (outm) ODW_LAUNCH_HALO2(1, 2, false); else ODW_LAUNCH_HALO2(0, 2, false);
+    }
 #undef ODW_LAUNCH_HALO2
     ODW_CHECK_HIP(hipGetLastError(), "conv3x3_planes2 launch");
     if (hp.splits > 1) {

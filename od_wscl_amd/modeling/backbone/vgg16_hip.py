@@ -78,14 +78,17 @@ def planes2_body(net):
 
 
 def _conv3x3_planes2(lib, xs, m, h, w, l, y, y_planes, zero_page, st):
-    """One forward convolution over the two-plane operand xs (m, >= 2 cp) -> y fp32 (m, cout) or planes (m, 2 cout)."""
+    """One forward convolution over the two-plane operand xs (m, >= 2 cp) -> y fp32 (m, cout) [y_planes 0], planes (m, 2 cout)
+    [1], or -- 2 -- the planes of the 2 x 2 max-pooled result (m / 4, 2 cout): pool and split in the epilogue."""
     ws_bytes = lib.odw_conv3x3_planes2_workspace(m, h, w, l.cp, l.cout)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=y.device) if ws_bytes else None
-    sym = "conv3x3_planes2<%s>%s" % ("planes" if y_planes else "f32", " split-K+reduce" if ws_bytes else "")
+    if y_planes == 2:
+        ws_bytes, ws = 0, None              # (the pooled epilogue takes whole sums: the launcher does not slice K)
+    sym = "conv3x3_planes2<%s>%s" % (("f32", "planes", "pool+planes")[int(y_planes)], " split-K+reduce" if ws_bytes else "")
     issued = 2.0 * m * l.cout * 9 * l.cin * 3
     with kernel_timer.region(sym, flops=issued, alg=issued / 3.0, shape="m=%d,hw=%dx%d,c=%d,n=%d,dil=%d" % (m, h, w, l.cp, l.cout, l.dil)):
         L.check(lib.odw_conv3x3_planes2_ws(L.ptr(xs), xs.stride(0), m, h, w, l.cp, l.dil, L.ptr(l.wk), l.wk.stride(0), l.cout,
-                                           L.ptr(y), y.stride(0), 1 if y_planes else 0, L.ptr(l.conv.bias), 1 if l.relu else 0,
+                                           L.ptr(y), y.stride(0), int(y_planes), L.ptr(l.conv.bias), 1 if l.relu else 0,
                                            L.ptr(zero_page), L.ptr(ws), ws_bytes, st), "conv3x3_planes2")
 
 
@@ -434,9 +437,20 @@ class _VGGMixedFn(torch.autograd.Function):
             l = net.layers[li]
             m = B * h * w
             to_planes = not l.pool and li != last
+            # a pooled layer nobody differentiates (the frozen conv1_2 / conv2_2) pools and splits in its epilogue: no fp32
+            # activation, no pooling pass (ODW_CONV_POOL_EPILOGUE=0: the separate pass, for comparison)
+            pooled_out = (l.pool and not l.trainable and l.relu and h % 2 == 0 and w % 2 == 0
+                          and os.environ.get("ODW_CONV_POOL_EPILOGUE") != "0")
+            if pooled_out:
+                y = torch.empty((B * (h // 2) * (w // 2), 2 * l.cout), dtype=torch.bfloat16, device=dev)
+                _conv3x3_planes2(lib, xs, m, h, w, l, y, 2, net.zero_page, st)
+                saved.append((None, None, h, w))
+                xs = y
+                h, w = h // 2, w // 2
+                continue
             y = torch.empty((m, 2 * l.cout), dtype=torch.bfloat16, device=dev) if to_planes else \
                 torch.empty((m, l.cout), dtype=torch.float32, device=dev)
-            _conv3x3_planes2(lib, xs, m, h, w, l, y, to_planes, net.zero_page, st)
+            _conv3x3_planes2(lib, xs, m, h, w, l, y, 1 if to_planes else 0, net.zero_page, st)
             x16 = None
             if l.trainable:
                 # the TN / halo weight-gradient kernels read the hi plane in place (row stride 2 cp); the others want it dense

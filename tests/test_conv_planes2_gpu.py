@@ -74,12 +74,14 @@ def run_conv(L, x, w, b, dil, relu, planes_out):
     zero = torch.zeros(64, dtype=torch.bfloat16, device="cuda")
     ws_bytes = L.lib().odw_conv3x3_planes2_workspace(m, H, W, Cin, Cout)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
-    if planes_out:
+    if planes_out == 2:
+        y = torch.full((B * (H // 2) * (W // 2), 2 * Cout), 5.0, dtype=torch.bfloat16, device="cuda")
+    elif planes_out:
         y = torch.full((m, 2 * Cout), 5.0, dtype=torch.bfloat16, device="cuda")
     else:
         y = torch.full((m, Cout), 5.0, dtype=torch.float32, device="cuda")
     L.check(L.lib().odw_conv3x3_planes2_ws(L.ptr(xs), xs.stride(0), m, H, W, Cin, dil, L.ptr(wk), wk.stride(0), Cout, L.ptr(y),
-                                           y.stride(0), 1 if planes_out else 0, L.ptr(b), 1 if relu else 0, L.ptr(zero),
+                                           y.stride(0), int(planes_out), L.ptr(b), 1 if relu else 0, L.ptr(zero),
                                            L.ptr(ws) if ws_bytes else None, ws_bytes, L.stream()), "conv3x3_planes2")
     return y, ws_bytes
 
@@ -126,6 +128,25 @@ def test_two_plane_convolution_matches_fp64(L, B, Cin, Cout, H, W, dil, relu):
         assert (yk.double() - ref).abs().max().item() <= 2.0 ** -14 * scale
         hk, mk = split_planes(yk)
         assert torch.equal(ykp[:, :Cout], hk) and torch.equal(ykp[:, Cout:], mk)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 64, 64, 40, 36), (2, 64, 128, 18, 22), (1, 128, 128, 34, 50)])
+def test_pool_and_split_in_the_convolution_epilogue(L, B, Cin, Cout, H, W, monkeypatch):
+    """y_planes = 2: bias + ReLU + 2 x 2 max pool + split in the epilogue == the fp32 output pooled and split afterwards, bit for
+    bit (the same accumulators; max and split are exact operations).  The pooled form never slices K, so the fp32 side is run
+    unsliced too (a sliced sum differs in its last bit); the second half runs the pooled form where the plan WOULD slice."""
+    x = rnd(41, (B, Cin, H, W))
+    w = rnd(42, (Cout, Cin, 3, 3), 0.05)
+    b = rnd(43, (Cout,), 0.1)
+    yp_sliced_plan, _ = run_conv(L, x, w, b, 1, True, 2)        # these shapes have < 256 tiles: the plan asks for K slices
+    monkeypatch.setenv("ODW_CONV_SPLITK", "1")
+    y, _ = run_conv(L, x, w, b, 1, True, False)
+    pooled = F.max_pool2d(y.view(B, H, W, Cout).permute(0, 3, 1, 2), 2)
+    hi, mid = split_planes(nhwc(pooled))
+    yp, _ = run_conv(L, x, w, b, 1, True, 2)
+    assert yp.shape == (B * (H // 2) * (W // 2), 2 * Cout)
+    assert torch.equal(yp[:, :Cout], hi) and torch.equal(yp[:, Cout:], mid)
+    assert torch.equal(yp_sliced_plan, yp)
 
 
 def test_weight_layout_is_hi_mid_per_block_of_32_channels(L):
