@@ -2341,7 +2341,12 @@ __host__ Plan pick_plan(int M, int N, int K, int lda, int ldb, const void* C, in
             const int kc = ((K + sp - 1) / sp + 63) / 64 * 64;
             if (sp > 1 && (kc < 256 || (long)kc * (sp - 1) >= K)) break;
             const long rounds = (tiles * sp + 256L * v.per_cu - 1) / (256L * v.per_cu);
-            double t = (double)rounds * v.per_cu * v.tm * v.tn * 2.0 * kc / (v.rate * kCuRate) + rounds * 2e-6;
+            // (the 256x256 kernel run UNSPLIT sustains 1.7, not 1.25: a round of fc6's input gradient, 256 tiles x K = 4096,
+            // takes 90 us -- profiles/r05/gemm_smallm.txt; the sampled-row views, M = 750-900, went to the 128x128 kernel at
+            // 213-235 us where this one takes 186.  Its split form is priced as before: the partials' traffic costs it more
+            // than the term below says, and the 256x128 ring wins those shapes.)
+            const double rate = (v.id == 3 && sp == 1) ? 1.7 : v.rate;
+            double t = (double)rounds * v.per_cu * v.tm * v.tn * 2.0 * kc / (rate * kCuRate) + rounds * 2e-6;
             if (sp > 1) t += ((double)sp * M * N * 4.0 + (double)M * N * c_el) / 2.5e12 + 4e-6;
             if (t < best_t) { best_t = t; best = {v.id, sp, sp > 1 ? kc : 0}; }
         }
