@@ -151,6 +151,8 @@ __device__ __forceinline__ void normal_pair(uint32_t p, uint32_t k0, uint32_t k1
     z1 = r * sinf(t);
 }
 
+constexpr int kRowSlices = 8;          // workgroups per row of rows_drop_noise_kernel (blockIdx.y)
+
 // BWD = false: out rows from pooled;  BWD = true: dpooled[rows[r]] += d(drop row) and d(noise row) folded back
 template <bool BWD, bool DX_F32, bool SRC_BF16 = false, bool OUT_F32 = false>
 __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __restrict__ pooled, const void* __restrict__ dXv,
@@ -167,7 +169,11 @@ __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __res
     __syncthreads();
     const float sum = *keep_sum, numel = (float)((double)k * S);
     const size_t src_row = (size_t)(row_base + rows[r]);
-    for (int q = threadIdx.x; q < CS / 4; q += blockDim.x) {
+    // blockIdx.y = a slice of the row: k ~ 200 rows alone leave most of the chip idle behind one 256-thread block per CU
+    // (37 us per launch on 225 x 25088 elements; the Box-Muller pair of every element is what a thread waits on)
+    const int per = (CS / 4 + gridDim.y - 1) / gridDim.y;
+    const int q_end = min(CS / 4, (int)(blockIdx.y + 1) * per);
+    for (int q = blockIdx.y * per + threadIdx.x; q < q_end; q += blockDim.x) {
         const int s0 = (q * 4) % S;
         const uint32_t e = (uint32_t)r * (uint32_t)CS + (uint32_t)q * 4u;       // element index in the (k, C, S) draw
         float z[4];
@@ -346,11 +352,11 @@ ODW_EXPORT int odw_rows_drop_noise(const void* pooled, int src_is_bf16, const in
     ODW_REQUIRE((((uintptr_t)pooled) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0, "rows_drop_noise: alignment");
     rows_keep_sum_kernel<<<1, 256, 0, stream>>>(k * S, gamma, kd0, kd1, keep_sum);
     if (src_is_bf16)          // source rows have the same stride as the output (rows of one (2R x ld) operand)
-        rows_drop_noise_kernel<false, false, true><<<k, 256, 0, stream>>>((const float*)pooled, nullptr, rows, row_base, k,
+        rows_drop_noise_kernel<false, false, true><<<dim3(k, kRowSlices), 256, 0, stream>>>((const float*)pooled, nullptr, rows, row_base, k,
                                                                           (int)cs, S, gamma, kd0, kd1, kn0, kn1, keep_sum,
                                                                           (unsigned short*)out_bf16, ld, out_row0, nullptr);
     else
-        rows_drop_noise_kernel<false, false><<<k, 256, 0, stream>>>((const float*)pooled, nullptr, rows, row_base, k, (int)cs,
+        rows_drop_noise_kernel<false, false><<<dim3(k, kRowSlices), 256, 0, stream>>>((const float*)pooled, nullptr, rows, row_base, k, (int)cs,
                                                                     S, gamma, kd0, kd1, kn0, kn1, keep_sum,
                                                                     (unsigned short*)out_bf16, ld, out_row0, nullptr);
     ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
@@ -368,7 +374,7 @@ ODW_EXPORT int odw_rows_drop_noise_f32(const float* pooled, const int* rows, int
     ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0 && (long)k * cs < (1ll << 32), "rows_drop_noise_f32: C*S=%ld, ld=%d", cs, ld);
     ODW_REQUIRE((((uintptr_t)pooled) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "rows_drop_noise_f32: alignment");
     rows_keep_sum_kernel<<<1, 256, 0, stream>>>(k * S, gamma, kd0, kd1, keep_sum);
-    rows_drop_noise_kernel<false, false, false, true><<<k, 256, 0, stream>>>(pooled, nullptr, rows, row_base, k, (int)cs, S, gamma,
+    rows_drop_noise_kernel<false, false, false, true><<<dim3(k, kRowSlices), 256, 0, stream>>>(pooled, nullptr, rows, row_base, k, (int)cs, S, gamma,
                                                                              kd0, kd1, kn0, kn1, keep_sum,
                                                                              reinterpret_cast<unsigned short*>(out), ld, out_row0,
                                                                              nullptr);
@@ -387,10 +393,10 @@ ODW_EXPORT int odw_rows_drop_noise_bwd(const void* dX, int dx_is_f32, int ld, in
     ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0, "rows_drop_noise_bwd: C*S=%ld, ld=%d", cs, ld);
     ODW_REQUIRE((((uintptr_t)dX) & 15) == 0 && (((uintptr_t)dpooled) & 15) == 0, "rows_drop_noise_bwd: alignment");
     if (dx_is_f32)
-        rows_drop_noise_kernel<true, true><<<k, 256, 0, stream>>>(nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1,
+        rows_drop_noise_kernel<true, true><<<dim3(k, kRowSlices), 256, 0, stream>>>(nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1,
                                                                   kn0, kn1, keep_sum, nullptr, ld, dx_row0, dpooled);
     else
-        rows_drop_noise_kernel<true, false><<<k, 256, 0, stream>>>(nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1,
+        rows_drop_noise_kernel<true, false><<<dim3(k, kRowSlices), 256, 0, stream>>>(nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1,
                                                                    kn0, kn1, keep_sum, nullptr, ld, dx_row0, dpooled);
     ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
     return ODW_OK;
