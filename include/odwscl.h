@@ -579,6 +579,15 @@ int odw_stack_clean_aug_f32(const float* pooled, const float* block, const float
 int odw_rows_drop_noise_f32(const float* pooled, const int* rows, int row_base, int k, int C, int S, float gamma,
                             uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1, float* keep_sum, float* out, int ld,
                             int out_row0, void* stream);
+/* The two views as the OPERAND of the first head Linear in the "bf16x2f" mode: the sampled rows are read from the clean rows'
+ * cell-major planes [hi | mid] (k' = cell * C + channel; src_cm, row stride ld_src, mid plane src_mid elements after the hi
+ * plane: what odw_roi_pool_stack_forward_nhwc_f32_cm writes) as x = hi + mid, and the 2k view rows (drop rows [out_row0, +k),
+ * noise rows [out_row0 + k, +k)) are written as cell-major planes (out_cm, ld_cm, cm_mid: the forward operand of
+ * odw_gemm_nt_cm) and as their channel-major hi plane (out_hi, ld_hi: what the single-plane backward transposes).  Same
+ * draws, same evaluation order as odw_rows_drop_noise; C a multiple of 64; gradient = odw_rows_drop_noise_bwd. */
+int odw_rows_views_cm(const void* src_cm, int64_t ld_src, int64_t src_mid, const int* rows, int row_base, int k, int C, int S,
+                      float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1, float* keep_sum, void* out_cm,
+                      int64_t ld_cm, int64_t cm_mid, void* out_hi, int64_t ld_hi, int out_row0, void* stream);
 
 #ifdef __cplusplus
 }

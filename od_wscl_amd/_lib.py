@@ -147,6 +147,7 @@ SIGNATURES = {
     "odw_linear_bwd_mask_f32": (c_i, [c_p, c_l, c_p, c_i, c_l, c_i, c_i, c_f, c_p, c_l, c_p, c_p, c_l, c_p]),
     "odw_stack_clean_aug_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "odw_rows_drop_noise_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_i, c_i, c_p]),
+    "odw_rows_views_cm": (c_i, [c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_l, c_l, c_p, c_l, c_i, c_p]),
     "odw_add_relu_f32": (c_i, [c_p, c_p, c_p, c_l, c_p]),
     "odw_relu_bwd_f32": (c_i, [c_p, c_p, c_p, c_l, c_p]),
     "odw_stem_conv7x7_bn_relu_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),

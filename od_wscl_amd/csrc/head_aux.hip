@@ -10,6 +10,7 @@
 // `block` is the (P, S) keep mask after dilation (S = 7*7), `block_sum` its sum on the device (no host sync).
 #include "odw_common.h"
 #include "odw_rng.h"
+#include "odw_planes.h"
 
 namespace {
 
@@ -379,6 +380,113 @@ ODW_EXPORT int odw_rows_drop_noise_f32(const float* pooled, const int* rows, int
                                                                              reinterpret_cast<unsigned short*>(out), ld, out_row0,
                                                                              nullptr);
     ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
+    return ODW_OK;
+}
+
+// ---- the same two views written as the OPERAND of the first head Linear in the "bf16x2f" mode (round 5) ---------------
+// There the pooling kernel leaves the clean rows as two cell-major planes [hi | mid] (k' = cell * C + channel: what
+// gemm_nt_cm_kernel sweeps) and the views went pooled32 (an fp32 copy of all P rows that only these ~10^2-10^3 sampled rows
+// ever read: 200 MB of the pooling kernel's 700) -> fp32 views -> split_rows_cm -> cell-major planes.  This kernel reads the
+// sampled rows FROM the clean planes (x = hi + mid: the 16 leading bits of the pooled value, which is all the three plane
+// products of the forward see of any operand) and writes what the Linear reads: the views' cell-major planes for the forward
+// and their channel-major hi plane (the bf16 the single-plane backward transposes) -- no fp32 copy of the pooled rows, no fp32
+// views, no split pass.  Same draws as rows_drop_noise_kernel (element index in the (k, C, S) draw, Box-Muller on pairs),
+// same evaluation order.  A workgroup = (sampled row, 64 channels): the slice is staged channel-major in LDS so that
+// the draw runs over pairs of consecutive elements and both layouts leave as full 16-byte vectors.
+constexpr int kViewCh = 64;
+__global__ __launch_bounds__(256) void rows_views_cm_kernel(const unsigned short* __restrict__ src, long long ld_src,
+                                                            long long src_mid, const int* __restrict__ rows, int row_base,
+                                                            int k, int C, int S, float gamma, uint32_t kd0, uint32_t kd1,
+                                                            uint32_t kn0, uint32_t kn1, const float* __restrict__ keep_sum,
+                                                            unsigned short* __restrict__ out_cm, long long ld_cm,
+                                                            long long cm_mid, unsigned short* __restrict__ out_hi,
+                                                            long long ld_hi, int row0) {
+    extern __shared__ __attribute__((aligned(16))) float vlds[];     // x | drop view | noise view, each [64][S]
+    __shared__ float keep[kMaxS];
+    const int r = blockIdx.x, c0 = blockIdx.y * kViewCh;
+    const int n = kViewCh * S;
+    float* xs = vlds;
+    float* dl = vlds + n;
+    float* nl = vlds + 2 * n;
+    for (int s = threadIdx.x; s < S; s += blockDim.x)
+        keep[s] = odw_uniform((uint32_t)(r * S + s), kd0, kd1) < gamma ? 0.0f : 1.0f;
+    const size_t src_row = (size_t)(row_base + rows[r]);
+    for (int t = threadIdx.x; t < S * 8; t += blockDim.x) {
+        const int cell = t >> 3, cg = t & 7;
+        const unsigned short* p = src + src_row * ld_src + (size_t)cell * C + c0 + cg * 8;
+        const uint4 h = *reinterpret_cast<const uint4*>(p), m = *reinterpret_cast<const uint4*>(p + src_mid);
+        const unsigned hw[4] = {h.x, h.y, h.z, h.w}, mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xs[(cg * 8 + 2 * j) * S + cell] = bf2f(hw[j] & 0xffffu) + bf2f(mw[j] & 0xffffu);
+            xs[(cg * 8 + 2 * j + 1) * S + cell] = bf2f(hw[j] >> 16) + bf2f(mw[j] >> 16);
+        }
+    }
+    __syncthreads();
+    const float sum = *keep_sum, numel = (float)((double)k * S);
+    const int CS = C * S;
+    for (int q = threadIdx.x; q < n / 4; q += blockDim.x) {
+        const int l0 = q * 4, s0 = l0 % S;
+        const uint32_t e = (uint32_t)r * (uint32_t)CS + (uint32_t)c0 * (uint32_t)S + (uint32_t)l0;
+        float z[4];
+        normal_pair(e / 2, kn0, kn1, z[0], z[1]);
+        normal_pair(e / 2 + 1, kn0, kn1, z[2], z[3]);
+        const float4 v = *reinterpret_cast<const float4*>(xs + l0);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        float df[4], nf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int sidx = s0 + t;
+            sidx = sidx >= S ? sidx - S : sidx;
+            df[t] = ((x[t] * keep[sidx]) * numel) / sum;
+            nf[t] = z[t] * x[t] + x[t];
+        }
+        *reinterpret_cast<float4*>(dl + l0) = make_float4(df[0], df[1], df[2], df[3]);
+        *reinterpret_cast<float4*>(nl + l0) = make_float4(nf[0], nf[1], nf[2], nf[3]);
+        const size_t col = (size_t)c0 * S + l0;
+        *reinterpret_cast<uint2*>(out_hi + (size_t)(row0 + r) * ld_hi + col) = make_uint2(odwpl::pk(df[0], df[1]), odwpl::pk(df[2], df[3]));
+        *reinterpret_cast<uint2*>(out_hi + (size_t)(row0 + k + r) * ld_hi + col) = make_uint2(odwpl::pk(nf[0], nf[1]), odwpl::pk(nf[2], nf[3]));
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < S * 8; t += blockDim.x) {
+        const int cell = t >> 3, cg = t & 7;
+#pragma unroll
+        for (int view = 0; view < 2; ++view) {
+            const float* vv = view ? nl : dl;
+            unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                odwpl::split2(vv[(cg * 8 + 2 * j) * S + cell], vv[(cg * 8 + 2 * j + 1) * S + cell], false, hi[j], mid[j], lo[j]);
+            unsigned short* dst = out_cm + (size_t)(row0 + (view ? k : 0) + r) * ld_cm + (size_t)cell * C + c0 + cg * 8;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(dst + cm_mid) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+        }
+    }
+}
+
+ODW_EXPORT int odw_rows_views_cm(const void* src_cm, int64_t ld_src, int64_t src_mid, const int* rows, int row_base, int k, int C,
+                                 int S, float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1, float* keep_sum,
+                                 void* out_cm, int64_t ld_cm, int64_t cm_mid, void* out_hi, int64_t ld_hi, int out_row0,
+                                 void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(k >= 0 && C > 0 && C % kViewCh == 0 && S >= 4 && S <= kMaxS && row_base >= 0 && out_row0 >= 0,
+                "rows_views_cm: bad dims (k=%d, C=%d a multiple of 64, S=%d)", k, C, S);
+    if (k == 0) return ODW_OK;
+    const long long cs = (long long)C * S;
+    ODW_REQUIRE(src_cm && rows && keep_sum && out_cm && out_hi, "rows_views_cm: null pointer");
+    ODW_REQUIRE(src_mid >= cs && ld_src >= src_mid + cs && cm_mid >= cs && ld_cm >= cm_mid + cs && ld_hi >= cs && ld_src % 8 == 0 &&
+                src_mid % 8 == 0 && ld_cm % 8 == 0 && cm_mid % 8 == 0 && ld_hi % 4 == 0 && (long long)k * cs < (1ll << 32),
+                "rows_views_cm: planes [hi | mid] of %lld elements must fit the rows (ld_src=%lld src_mid=%lld ld_cm=%lld cm_mid=%lld "
+                "ld_hi=%lld)", cs, (long long)ld_src, (long long)src_mid, (long long)ld_cm, (long long)cm_mid, (long long)ld_hi);
+    ODW_REQUIRE((((uintptr_t)src_cm) & 15) == 0 && (((uintptr_t)out_cm) & 15) == 0 && (((uintptr_t)out_hi) & 7) == 0,
+                "rows_views_cm: alignment");
+    rows_keep_sum_kernel<<<1, 256, 0, stream>>>(k * S, gamma, kd0, kd1, keep_sum);
+    const size_t lds = (size_t)3 * kViewCh * S * sizeof(float);
+    ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(rows_views_cm_kernel), (int)lds), "rows_views_cm attr");
+    rows_views_cm_kernel<<<dim3(k, C / kViewCh), 256, lds, stream>>>(
+        (const unsigned short*)src_cm, ld_src, src_mid, rows, row_base, k, C, S, gamma, kd0, kd1, kn0, kn1, keep_sum,
+        (unsigned short*)out_cm, ld_cm, cm_mid, (unsigned short*)out_hi, ld_hi, out_row0);
+    ODW_CHECK_LAUNCH("rows_views_cm_kernel");
     return ODW_OK;
 }
 

@@ -85,9 +85,30 @@ class _RowViews(torch.autograd.Function):
     src = the fp32 pooled tensor (P,C,h,w), or the bf16 stacked operand of _PoolStack (its first P rows)."""
 
     @staticmethod
-    def forward(ctx, src, groups, holder, gamma, S, values=None):
+    def forward(ctx, src, groups, holder, gamma, S, values=None, src_cm=None):
         """values: the fp32 pooled tensor to read when `src` is only the autograd handle of a planes operand
-        (_PoolStackPlanes: its gradient is parked in `holder` like that of the bf16 stacked operand)."""
+        (_PoolStackPlanes: its gradient is parked in `holder` like that of the bf16 stacked operand).
+        src_cm ("bf16x2f", shared clean + DropBlock forward): the clean rows as cell-major planes (R x 2K, [hi | mid]) -- the
+        views are read from them and come back as (handle, channel-major hi plane, cell-major planes) of the 2 x total view
+        rows (csrc/head_aux.hip: rows_views_cm_kernel): the operand of the first head Linear, no fp32 views, no split pass."""
+        if src_cm is not None:
+            CS = src.shape[1]
+            C = CS // S
+            assert src_cm.dim() == 2 and src_cm.shape[1] == 2 * CS and src_cm.dtype == torch.bfloat16 and src_cm.stride(1) == 1
+            total = sum(g[2] for g in groups)
+            out_cm = torch.empty((2 * total, 2 * CS), dtype=torch.bfloat16, device=src_cm.device)
+            out_hi = torch.empty((2 * total, CS), dtype=torch.bfloat16, device=src_cm.device)
+            sums = torch.empty(len(groups), dtype=torch.float32, device=src_cm.device)
+            lib, st, row0 = L.lib(), L.stream(), 0
+            for gi, (base, rows, k, kd, kn) in enumerate(groups):
+                L.check(lib.odw_rows_views_cm(L.ptr(src_cm), src_cm.stride(0), CS, L.ptr(rows), base, k, C, S, gamma, kd[0], kd[1],
+                                              kn[0], kn[1], L.ptr(sums[gi:]), L.ptr(out_cm), out_cm.stride(0), CS, L.ptr(out_hi),
+                                              out_hi.stride(0), row0, st), "rows_views_cm")
+                row0 += 2 * k
+            ctx.args = (groups, holder, gamma, tuple(src.shape), sums, C, S, False)
+            ctx.set_materialize_grads(False)
+            ctx.mark_non_differentiable(out_hi, out_cm)
+            return gemm.planes_handle(src_cm.device, 2 * total, CS), out_hi, out_cm
         if values is not None:
             src = values
         src = src.contiguous()
@@ -114,7 +135,7 @@ class _RowViews(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dx):
+    def backward(ctx, dx, *unused):
         groups, holder, gamma, shape, sums, C, S, from_bf16 = ctx.args
         dx = dx if dx.stride(1) == 1 else dx.contiguous()
         f32 = 1 if dx.dtype == torch.float32 else 0
@@ -133,14 +154,14 @@ class _RowViews(torch.autograd.Function):
 
         if holder is not None and not holder.done:
             holder.pending.append(fold)          # the stacked node has not produced its gradient yet: it folds this in
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         if from_bf16:      # (never taken in the training step) dense gradient of the stacked operand itself
             d = torch.zeros((shape[0], C * S), dtype=torch.float32, device=dx.device)
             fold(d, False)
-            return d.to(torch.bfloat16), None, None, None, None, None
+            return d.to(torch.bfloat16), None, None, None, None, None, None
         dp = torch.zeros(shape, dtype=torch.float32, device=dx.device)
         fold(dp, False)
-        return dp, None, None, None, None, None
+        return dp, None, None, None, None, None, None
 
 
 class _RowGather(torch.autograd.Function):
@@ -266,7 +287,10 @@ class _PoolStackPlanes(torch.autograd.Function):
         if blk != K:
             planes.zero_()                      # (never for C % 64 == 0 and 7 x 7: C*49 is then a multiple of 64)
         planes_cm = torch.empty((R, 2 * K), dtype=torch.bfloat16, device=feat.device) if pair else None
-        pooled32 = torch.empty((R, C, ph, pw), dtype=torch.float32, device=feat.device)
+        # the fp32 pooled values are what the sampled-row views read -- except in the pair layout, where they are read from the
+        # clean rows' cell-major planes (_RowViews, src_cm): 200 MB of this kernel's 700 not written (ODW_VIEWS_F32=1: as before)
+        views_from_planes = pair and os.environ.get("ODW_VIEWS_F32") != "1"
+        pooled32 = None if views_from_planes else torch.empty((R, C, ph, pw), dtype=torch.float32, device=feat.device)
         argmax = torch.empty((R, K), dtype=torch.int16, device=feat.device)
         lib = L.lib()
         ws_bytes = lib.odw_roi_pool_stack_nhwc_f32_workspace(R, B, C, H, W)
@@ -274,7 +298,8 @@ class _PoolStackPlanes(torch.autograd.Function):
         import ctypes
         pat = (ctypes.c_int * T)(*pa)
         with kernel_timer.region("roi_pool_stack_fwd_nhwc_f32",
-                                 nbytes=float(B * C * H * W * 4 + 2 * R * T * K * 2 + (2 * R * K * 2 if pair else 0) + R * K * 6),
+                                 nbytes=float(B * C * H * W * 4 + 2 * R * T * K * 2 + (2 * R * K * 2 if pair else 0) + R * K * 2
+                                              + (0 if pooled32 is None else R * K * 4)),
                                  alg=float(2 * R * K * 4 + B * C * H * W * 4)):
             L.check(lib.odw_roi_pool_stack_forward_nhwc_f32_cm(L.ptr(nhwc32), L.ptr(rois5), scale, B, C, H, W, R, L.ptr(keep),
                                                                L.ptr(keep_sum), ctypes.cast(pat, ctypes.c_void_p), T, L.ptr(planes),
@@ -286,7 +311,7 @@ class _PoolStackPlanes(torch.autograd.Function):
         ctx.holder = holder
         ctx.set_materialize_grads(False)            # (or autograd hands backward 800 MB of zeros for the two)
         if pair:
-            ctx.mark_non_differentiable(planes, pooled32, planes_cm)
+            ctx.mark_non_differentiable(*[t for t in (planes, pooled32, planes_cm) if t is not None])
             return gemm.planes_handle(feat.device, 2 * R, K), planes, pooled32, planes_cm
         ctx.mark_non_differentiable(planes, pooled32)
         return gemm.planes_handle(feat.device, 2 * R, K), planes, pooled32
@@ -422,8 +447,12 @@ class TwoFCROIFeatureExtractor(nn.Module):
             segs6 += [(row0,) + k6d, (row0 + k,) + k6n]
             segs7 += [(row0,) + k7d, (row0 + k,) + k7n]
             row0 += 2 * k
-        x = _RowViews.apply(pooled, specs, holder, float(self.sim_drop.drop_prob), S,
-                            pooled._odw_pooled32 if planes is not None else None)
+        pooled32 = pooled._odw_pooled32 if planes is not None else None
+        if planes is not None and pooled32 is None:         # the views straight as the operand of fc6 (its planes)
+            x, hi, cm = _RowViews.apply(pooled, specs, holder, float(self.sim_drop.drop_prob), S, None, pooled._odw_planes_cm)
+            x._odw_planes, x._odw_planes_cm = hi, cm
+            return x, segs6, segs7
+        x = _RowViews.apply(pooled, specs, holder, float(self.sim_drop.drop_prob), S, pooled32)
         return x, segs6, segs7
 
     def can_pool_stack(self, features):

@@ -29,6 +29,18 @@ from .loss import RoIRegLossComputation
 _CONST_CACHE = {}
 
 
+def _rows_of(x, a, b):
+    """Rows [a, b) of a stacked operand; one that exists as bf16 planes (gemm.planes_handle) keeps them attached."""
+    if a == 0 and b == x.shape[0]:
+        return x
+    y = x[a:b]
+    for name in ("_odw_planes", "_odw_planes_cm"):
+        t = getattr(x, name, None)
+        if t is not None:
+            setattr(y, name, t[a:b])
+    return y
+
+
 def _i32(values, device):
     """Small int32 device array whose content is the same step after step (image offsets, positive
     classes): uploaded once and cached -- a fresh torch.tensor(..., device=cuda) is a blocking
@@ -335,7 +347,7 @@ class RoIRegLossFused(RoIRegLossComputation):
                 b = segs6[s0 + ms][0] if s0 + ms < len(segs6) else x.shape[0]
                 s6 = [(r - a, k0, k1) for (r, k0, k1) in segs6[s0:s0 + ms]]
                 s7 = [(r - a, k0, k1) for (r, k0, k1) in segs7[s0:s0 + ms]]
-                embs.append(model_sim(feature_extractor._fc(x[a:b], segs6=s6, segs7=s7)).float())
+                embs.append(model_sim(feature_extractor._fc(_rows_of(x, a, b), segs6=s6, segs7=s7)).float())
             emb = embs[0] if len(embs) == 1 else torch.cat(embs, dim=0)
         else:
             parts, segs6, segs7 = [], [], []

@@ -283,3 +283,38 @@ def test_dropblock_keep_mask_kernel_equals_the_reference_formula(n, h, w, bs, p)
         got = db.train()(x, rand=DeviceRand(77, first_stream=9, device="cuda"))
         ref = x.cpu() * want[:, None] * want.numel() / want.sum()
         assert torch.allclose(got.cpu(), ref, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("R,C,S,ks", [(40, 64, 49, (7, 12)), (9, 512, 49, (5,)), (6, 128, 16, (3, 2))])
+def test_views_written_as_planes_equal_the_fp32_views_split_afterwards(R, C, S, ks):
+    """odw_rows_views_cm (bf16x2f: the sampled-row views straight as the operand of fc6) == odw_rows_drop_noise_f32 of the
+    value the planes hold (x = hi + mid) followed by the split pass, bit for bit: the cell-major planes of the forward and the
+    channel-major hi plane of the backward."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd import _lib as L, gemm
+    CS = C * S
+    x = torch.from_numpy(rng.normal(31, 1, R * CS).reshape(R, CS).astype(np.float32)).cuda().relu()
+    src_cm = gemm.split_rows_cm(x, C, S)                                    # (R, 2 CS): [hi | mid], k' = cell * C + channel
+    hi = src_cm[:, :CS].float().view(R, S, C).permute(0, 2, 1).reshape(R, CS)
+    mid = src_cm[:, CS:].float().view(R, S, C).permute(0, 2, 1).reshape(R, CS)
+    x16 = (hi + mid).contiguous()                                          # what the planes hold, channel-major
+    total = sum(ks)
+    out_cm = torch.full((2 * total, 2 * CS), 7.0, dtype=torch.bfloat16, device="cuda")
+    out_hi = torch.full((2 * total, CS), 7.0, dtype=torch.bfloat16, device="cuda")
+    ref32 = torch.empty((2 * total, CS), dtype=torch.float32, device="cuda")
+    sums = torch.empty(2 * len(ks), dtype=torch.float32, device="cuda")
+    row0, base = 0, 0
+    for gi, k in enumerate(ks):
+        rows = torch.from_numpy(np.sort(np.random.RandomState(gi).choice(R - base, k, replace=False)).astype(np.int32)).cuda()
+        keys = (11 + gi, 22, 33 + gi, 44)
+        L.check(L.lib().odw_rows_views_cm(L.ptr(src_cm), src_cm.stride(0), CS, L.ptr(rows), base, k, C, S, 0.3, *keys,
+                                          L.ptr(sums[2 * gi:]), L.ptr(out_cm), out_cm.stride(0), CS, L.ptr(out_hi), out_hi.stride(0),
+                                          row0, L.stream()), "rows_views_cm")
+        L.check(L.lib().odw_rows_drop_noise_f32(L.ptr(x16), L.ptr(rows), base, k, C, S, 0.3, *keys, L.ptr(sums[2 * gi + 1:]),
+                                                L.ptr(ref32), ref32.stride(0), row0, L.stream()), "rows_drop_noise_f32")
+        row0 += 2 * k
+        base = 1
+    assert torch.equal(sums[0::2], sums[1::2])
+    assert torch.equal(out_hi.view(torch.int16), ref32.to(torch.bfloat16).view(torch.int16))
+    assert torch.equal(out_cm.view(torch.int16), gemm.split_rows_cm(ref32, C, S).view(torch.int16))

@@ -1,8 +1,12 @@
-#!/bin/bash
-# usage: tools/exp/ab_env.sh ROUNDS "ENV1=.." "ENV2=.." ...   -- alternating short bench runs on one box
-rounds=$1; shift
-S="--no-cpu-baseline --no-secondary --no-microbench --steps 30 --warmup 6"
-for r in $(seq $rounds); do
-for v in "$@"; do
-  echo "$v: $(env $v python bench.py $S 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["median_ms_per_step"], d["value"])')"
-done; done
+# A/B of one environment switch on the default bench, alternating runs on one box: usage ab_env.sh NAME=VALUE [runs]
+sw=$1; n=${2:-2}
+mkdir -p gpurun_out/ab
+B="python bench.py --no-cpu-baseline --no-secondary --no-microbench --steps 40"
+for i in $(seq 1 $n); do
+$B > gpurun_out/ab/on_$i.json 2>/dev/null
+env $sw $B > gpurun_out/ab/off_$i.json 2>/dev/null
+done
+for i in $(seq 1 $n); do for f in on_$i off_$i; do python -c "
+import json
+d=json.loads(open('gpurun_out/ab/$f.json').read().strip().splitlines()[-1])
+print('$f (off = $sw)', d['value'], d['ms_per_step'], 'median', d['median_ms_per_step'])"; done; done
