@@ -281,6 +281,11 @@ int odw_rows_drop_noise(const void* pooled, int src_is_bf16, const int* rows, in
 int odw_rows_drop_noise_bwd(const void* dX, int dx_is_f32, int ld, int dx_row0, const int* rows, int row_base, int k,
                             int C, int S, float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1,
                             const float* keep_sum, float* dpooled, void* stream);
+/* The same with dpooled[row_base + rows[r]] WRITTEN instead of added to: for rows that belong to this launch alone (the entries
+ * of the pooling node's side buffer) -- the buffer then needs no zero fill and is not read. */
+int odw_rows_drop_noise_bwd_store(const void* dX, int dx_is_f32, int ld, int dx_row0, const int* rows, int row_base, int k,
+                                  int C, int S, float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1,
+                                  const float* keep_sum, float* dpooled, void* stream);
 /* Row-wise L2 normalisation of the (R x D) embeddings (Sim_Net.forward, sim_head/sim_net.py:25-26, F.normalize with
  * eps): y = x / max(||x||, eps), norm[r] = ||x_r||; bwd: dx = (g - y (g.y)) / max(||x||, eps). */
 int odw_l2norm_rows(const float* x, int R, int D, float eps, float* y, float* norm, void* stream);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "odw_roi_pool_stack_backward_ws": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                              c_i, c_i, c_p, c_p, c_l, c_p]),
     "odw_rows_drop_noise_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_p]),
+    "odw_rows_drop_noise_bwd_store": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_u, c_u, c_u, c_u, c_p, c_p, c_p]),
     "odw_l2norm_rows": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
     "odw_l2norm_rows_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p]),
     "odw_gemm_nt_bf16_variant": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i]),

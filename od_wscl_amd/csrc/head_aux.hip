@@ -155,7 +155,7 @@ __device__ __forceinline__ void normal_pair(uint32_t p, uint32_t k0, uint32_t k1
 constexpr int kRowSlices = 8;          // workgroups per row of rows_drop_noise_kernel (blockIdx.y)
 
 // BWD = false: out rows from pooled;  BWD = true: dpooled[rows[r]] += d(drop row) and d(noise row) folded back
-template <bool BWD, bool DX_F32, bool SRC_BF16 = false, bool OUT_F32 = false>
+template <bool BWD, bool DX_F32, bool SRC_BF16 = false, bool OUT_F32 = false, bool STORE = false>
 __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __restrict__ pooled, const void* __restrict__ dXv,
                                                               const int* __restrict__ rows, int row_base, int k, int CS,
                                                               int S, float gamma, uint32_t kd0, uint32_t kd1,
@@ -231,7 +231,9 @@ __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __res
                 gn[0] = bf2f(b.x & 0xffff); gn[1] = bf2f(b.x >> 16); gn[2] = bf2f(b.y & 0xffff); gn[3] = bf2f(b.y >> 16);
             }
             float4* dst = reinterpret_cast<float4*>(dpooled + src_row * CS + q * 4);
-            float4 acc = *dst;                       // rows of one launch are distinct; launches are stream-ordered
+            // rows of one launch are distinct; launches are stream-ordered.  STORE: the row is this launch's alone (an entry
+            // of the pooling node's side buffer): written, not added to -- the buffer needs no zero fill and is not read
+            float4 acc = STORE ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : *dst;
             float add[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -506,6 +508,26 @@ ODW_EXPORT int odw_rows_drop_noise_bwd(const void* dX, int dx_is_f32, int ld, in
     else
         rows_drop_noise_kernel<true, false><<<dim3(k, kRowSlices), 256, 0, stream>>>(nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1,
                                                                    kn0, kn1, keep_sum, nullptr, ld, dx_row0, dpooled);
+    ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_rows_drop_noise_bwd_store(const void* dX, int dx_is_f32, int ld, int dx_row0, const int* rows, int row_base,
+                                             int k, int C, int S, float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0,
+                                             uint32_t kn1, const float* keep_sum, float* dpooled, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(k >= 0 && C > 0 && S >= 4 && S <= kMaxS && row_base >= 0 && dx_row0 >= 0, "rows_drop_noise_bwd_store: bad dims");
+    if (k == 0) return ODW_OK;
+    const long cs = (long)C * S;
+    ODW_REQUIRE(dX && rows && keep_sum && dpooled, "rows_drop_noise_bwd_store: null pointer");
+    ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0, "rows_drop_noise_bwd_store: C*S=%ld, ld=%d", cs, ld);
+    ODW_REQUIRE((((uintptr_t)dX) & 15) == 0 && (((uintptr_t)dpooled) & 15) == 0, "rows_drop_noise_bwd_store: alignment");
+    if (dx_is_f32)
+        rows_drop_noise_kernel<true, true, false, false, true><<<dim3(k, kRowSlices), 256, 0, stream>>>(
+            nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1, kn0, kn1, keep_sum, nullptr, ld, dx_row0, dpooled);
+    else
+        rows_drop_noise_kernel<true, false, false, false, true><<<dim3(k, kRowSlices), 256, 0, stream>>>(
+            nullptr, dX, rows, row_base, k, (int)cs, S, gamma, kd0, kd1, kn0, kn1, keep_sum, nullptr, ld, dx_row0, dpooled);
     ODW_CHECK_LAUNCH("rows_drop_noise_kernel");
     return ODW_OK;
 }

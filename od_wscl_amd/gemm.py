@@ -697,7 +697,13 @@ def planes_handle(device, rows, cols):
     (4 bytes of storage) that carries the graph edge and the gradient's shape / dtype.  Its producer (an autograd
     Function) returns it and attaches the planes as `_odw_planes`; fused_linear() picks them up; nothing ever reads
     the handle's values (never call .contiguous() on one: that would materialise rows x cols zeros)."""
-    return torch.zeros(1, dtype=torch.float32, device=device).expand(rows, cols)
+    z = _HANDLE_ZERO.get(str(device))
+    if z is None:           # one 4-byte zero per device for every handle (was a fill launch per handle, ~5 us each)
+        z = _HANDLE_ZERO[str(device)] = torch.zeros(1, dtype=torch.float32, device=device)
+    return z.expand(rows, cols)
+
+
+_HANDLE_ZERO = {}
 
 
 def fused_linear(x, weight, bias, shadow, relu=False, drop_p=0.0, segs=None, out_f32=False, tag=None, grad_rows=None,

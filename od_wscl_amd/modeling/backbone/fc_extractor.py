@@ -65,6 +65,7 @@ class _GradHolder(object):
         # kind "extra": there is no pooled tensor (ROI pooling writes the stacked operand itself) -- folds fill an
         #               (E, C*h*w) fp32 side buffer, one row per sampled entry, roi_index[e] = the ROI it belongs to
         self.kind, self.pending, self.done, self.roi_index = kind, [], False, None
+        self.grad_out = None        # where the pooling node writes d(feature map) (a HIP-graphed body: its static input buffer)
         self.clean_rows = None      # _PoolStack: number of leading rows of dX whose gradient is meaningful (None = all)
 
 
@@ -140,17 +141,20 @@ class _RowViews(torch.autograd.Function):
         dx = dx if dx.stride(1) == 1 else dx.contiguous()
         f32 = 1 if dx.dtype == torch.float32 else 0
 
-        def fold(target, identity_rows):
+        def fold(target, identity_rows, fresh=False):
             """accumulate d(src rows) into `target`: the dense fp32 gradient of pooled at the sampled rows, or
-            (identity_rows) the (E, C*S) side buffer at consecutive entries"""
+            (identity_rows) the (E, C*S) side buffer at consecutive entries; fresh: the side buffer is uninitialised and
+            every entry is written by exactly one fold (a store instead of a read-add-write of a zero-filled buffer)"""
             lib, st, row0, e0 = L.lib(), L.stream(), 0, 0
+            fn = lib.odw_rows_drop_noise_bwd_store if (fresh and identity_rows) else lib.odw_rows_drop_noise_bwd
             for gi, (base, rows, k, kd, kn) in enumerate(groups):
                 r = _iota(k, dx.device) if identity_rows else rows
-                L.check(lib.odw_rows_drop_noise_bwd(L.ptr(dx), f32, dx.stride(0), row0, L.ptr(r),
-                                                    e0 if identity_rows else base, k, C, S, gamma, kd[0], kd[1], kn[0],
-                                                    kn[1], L.ptr(sums[gi:]), L.ptr(target), st), "rows_drop_noise_bwd")
+                L.check(fn(L.ptr(dx), f32, dx.stride(0), row0, L.ptr(r), e0 if identity_rows else base, k, C, S, gamma, kd[0], kd[1],
+                           kn[0], kn[1], L.ptr(sums[gi:]), L.ptr(target), st), "rows_drop_noise_bwd")
                 row0 += 2 * k
                 e0 += k
+
+        fold.entries = sum(g[2] for g in groups)         # side-buffer entries [0, entries) are this fold's alone
 
         if holder is not None and not holder.done:
             holder.pending.append(fold)          # the stacked node has not produced its gradient yet: it folds this in
@@ -190,9 +194,11 @@ class _RowGather(torch.autograd.Function):
     def backward(ctx, dx, *unused):
         holder, e0, n = ctx.args
 
-        def fold(extra, identity_rows):
+        def fold(extra, identity_rows, fresh=False):
             extra[e0:e0 + n].copy_(dx)       # the entries are this node's alone (zero before): a converting copy, not
                                              # the mixed-dtype add_ (104 us for 250 rows against ~10)
+
+        fold.entries = n
 
         if holder is None or holder.done:
             raise RuntimeError("_RowGather: the pooling node already ran its backward")
@@ -247,13 +253,17 @@ class _PoolStack(torch.autograd.Function):
             if isinstance(roi_index, (list, tuple)):
                 roi_index = roi_index[0] if len(roi_index) == 1 else torch.cat(list(roi_index))
             E = int(roi_index.numel())
-            extra = torch.zeros((E, C * ph * pw), dtype=torch.float32, device=dx.device)
+            # every entry written by exactly one parked fold (the usual case): no zero fill of the 45-90 MB buffer
+            fresh = sum(getattr(f, "entries", 0) for f in holder.pending) == E and os.environ.get("ODW_EXTRA_ZEROS") != "1"
+            extra = (torch.empty if fresh else torch.zeros)((E, C * ph * pw), dtype=torch.float32, device=dx.device)
             for fold in holder.pending:
-                fold(extra, True)
+                fold(extra, True, fresh)
             holder.pending = []
         if holder is not None:
             holder.done = True
-        dfeat = torch.empty((B, C, H, W), dtype=torch.float32, device=dx.device)
+        dfeat = getattr(holder, "grad_out", None) if holder is not None else None     # the body graph's own input buffer
+        if dfeat is None or tuple(dfeat.shape) != (B, C, H, W) or dfeat.dtype != torch.float32 or not dfeat.is_contiguous():
+            dfeat = torch.empty((B, C, H, W), dtype=torch.float32, device=dx.device)
         skip_clean = 1 if (holder is not None and holder.clean_rows == 0) else 0      # sparse backward: clean half unset
         ws = torch.empty(64, dtype=torch.uint8, device=dx.device)       # the launch's fixed-point scale (odw_fixed.h)
         K = C * ph * pw
@@ -488,6 +498,7 @@ class TwoFCROIFeatureExtractor(nn.Module):
         if self._grad_holder is not None and self._grad_holder.pending:
             raise RuntimeError("the gradient of the previous step's sampled-row views was never folded")
         self._grad_holder = _GradHolder("extra")
+        self._grad_holder.grad_out = getattr(feat, "_odw_grad_out", None)
         nhwc = getattr(feat, "_odw_nhwc", None) if os.environ.get("ODW_POOL_NHWC") != "0" else None
         pair = None
         if precision.split_mode():

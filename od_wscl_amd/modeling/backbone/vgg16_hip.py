@@ -640,6 +640,8 @@ class VGGBackboneHip(nn.Module):
             feat = fn.apply(images.float(), self, *params)
         feat._odw_nhwc = self.last_nhwc
         feat._odw_nhwc_f32 = getattr(self, "last_nhwc_f32", None) if fn is _VGGMixedFn else None
+        # a consumer that produces d(feat) itself (fused ROI pooling) may write it straight into the graph's static input
+        feat._odw_grad_out = graphed.dfeat if graphed is not None else None
         return [feat]
 
 
@@ -720,7 +722,8 @@ class _GraphedVGGFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         g = ctx.graphed
-        g.dfeat.copy_(dfeat)
+        if dfeat.data_ptr() != g.dfeat.data_ptr():      # (the pooling node wrote straight into the buffer: _odw_grad_out)
+            g.dfeat.copy_(dfeat)
         with kernel_timer.region("VGG body backward (HIP graph)", flops=g.flops_bwd, alg=g.alg_bwd):
             cb = getattr(g.net, "on_segment_done", None)
             for k, gk in enumerate(g.g_bwd):
