@@ -133,6 +133,9 @@ class ResNet50Conv5ROIFeatureExtractor(TwoFCROIFeatureExtractor):
         self.classifier = nn.Sequential(self.Linear(7 * 7 * 2048, 2048), nn.ReLU(inplace=True), nn.Dropout(),
                                         self.Linear(2048, 4096), nn.ReLU(inplace=True), nn.Dropout())
         self.fc_index = (0, 3)
+        # fc6 reduces over (channel, cell) of a 2048 x 7 x 7 map: the shared clean + DropBlock forward of "bf16x2f" walks it cell
+        # by cell (gemm.pair_linear: half the matrix-core work of the stacked pass), as for VGG16's fc6 (vgg16.py)
+        self.fc6.cm_layout = (2048, 7 * 7)
         self.out_channels = 4096
         if init_weights:
             self.init_fc()
