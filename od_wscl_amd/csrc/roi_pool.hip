@@ -619,12 +619,18 @@ __global__ __launch_bounds__(512) void roi_pool_stack_fwd_nhwc_f32(const unsigne
                                                                    float* __restrict__ pooled,
                                                                    unsigned short* __restrict__ argmax,
                                                                    unsigned short* __restrict__ X_cm, long long ld_cm,
-                                                                   long long cm_mid) {
+                                                                   long long cm_mid, int slice_fast) {
     __shared__ __attribute__((aligned(16))) float s_val[64 * 49];
     __shared__ __attribute__((aligned(16))) unsigned short s_arg[64 * 49];
     __shared__ float s_keep[49];
     __shared__ int s_tab[29];
-    const int n = blockIdx.x, c0 = blockIdx.y * 64;
+    // workgroup -> (ROI, 64-channel slice).  A one-dimensional grid with the slice as the FAST index: workgroup b runs on XCD
+    // b % 8, so with C / 64 a multiple of 8 every XCD pools ONE eighth of the channels for all ROIs and its 4 MB L2 holds that
+    // slice of the map (1.5 MB at 76 x 76 x 512) instead of competing for all of it (slice_fast = 0: the ROI as the fast index,
+    // rounds 2-4).
+    const int nsl = C / 64;
+    const int n = slice_fast ? (int)(blockIdx.x / nsl) : (int)(blockIdx.x % R);
+    const int c0 = (slice_fast ? (int)(blockIdx.x % nsl) : (int)(blockIdx.x / R)) * 64;
     if (threadIdx.x < 29) s_tab[threadIdx.x] = tab[(size_t)n * 29 + threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 49) s_keep[threadIdx.x - 64] = keep ? keep[(size_t)n * 49 + threadIdx.x - 64] : 0.0f;
     __syncthreads();
@@ -1171,19 +1177,20 @@ ODW_EXPORT int odw_roi_pool_stack_forward_nhwc_f32_cm(const float* feat_nhwc, co
         (const uint4*)feat_nhwc, (uint4*)ordmap, n16);
     ODW_CHECK_LAUNCH("nhwc_ord_f32_kernel");
     static const int fly = getenv("ODW_POOL_F32_FLY") ? atoi(getenv("ODW_POOL_F32_FLY")) : 2;
-    const dim3 grid((unsigned)R, (unsigned)(C / 64));
+    static const int slice_fast = getenv("ODW_POOL_SLICE_FAST") ? atoi(getenv("ODW_POOL_SLICE_FAST")) : 1;
+    const unsigned grid = (unsigned)R * (unsigned)(C / 64);
     if (fly == 4)
         roi_pool_stack_fwd_nhwc_f32<4><<<grid, 512, 0, stream>>>(ordmap, tab, C, H, W, R, keep, keep_sum, pat, (unsigned short*)X_planes,
                                                                  (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16,
-                                                                 (unsigned short*)X_cm, (long long)ld_cm, (long long)cm_mid);
+                                                                 (unsigned short*)X_cm, (long long)ld_cm, (long long)cm_mid, slice_fast);
     else if (fly == 1)
         roi_pool_stack_fwd_nhwc_f32<1><<<grid, 512, 0, stream>>>(ordmap, tab, C, H, W, R, keep, keep_sum, pat, (unsigned short*)X_planes,
                                                                  (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16,
-                                                                 (unsigned short*)X_cm, (long long)ld_cm, (long long)cm_mid);
+                                                                 (unsigned short*)X_cm, (long long)ld_cm, (long long)cm_mid, slice_fast);
     else
         roi_pool_stack_fwd_nhwc_f32<2><<<grid, 512, 0, stream>>>(ordmap, tab, C, H, W, R, keep, keep_sum, pat, (unsigned short*)X_planes,
                                                                  (long long)ld, block, pooled_f32, (unsigned short*)argmax_u16,
-                                                                 (unsigned short*)X_cm, (long long)ld_cm, (long long)cm_mid);
+                                                                 (unsigned short*)X_cm, (long long)ld_cm, (long long)cm_mid, slice_fast);
     ODW_CHECK_LAUNCH("roi_pool_stack_fwd_nhwc_f32");
     return ODW_OK;
 }

@@ -20,14 +20,24 @@ against itself; what CAN be asserted is that the product is no further from the 
   * CONTROL: a second oracle started 2^-22 away runs beside the first (same inputs, same draws);
   * while the product's selections equal the oracle's (the first ~10 steps) the 8 losses agree within LOSS_TOL = 1 %
     (measured <= 3e-3 before the first differing step);
-  * the product's selections agree with the oracle's for the first FIRST_DIV_SLACK steps at least (measured: 10, the control's
-    12), the number of differing steps is at most the control's + 20 % of the run, and the distance between the weight trajectories
-    |w_product - w_oracle| / |w_oracle - w_0| is at most 1.5 x the control's (measured: 6.2e-2 vs 6.8e-2 at lr 1e-5,
-    3.3e-2 vs 4.0e-2 at lr 5e-6) -- the single-plane bf16 backward's 0.5 % gradient error adds nothing measurable to
-    what fp32 rounding already does to this run;
+  * the product's selections agree with the oracle's for the first FIRST_DIV_SLACK steps at least, and the distance between
+    the weight trajectories |w_product - w_oracle| / |w_oracle - w_0| is at most 1.5 x the control's (measured: 6.2e-2 vs
+    6.8e-2 at lr 1e-5, 3.3e-2 vs 4.0e-2 at lr 5e-6; 7.3e-2 vs 5.0e-2 at the end of round 5) -- the single-plane bf16
+    backward's 0.5 % gradient error adds nothing measurable to what fp32 rounding already does to this run;
+  * the two loss curves end in the same place (mean total loss of the last five steps within max(3 x the control's gap, 15 %));
+  * ONE STEP AT A TIME along the product's own free run (end of round 5): before every step a third oracle is restarted from
+    the PRODUCT's current weights and its step is compared with the product's decision by decision, with the margin-gated
+    replay of tests/test_fullsize_gpu.py -- a selection may differ only in proposals whose distance from their threshold is
+    below the mode's numeric noise (1e-4), and then everything downstream must be exactly what the oracle's own discovery
+    tail makes of the flipped candidate set; the 8 losses within 1e-3 wherever nothing flipped.  Measured over 24 steps: 17
+    exact (worst loss deviation 9.5e-5), 6 with ONE near-threshold flip each and an exact downstream, 1 undecidable (an
+    arg-max gap inside the noise band), 0 wrong.  This is what explains the free runs: on this workload (128 proposals,
+    random-init scores) one step in four holds a decision closer to its threshold than any two fp32 evaluations agree to, so
+    WHEN two runs part is noise (the same code parted from the oracle in step 11, and after a 2^-17 change of the contrastive
+    views' inputs in step 5) -- the earlier assertion on the NUMBER of differing steps tested that noise and was removed;
   * the run moves the loss by >= 5 %, and every loss stays finite.
 ODW_TRAJ_STEPS / ODW_TRAJ_LR / ODW_TRAJ_REPORT=1 (print only) run other settings; the default (24 steps at bench.py's
-learning rate) keeps the GPU suite's time in bounds -- two CPU oracles are stepped per product step.
+learning rate) keeps the GPU suite's time in bounds -- two CPU oracles are stepped and a third evaluated per product step.
 """
 import os
 import sys
@@ -62,6 +72,8 @@ def _groups(cfg, names):
 
 def test_trajectory_tracks_the_oracle():
     import bench
+    global _replay_selections, TOL, ORDER_TOL
+    from test_fullsize_gpu import _replay_selections, TOL, ORDER_TOL
     from oracle import hotpath_ref as H
     from od_wscl_amd import engine, synthetic
     from od_wscl_amd.structures import BoxList, to_image_list
@@ -141,10 +153,24 @@ def _run(bench, H, engine, synthetic, BoxList, to_image_list, DeviceRand, dev):
 
     diverged_steps, control_diverged, last_disagree = [], [], {}
     devs_same, control_devs_same = [], []
+    tf_devs_same, tf_diverged, tf_unusable, tf_wrong = [], [], [], []
+    totals_ref, totals_prod, totals_ctl = [], [], []
     first_total, last_total = None, None
     lines = []
+    sd_tf = {k: torch.from_numpy(v.copy()) for k, v in w_np.items()}
     for it in range(STEPS):
         stream0 = (1 << 20) + (it << 12)
+        # TEACHER-FORCED oracle: restarted from the PRODUCT's current weights, one step at a time along the product's own free run
+        # (what tests/test_timed_step_gpu.py does for three steps, here at every point of the trajectory): no chaos in one step
+        opt.join_side()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for n in trainable:
+                o, k = opt.slices[n]
+                sd_tf[n].copy_(opt.flat_p[o:o + k].cpu().view(sd_tf[n].shape))
+            tr_tf = {"_decisions": True}      # (records the margin of every discovery decision: test_fullsize_gpu's replay)
+            tf_losses, _ = H.forward(batch, boxes, lab, sd_tf, H.Rand(SEED, first_stream=stream0), ocfg, tr_tf)
+            tf = {k: float(v) for k, v in tf_losses.items()}
         tr = {}
         ref_losses, _ = H.forward(batch, boxes, lab, sd, H.Rand(SEED, first_stream=stream0), ocfg, tr)
         ref_opt.zero_grad(set_to_none=True)
@@ -165,6 +191,7 @@ def _run(bench, H, engine, synthetic, BoxList, to_image_list, DeviceRand, dev):
             else:
                 control_devs_same.append(dev2)
             ctl_note = "  | control: dev %.2e %s" % (dev2, "same" if not bad2 else "DIFFER")
+            totals_ctl.append(sum(float(v) for v in l2.values()))
         trace = {}
         model.roi_heads.loss_evaluator.trace = trace
         losses, _ = step(images, targets, rois, DeviceRand(SEED, first_stream=stream0, device=dev))
@@ -182,9 +209,31 @@ def _run(bench, H, engine, synthetic, BoxList, to_image_list, DeviceRand, dev):
             diverged_steps.append(it)
         else:
             devs_same.append(dev_loss)
+        totals_ref.append(total)
+        totals_prod.append(sum(got.values()))
+        bad_tf = differing(tr_tf, trace)
+        dev_tf = max(abs(got[k] - tf[k]) / max(abs(tf[k]), 1e-4) for k in tf)
+        # decision by decision, as tests/test_fullsize_gpu.py does for one step: a selection may differ from the oracle's only
+        # in proposals whose margin is below the mode's numeric noise, and then everything downstream must be exactly what the
+        # oracle's own discovery tail makes of the flipped candidate set
+        try:
+            flips_tf, _, _ = _replay_selections(H, tr_tf, trace, boxes, lab, CLASSES, TOL[MODE], ORDER_TOL[MODE])
+            tf_status = "exact" if flips_tf == 0 else "%d near-threshold flip(s), downstream exact" % flips_tf
+            if flips_tf or bad_tf:
+                tf_diverged.append(it)
+            else:
+                tf_devs_same.append(dev_tf)
+        except AssertionError as e:
+            if "seed unusable" in str(e):          # an arg-max gap / too many proposals inside the noise band: nothing to decide
+                tf_status = "undecidable (%s)" % str(e)[:90]
+                tf_unusable.append(it)
+            else:
+                tf_status = "WRONG: " + str(e)[:400]
+                tf_wrong.append((it + 1, str(e)[:400]))
         lines.append("TRAJ step %2d: total %.5f (oracle) %.5f (product)  worst loss dev %.2e  loss_sim %.3e  selections %s%s"
+                     "  | from the product's weights: dev %.2e %s"
                      % (it + 1, total, sum(got.values()), dev_loss, ref["loss_sim"],
-                        "same" if not bad else "DIFFER " + ",".join(sorted(bad)[:3]), ctl_note))
+                        "same" if not bad else "DIFFER " + ",".join(sorted(bad)[:3]), ctl_note, dev_tf, tf_status))
         print(lines[-1], flush=True)
     compared = len(devs_same)
     worst_loss = max(devs_same) if devs_same else 0.0
@@ -225,6 +274,15 @@ def _run(bench, H, engine, synthetic, BoxList, to_image_list, DeviceRand, dev):
                     "loss deviation on the others %.2e / %.2e, |w_a - w_b| / |w_a - w_0| = %.3e"
                     % (len(control_diverged), [s + 1 for s in control_diverged], max(control_devs_same) if control_devs_same else 0.0,
                        float(np.median(control_devs_same)) if control_devs_same else 0.0, ratio2))
+    tail = min(5, STEPS)
+    gap_prod = abs(np.mean(totals_prod[-tail:]) - np.mean(totals_ref[-tail:])) / abs(np.mean(totals_ref[-tail:]))
+    gap_ctl = (abs(np.mean(totals_ctl[-tail:]) - np.mean(totals_ref[-tail:])) / abs(np.mean(totals_ref[-tail:]))) if control else None
+    summary += ("\nTRAJ one step at a time from the product's weights (the oracle restarted at every point of the product's run): %d steps "
+                "exact (worst loss deviation %.2e), %d with near-threshold flips and an exact downstream %s, %d undecidable %s, %d WRONG; "
+                "mean total loss of the last %d steps: product %.4f, oracle %.4f (gap %.2e%s)"
+                % (len(tf_devs_same), max(tf_devs_same) if tf_devs_same else 0.0, len(tf_diverged), [s + 1 for s in tf_diverged],
+                   len(tf_unusable), [s + 1 for s in tf_unusable], len(tf_wrong), tail, float(np.mean(totals_prod[-tail:])),
+                   float(np.mean(totals_ref[-tail:])), gap_prod, ", the control's %.2e" % gap_ctl if control else ""))
     print(summary, flush=True)
     out = os.path.join(ROOT, "gpurun_out", "trajectory_report.txt")
     try:
@@ -247,5 +305,15 @@ def _run(bench, H, engine, synthetic, BoxList, to_image_list, DeviceRand, dev):
     # at lr 1e-5 11 and 13 -- so the first differing step is only required not to be the very first steps: from identical
     # weights the selections must be identical, which is what the e2e and timed-step tests assert one step at a time)
     assert first >= FIRST_DIV_SLACK, ("selections differed in step %d already" % (first + 1), diverged_steps)
-    assert len(diverged_steps) <= len(control_diverged) + max(2, STEPS // 5), (len(diverged_steps), len(control_diverged))
+    # (HOW MANY steps differ is decided by when the first near-tie flips -- after it the two runs are different samples of a chaotic
+    # system.  The same code parted from the oracle in step 11 and, after a change of 2^-17 in the contrastive views' inputs, in
+    # step 5: the count is not a property of the arithmetic.  What IS one: every single step of the product's run, taken from the
+    # product's own weights, is the oracle's step -- below -- and the two loss curves end in the same place.)
+    assert gap_prod <= max(3.0 * gap_ctl, 0.15), ("the product's loss curve ends away from the oracle's", gap_prod, gap_ctl)
+    # 3. one step at a time along the product's trajectory: never a selection the oracle's margins do not allow, losses within the
+    # 1e-3 bar wherever no near-threshold decision flipped, and most steps decidable
+    assert not tf_wrong, tf_wrong
+    assert tf_devs_same and max(tf_devs_same) <= 1e-3, max(tf_devs_same) if tf_devs_same else None
+    assert len(tf_unusable) <= STEPS // 3, tf_unusable
+    assert len(tf_devs_same) >= STEPS // 2, (len(tf_devs_same), tf_diverged, tf_unusable)
     assert ratio <= 1.5 * ratio2 + 5e-3, ("the product drifts from the oracle faster than fp32 rounding noise does", ratio, ratio2)
