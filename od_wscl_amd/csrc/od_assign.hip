@@ -2,12 +2,13 @@
 // IoU(P,G) -> row max / FIRST argmax -> labels, loss weights, background test, box-regression
 // targets.  Reference: roi_heads/weak_head/pseudo_label_generator.py:171-190 (the IoU matrix is
 // copied to the host and reduced with numpy there, :176-177) + modeling/box_coder.py:22-50.
-// One thread per proposal; the G pseudo-GT boxes (a handful) sit in LDS.
+// Eight lanes per proposal; the G pseudo-GT boxes (a handful) sit in LDS.
 #include "odw_common.h"
 
 namespace {
 
 constexpr int kMaxGT = 2048;
+constexpr int kLanes = 8;             // lanes per proposal in od_assign_kernel (a power of two <= 64)
 
 // INDEXED: the pseudo-GT are given as int32 indices into `boxes` (gt_boxes = the index list) with int32 classes --
 // the form the discovery kernels emit -- instead of gathered boxes + int64 classes.
@@ -42,21 +43,34 @@ __global__ __launch_bounds__(256) void od_assign_kernel(const float* __restrict_
         sh[5 * j + 4] = (q.z - q.x + 1) * (q.w - q.y + 1);
     }
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const float4 p = reinterpret_cast<const float4*>(boxes)[i];
+    // kLanes lanes per proposal, lane l taking the pseudo-GT boxes l, l + kLanes, ...: with one thread per proposal the launch
+    // was 8 workgroups walking ~10^2 IoUs (a division each) one after the other -- 22 us of VALU latency on 3 % of the chip,
+    // three times per step.  The lanes' (IoU, index) pairs are merged "larger IoU, then smaller index": the FIRST maximum, as the
+    // sequential scan (numpy argmax) finds it.
+    const int gt_ = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gt_ / kLanes, l = gt_ % kLanes;
+    const bool live = i < P;
+    const float4 p = reinterpret_cast<const float4*>(boxes)[live ? i : 0];
     const float ap = (p.z - p.x + 1) * (p.w - p.y + 1);
     float best = -1.0f;
     int bj = 0;
-    for (int j = 0; j < G; ++j) {
+    for (int j = l; j < G; j += kLanes) {
         float w = fminf(p.z, sh[5 * j + 2]) - fmaxf(p.x, sh[5 * j + 0]) + 1;
         float h = fminf(p.w, sh[5 * j + 3]) - fmaxf(p.y, sh[5 * j + 1]) + 1;
         w = w < 0 ? 0 : w;
         h = h < 0 ? 0 : h;
         const float inter = w * h;
         const float iou = inter / (ap + sh[5 * j + 4] - inter);   // boxlist_ops.py:154-159
-        if (iou > best) { best = iou; bj = j; }                    // first maximum (numpy argmax)
+        if (iou > best) { best = iou; bj = j; }                    // first maximum of this lane's subsequence
     }
+#pragma unroll
+    for (int off = 1; off < kLanes; off <<= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oj = __shfl_xor(bj, off, 64);
+        // (a lane with no box holds (-1, 0): never larger than a real IoU >= 0, and G >= 1 gives lane 0 a box)
+        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+    }
+    if (!live || l != 0) return;
     const long long cls = INDEXED ? (long long)reinterpret_cast<const int*>(gt_classes)[bj]
                                   : reinterpret_cast<const long long*>(gt_classes)[bj];
     labels[i] = best <= fg_thresh ? 0 : cls;                       // bg test is <= (:183)
@@ -85,7 +99,7 @@ ODW_EXPORT int odw_od_assign(const float* boxes, int P, const float* gt_boxes, c
                 "od_assign: null pointer");
     ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)gt_boxes) & 15) == 0 &&
                 (((uintptr_t)targets) & 15) == 0, "od_assign: boxes/targets must be 16-byte aligned");
-    od_assign_kernel<false><<<(P + 255) / 256, 256, (size_t)G * 5 * 4, (hipStream_t)stream_>>>(
+    od_assign_kernel<false><<<(P * kLanes + 255) / 256, 256, (size_t)G * 5 * 4, (hipStream_t)stream_>>>(
         boxes, P, gt_boxes, gt_classes, gt_scores, G, fg_thresh, wx, wy, ww, wh,
         (long long*)labels, weights, targets);
     ODW_CHECK_LAUNCH("od_assign_kernel");
@@ -101,7 +115,7 @@ ODW_EXPORT int odw_od_assign_indexed(const float* boxes, int P, const int* gt_in
                 "od_assign_indexed: null pointer");
     ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)targets) & 15) == 0,
                 "od_assign_indexed: boxes/targets must be 16-byte aligned");
-    od_assign_kernel<true><<<(P + 255) / 256, 256, (size_t)G * 5 * 4, (hipStream_t)stream_>>>(
+    od_assign_kernel<true><<<(P * kLanes + 255) / 256, 256, (size_t)G * 5 * 4, (hipStream_t)stream_>>>(
         boxes, P, gt_index, gt_classes, gt_scores, G, fg_thresh, wx, wy, ww, wh, (long long*)labels, weights, targets);
     ODW_CHECK_LAUNCH("od_assign_kernel");
     return ODW_OK;
@@ -120,7 +134,7 @@ ODW_EXPORT int odw_od_assign_indexed_dev(const float* boxes, int P, const int* g
                 "od_assign_indexed_dev: null pointer");
     ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)targets) & 15) == 0,
                 "od_assign_indexed_dev: boxes/targets must be 16-byte aligned");
-    od_assign_kernel<true><<<(P + 255) / 256, 256, (size_t)g_cap * 5 * 4, (hipStream_t)stream_>>>(
+    od_assign_kernel<true><<<(P * kLanes + 255) / 256, 256, (size_t)g_cap * 5 * 4, (hipStream_t)stream_>>>(
         boxes, P, gt_index, gt_classes, gt_scores, g_cap, fg_thresh, wx, wy, ww, wh, (long long*)labels, weights, targets,
         n_gt_dev);
     ODW_CHECK_LAUNCH("od_assign_kernel");
