@@ -66,9 +66,21 @@ __global__ __launch_bounds__(1024) void det_colstats_kernel(const float* __restr
     const int CL = C <= 32 ? 32 : (C <= 64 ? 64 : 128);
     const int c = threadIdx.x % CL, sl = threadIdx.x / CL, S = 1024 / CL;
     const float* y = Y + (size_t)base * h.ldy + h.det;
+    // (eight rows of loads in flight per thread: a row per iteration was 2 x 63 dependent L2 round trips = 27 us for one
+    //  workgroup; the running maximum / sum still take the rows in ascending order)
+    constexpr int kFly = 8;
     float m = -__builtin_inff();
-    if (c < C)
-        for (int r = sl; r < P; r += S) m = fmaxf(m, y[(size_t)r * h.ldy + c]);
+    if (c < C) {
+        int r = sl;
+        for (; r + (kFly - 1) * S < P; r += kFly * S) {
+            float v[kFly];
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) v[u] = y[(size_t)(r + u * S) * h.ldy + c];
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) m = fmaxf(m, v[u]);
+        }
+        for (; r < P; r += S) m = fmaxf(m, y[(size_t)r * h.ldy + c]);
+    }
     part[threadIdx.x] = m;
     __syncthreads();
     if ((int)threadIdx.x < C) {
@@ -78,8 +90,18 @@ __global__ __launch_bounds__(1024) void det_colstats_kernel(const float* __restr
     }
     __syncthreads();
     float sum = 0.0f;
-    if (c < C)
-        for (int r = sl; r < P; r += S) sum += expf(y[(size_t)r * h.ldy + c] - cmax[c]);
+    if (c < C) {
+        const float cm = cmax[c];
+        int r = sl;
+        for (; r + (kFly - 1) * S < P; r += kFly * S) {
+            float v[kFly];
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) v[u] = y[(size_t)(r + u * S) * h.ldy + c];
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) sum += expf(v[u] - cm);
+        }
+        for (; r < P; r += S) sum += expf(y[(size_t)r * h.ldy + c] - cm);
+    }
     part[threadIdx.x] = sum;
     __syncthreads();
     if ((int)threadIdx.x < C) {
@@ -139,11 +161,26 @@ __global__ __launch_bounds__(kRowThreads) void scores_rows_kernel(const float* _
     }
 }
 
+// sum of n values `stride` floats apart, added in ascending order (the bits of the plain loop), eight loads in flight:
+// the finish kernels are one small workgroup per image walking <= 64 partials -- a load-use chain per partial otherwise
+__device__ __forceinline__ float ordered_sum(const float* __restrict__ p, int n, size_t stride) {
+    float a = 0.0f;
+    int b = 0;
+    for (; b + 8 <= n; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; b < n; ++b) a += p[(size_t)b * stride];
+    return a;
+}
+
 __global__ void scores_finish_kernel(const float* __restrict__ fpart, int nblocks, int C, float* __restrict__ colstat) {
     const int img = blockIdx.x, c = threadIdx.x;
     if (c >= C) return;
-    float a = 0.0f;
-    for (int b = 0; b < nblocks; ++b) a += fpart[((size_t)img * nblocks + b) * kMaxC + c];
+    const float a = ordered_sum(fpart + (size_t)img * nblocks * kMaxC + c, nblocks, kMaxC);
     colstat[(size_t)img * 3 * kMaxC + 2 * kMaxC + c] = a;       // column sums of final_score (unclamped)
 }
 
@@ -310,14 +347,10 @@ __global__ __launch_bounds__(512) void refine_finish_kernel(const float* __restr
         bce[c] = -(lv[c] * lp + (1.0f - lv[c]) * lq) / (float)C;
     }
     if (grp < 3 && c < C) {
-        float a = 0.0f;
-        for (int b = 0; b < nblocks; ++b) a += part[((size_t)img * nblocks + b) * stride + 8 + grp * kMaxC + c];
-        rsum[grp][c] = a;
+        rsum[grp][c] = ordered_sum(part + (size_t)img * nblocks * stride + 8 + grp * kMaxC + c, nblocks, stride);
     }
     if (grp == 3 && c < 6) {
-        float a = 0.0f;
-        for (int b = 0; b < nblocks; ++b) a += part[((size_t)img * nblocks + b) * stride + c];
-        ls[c] = a;
+        ls[c] = ordered_sum(part + (size_t)img * nblocks * stride + c, nblocks, stride);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
