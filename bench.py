@@ -53,7 +53,7 @@ ARCH_NAME = {"vgg16": "VGG16", "r50": "R-50-C5"}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)          # ten rotations over the five warmed-up images: ~0.45 s of timed region
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--size", type=int, default=600)
@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--arch", default="vgg16", choices=["vgg16", "r50"],
                     help="vgg16 = the headline workload (BASELINE.json configs[1]); r50 = the R-50-C5 config "
                          "(configs/voc/voc07_r50_c5_*.yaml), a secondary line")
-    ap.add_argument("--time-every", type=int, default=10,
+    ap.add_argument("--time-every", type=int, default=13,     # (coprime with the rotation: the timed steps fall on different images)
                     help="bracket the GEMM / conv launches of 1 timed step in N with HIP events (roofline object); such a step "
                          "carries ~220 event records and takes ~1.1 ms longer (`per_step_ms`), inside the timed region")
     ap.add_argument("--pooler", default="ROIPool", choices=["ROIPool", "ROIAlign"],
