@@ -109,7 +109,7 @@ __device__ int mask_to_list(const unsigned int* mask, int W, int* out, int* scan
 }
 
 // ------------------------------------------------------------------------------- kernel A
-// one workgroup per image.  src: 3 score matrices (sumP x C); tops [img][3][maxpos];
+// one workgroup per (image, positive class).  src: 3 score matrices (sumP x C); tops [img][3][maxpos];
 // masks uint32 [img][maxpos][W32]; rows int32 [img][maxpos][pstride]; counts [img][maxpos]
 __global__ __launch_bounds__(kThreads) void discover_iou_kernel(
     const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2, int C,
@@ -124,7 +124,11 @@ __global__ __launch_bounds__(kThreads) void discover_iou_kernel(
     const int base = img_off[img], P = img_off[img + 1] - base;
     const float* src[3] = {s0, s1, s2};
     const float4* bx = reinterpret_cast<const float4*>(boxes) + base;
-    for (int ci = 0; ci < n_pos[img]; ++ci) {
+    // blockIdx.y = the positive class (its three branches OR into ONE mask; the classes share nothing): an image with three labels
+    // walked 9 arg-max + IoU rounds in one workgroup
+    {
+        const int ci = blockIdx.y;
+        if (ci >= n_pos[img]) return;
         const int c = pos_cls[img * maxpos + ci];
         for (int w = threadIdx.x; w < W32; w += kThreads) mask[w] = 0;
         __syncthreads();
@@ -416,9 +420,16 @@ __global__ __launch_bounds__(kThreads) void discover_finish_kernel(SimArgs a) {
     const int img = blockIdx.x;
     const int base = a.img_off[img], P = a.img_off[img + 1] - base;
     const int npos = a.n_pos[img];
-    for (int i = 0; i < 3; ++i) {
+    // blockIdx.y < maxpos: the fresh lists of positive class ci over the three branches (the class's pgt_index accumulates over
+    // them; classes share nothing); blockIdx.y >= maxpos: od_layer's pseudo-GT of branch y - maxpos (classes in order: each reads
+    // the rows earlier classes zeroed; it needs the instance lists only, not the fresh ones).  One workgroup walked all
+    // 3 x npos + 3 x npos rounds in sequence before (52 us at two labels).
+    const bool fresh_part = (int)blockIdx.y < a.maxpos;
+    if (fresh_part && (int)blockIdx.y >= npos) return;
+    const int i_lo = fresh_part ? 0 : (int)blockIdx.y - a.maxpos, i_hi = fresh_part ? 3 : i_lo + 1;
+    for (int i = i_lo; i < i_hi; ++i) {
         const float* S = a.src[i] + (size_t)base * a.C;
-        for (int ci = 0; ci < npos; ++ci) {
+        for (int ci = fresh_part ? (int)blockIdx.y : npos; ci < (fresh_part ? (int)blockIdx.y + 1 : npos); ++ci) {
             const int top = a.tops[(img * 3 + i) * a.maxpos + ci];
             const size_t slot = ((size_t)(img * 3 + i) * a.maxpos + ci);
             const int* inst = a.inst_idx + slot * a.pstride;
@@ -444,6 +455,7 @@ __global__ __launch_bounds__(kThreads) void discover_finish_kernel(SimArgs a) {
             if (threadIdx.x == 0) a.fresh_cnt[slot] = n_fresh;
             __syncthreads();
         }
+        if (fresh_part) continue;
         // ---- od_layer pseudo-GT for branch i (pseudo_label_generator.py:143-166): classes ascending,
         // scores read from a clone whose rows are zeroed at each earlier class's (mutated) argmax
         for (int w = threadIdx.x; w < a.W32; w += kThreads) zeroed[w] = 0;
@@ -488,7 +500,7 @@ ODW_EXPORT int odw_discover_iou(const float* s0, const float* s1, const float* s
     ODW_REQUIRE((((uintptr_t)boxes) & 15) == 0, "discover_iou: boxes must be 16-byte aligned");
     const int W32 = (max_p + 31) / 32;
     size_t lds = kThreads * sizeof(ArgMax) + (size_t)W32 * 4 + (size_t)(W32 + 1) * 4;
-    discover_iou_kernel<<<n_img, kThreads, lds, (hipStream_t)stream_>>>(s0, s1, s2, C, boxes, img_off, pos_cls, n_pos,
+    discover_iou_kernel<<<dim3(n_img, maxpos), kThreads, lds, (hipStream_t)stream_>>>(s0, s1, s2, C, boxes, img_off, pos_cls, n_pos,
                                                                       maxpos, thres, W32, pstride, tops, masks, rows,
                                                                       counts);
     ODW_CHECK_LAUNCH("discover_iou_kernel");
@@ -524,7 +536,7 @@ ODW_EXPORT int odw_discover_sim(const float* E, const float* s0, const float* s1
     discover_sim_kernel<<<dim3(n_img, 3 * maxpos), kThreads, lds, (hipStream_t)stream_>>>(a, ppow2, sbox_off);
     ODW_CHECK_LAUNCH("discover_sim_kernel");
     const size_t lds2 = kThreads * sizeof(ArgMax) + (size_t)a.W32 * 4 * 2 + (size_t)(a.W32 + 1) * 4;
-    discover_finish_kernel<<<n_img, kThreads, lds2, (hipStream_t)stream_>>>(a);
+    discover_finish_kernel<<<dim3(n_img, maxpos + 3), kThreads, lds2, (hipStream_t)stream_>>>(a);
     ODW_CHECK_LAUNCH("discover_finish_kernel");
     return ODW_OK;
 }
