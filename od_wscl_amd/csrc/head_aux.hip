@@ -484,6 +484,8 @@ ODW_EXPORT int odw_rows_views_cm(const void* src_cm, int64_t ld_src, int64_t src
                 "rows_views_cm: alignment");
     rows_keep_sum_kernel<<<1, 256, 0, stream>>>(k * S, gamma, kd0, kd1, keep_sum);
     const size_t lds = (size_t)3 * kViewCh * S * sizeof(float);
+    ODW_REQUIRE(lds + kMaxS * sizeof(float) <= (size_t)ODW_LDS_BYTES, "rows_views_cm: S=%d cells per ROI need %zu bytes of LDS "
+                "(a 64-channel slice of the row and of both views)", S, lds);
     ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(rows_views_cm_kernel), (int)lds), "rows_views_cm attr");
     rows_views_cm_kernel<<<dim3(k, C / kViewCh), 256, lds, stream>>>(
         (const unsigned short*)src_cm, ld_src, src_mid, rows, row_base, k, C, S, gamma, kd0, kd1, kn0, kn1, keep_sum,
