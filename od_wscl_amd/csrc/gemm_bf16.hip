@@ -1547,7 +1547,12 @@ __device__ __forceinline__ void band_store_pool_planes2(const f32x16 (&acc)[NI][
     }
 }
 
-template <int OUTM, int DIL, bool N64 = false>
+// PAIR (dilation 1, end of round 5): TWO K steps per workgroup barrier on a ring of four weight slots.  The barrier of a K step
+// is where a one-workgroup-per-CU kernel loses its matrix pipe (all eight waves meet, then all eight start on LDS reads); with the
+// tiles of steps 2m and 2m + 1 both landed at the barrier of pair m, the second step of a pair starts behind the first without
+// one, and the tiles of the next pair (and, once per channel block, the next patch) are issued for a whole pair of steps.
+// 2 x 48 KB of patches + 4 x 16 KB of weights = the 160 KB of a CU (dilation 2's patches leave no room for the fourth slot).
+template <int OUTM, int DIL, bool N64 = false, bool PAIR = false>
 __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo2_kernel(
     const unsigned short* __restrict__ X, int ldx, ConvGeom g, const unsigned short* __restrict__ B, int ldb, int n_img, int N,
     void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_y, int tiles_x, int tiles_n, int splits, int cb_per_split) {
@@ -1616,21 +1621,9 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo2_kernel(
     dma_patch(cb0, lds);
     dma_rows<16>(B, ldb, N, n0, cb0 * 64, bring, wave, lane);
     if (nsteps > 1) dma_rows<16>(B, ldb, N, n0, ktap + cb0 * 64, bring + kHaloBStage, wave, lane);
-    int tap = 0, cb = cb0, slot = 0;
-    int tap2 = 2, cb2 = cb0;
-    for (int st = 0; st < nsteps; ++st) {
-        if (st + 2 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if ((tap == 1 || tap == 2) && cb + 1 < cb1) {
-            if (HC::NA == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (st + 2 < nsteps) {
-            const int s2 = slot + 2 >= 3 ? slot - 1 : slot + 2;
-            dma_rows<16>(B, ldb, N, n0, tap2 * ktap + cb2 * 64, bring + s2 * kHaloBStage, wave, lane);
-        }
-        if (tap == 0 && cb + 1 < cb1) dma_patch(cb + 1, lds + (((cb - cb0) + 1) & 1) * HC::kBufChunks);
-        const uint4* sa = lds + ((cb - cb0) & 1) * HC::kBufChunks;
+    // one K step = (tap, 32-channel block): 16 fragment reads + 24 MFMAs per wave out of patch `cbrel & 1` and weight slot `slot`
+    auto k_step = [&](int tap, int cbrel, int slot) {
+        const uint4* sa = lds + (cbrel & 1) * HC::kBufChunks;
         const uint4* sb = bring + slot * kHaloBStage;
         const int ty_ = (tap * 11) >> 5, tx_ = tap - 3 * ty_;
         const int delta = ((ty_ - 1) * HC::HWp + (tx_ - 1)) * DIL * g.sign;
@@ -1676,9 +1669,58 @@ __global__ __launch_bounds__(kHaloThreads, 2) void conv3x3_halo2_kernel(
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         }
-        slot = slot == 2 ? 0 : slot + 1;
-        if (++tap == 9) { tap = 0; ++cb; }
-        if (++tap2 == 9) { tap2 = 0; ++cb2; }
+    };
+    if (PAIR) {
+        static_assert(!PAIR || (DIL == 1 && !N64), "the four-slot ring fits beside dilation 1's patches only");
+        // tile of step s lives in slot s & 3; pair m = steps (2m, 2m + 1).  Issue order inside a pair: tile 2m + 2, tile 2m + 3
+        // (2 pieces per wave each), then -- in the one pair of a channel block whose first step is its tap 0 or 1 -- the NEXT
+        // block's patch (NA pieces): its buffer was last read by the previous block's tap 8, which lies in an earlier pair
+        // either way (a block starts on an even or an odd step: 9 taps), and it is needed 8-9 steps later.  At the top of a
+        // pair everything but a patch issued in the pair before must have landed.
+        int tap_a = 0, cb_a = cb0;
+        bool patch_prev = false;
+        for (int st = 0; st < nsteps; st += 2) {
+            if (patch_prev) {
+                if (HC::NA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int tap_b = tap_a + 1, cb_b = cb_a;
+            if (tap_b == 9) { tap_b = 0; ++cb_b; }
+            int tap_c = tap_b + 1, cb_c = cb_b;
+            if (tap_c == 9) { tap_c = 0; ++cb_c; }
+            int tap_d = tap_c + 1, cb_d = cb_c;
+            if (tap_d == 9) { tap_d = 0; ++cb_d; }
+            if (st + 2 < nsteps)
+                dma_rows<16>(B, ldb, N, n0, tap_c * ktap + cb_c * 64, bring + ((st + 2) & 3) * kHaloBStage, wave, lane);
+            if (st + 3 < nsteps)
+                dma_rows<16>(B, ldb, N, n0, tap_d * ktap + cb_d * 64, bring + ((st + 3) & 3) * kHaloBStage, wave, lane);
+            patch_prev = tap_a <= 1 && cb_a + 1 < cb1;
+            if (patch_prev) dma_patch(cb_a + 1, lds + (((cb_a - cb0) + 1) & 1) * HC::kBufChunks);
+            k_step(tap_a, cb_a - cb0, st & 3);
+            if (st + 1 < nsteps) k_step(tap_b, cb_b - cb0, (st + 1) & 3);
+            tap_a = tap_c; cb_a = cb_c;
+        }
+    } else {
+        int tap = 0, cb = cb0, slot = 0;
+        int tap2 = 2, cb2 = cb0;
+        for (int st = 0; st < nsteps; ++st) {
+            if (st + 2 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if ((tap == 1 || tap == 2) && cb + 1 < cb1) {
+                if (HC::NA == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (st + 2 < nsteps) {
+                const int s2 = slot + 2 >= 3 ? slot - 1 : slot + 2;
+                dma_rows<16>(B, ldb, N, n0, tap2 * ktap + cb2 * 64, bring + s2 * kHaloBStage, wave, lane);
+            }
+            if (tap == 0 && cb + 1 < cb1) dma_patch(cb + 1, lds + (((cb - cb0) + 1) & 1) * HC::kBufChunks);
+            k_step(tap, cb - cb0, slot);
+            slot = slot == 2 ? 0 : slot + 1;
+            if (++tap == 9) { tap = 0; ++cb; }
+            if (++tap2 == 9) { tap2 = 0; ++cb2; }
+        }
     }
 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -3562,7 +3604,25 @@ ODW_EXPORT int odw_conv3x3_planes2_ws(const void* X, int ldx, int n_pix, int H, 
     if (N == 64 && dilation == 1) {
         if (outm == 2) ODW_LAUNCH_HALO2(2, 1, true); else if (outm) ODW_LAUNCH_HALO2(1, 1, true); else ODW_LAUNCH_HALO2(0, 1, true);
     } else if (dilation == 1) {
-        if (outm == 2) ODW_LAUNCH_HALO2(2, 1, false); else if (outm) ODW_LAUNCH_HALO2(1, 1, false); else ODW_LAUNCH_HALO2(0, 1, false);
+        // two K steps per barrier on a four-slot weight ring (the kernel's PAIR form; ODW_CONV_PAIRSTEP=0: one step per barrier)
+        const char* ps = getenv("ODW_CONV_PAIRSTEP");        // (read per launch: the tests run both forms in one process)
+        const bool pairstep = !(ps && atoi(ps) == 0);
+        if (pairstep) {
+#define ODW_LAUNCH_HALO2P(OM)                                                                                      \
+    do {                                                                                                           \
+        constexpr size_t kLdsP = Halo<1>::kLdsBytes + (size_t)kHaloBStage * sizeof(uint4);                         \
+        static_assert(kLdsP <= (size_t)ODW_LDS_BYTES, "the four-slot ring must fit the CU's LDS");                 \
+        ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_kernel<OM, 1, false, true>),     \
+                                      (int)kLdsP), "halo2 pair attr");                                             \
+        conv3x3_halo2_kernel<OM, 1, false, true><<<grid, kHaloThreads, kLdsP, stream>>>(                            \
+            (const unsigned short*)X, ldx, g, (const unsigned short*)Wk, ldw, n_img, N, out, ldo, pe, hp.tiles_y,   \
+            hp.tiles_x, hp.tiles_n, hp.splits, hp.cb_per_split);                                                   \
+    } while (0)
+            if (outm == 2) ODW_LAUNCH_HALO2P(2); else if (outm) ODW_LAUNCH_HALO2P(1); else ODW_LAUNCH_HALO2P(0);
+#undef ODW_LAUNCH_HALO2P
+        } else {
+            if (outm == 2) ODW_LAUNCH_HALO2(2, 1, false); else if (outm) ODW_LAUNCH_HALO2(1, 1, false); else ODW_LAUNCH_HALO2(0, 1, false);
+        }
     } else {
         if (outm == 2) ODW_LAUNCH_HALO2(2, 2, false); else if (outm) ODW_LAUNCH_HALO2(1, 2, false); else ODW_LAUNCH_HALO2(0, 2, false);
     }

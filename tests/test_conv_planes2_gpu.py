@@ -149,6 +149,28 @@ def test_pool_and_split_in_the_convolution_epilogue(L, B, Cin, Cout, H, W, monke
     assert torch.equal(yp_sliced_plan, yp)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,planes_out", [(1, 128, 128, 40, 36, 0), (2, 64, 128, 19, 23, 1), (1, 96, 256, 33, 17, 1),
+                                                        (1, 128, 128, 34, 50, 2), (1, 32, 128, 24, 24, 0)])
+def test_two_steps_per_barrier_equal_one_step_per_barrier(L, B, Cin, Cout, H, W, planes_out, monkeypatch):
+    """The PAIR form of the dilation-1 kernel (two K steps per workgroup barrier on a four-slot weight ring: the default) walks the
+    same K steps in the same order into the same accumulators as the one-step form (ODW_CONV_PAIRSTEP=0): identical bits, for an
+    even and an odd number of steps (9 x channel blocks), with and without K slices, for all three output forms."""
+    x = rnd(51, (B, Cin, H, W))
+    w = rnd(52, (Cout, Cin, 3, 3), 0.05)
+    b = rnd(53, (Cout,), 0.1)
+    for forced in (None, "1", "2"):
+        if forced is None:
+            monkeypatch.delenv("ODW_CONV_SPLITK", raising=False)
+        else:
+            monkeypatch.setenv("ODW_CONV_SPLITK", forced)
+        monkeypatch.delenv("ODW_CONV_PAIRSTEP", raising=False)
+        y_pair, _ = run_conv(L, x, w, b, 1, True, planes_out)
+        monkeypatch.setenv("ODW_CONV_PAIRSTEP", "0")
+        y_one, _ = run_conv(L, x, w, b, 1, True, planes_out)
+        assert torch.equal(y_pair.view(torch.int16) if y_pair.dtype == torch.bfloat16 else y_pair.view(torch.int32),
+                           y_one.view(torch.int16) if y_one.dtype == torch.bfloat16 else y_one.view(torch.int32)), forced
+
+
 def test_weight_layout_is_hi_mid_per_block_of_32_channels(L):
     cout, cin = 64, 96
     w = rnd(21, (cout, cin, 3, 3), 0.05)
