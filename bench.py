@@ -86,6 +86,10 @@ def parse():
     ap.add_argument("--first-image", type=int, default=0,
                     help="index of the first synthetic image of rank 0's rotation (--first-image 2 --rotate 1: the 3-label image alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timeline", default="",
+                    help="write a per-step HOST timeline of the timed region to this JSON file (od_wscl_amd/utils/step_trace.py: "
+                         "ms blocked in the two device->host reads, ms of index assembly, allocator / planner / ring misses per "
+                         "step, GPU time between the marks); the marks cost ~0.1 ms per step")
     ap.add_argument("--cpu-proposals", type=int, default=2000)
     # ---- data-parallel knobs (N > 1).  The defaults are what `bench.py --gpus N` runs: RCCL, fp32 gradients on the wire,
     # equal stream priorities
@@ -352,11 +356,19 @@ def main():
         barrier()
         allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
         t0 = time.perf_counter()
+        trace = engine.step_trace if (args.timeline and dtype == args.dtype) else None
+        if trace is not None:
+            trace.enabled, trace.gpu_events, trace.steps = True, True, []
         for it in range(steps):
             engine.kernel_timer.active = it % args.time_every == 0
             marks[it].record()
             bi, bt, br = batches[(warmup + it) % n_rot]
+            if trace is not None:
+                trace.begin(image=args.first_image + rank + (warmup + it) % n_rot, labels=labels_per_image[(warmup + it) % n_rot],
+                            event_step=bool(engine.kernel_timer.active))
             step_fn(bi, bt, br, DeviceRand(seed + rank, first_stream=(1 << 20) + ((warmup + it) << 12), device=device))
+            if trace is not None:
+                trace.end()
         marks[steps].record()
         barrier()
         dt = time.perf_counter() - t0
@@ -368,6 +380,14 @@ def main():
         gc.unfreeze()
         info = dict(info, device_allocs=int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0))
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        if trace is not None:
+            trace.enabled = False
+            if rank == 0:
+                rep = trace.report(per_step)
+                rep["cmd"] = " ".join(sys.argv)
+                rep["wall_ms_per_step"] = round(dt / steps * 1e3, 3)
+                with open(args.timeline, "w") as f:
+                    json.dump(rep, f, indent=1)
         exch.measure = False
         info = dict(info, collective=collective_report(exch, args, world, steps, shared))
         roof = engine.kernel_timer.roofline(dtype, MFMA_PEAK_TFLOPS, HBM_PEAK_GBPS) if rank == 0 else None

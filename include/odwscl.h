@@ -594,6 +594,89 @@ int odw_rows_views_cm(const void* src_cm, int64_t ld_src, int64_t src_mid, const
                       float gamma, uint32_t kd0, uint32_t kd1, uint32_t kn0, uint32_t kn1, float* keep_sum, void* out_cm,
                       int64_t ld_cm, int64_t cm_mid, void* out_hi, int64_t ld_hi, int out_row0, void* stream);
 
+/* ---- Device-resident control flow of the OD-WSCL loss (round 6) --------------------------------------------------------
+ * replaces the host side of roi_heads/weak_head/loss.py:281-347: its two loops append to Python lists whose lengths depend
+ * on the step's scores (pgt_collection, pgt_update, instance_diff).  Rounds 2-5 read the counts back twice per step and
+ * assembled the gather lists with numpy; these entry points keep the lists AND their lengths on the device, so the host
+ * thread never waits for the GPU inside a step.  Launches that consume a device-resident extent are sized for its
+ * CAPACITY (the `_cap` arguments: what exists as memory) and read the live value from a device int (`*_dev`).
+ *
+ * odw_loss_lists_a: after odw_discover_iou.  grp = host table [G][16] int32 per (image, positive class) group in loop-1
+ * order: {img, ci, cls, first proposal row of the image, k6 drop (2), k7 drop (2), k6 noise (2), k7 noise (2), -};
+ * cls_order = group indices sorted by (cls, loop-1 order).  Writes scal[16] = {E1, V = 2 E1, r64(V), 3 E1, overflow, ...},
+ * the entry prefix e0[G + 1], roi_index[E1] (proposal row of every sampled entry), the class banks (bank_index over the
+ * virtual table [P proposal embeddings; V view embeddings], bank_off / bank_cnt per class: loss.py:307, Q2) and the per-row
+ * dropout draws of the stacked views in fc6 / fc7 (row_tab6 / row_tab7: uint4 {row inside its pass, key0, key1, -}).
+ * odw_loss_lists_b: after odw_discover_sim.  Writes scal[16] = {N, A, E = A + E1, overflow, P64 + r64(V),
+ * P64 + r64(V) + r64(A), r64(V), r64(V) + r64(A), r64(A), pseudo-GT overflow, r64(N)}, the SupCon inputs in the reference's
+ * orders (features class-major: feat_index into [A_cap re-attached clean rows; views], labels; weights in APPEND order = Q1,
+ * = final_score[row, c + 1] / colstat[...]: Q12), the ascending unique proposal rows the features reference (act_rows) and
+ * the pooling node's side-buffer entry list roi_index_all = [act_rows | roi_index]. */
+int odw_loss_lists_a(const int* grp, const int* cls_order, int G, const int* counts, const int* rows, int maxpos, int pstride,
+                     int sum_p, int n_cls1, int e_cap, int* scal, int* e0, int* roi_index, int* bank_index, int* bank_off,
+                     int* bank_cnt, void* row_tab6, void* row_tab7, void* stream);
+int odw_loss_lists_b(const int* grp, const int* cls_order, int G, const int* img_off, const int* n_pos, const int* pos_cls,
+                     int n_img, int maxpos, int pstride, int sum_p, const int* scal_a, const int* e0, const int* roi_index,
+                     const int* bank_index, const int* bank_off, const int* bank_cnt, const int* fresh_idx, const int* fresh_cnt,
+                     const int* gt_cnt, int gt_max, const float* final_score, int fs_cols, const float* colstat, int cs_ld,
+                     int cs_off, int n_cap, int a_cap, int e_cap, int p64, int* scal, int* feat_index, int* labels, float* weights,
+                     int* act_rows, int* roi_index_all, void* stream);
+/* out[r] = index[r] < split ? t0[index[r]] : t1[index[r] - split], r < *n_dev (fp32 rows of D values); and its transpose
+ * d0 / d1 += scale * g (fp32 atomics; scale = a device scalar or NULL). */
+int odw_gather_rows2_dyn(const float* t0, const float* t1, int split, const int* index, const int* n_dev, int n_cap, int D,
+                         float* out, void* stream);
+int odw_scatter_rows2_dyn(const float* g, const int* index, const int* n_dev, int n_cap, int D, int split, const float* scale,
+                          float* d0, float* d1, void* stream);
+/* out[r][0 : row_bytes) = src[index[r]][0 : row_bytes), r < *n_dev; rows [0, *n_dev) of p zeroed (byte counts % 16 == 0). */
+int odw_gather_rows_dyn(const void* src, int64_t ld_src_bytes, const int* index, const int* n_dev, int n_cap, int64_t row_bytes,
+                        void* out, int64_t ld_out_bytes, void* stream);
+int odw_zero_rows_dyn(void* p, int64_t ld_bytes, int64_t row_bytes, const int* n_dev, int n_cap, void* stream);
+/* odw_gemm_nt_bf16_ws with device-resident extents: M_cap / K_cap bound the launch, *m_dev rows and a reduction of *k_dev
+ * (a multiple of 8; operand columns [*k_dev, r64(*k_dev)) zero) are computed; either may be NULL (= the capacity is exact).
+ * row_tab: per-row dropout draw (odw_loss_lists_a).  The hints pick the kernel variant and the K slices only. */
+int64_t odw_gemm_nt_bf16_dyn_workspace(int M_cap, int M_hint, int N, int K_cap, int K_hint, int lda, int ldb, const void* C, int ldc,
+                                       int c_is_bf16, int* variant_out);
+int odw_gemm_nt_bf16_dyn(const void* A, int lda, const void* B, int ldb, int M_cap, int N, int K_cap, void* C, int ldc,
+                         int c_is_bf16, const float* bias, int relu, float alpha, float drop_p, const void* row_tab,
+                         const int* m_dev, int M_hint, const int* k_dev, int K_hint, int accumulate, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+/* the plain form of odw_gemm_nt_cm (cell-major planes, the first head Linear over the sampled-row views) with *m_dev rows */
+int64_t odw_gemm_nt_cm_dyn_workspace(int M_cap, int M_hint, int N, int S);
+int odw_gemm_nt_cm_dyn(const void* A, int lda, int a_mid, const void* B, int ldb, int b_mid, int M_cap, int N, int C, int S,
+                       float* Cout, int ldc, const float* bias, int relu, float drop_p, const void* row_tab, const int* m_dev,
+                       int M_hint, void* workspace, int64_t workspace_bytes, void* stream);
+/* odw_transpose_to_bf16_part / odw_linear_bwd_prep_part / odw_split_rows_bf16 / odw_l2norm_rows(_bwd) over *r_dev rows;
+ * the transposed outputs land *col_off_dev columns into `out` / dZT, zero padded to r64(*r_dev) (the column block of a
+ * weight-gradient batch); src_rows / y_rows: the input / mask row of row r is row src_rows[r] of a larger table. */
+int odw_transpose_to_bf16_dyn(const void* in, int in_is_f32, int ld_in, int R_cap, int Cc, void* out, int ld_out, const int* r_dev,
+                              const int* col_off_dev, const int* src_rows, void* stream);
+int odw_linear_bwd_prep_dyn(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M_cap, int N, float scale,
+                            void* dZ, int ld_z, void* dZT, int ld_t, float* db, const int* m_dev, const int* tcol_off_dev,
+                            const int* y_rows, void* stream);
+int odw_split_rows_bf16_dyn(const float* in, int64_t ld_in, int R_cap, int Cc, const int* pattern, int T, void* out, int64_t ld_out,
+                            int block, const int* r_dev, void* stream);
+int odw_l2norm_rows_dyn(const float* x, int R_cap, int D, float eps, float* y, float* norm, const int* r_dev, void* stream);
+int odw_l2norm_rows_bwd_dyn(const float* g, const float* y, const float* norm, int R_cap, int D, float eps, float* dx,
+                            const int* r_dev, void* stream);
+/* odw_rows_views_cm / odw_rows_drop_noise_bwd_store for EVERY (image, class) group of the step in one launch (loss.py:292-305):
+ * group sizes from the entry prefix e0 (odw_loss_lists_a), keys (G x 4: kd0 kd1 kn0 kn1) from the host; entry e's
+ * gradient is stored at row *dst_off + e of the side buffer. */
+int odw_rows_views_cm_grouped(const void* src_cm, int64_t ld_src, int64_t src_mid, int G, int E_cap, const int* n_entries,
+                              const int* e0, const uint32_t* keys, const int* src_row, int C, int S, float gamma, float* keep_sum,
+                              void* out_cm, int64_t ld_cm, int64_t cm_mid, void* out_hi, int64_t ld_hi, void* stream);
+int odw_rows_views_bwd_store_grouped(const void* dX, int dx_is_f32, int ld, int G, int E_cap, const int* n_entries, const int* e0,
+                                     const uint32_t* keys, const float* keep_sum, int C, int S, float gamma, const int* dst_off,
+                                     float* extra, void* stream);
+/* odw_supcon_v2 over the first *n_dev rows (N_cap sizes the launch and the workspace: odw_supcon_dyn_workspace) */
+int64_t odw_supcon_dyn_workspace(int N_cap);
+int odw_supcon_v2_dyn(const float* F, const int32_t* labels, const float* w, int N_cap, int D, float tau, float grad_scale,
+                      float* loss, float* dF, const int* n_dev, void* workspace, int64_t workspace_bytes, void* stream);
+/* odw_roi_pool_stack_backward_ws with *e_dev side-buffer entries (E_cap exist as memory) */
+int odw_roi_pool_stack_backward_dyn(const void* dX, int dx_is_f32, int ld, const void* argmax_u16, const float* rois,
+                                    const float* keep, const float* keep_sum, const float* extra, const int* extra_roi, int E_cap,
+                                    const int* e_dev, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW,
+                                    float* grad_in, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,6 +154,32 @@ SIGNATURES = {
     "odw_stem_conv7x7_bn_relu_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_maxpool3x3s2_nhwc_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "odw_od_assign": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
+    # ---- device-resident control flow of the loss (round 6)
+    "odw_loss_lists_a": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "odw_loss_lists_b": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i,
+                               c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "odw_gather_rows2_dyn": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "odw_scatter_rows2_dyn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "odw_gather_rows_dyn": (c_i, [c_p, c_l, c_p, c_p, c_i, c_l, c_p, c_l, c_p]),
+    "odw_zero_rows_dyn": (c_i, [c_p, c_l, c_l, c_p, c_i, c_p]),
+    "odw_gemm_nt_bf16_dyn_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "odw_gemm_nt_bf16_dyn": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_f, c_f, c_p, c_p, c_i, c_p, c_i,
+                                   c_i, c_p, c_l, c_p]),
+    "odw_gemm_nt_cm_dyn_workspace": (c_l, [c_i, c_i, c_i, c_i]),
+    "odw_gemm_nt_cm_dyn": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_f, c_p, c_p, c_i, c_p,
+                                 c_l, c_p]),
+    "odw_transpose_to_bf16_dyn": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "odw_linear_bwd_prep_dyn": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "odw_split_rows_bf16_dyn": (c_i, [c_p, c_l, c_i, c_i, c_p, c_i, c_p, c_l, c_i, c_p, c_p]),
+    "odw_l2norm_rows_dyn": (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
+    "odw_l2norm_rows_bwd_dyn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "odw_rows_views_cm_grouped": (c_i, [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_l, c_l, c_p, c_l,
+                                        c_p]),
+    "odw_rows_views_bwd_store_grouped": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "odw_supcon_dyn_workspace": (c_l, [c_i]),
+    "odw_supcon_v2_dyn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_l, c_p]),
+    "odw_roi_pool_stack_backward_dyn": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
+                                              c_i, c_i, c_p, c_p, c_l, c_p]),
 }
 
 

@@ -122,6 +122,10 @@ def make_defaults():
     # HIP graphs of the body: how many input shapes stay captured at once (least recently used evicted; each holds its
     # body's activations, ~1 GB at VOC sizes); 0 = always eager
     c.ODW.GRAPH_CACHE = 4
+    # device-resident loss lists (weak_head/loss_device.py): capacity, per image, of the IoU-sampled rows of a step -- the
+    # stacked views' operand is allocated for twice that many rows (150 KB each at VGG16 / 7 x 7); a step that samples more
+    # raises (loudly, one or two steps later)
+    c.ODW.MAX_SAMPLED_ROWS = 4096
     c.SEED = -1
     c.min_size = 20                                           # :550
     return c

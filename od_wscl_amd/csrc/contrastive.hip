@@ -639,15 +639,35 @@ __global__ void pairwise_sim_generic(const float* __restrict__ E, int P, int D, 
 }
 
 // -------------------------------------------------------------------- supcon
+__host__ __device__ inline int supcon_nsplit(int N) {
+    const int nblk = (N + 31) / 32;
+    int s = 1024 / (nblk > 0 ? nblk : 1);
+    if (s > 16) s = 16;
+    if (s > nblk) s = nblk;
+    if (s < 1) s = 1;
+    return s;
+}
+// Device-resident N (round 6, loss_lists.hip): the launch is sized for the capacity, N and the split count derived from it
+// are read on the device -- the same values, the same summation order as the static launch of that N.
+#define ODW_SUPCON_DYN_N()                                                  \
+    int nsplit = gridDim.y;                                                 \
+    if (n_dev) {                                                            \
+        const int nd_ = *n_dev;                                             \
+        N = nd_ < N ? nd_ : N;                                              \
+        nsplit = supcon_nsplit(N);                                          \
+        if ((int)blockIdx.y >= nsplit || (int)blockIdx.x * 32 >= N) return; \
+    }
 // partial statistics of rows i over the j blocks of one split.
 // part layout: [nsplit][3][Npad], Npad = 32*ceil(N/32)
 __global__ __launch_bounds__(64) void supcon_stats_kernel(const float* __restrict__ F,
                                                           const int* __restrict__ labels, int N,
-                                                          float inv_tau, float* __restrict__ part) {
+                                                          float inv_tau, float* __restrict__ part,
+                                                          const int* __restrict__ n_dev) {
+    ODW_SUPCON_DYN_N();
     const int lane = threadIdx.x, half = lane >> 5, c = lane & 31;
     const int nblk = (N + 31) / 32, npad = nblk * 32;
     const int I = blockIdx.x * 32, i = I + c;
-    const int sp = blockIdx.y, nsplit = gridDim.y;
+    const int sp = blockIdx.y;
     float b[kHalf];
     load_half_row(F, i, N, half, b);
     const int yi = i < N ? labels[i] : -1;
@@ -697,7 +717,9 @@ constexpr int kCombineThreads = 1024, kMaxSplit = 16;
 __global__ __launch_bounds__(kCombineThreads) void supcon_combine_kernel(const float* __restrict__ part, int nsplit,
                                                                          const float* __restrict__ w, int N,
                                                                          float* __restrict__ stats,
-                                                                         float* __restrict__ loss) {
+                                                                         float* __restrict__ loss,
+                                                                         const int* __restrict__ n_dev) {
+    if (n_dev) { const int nd_ = *n_dev; N = nd_ < N ? nd_ : N; nsplit = supcon_nsplit(N); }
     const int npad = ((N + 31) / 32) * 32;
     __shared__ float red[kCombineThreads];
     float local = 0.0f;
@@ -739,11 +761,12 @@ __global__ __launch_bounds__(64) void supcon_grad_kernel(const float* __restrict
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ stats, int N,
                                                          float inv_tau, float out_scale,
-                                                         float* __restrict__ dpart) {
+                                                         float* __restrict__ dpart, const int* __restrict__ n_dev) {
+    ODW_SUPCON_DYN_N();
     const int lane = threadIdx.x, half = lane >> 5, c = lane & 31;
     const int nblk = (N + 31) / 32, npad = nblk * 32;
     const int I = blockIdx.x * 32, i = I + c;
-    const int sp = blockIdx.y, nsplit = gridDim.y;
+    const int sp = blockIdx.y;
     const float invN = 1.0f / (float)N;
     float b[kHalf];
     load_half_row(F, i, N, half, b);
@@ -801,7 +824,8 @@ __global__ __launch_bounds__(64) void supcon_grad_kernel(const float* __restrict
 }
 
 __global__ void supcon_grad_combine(const float* __restrict__ dpart, int nsplit, int N, int npad,
-                                    float* __restrict__ dF) {
+                                    float* __restrict__ dF, const int* __restrict__ n_dev) {
+    if (n_dev) { const int nd_ = *n_dev; N = nd_ < N ? nd_ : N; nsplit = supcon_nsplit(N); npad = ((N + 31) / 32) * 32; }
     const int total = N * kD / 4;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         float4 acc = reinterpret_cast<const float4*>(dpart)[t];
@@ -813,14 +837,6 @@ __global__ void supcon_grad_combine(const float* __restrict__ dpart, int nsplit,
     }
 }
 
-int supcon_nsplit(int N) {
-    const int nblk = (N + 31) / 32;
-    int s = 1024 / (nblk > 0 ? nblk : 1);
-    if (s > 16) s = 16;
-    if (s > nblk) s = nblk;
-    if (s < 1) s = 1;
-    return s;
-}
 
 }  // namespace
 
@@ -947,9 +963,34 @@ ODW_EXPORT int64_t odw_supcon_workspace(int N) {
            odw_align_up(ns * npad * kD * 4, 256);
 }
 
+static int supcon_launch(const float* F, const int32_t* labels, const float* w, int N, int D, float tau,
+                         float grad_scale, float* loss, float* dF, void* workspace,
+                         int64_t workspace_bytes, void* stream_, const int* n_dev);
+
 ODW_EXPORT int odw_supcon_v2(const float* F, const int32_t* labels, const float* w, int N, int D, float tau,
                              float grad_scale, float* loss, float* dF, void* workspace,
                              int64_t workspace_bytes, void* stream_) {
+    return supcon_launch(F, labels, w, N, D, tau, grad_scale, loss, dF, workspace, workspace_bytes, stream_, nullptr);
+}
+
+// SupConLossV2 over the first *n_dev rows of (F, labels, w); N_cap rows exist and size the workspace
+// (odw_supcon_workspace(N_cap)) and the launch.  Same arithmetic, same order of sums as odw_supcon_v2 at N = *n_dev.
+ODW_EXPORT int64_t odw_supcon_dyn_workspace(int N_cap) {
+    if (N_cap < 1) N_cap = 1;
+    const int64_t npad = ((N_cap + 31) / 32) * 32;
+    return odw_align_up(3 * npad * 4, 256) + odw_align_up(16 * 3 * npad * 4, 256) + odw_align_up(16 * npad * kD * 4, 256);
+}
+
+ODW_EXPORT int odw_supcon_v2_dyn(const float* F, const int32_t* labels, const float* w, int N_cap, int D, float tau,
+                                 float grad_scale, float* loss, float* dF, const int* n_dev, void* workspace,
+                                 int64_t workspace_bytes, void* stream_) {
+    ODW_REQUIRE(n_dev, "supcon_v2_dyn: n_dev is null");
+    return supcon_launch(F, labels, w, N_cap, D, tau, grad_scale, loss, dF, workspace, workspace_bytes, stream_, n_dev);
+}
+
+static int supcon_launch(const float* F, const int32_t* labels, const float* w, int N, int D, float tau,
+                         float grad_scale, float* loss, float* dF, void* workspace,
+                         int64_t workspace_bytes, void* stream_, const int* n_dev) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(N >= 1, "supcon_v2: N=%d (the reference would take the mean of an empty tensor)", N);
     ODW_REQUIRE(D == kD, "supcon_v2: D=%d unsupported (Sim_Net emits 128-d embeddings)", D);
@@ -957,29 +998,31 @@ ODW_EXPORT int odw_supcon_v2(const float* F, const int32_t* labels, const float*
     ODW_REQUIRE(F && labels && w && loss, "supcon_v2: null pointer");
     ODW_REQUIRE((((uintptr_t)F) & 15) == 0 && (dF == nullptr || (((uintptr_t)dF) & 15) == 0),
                 "supcon_v2: F/dF must be 16-byte aligned");
-    if (!workspace || workspace_bytes < odw_supcon_workspace(N)) {
-        odw_set_error("supcon_v2: workspace %lld < %lld bytes", (long long)workspace_bytes,
-                      (long long)odw_supcon_workspace(N));
+    const int64_t need = n_dev ? odw_supcon_dyn_workspace(N) : odw_supcon_workspace(N);
+    if (!workspace || workspace_bytes < need) {
+        odw_set_error("supcon_v2: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
         return ODW_EWORKSPACE;
     }
     const int nblk = (N + 31) / 32, npad = nblk * 32;
-    const int ns = supcon_nsplit(N);
+    // (device-resident N: the regions are carved for the capacity and 16 splits; the kernels index them with the npad and
+    // the split count of the live N -- they all derive both from *n_dev the same way)
+    const int ns = n_dev ? 16 : supcon_nsplit(N);
     unsigned char* p = (unsigned char*)workspace;
     float* stats = (float*)p; p += odw_align_up((int64_t)3 * npad * 4, 256);
     float* part = (float*)p;  p += odw_align_up((int64_t)ns * 3 * npad * 4, 256);
     float* dpart = (float*)p;
     const float inv_tau = 1.0f / tau;
-    supcon_stats_kernel<<<dim3(nblk, ns), 64, 0, stream>>>(F, labels, N, inv_tau, part);
+    supcon_stats_kernel<<<dim3(nblk, ns), 64, 0, stream>>>(F, labels, N, inv_tau, part, n_dev);
     ODW_CHECK_LAUNCH("supcon_stats_kernel");
     static_assert(kMaxSplit == 16, "supcon_nsplit caps the splits at 16");
-    supcon_combine_kernel<<<1, kCombineThreads, 0, stream>>>(part, ns, w, N, stats, loss);
+    supcon_combine_kernel<<<1, kCombineThreads, 0, stream>>>(part, ns, w, N, stats, loss, n_dev);
     ODW_CHECK_LAUNCH("supcon_combine_kernel");
     if (dF) {
         supcon_grad_kernel<<<dim3(nblk, ns), 64, 0, stream>>>(F, labels, w, stats, N, inv_tau,
-                                                             grad_scale * inv_tau, dpart);
+                                                             grad_scale * inv_tau, dpart, n_dev);
         ODW_CHECK_LAUNCH("supcon_grad_kernel");
         int total = N * kD / 4;
-        supcon_grad_combine<<<(total + 255) / 256, 256, 0, stream>>>(dpart, ns, N, npad, dF);
+        supcon_grad_combine<<<(total + 255) / 256, 256, 0, stream>>>(dpart, ns, N, npad, dF, n_dev);
         ODW_CHECK_LAUNCH("supcon_grad_combine");
     }
     return ODW_OK;

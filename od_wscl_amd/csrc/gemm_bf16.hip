@@ -41,9 +41,10 @@ constexpr int kChunksPerRow = BK / 8;                 // 16-byte chunks per LDS 
 constexpr int kTileChunks = BM * kChunksPerRow;       // 1024 uint4 per operand tile
 constexpr int kLoadsPerThread = kTileChunks / kThreads;  // 4
 
-template <int NSEG>
+template <int NSEG, bool DYN = true>
 struct EpilogueT {
     static constexpr int kSegs = NSEG;
+    static constexpr bool kDyn = DYN;      // the dynamic-row fields below are honoured (false: the pair kernel, whose registers are spoken for)
     const float* bias;     // (N) or null
     int relu;
     float drop_p;          // 0 = no dropout
@@ -58,17 +59,27 @@ struct EpilogueT {
     const int* row_ids;    // dropout of a gathered row subset: logical row of GEMM row m (with segment 0's key); null = m
     int kchunk;            // split-K: > 0 = this launch's blockIdx.y owns K range [y*kchunk, (y+1)*kchunk) and writes
     long long split_stride;  //          its partial product split_stride bytes further into C (an fp32 workspace)
+    // ---- device-resident extents (round 6: the loss's control flow stays on the GPU, loss_lists.hip).  The launch is
+    // sized for the CAPACITY of its operands; the number of rows that exist (m_dev) / the length of the reduction (k_dev)
+    // is read from device memory when the kernel starts: workgroups past it exit, the K loop stops at it.  null = the
+    // host's M / K are exact.
+    const int* m_dev = nullptr;
+    const int* k_dev = nullptr;
+    const uint4* row_tab = nullptr;  // dropout draws of stacked passes whose boundaries live on the device: row m draws element
+                           // (row_tab[m].x, column) of the stream keyed (row_tab[m].y, row_tab[m].z); replaces seg_* / row_ids
 };
 typedef EpilogueT<kMaxSeg> Epilogue;
 // The pair form of gemm_nt_cm_kernel (two accumulator sets, 256 VGPRs, counted vmcnt waits) takes the two segments it
 // needs and no more: with the eight-entry table the compiler spilled 16 SGPRs and one more VGPR INSIDE its main loop,
 // and a scratch reload sits in the same vmcnt queue as the operand DMA the loop's counted waits are written for --
 // four rows of the DropBlock half came out wrong (tests/test_pair_gpu.py caught it).
-typedef EpilogueT<2> EpilogueS;
+typedef EpilogueT<2, false> EpilogueS;
 
-template <int NSEG>
-inline EpilogueT<NSEG> epilogue_narrow(const Epilogue& e) {
-    EpilogueT<NSEG> o;
+template <class EPO>
+inline EPO epilogue_narrow(const Epilogue& e) {
+    constexpr int NSEG = EPO::kSegs;
+    EPO o;
+    o.m_dev = e.m_dev; o.k_dev = e.k_dev; o.row_tab = e.row_tab;
     o.bias = e.bias; o.relu = e.relu; o.drop_p = e.drop_p; o.nseg = e.nseg < NSEG ? e.nseg : NSEG;
     for (int i = 0; i < NSEG; ++i) { o.seg_row[i] = e.seg_row[i]; o.seg_k0[i] = e.seg_k0[i]; o.seg_k1[i] = e.seg_k1[i]; }
     o.accumulate = e.accumulate; o.alpha = e.alpha; o.mask = e.mask; o.ldmask = e.ldmask; o.pm = e.pm; o.row_ids = e.row_ids;
@@ -77,13 +88,38 @@ inline EpilogueT<NSEG> epilogue_narrow(const Epilogue& e) {
 }
 
 // split-K entry of a DMA kernel: narrow the operands / output to this workgroup's K range
-#define ODW_SPLITK_ENTER()                                                                 \
-    if (ep.kchunk > 0) {                                                                   \
-        const int ks_ = blockIdx.y * ep.kchunk;                                            \
+#define ODW_SPLITK_ENTER(ODW_TILE_M)                                                               \
+    int kchunk_ = ep.kchunk;                                                               \
+    if (ep.m_dev) {             /* rows that exist: workgroups of the capacity-sized grid past them exit */ \
+        const int md_ = *ep.m_dev;                                                         \
+        M = md_ < M ? md_ : M;                                                             \
+        tiles_m = (M + ODW_TILE_M - 1) / ODW_TILE_M;                                       \
+        if ((int)blockIdx.x >= tiles_m * tiles_n) return;                                  \
+    }                                                                                      \
+    if (ep.k_dev) {             /* reduction length on the device; the K slices are cut from IT (none is left empty) */ \
+        const int kd_ = *ep.k_dev;                                                         \
+        K = kd_ < K ? kd_ : K;                                                             \
+        if (kchunk_ > 0) {                                                                 \
+            kchunk_ = ((K + (int)gridDim.y - 1) / (int)gridDim.y + 63) / 64 * 64;          \
+            kchunk_ = kchunk_ < 64 ? 64 : kchunk_;                                         \
+        }                                                                                  \
+    }                                                                                      \
+    if (kchunk_ > 0) {                                                                     \
+        const int ks_ = blockIdx.y * kchunk_;                                              \
         A += ks_; B += ks_;                                                                \
-        K = K - ks_ < ep.kchunk ? K - ks_ : ep.kchunk;                                     \
+        K = K - ks_ < kchunk_ ? K - ks_ : kchunk_;                                         \
+        K = K < 0 ? 0 : K;                                                                 \
         Cv = reinterpret_cast<char*>(Cv) + (long long)blockIdx.y * ep.split_stride;        \
     }
+// (kernels without a split-K form)
+#define ODW_DYN_ENTER(ODW_TILE_M)                                                                  \
+    if (ep.m_dev) {                                                                        \
+        const int md_ = *ep.m_dev;                                                         \
+        M = md_ < M ? md_ : M;                                                             \
+        tiles_m = (M + ODW_TILE_M - 1) / ODW_TILE_M;                                       \
+        if ((int)blockIdx.x >= tiles_m * tiles_n) return;                                  \
+    }                                                                                      \
+    if (ep.k_dev) { const int kd_ = *ep.k_dev; K = kd_ < K ? kd_ : K; }
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * kChunksPerRow + (chunk ^ ((row >> 1) & 7)); }
 
@@ -161,7 +197,8 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[MI][NJ], void
                     #pragma unroll
                     for (int sg = 1; sg < kMaxSeg; ++sg)
                         if (ep.nseg > sg && m >= ep.seg_row[sg]) { srow = ep.seg_row[sg]; k0 = ep.seg_k0[sg]; k1 = ep.seg_k1[sg]; }
-                    const uint32_t lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
+                    uint32_t lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
+                    if (ep.row_tab) { const uint4 rt = ep.row_tab[m]; lrow = rt.x; k0 = rt.y; k1 = rt.z; }
                     const uint32_t idx = lrow * (uint32_t)N + (uint32_t)n;
                     v = odw_uniform(idx, k0, k1) >= ep.drop_p ? v * (1.0f / (1.0f - ep.drop_p)) : 0.0f;
                 }
@@ -201,6 +238,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [stage][A|B][kTileChunks]
+    ODW_DYN_ENTER(BM);
     // ---- XCD-aware tile mapping (block b runs on XCD b % 8; correctness never depends on it)
     int tm, tn;
     tile_coords<8>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
@@ -288,6 +326,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_bf16_glds_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    ODW_DYN_ENTER(BM);
     int tm, tn;
     tile_coords<8>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -405,6 +444,7 @@ __device__ __forceinline__ void band_store(const f32x16 (&acc)[NI][2], void* __r
             for (int sg = 1; sg < EP::kSegs; ++sg)
                 if (ep.nseg > sg && m >= ep.seg_row[sg]) { srow = ep.seg_row[sg]; k0 = ep.seg_k0[sg]; k1 = ep.seg_k1[sg]; }
             lrow = (ep.row_ids && m >= 0) ? (uint32_t)ep.row_ids[m] : (uint32_t)((int)m - srow);
+            if (EP::kDyn && ep.row_tab && m >= 0) { const uint4 rt = ep.row_tab[m]; lrow = rt.x; k0 = rt.y; k1 = rt.z; }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -476,6 +516,7 @@ __device__ __forceinline__ void band_store_scalar(const f32x16 (&acc)[NI][2], vo
             for (int sg = 1; sg < EP::kSegs; ++sg)
                 if (ep.nseg > sg && m >= ep.seg_row[sg]) { srow = ep.seg_row[sg]; k0 = ep.seg_k0[sg]; k1 = ep.seg_k1[sg]; }
             lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)((int)m - srow);
+            if (EP::kDyn && ep.row_tab) { const uint4 rt = ep.row_tab[m]; lrow = rt.x; k0 = rt.y; k1 = rt.z; }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -542,7 +583,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [stage][A 256 rows | B 128 rows]
-    ODW_SPLITK_ENTER();
+    ODW_SPLITK_ENTER(RM);
     int tm, tn;
     tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * RM, n0 = tn * RN;
@@ -636,6 +677,12 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_cm_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     void* __restrict__ Cv, int ldc, typename CmEp<PAIR>::type ep, CmArgs cm, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // SHARE: [3 A slots | 4 B slots]; else [stage][A | B]
+    if (!PAIR && ep.m_dev) {          // rows that exist (device-resident count): the capacity-sized grid's other workgroups exit
+        const int md_ = *ep.m_dev;
+        M = md_ < M ? md_ : M;
+        tiles_m = (M + RM - 1) / RM;
+        if ((int)blockIdx.x >= tiles_m * tiles_n) return;
+    }
     int cell_lo = 0, cell_hi = cm.S;
     if (ep.kchunk > 0) {                                              // split over cells (plain mode)
         cell_lo = blockIdx.y * ep.kchunk;
@@ -918,7 +965,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [slot][A 256 rows | B 256 rows]
-    ODW_SPLITK_ENTER();
+    ODW_SPLITK_ENTER(GM);
     int tm, tn;
     tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * GM, n0 = tn * GN;
@@ -1920,20 +1967,41 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_tn_bf16_ring_kernel(
 
 // ---- layout helpers ---------------------------------------------------------------------
 // out[c][r] = bf16(in[r][c]); in is fp32 or bf16 (IN_F32).  32x32 tiles through LDS.
+// Device-resident row count of the transposes / backward prologues below (round 6): R / M of the launch is the CAPACITY the
+// grid covers; *r_dev rows exist; the transposed output is zero padded up to r64(*r_dev) columns and starts *col_off_dev
+// columns into `out` (the column block of a weight-gradient batch whose predecessors have device-resident widths too);
+// src_rows: row r of the input is in[src_rows[r]] (a fused gather).  All three null = the static form.
+struct DynRows {
+    const int* r_dev;
+    const int* col_off_dev;
+    const int* src_rows;
+};
+#define ODW_DYNROWS_ENTER(ROWS, OUT_COLS, OUT_PTR, ROW0)                                    \
+    if (dyn.r_dev) {                                                                       \
+        const int rd_ = *dyn.r_dev;                                                        \
+        ROWS = rd_ < ROWS ? rd_ : ROWS;                                                    \
+        OUT_COLS = (ROWS + 63) / 64 * 64;                                                  \
+        if ((ROW0) >= OUT_COLS) return;                                                    \
+        if (dyn.col_off_dev) OUT_PTR += *dyn.col_off_dev;                                  \
+    }
+
 template <bool IN_F32>
 __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __restrict__ in, int ld_in, int R,
                                                                 int Cc, unsigned short* __restrict__ out,
-                                                                int ld_out, int out_cols) {
+                                                                int ld_out, int out_cols, DynRows dyn) {
     __shared__ unsigned short t[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    ODW_DYNROWS_ENTER(R, out_cols, out, r0);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = r0 + ty + 8 * k, c = c0 + tx;
         unsigned short v = 0;
-        if (r < R && c < Cc)
-            v = IN_F32 ? f2bf(reinterpret_cast<const float*>(in)[(size_t)r * ld_in + c])
-                       : reinterpret_cast<const unsigned short*>(in)[(size_t)r * ld_in + c];
+        if (r < R && c < Cc) {
+            const size_t sr = dyn.src_rows ? (size_t)dyn.src_rows[r] : (size_t)r;
+            v = IN_F32 ? f2bf(reinterpret_cast<const float*>(in)[sr * ld_in + c])
+                       : reinterpret_cast<const unsigned short*>(in)[sr * ld_in + c];
+        }
         t[ty + 8 * k][tx] = v;
     }
     __syncthreads();
@@ -1948,16 +2016,17 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __re
 // needs Cc, ld_in, ld_out, out_cols multiples of 8 and 16-byte-aligned pointers (every operand of the head's GEMMs).
 __global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const unsigned short* __restrict__ in, int ld_in, int R,
                                                                  int Cc, unsigned short* __restrict__ out, int ld_out,
-                                                                 int out_cols) {
+                                                                 int out_cols, DynRows dyn) {
     __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    ODW_DYNROWS_ENTER(R, out_cols, out, r0);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int item = threadIdx.x + 256 * k;
         const int rl = item >> 3, ch = item & 7;
         const int r = r0 + rl, c = c0 + ch * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < R && c < Cc) v = *reinterpret_cast<const uint4*>(in + (size_t)r * ld_in + c);
+        if (r < R && c < Cc) v = *reinterpret_cast<const uint4*>(in + (dyn.src_rows ? (size_t)dyn.src_rows[r] : (size_t)r) * ld_in + c);
         *reinterpret_cast<uint4*>(&tile[rl][ch * 8]) = v;
     }
     __syncthreads();
@@ -2002,11 +2071,12 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __rest
                                                               int M, int N, float scale,
                                                               unsigned short* __restrict__ dZ, int ld_z,
                                                               unsigned short* __restrict__ dZT, int ld_t, int t_cols,
-                                                              float* __restrict__ db) {
+                                                              float* __restrict__ db, DynRows dyn) {
     __shared__ float t[32][33];
     const unsigned short* Y = reinterpret_cast<const unsigned short*>(Y_);
     const unsigned int* Y32 = reinterpret_cast<const unsigned int*>(Y_);
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    ODW_DYNROWS_ENTER(M, t_cols, dZT, m0);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2016,7 +2086,8 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __rest
             v = DY_F32 ? reinterpret_cast<const float*>(dY)[(size_t)m * ld_dy + n]
                        : __uint_as_float((unsigned int)reinterpret_cast<const unsigned short*>(dY)[(size_t)m * ld_dy + n] << 16);
             if (Y_) {
-                const bool on = Y_F32 ? (Y32[(size_t)m * ld_y + n] & 0x7fffffffu) != 0 : (Y[(size_t)m * ld_y + n] & 0x7fff) != 0;
+                const size_t my = dyn.src_rows ? (size_t)dyn.src_rows[m] : (size_t)m;
+                const bool on = Y_F32 ? (Y32[my * ld_y + n] & 0x7fffffffu) != 0 : (Y[my * ld_y + n] & 0x7fff) != 0;
                 v = on ? v * scale : 0.0f;
             }
         }
@@ -2045,14 +2116,16 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_vec_kernel(const void* __
                                                                   int M, int N, float scale,
                                                                   unsigned short* __restrict__ dZ, int ld_z,
                                                                   unsigned short* __restrict__ dZT, int ld_t, int t_cols,
-                                                                  float* __restrict__ db) {
+                                                                  float* __restrict__ db, DynRows dyn) {
     __shared__ float t[64][65];
     const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+    ODW_DYNROWS_ENTER(M, t_cols, dZT, m0);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int item = threadIdx.x + 256 * k;
         const int ml = item >> 3, ch = item & 7;
         const int m = m0 + ml, n = n0 + ch * 8;
+        const size_t my = (dyn.src_rows && m < M) ? (size_t)dyn.src_rows[m] : (size_t)m;
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (m < M && n < N) {            // N % 8 == 0: a chunk is all-in or all-out
             if (DY_F32) {
@@ -2066,13 +2139,13 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_vec_kernel(const void* __
                 for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
             }
             if (Y_ && Y_F32) {         // the saved fp32 output of a split-precision forward (precision "bf16x2f")
-                const uint4 ya = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned int*>(Y_) + (size_t)m * ld_y + n);
-                const uint4 yb = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned int*>(Y_) + (size_t)m * ld_y + n + 4);
+                const uint4 ya = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned int*>(Y_) + my * ld_y + n);
+                const uint4 yb = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned int*>(Y_) + my * ld_y + n + 4);
                 const unsigned w[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = (w[q] & 0x7fffffffu) ? v[q] * scale : 0.0f;
             } else if (Y_) {
-                const uint4 yv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(Y_) + (size_t)m * ld_y + n);
+                const uint4 yv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(Y_) + my * ld_y + n);
                 const unsigned w[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -2205,6 +2278,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int M, int N, int ldw, void* __restrict__ Cv, int ldc,
                                                             Epilogue ep) {
     const int n4 = ldw / 4;             // ldw = row stride of the partials, N rounded up to 4 (N itself may be odd)
+    if (ep.m_dev) { const int md_ = *ep.m_dev; M = md_ < M ? md_ : M; }
     const long long total = (long long)M * n4;
     const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -2243,7 +2317,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             if (ep.relu) x = fmaxf(x, 0.0f);
             if ((mq[q] & 0x7fff) == 0) x = 0.0f;
             if (ep.drop_p > 0.0f) {
-                const uint32_t lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
+                uint32_t lrow = ep.row_ids ? (uint32_t)ep.row_ids[m] : (uint32_t)(m - srow);
+                if (ep.row_tab) { const uint4 rt = ep.row_tab[m]; lrow = rt.x; k0 = rt.y; k1 = rt.z; }
                 const uint32_t idx = lrow * (uint32_t)N + (uint32_t)(n + q);
                 x = odw_uniform(idx, k0, k1) >= ep.drop_p ? x * keep_scale : 0.0f;
             }
@@ -2449,11 +2524,48 @@ ODW_EXPORT int64_t odw_gemm_nt_cm_pair_workspace(int M, int N, int S) {      // 
     return 2 * odw_gemm_nt_cm_workspace(M, N, S);
 }
 
+struct CmDyn { const int* m_dev; int m_hint; const uint4* row_tab; };
+
+static int gemm_nt_cm_launch(const void* A, int lda, int a_mid, const void* B, int ldb, int b_mid, int M, int N, int C, int S,
+                             const float* keep, const float* keep_sum, int drop_row0, float* Cout, int ldc,
+                             const float* bias, int relu, float drop_p, int nseg, const int* seg_rows,
+                             const uint32_t* seg_keys, const int* row_ids, void* workspace, int64_t workspace_bytes,
+                             void* stream_, const CmDyn* dyn);
+
 ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, int ldb, int b_mid, int M, int N, int C, int S,
                               const float* keep, const float* keep_sum, int drop_row0, float* Cout, int ldc,
                               const float* bias, int relu, float drop_p, int nseg, const int* seg_rows,
                               const uint32_t* seg_keys, const int* row_ids, void* workspace, int64_t workspace_bytes,
                               void* stream_) {
+    return gemm_nt_cm_launch(A, lda, a_mid, B, ldb, b_mid, M, N, C, S, keep, keep_sum, drop_row0, Cout, ldc, bias, relu, drop_p, nseg,
+                             seg_rows, seg_keys, row_ids, workspace, workspace_bytes, stream_, nullptr);
+}
+
+// The plain (non-pair) product over cell-major planes with the number of rows on the device (the sampled-row views of the
+// contrastive loss: their count is what loss_lists.hip computes).  M_cap rows of A / Cout exist as memory; *m_dev of them
+// are computed.  The cell split is planned for M_hint, its partials sized for M_cap.
+ODW_EXPORT int64_t odw_gemm_nt_cm_dyn_workspace(int M_cap, int M_hint, int N, int S) {
+    const int kc = cm_cells_per_split(M_hint > 0 && M_hint < M_cap ? M_hint : M_cap, N, S, true);
+    if (kc == 0) return 0;
+    return (int64_t)((S + kc - 1) / kc) * M_cap * ((N + 3) / 4 * 4) * 4;
+}
+
+ODW_EXPORT int odw_gemm_nt_cm_dyn(const void* A, int lda, int a_mid, const void* B, int ldb, int b_mid, int M_cap, int N, int C,
+                                  int S, float* Cout, int ldc, const float* bias, int relu, float drop_p, const void* row_tab,
+                                  const int* m_dev, int M_hint, void* workspace, int64_t workspace_bytes, void* stream_) {
+    ODW_REQUIRE(m_dev, "gemm_nt_cm_dyn: m_dev is null (use odw_gemm_nt_cm)");
+    ODW_REQUIRE(drop_p == 0.0f || row_tab, "gemm_nt_cm_dyn: dropout needs the per-row draw table");
+    CmDyn d;
+    d.m_dev = m_dev; d.m_hint = M_hint > 0 && M_hint < M_cap ? M_hint : M_cap; d.row_tab = (const uint4*)row_tab;
+    return gemm_nt_cm_launch(A, lda, a_mid, B, ldb, b_mid, M_cap, N, C, S, nullptr, nullptr, 0, Cout, ldc, bias, relu, drop_p, 0,
+                             nullptr, nullptr, nullptr, workspace, workspace_bytes, stream_, &d);
+}
+
+static int gemm_nt_cm_launch(const void* A, int lda, int a_mid, const void* B, int ldb, int b_mid, int M, int N, int C, int S,
+                             const float* keep, const float* keep_sum, int drop_row0, float* Cout, int ldc,
+                             const float* bias, int relu, float drop_p, int nseg, const int* seg_rows,
+                             const uint32_t* seg_keys, const int* row_ids, void* workspace, int64_t workspace_bytes,
+                             void* stream_, const CmDyn* dyn) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(M >= 0 && N >= 0 && C > 0 && C % BK == 0 && S >= 1 && S <= 64, "gemm_nt_cm: bad dims M=%d N=%d C=%d S=%d", M, N, C, S);
     if (M == 0 || N == 0) return ODW_OK;
@@ -2473,7 +2585,9 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
         ep.seg_k0[i] = (i < nseg && seg_keys) ? seg_keys[2 * i] : 0;
         ep.seg_k1[i] = (i < nseg && seg_keys) ? seg_keys[2 * i + 1] : 0;
     }
-    if (drop_p > 0.0f) ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_cm: dropout needs row segments starting at 0");
+    if (dyn) { ep.m_dev = dyn->m_dev; ep.row_tab = dyn->row_tab; }
+    if (drop_p > 0.0f && !(dyn && dyn->row_tab))
+        ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_cm: dropout needs row segments starting at 0");
     if (keep && drop_p > 0.0f) ODW_REQUIRE(nseg == 2 && seg_rows[1] == drop_row0, "gemm_nt_cm: the pair form takes two dropout segments (clean rows, DropBlock rows)");
     CmArgs cm;
     cm.C = C; cm.S = S; cm.a_mid = a_mid; cm.b_mid = b_mid; cm.keep = keep; cm.keep_sum = keep_sum; cm.drop_row0 = drop_row0;
@@ -2495,7 +2609,7 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
             ODW_CHECK_HIP(attr_, "gemm_nt_cm attr");                                                                     \
             gemm_nt_cm_kernel<PAIRV, SV><<<GRID, kRingThreads, LDSB, stream>>>(                                          \
                 (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, OUT, ldc_,                           \
-                epilogue_narrow<CmEp<PAIRV>::type::kSegs>(EP), cm, tiles_m, tiles_n);                                    \
+                epilogue_narrow<CmEp<PAIRV>::type>(EP), cm, tiles_m, tiles_n);                                    \
         } while (0)
         const int ldc_ = ldc;
         // few ROIs: the cells are split over blockIdx.y; a split's partial clean sums land in rows [0, M) of its slice
@@ -2526,7 +2640,7 @@ ODW_EXPORT int odw_gemm_nt_cm(const void* A, int lda, int a_mid, const void* B, 
         return ODW_OK;
     }
     const int ldw = (N + 3) / 4 * 4;
-    int kc = cm_cells_per_split(M, N, S, workspace != nullptr);
+    int kc = cm_cells_per_split(dyn ? dyn->m_hint : M, N, S, workspace != nullptr);
     if (kc > 0 && workspace_bytes < (int64_t)((S + kc - 1) / kc) * M * ldw * 4) kc = 0;
     if (kc > 0) {
         ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "gemm_nt_cm: workspace must be 16-byte aligned");
@@ -2587,10 +2701,60 @@ ODW_EXPORT int odw_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, 
                                seg_keys, nullptr, accumulate, nullptr, 0, stream_);
 }
 
+// Device-resident extents of a launch (odw_gemm_nt_bf16_dyn): M / K of the call are CAPACITIES (grid, workspace, bounds);
+// the kernels read the live values from m_dev / k_dev; the plan (kernel variant, K slices) is made for the hints.
+struct DynExtent {
+    const int* m_dev; int m_hint;
+    const int* k_dev; int k_hint;
+    const uint4* row_tab;
+};
+
+static int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
+                          int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
+                          int nseg, const int* seg_rows, const uint32_t* seg_keys, const int* row_ids,
+                          int accumulate, void* workspace, int64_t workspace_bytes, void* stream_, const DynExtent* dyn);
+
 ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
                                    int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
                                    int nseg, const int* seg_rows, const uint32_t* seg_keys, const int* row_ids,
                                    int accumulate, void* workspace, int64_t workspace_bytes, void* stream_) {
+    return gemm_nt_launch(A, lda, B, ldb, M, N, K, C, ldc, c_is_bf16, bias, relu, alpha, drop_p, nseg, seg_rows, seg_keys, row_ids,
+                          accumulate, workspace, workspace_bytes, stream_, nullptr);
+}
+
+static int dyn_hint(int hint, int cap) { return hint > 0 ? (hint < cap ? hint : cap) : cap; }
+
+// workspace of the dynamic form: the split-K partials of the plan made for the hints, over the CAPACITY rows
+ODW_EXPORT int64_t odw_gemm_nt_bf16_dyn_workspace(int M_cap, int M_hint, int N, int K_cap, int K_hint, int lda, int ldb,
+                                                  const void* C, int ldc, int c_is_bf16, int* variant_out) {
+    const Plan p = pick_plan(dyn_hint(M_hint, M_cap), N, dyn_hint(K_hint, K_cap), lda, ldb, C, ldc, c_is_bf16, true);
+    if (variant_out) *variant_out = p.variant;
+    return p.splits > 1 ? (int64_t)p.splits * M_cap * ((N + 3) / 4 * 4) * 4 : 0;
+}
+
+// C[M x N] (+)= epilogue(alpha A B^T) where the number of rows M and / or the reduction length K live on the DEVICE
+// (loss_lists.hip writes them): the launch covers M_cap rows and K_cap columns of the operands, which must exist as memory
+// (rows >= *m_dev may hold anything finite or not: they are never read into a stored result; columns of A / B in
+// [*k_dev, r64(*k_dev)) must be zero).  *k_dev must be a multiple of 8.  row_tab (M_cap x uint4, device): per-row dropout
+// draw (logical row, key0, key1, -) -- the stacked views' segment boundaries are device values too.  The hints size nothing:
+// they pick the kernel variant and the number of K slices (performance only).
+ODW_EXPORT int odw_gemm_nt_bf16_dyn(const void* A, int lda, const void* B, int ldb, int M_cap, int N, int K_cap, void* C,
+                                    int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
+                                    const void* row_tab, const int* m_dev, int M_hint, const int* k_dev, int K_hint,
+                                    int accumulate, void* workspace, int64_t workspace_bytes, void* stream_) {
+    ODW_REQUIRE(m_dev || k_dev, "gemm_nt_bf16_dyn: neither extent is device-resident (use odw_gemm_nt_bf16_ws)");
+    ODW_REQUIRE(drop_p == 0.0f || row_tab, "gemm_nt_bf16_dyn: dropout needs the per-row draw table");
+    DynExtent d;
+    d.m_dev = m_dev; d.m_hint = dyn_hint(M_hint, M_cap); d.k_dev = k_dev; d.k_hint = dyn_hint(K_hint, K_cap);
+    d.row_tab = (const uint4*)row_tab;
+    return gemm_nt_launch(A, lda, B, ldb, M_cap, N, K_cap, C, ldc, c_is_bf16, bias, relu, alpha, drop_p, 0, nullptr, nullptr,
+                          nullptr, accumulate, workspace, workspace_bytes, stream_, &d);
+}
+
+static int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
+                          int ldc, int c_is_bf16, const float* bias, int relu, float alpha, float drop_p,
+                          int nseg, const int* seg_rows, const uint32_t* seg_keys, const int* row_ids,
+                          int accumulate, void* workspace, int64_t workspace_bytes, void* stream_, const DynExtent* dyn) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_nt_bf16: bad dims M=%d N=%d K=%d", M, N, K);
     if (M == 0 || N == 0) return ODW_OK;
@@ -2601,7 +2765,7 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
                 "gemm_nt_bf16: K=%d rounded up to 8 must fit in lda=%d / ldb=%d (zero padded)", K, lda, ldb);
     ODW_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && nseg >= 0 && nseg <= kMaxSeg, "gemm_nt_bf16: bad dropout args");
     ODW_REQUIRE(!(accumulate && c_is_bf16), "gemm_nt_bf16: accumulate needs an fp32 C");
-    if (const int nt = tail_columns(M, N, K, lda, ldb, C, ldc, c_is_bf16, drop_p, workspace != nullptr)) {
+    if (const int nt = dyn ? 0 : tail_columns(M, N, K, lda, ldb, C, ldc, c_is_bf16, drop_p, workspace != nullptr)) {
         const int n1 = N - nt;
         const int rc = odw_gemm_nt_bf16_ws(A, lda, B, ldb, M, n1, K, C, ldc, c_is_bf16, bias, relu, alpha, 0.0f, 0, nullptr,
                                            nullptr, nullptr, accumulate, nullptr, 0, stream_);
@@ -2620,13 +2784,18 @@ ODW_EXPORT int odw_gemm_nt_bf16_ws(const void* A, int lda, const void* B, int ld
         ep.seg_k0[i] = (i < nseg && seg_keys) ? seg_keys[2 * i] : 0;
         ep.seg_k1[i] = (i < nseg && seg_keys) ? seg_keys[2 * i + 1] : 0;
     }
-    if (drop_p > 0.0f) ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_bf16: dropout needs row segments starting at 0");
+    if (dyn) { ep.m_dev = dyn->m_dev; ep.k_dev = dyn->k_dev; ep.row_tab = dyn->row_tab; }
+    if (drop_p > 0.0f && !(dyn && dyn->row_tab))
+        ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_bf16: dropout needs row segments starting at 0");
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds_bytes = (size_t)2 * 2 * kTileChunks * sizeof(uint4);   // 64 KB
-    Plan plan = pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, workspace != nullptr);
+    // (device-resident extents: the plan is made for the HINTS -- what the extents are expected to be --, every grid and
+    // the workspace for the capacities M / K of the call)
+    const int Mp = dyn ? dyn->m_hint : M, Kp = dyn ? dyn->k_hint : K;
+    Plan plan = pick_plan(Mp, N, Kp, lda, ldb, C, ldc, c_is_bf16, workspace != nullptr);
     const int ldw = (N + 3) / 4 * 4;        // row stride of the fp32 partials
     if (plan.splits > 1 && workspace_bytes < (int64_t)plan.splits * M * ldw * 4)
-        plan = pick_plan(M, N, K, lda, ldb, C, ldc, c_is_bf16, false);
+        plan = pick_plan(Mp, N, Kp, lda, ldb, C, ldc, c_is_bf16, false);
     if (plan.splits > 1) {
         // partial products (plain, fp32) into the workspace, then one reduction pass with the fused epilogue
         ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "gemm_nt_bf16: workspace must be 16-byte aligned");
@@ -3204,8 +3373,8 @@ ODW_EXPORT int odw_transpose_to_bf16(const void* in, int in_is_f32, int ld_in, i
     return odw_transpose_to_bf16_part(in, in_is_f32, ld_in, R, Cc, out, ld_out, ld_out, stream_);
 }
 
-ODW_EXPORT int odw_transpose_to_bf16_part(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
-                                          int out_cols, void* stream_) {
+static int transpose_to_bf16_launch(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
+                                    int out_cols, void* stream_, DynRows dyn) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(R >= 0 && Cc >= 0 && ld_in >= Cc && out_cols >= R && ld_out >= out_cols, "transpose_to_bf16: bad dims");
     if (R == 0 || Cc == 0) return ODW_OK;
@@ -3214,17 +3383,33 @@ ODW_EXPORT int odw_transpose_to_bf16_part(const void* in, int in_is_f32, int ld_
         (((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 15) == 0) {
         dim3 vgrid((Cc + 63) / 64, (out_cols + 63) / 64);
         transpose_bf16_vec_kernel<<<vgrid, 256, 0, stream>>>((const unsigned short*)in, ld_in, R, Cc, (unsigned short*)out,
-                                                             ld_out, out_cols);
+                                                             ld_out, out_cols, dyn);
         ODW_CHECK_LAUNCH("transpose_bf16_vec_kernel");
         return ODW_OK;
     }
     dim3 grid((Cc + 31) / 32, (out_cols + 31) / 32);   // covers the zero padding up to out_cols
     if (in_is_f32)
-        transpose_to_bf16_kernel<true><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out, out_cols);
+        transpose_to_bf16_kernel<true><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out, out_cols, dyn);
     else
-        transpose_to_bf16_kernel<false><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out, out_cols);
+        transpose_to_bf16_kernel<false><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out, out_cols, dyn);
     ODW_CHECK_LAUNCH("transpose_to_bf16_kernel");
     return ODW_OK;
+}
+
+ODW_EXPORT int odw_transpose_to_bf16_part(const void* in, int in_is_f32, int ld_in, int R, int Cc, void* out, int ld_out,
+                                          int out_cols, void* stream_) {
+    return transpose_to_bf16_launch(in, in_is_f32, ld_in, R, Cc, out, ld_out, out_cols, stream_, DynRows{nullptr, nullptr, nullptr});
+}
+
+// out[c][*col_off_dev + r] = bf16(in[src_rows ? src_rows[r] : r][c]) for r < *r_dev, zeros up to r64(*r_dev): the X^T / dZ^T
+// column block of an evaluation whose row count (and whose predecessors' widths in the batch) live on the device.
+// R_cap rows bound the launch; `out` must hold *col_off_dev + r64(*r_dev) <= ld_out columns (the caller's capacity).
+ODW_EXPORT int odw_transpose_to_bf16_dyn(const void* in, int in_is_f32, int ld_in, int R_cap, int Cc, void* out, int ld_out,
+                                         const int* r_dev, const int* col_off_dev, const int* src_rows, void* stream_) {
+    ODW_REQUIRE(r_dev, "transpose_to_bf16_dyn: r_dev is null");
+    const int cols = (R_cap + 63) / 64 * 64;
+    ODW_REQUIRE(ld_out >= cols, "transpose_to_bf16_dyn: ld_out=%d < r64(R_cap)=%d", ld_out, cols);
+    return transpose_to_bf16_launch(in, in_is_f32, ld_in, R_cap, Cc, out, ld_out, cols, stream_, DynRows{r_dev, col_off_dev, src_rows});
 }
 
 ODW_EXPORT int odw_f32_to_bf16(const float* in, void* out, int64_t n, void* stream_) {
@@ -3246,9 +3431,33 @@ ODW_EXPORT int odw_linear_bwd_prep(const void* dY, int dy_is_f32, int ld_dy, con
     return odw_linear_bwd_prep_part(dY, dy_is_f32, ld_dy, Y, ld_y, M, N, scale, dZ, ld_z, dZT, ld_t, ld_t, db, stream_);
 }
 
+static int linear_bwd_prep_launch(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
+                                  float scale, void* dZ, int ld_z, void* dZT, int ld_t, int t_cols, float* db,
+                                  void* stream_, DynRows dyn);
+
 ODW_EXPORT int odw_linear_bwd_prep_part(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
                                         float scale, void* dZ, int ld_z, void* dZT, int ld_t, int t_cols, float* db,
                                         void* stream_) {
+    return linear_bwd_prep_launch(dY, dy_is_f32, ld_dy, Y, ld_y, M, N, scale, dZ, ld_z, dZT, ld_t, t_cols, db, stream_,
+                                  DynRows{nullptr, nullptr, nullptr});
+}
+
+// The backward prologue of a Linear whose row count lives on the device: M_cap bounds the launch, *m_dev rows exist; dZ^T
+// goes to column block [*tcol_off_dev, + r64(*m_dev)) of dZT (zero padded); y_rows: row m of the mask source is Y[y_rows[m]]
+// (the saved output of a LARGER evaluation these rows are re-attached from -- no gathered copy of it).
+ODW_EXPORT int odw_linear_bwd_prep_dyn(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M_cap, int N,
+                                       float scale, void* dZ, int ld_z, void* dZT, int ld_t, float* db, const int* m_dev,
+                                       const int* tcol_off_dev, const int* y_rows, void* stream_) {
+    ODW_REQUIRE(m_dev, "linear_bwd_prep_dyn: m_dev is null");
+    const int cols = (M_cap + 63) / 64 * 64;
+    ODW_REQUIRE(ld_t >= cols, "linear_bwd_prep_dyn: ld_t=%d < r64(M_cap)=%d", ld_t, cols);
+    return linear_bwd_prep_launch(dY, dy_is_f32, ld_dy, Y, ld_y, M_cap, N, scale, dZ, ld_z, dZT, ld_t, cols, db, stream_,
+                                  DynRows{m_dev, tcol_off_dev, y_rows});
+}
+
+static int linear_bwd_prep_launch(const void* dY, int dy_is_f32, int ld_dy, const void* Y, int ld_y, int M, int N,
+                                  float scale, void* dZ, int ld_z, void* dZT, int ld_t, int t_cols, float* db,
+                                  void* stream_, DynRows dyn) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(M >= 0 && N >= 0 && ld_z >= N && t_cols >= M && ld_t >= t_cols && ld_dy >= N, "linear_bwd_prep: bad dims");
     if (M == 0 || N == 0) return ODW_OK;
@@ -3260,10 +3469,10 @@ ODW_EXPORT int odw_linear_bwd_prep_part(const void* dY, int dy_is_f32, int ld_dy
                      (((uintptr_t)dZT) & 15) == 0;
 #define ODW_PREP_LAUNCH(KERNEL, GRID)                                                                                  \
     do {                                                                                                               \
-        if (dyf && yf) KERNEL<true, true><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db); \
-        else if (dyf) KERNEL<true, false><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db); \
-        else if (yf) KERNEL<false, true><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db); \
-        else KERNEL<false, false><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db); \
+        if (dyf && yf) KERNEL<true, true><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db, dyn); \
+        else if (dyf) KERNEL<true, false><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db, dyn); \
+        else if (yf) KERNEL<false, true><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db, dyn); \
+        else KERNEL<false, false><<<GRID, 256, 0, stream>>>(dY, ld_dy, Y, ld_y, M, N, scale, (unsigned short*)dZ, ld_z, (unsigned short*)dZT, ld_t, t_cols, db, dyn); \
     } while (0)
     if (vec) {
         dim3 vgrid((ld_z + 63) / 64, (t_cols + 63) / 64);

@@ -155,21 +155,20 @@ __device__ __forceinline__ void normal_pair(uint32_t p, uint32_t k0, uint32_t k1
 constexpr int kRowSlices = 8;          // workgroups per row of rows_drop_noise_kernel (blockIdx.y)
 
 // BWD = false: out rows from pooled;  BWD = true: dpooled[rows[r]] += d(drop row) and d(noise row) folded back
+// (body: r = the sampled row's position inside its (image, class) group of k rows; src_row = the row of `pooled` / `dpooled`
+// it belongs to; row0 = the group's first row in the stacked views.  The per-group launch below and the grouped launch
+// whose group boundaries live on the device share it.)
 template <bool BWD, bool DX_F32, bool SRC_BF16 = false, bool OUT_F32 = false, bool STORE = false>
-__global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __restrict__ pooled, const void* __restrict__ dXv,
-                                                              const int* __restrict__ rows, int row_base, int k, int CS,
-                                                              int S, float gamma, uint32_t kd0, uint32_t kd1,
-                                                              uint32_t kn0, uint32_t kn1,
-                                                              const float* __restrict__ keep_sum,
-                                                              unsigned short* __restrict__ out, int ld, int row0,
-                                                              float* __restrict__ dpooled) {
-    __shared__ float keep[kMaxS];
-    const int r = blockIdx.x;
+__device__ __forceinline__ void rows_drop_noise_body(const float* __restrict__ pooled, const void* __restrict__ dXv,
+                                                     const int r, const size_t src_row, int k, int CS,
+                                                     int S, float gamma, uint32_t kd0, uint32_t kd1,
+                                                     uint32_t kn0, uint32_t kn1, const float sum,
+                                                     unsigned short* __restrict__ out, int ld, int row0,
+                                                     float* __restrict__ dpooled, float* keep) {
     for (int s = threadIdx.x; s < S; s += blockDim.x)
         keep[s] = odw_uniform((uint32_t)(r * S + s), kd0, kd1) < gamma ? 0.0f : 1.0f;
     __syncthreads();
-    const float sum = *keep_sum, numel = (float)((double)k * S);
-    const size_t src_row = (size_t)(row_base + rows[r]);
+    const float numel = (float)((double)k * S);
     // blockIdx.y = a slice of the row: k ~ 200 rows alone leave most of the chip idle behind one 256-thread block per CU
     // (37 us per launch on 225 x 25088 elements; the Box-Muller pair of every element is what a thread waits on)
     const int per = (CS / 4 + gridDim.y - 1) / gridDim.y;
@@ -259,15 +258,84 @@ __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __res
     }
 }
 
+template <bool BWD, bool DX_F32, bool SRC_BF16 = false, bool OUT_F32 = false, bool STORE = false>
+__global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __restrict__ pooled, const void* __restrict__ dXv,
+                                                              const int* __restrict__ rows, int row_base, int k, int CS,
+                                                              int S, float gamma, uint32_t kd0, uint32_t kd1,
+                                                              uint32_t kn0, uint32_t kn1,
+                                                              const float* __restrict__ keep_sum,
+                                                              unsigned short* __restrict__ out, int ld, int row0,
+                                                              float* __restrict__ dpooled) {
+    __shared__ float keep[kMaxS];
+    const int r = blockIdx.x;
+    rows_drop_noise_body<BWD, DX_F32, SRC_BF16, OUT_F32, STORE>(pooled, dXv, r, (size_t)(row_base + rows[r]), k, CS, S, gamma, kd0,
+                                                                kd1, kn0, kn1, *keep_sum, out, ld, row0, dpooled, keep);
+}
+
+// ---- grouped forms (round 6): every (image, class) group of the step in ONE launch, group boundaries on the device ----
+// The loss's first selection kernel (discover.hip: discover_iou) leaves the sampled rows of each positive class in device
+// memory; odw_loss_lists_a (loss_lists.hip) turns their counts into k[g] and the entry prefix e0[g].  Nothing of that is
+// known to the host when these kernels are launched: the grid covers the CAPACITY (every entry that could exist), an entry
+// e < *n_entries finds its group by walking the prefix, and the per-group constants the host does know -- the
+// counter-based keys of the group's draws -- come from a table uploaded before the step's first read would have happened.
+struct ViewGroups {
+    const int* n_entries;       // [1]   number of sampled rows over all groups (E1)
+    const int* e0;              // [G+1] entry prefix: group g owns entries [e0[g], e0[g+1]); its views are rows [2 e0[g], 2 e0[g+1])
+    const uint32_t* keys;       // [G][4] kd0, kd1 (drop mask draw), kn0, kn1 (noise draw)
+    const int* src_row;         // [E1]  row of the source (a proposal of the concatenated batch) of every entry
+    const float* keep_sum;      // [G]   sum of the group's keep mask (rows_keep_sum_grouped_kernel)
+    int G;
+};
+__device__ __forceinline__ int view_group_of(const ViewGroups& vg, int e) {
+    int g = 0;
+    while (g + 1 < vg.G && e >= vg.e0[g + 1]) ++g;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void rows_keep_sum_grouped_kernel(ViewGroups vg, int S, float gamma, float* __restrict__ sum_out) {
+    __shared__ float red[256];
+    const int g = blockIdx.x;
+    const int n = (vg.e0[g + 1] - vg.e0[g]) * S;
+    const uint32_t k0 = vg.keys[4 * g], k1 = vg.keys[4 * g + 1];
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += odw_uniform((uint32_t)i, k0, k1) < gamma ? 0.0f : 1.0f;
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sum_out[g] = red[0];          // a count <= 2^24: exact in fp32 whatever the order
+}
+
+// backward of the grouped views into the pooling node's side buffer: entry e's row is *dst_off + e (STORE: written, not added)
+template <bool DX_F32>
+__global__ __launch_bounds__(256) void rows_views_bwd_store_grouped_kernel(const void* __restrict__ dXv, int ld, ViewGroups vg,
+                                                                           int CS, int S, float gamma,
+                                                                           const int* __restrict__ dst_off,
+                                                                           float* __restrict__ extra) {
+    __shared__ float keep[kMaxS];
+    const int e = blockIdx.x;
+    if (e >= *vg.n_entries) return;
+    const int g = view_group_of(vg, e);
+    const int e0 = vg.e0[g], k = vg.e0[g + 1] - e0;
+    const uint32_t* ky = vg.keys + 4 * g;
+    rows_drop_noise_body<true, DX_F32, false, false, true>(nullptr, dXv, e - e0, (size_t)((dst_off ? *dst_off : 0) + e), k, CS, S,
+                                                           gamma, ky[0], ky[1], ky[2], ky[3], vg.keep_sum[g], nullptr, ld, 2 * e0,
+                                                           extra, keep);
+}
+
 // ---- row-wise L2 normalisation of the 128-d embeddings (Sim_Net.forward, sim_head/sim_net.py:25-26: F.normalize) ------
 // y = x / max(||x||, eps); backward dx = (g - y (g.y)) / max(||x||, eps).  One wavefront per row; the PyTorch
 // rendition is 3 launches forward and ~12 backward, twice per step, in the latency-bound part of the step.
 template <bool BWD>
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ a, const float* __restrict__ y_in,
                                                           const float* __restrict__ norm_in, int R, int D, float eps,
-                                                          float* __restrict__ out, float* __restrict__ norm_out) {
+                                                          float* __restrict__ out, float* __restrict__ norm_out,
+                                                          const int* __restrict__ r_dev) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r_dev) { const int rd = *r_dev; R = rd < R ? rd : R; }      // rows that exist (device-resident count)
     if (row >= R) return;
     const float* src = a + (size_t)row * D;
     float acc = 0.0f;
@@ -396,23 +464,19 @@ ODW_EXPORT int odw_rows_drop_noise_f32(const float* pooled, const int* rows, int
 // same evaluation order.  A workgroup = (sampled row, 64 channels): the slice is staged channel-major in LDS so that
 // the draw runs over pairs of consecutive elements and both layouts leave as full 16-byte vectors.
 constexpr int kViewCh = 64;
-__global__ __launch_bounds__(256) void rows_views_cm_kernel(const unsigned short* __restrict__ src, long long ld_src,
-                                                            long long src_mid, const int* __restrict__ rows, int row_base,
-                                                            int k, int C, int S, float gamma, uint32_t kd0, uint32_t kd1,
-                                                            uint32_t kn0, uint32_t kn1, const float* __restrict__ keep_sum,
-                                                            unsigned short* __restrict__ out_cm, long long ld_cm,
-                                                            long long cm_mid, unsigned short* __restrict__ out_hi,
-                                                            long long ld_hi, int row0) {
-    extern __shared__ __attribute__((aligned(16))) float vlds[];     // x | drop view | noise view, each [64][S]
-    __shared__ float keep[kMaxS];
-    const int r = blockIdx.x, c0 = blockIdx.y * kViewCh;
+__device__ __forceinline__ void rows_views_cm_body(const unsigned short* __restrict__ src, long long ld_src,
+                                                   long long src_mid, const int r, const size_t src_row, const int c0,
+                                                   int k, int C, int S, float gamma, uint32_t kd0, uint32_t kd1,
+                                                   uint32_t kn0, uint32_t kn1, const float sum,
+                                                   unsigned short* __restrict__ out_cm, long long ld_cm,
+                                                   long long cm_mid, unsigned short* __restrict__ out_hi,
+                                                   long long ld_hi, int row0, float* vlds, float* keep) {
     const int n = kViewCh * S;
     float* xs = vlds;
     float* dl = vlds + n;
     float* nl = vlds + 2 * n;
     for (int s = threadIdx.x; s < S; s += blockDim.x)
         keep[s] = odw_uniform((uint32_t)(r * S + s), kd0, kd1) < gamma ? 0.0f : 1.0f;
-    const size_t src_row = (size_t)(row_base + rows[r]);
     for (int t = threadIdx.x; t < S * 8; t += blockDim.x) {
         const int cell = t >> 3, cg = t & 7;
         const unsigned short* p = src + src_row * ld_src + (size_t)cell * C + c0 + cg * 8;
@@ -425,7 +489,7 @@ __global__ __launch_bounds__(256) void rows_views_cm_kernel(const unsigned short
         }
     }
     __syncthreads();
-    const float sum = *keep_sum, numel = (float)((double)k * S);
+    const float numel = (float)((double)k * S);
     const int CS = C * S;
     for (int q = threadIdx.x; q < n / 4; q += blockDim.x) {
         const int l0 = q * 4, s0 = l0 % S;
@@ -464,6 +528,36 @@ __global__ __launch_bounds__(256) void rows_views_cm_kernel(const unsigned short
             *reinterpret_cast<uint4*>(dst + cm_mid) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void rows_views_cm_kernel(const unsigned short* __restrict__ src, long long ld_src,
+                                                            long long src_mid, const int* __restrict__ rows, int row_base,
+                                                            int k, int C, int S, float gamma, uint32_t kd0, uint32_t kd1,
+                                                            uint32_t kn0, uint32_t kn1, const float* __restrict__ keep_sum,
+                                                            unsigned short* __restrict__ out_cm, long long ld_cm,
+                                                            long long cm_mid, unsigned short* __restrict__ out_hi,
+                                                            long long ld_hi, int row0) {
+    extern __shared__ __attribute__((aligned(16))) float vlds[];     // x | drop view | noise view, each [64][S]
+    __shared__ float keep[kMaxS];
+    const int r = blockIdx.x;
+    rows_views_cm_body(src, ld_src, src_mid, r, (size_t)(row_base + rows[r]), blockIdx.y * kViewCh, k, C, S, gamma, kd0, kd1, kn0,
+                       kn1, *keep_sum, out_cm, ld_cm, cm_mid, out_hi, ld_hi, row0, vlds, keep);
+}
+
+__global__ __launch_bounds__(256) void rows_views_cm_grouped_kernel(const unsigned short* __restrict__ src, long long ld_src,
+                                                                    long long src_mid, ViewGroups vg, int C, int S, float gamma,
+                                                                    unsigned short* __restrict__ out_cm, long long ld_cm,
+                                                                    long long cm_mid, unsigned short* __restrict__ out_hi,
+                                                                    long long ld_hi) {
+    extern __shared__ __attribute__((aligned(16))) float vlds[];
+    __shared__ float keep[kMaxS];
+    const int e = blockIdx.x;
+    if (e >= *vg.n_entries) return;
+    const int g = view_group_of(vg, e);
+    const int e0 = vg.e0[g], k = vg.e0[g + 1] - e0;
+    const uint32_t* ky = vg.keys + 4 * g;
+    rows_views_cm_body(src, ld_src, src_mid, e - e0, (size_t)vg.src_row[e], blockIdx.y * kViewCh, k, C, S, gamma, ky[0], ky[1], ky[2],
+                       ky[3], vg.keep_sum[g], out_cm, ld_cm, cm_mid, out_hi, ld_hi, 2 * e0, vlds, keep);
 }
 
 ODW_EXPORT int odw_rows_views_cm(const void* src_cm, int64_t ld_src, int64_t src_mid, const int* rows, int row_base, int k, int C,
@@ -538,7 +632,7 @@ ODW_EXPORT int odw_l2norm_rows(const float* x, int R, int D, float eps, float* y
     ODW_REQUIRE(R >= 0 && D >= 1, "l2norm_rows: bad dims R=%d D=%d", R, D);
     if (R == 0) return ODW_OK;
     ODW_REQUIRE(x && y && norm, "l2norm_rows: null pointer");
-    l2norm_rows_kernel<false><<<(R + 3) / 4, 256, 0, (hipStream_t)stream_>>>(x, nullptr, nullptr, R, D, eps, y, norm);
+    l2norm_rows_kernel<false><<<(R + 3) / 4, 256, 0, (hipStream_t)stream_>>>(x, nullptr, nullptr, R, D, eps, y, norm, nullptr);
     ODW_CHECK_LAUNCH("l2norm_rows_kernel");
     return ODW_OK;
 }
@@ -548,7 +642,85 @@ ODW_EXPORT int odw_l2norm_rows_bwd(const float* g, const float* y, const float* 
     ODW_REQUIRE(R >= 0 && D >= 1, "l2norm_rows_bwd: bad dims R=%d D=%d", R, D);
     if (R == 0) return ODW_OK;
     ODW_REQUIRE(g && y && norm && dx, "l2norm_rows_bwd: null pointer");
-    l2norm_rows_kernel<true><<<(R + 3) / 4, 256, 0, (hipStream_t)stream_>>>(g, y, norm, R, D, eps, dx, nullptr);
+    l2norm_rows_kernel<true><<<(R + 3) / 4, 256, 0, (hipStream_t)stream_>>>(g, y, norm, R, D, eps, dx, nullptr, nullptr);
     ODW_CHECK_LAUNCH("l2norm_rows_kernel");
+    return ODW_OK;
+}
+
+// ---- device-resident forms (round 6; see the grouped kernels above) ------------------------------------------------------
+ODW_EXPORT int odw_l2norm_rows_dyn(const float* x, int R_cap, int D, float eps, float* y, float* norm, const int* r_dev,
+                                   void* stream_) {
+    ODW_REQUIRE(R_cap >= 0 && D >= 1 && r_dev, "l2norm_rows_dyn: bad arguments R_cap=%d D=%d", R_cap, D);
+    if (R_cap == 0) return ODW_OK;
+    ODW_REQUIRE(x && y && norm, "l2norm_rows_dyn: null pointer");
+    l2norm_rows_kernel<false><<<(R_cap + 3) / 4, 256, 0, (hipStream_t)stream_>>>(x, nullptr, nullptr, R_cap, D, eps, y, norm, r_dev);
+    ODW_CHECK_LAUNCH("l2norm_rows_kernel");
+    return ODW_OK;
+}
+
+ODW_EXPORT int odw_l2norm_rows_bwd_dyn(const float* g, const float* y, const float* norm, int R_cap, int D, float eps, float* dx,
+                                       const int* r_dev, void* stream_) {
+    ODW_REQUIRE(R_cap >= 0 && D >= 1 && r_dev, "l2norm_rows_bwd_dyn: bad arguments R_cap=%d D=%d", R_cap, D);
+    if (R_cap == 0) return ODW_OK;
+    ODW_REQUIRE(g && y && norm && dx, "l2norm_rows_bwd_dyn: null pointer");
+    l2norm_rows_kernel<true><<<(R_cap + 3) / 4, 256, 0, (hipStream_t)stream_>>>(g, y, norm, R_cap, D, eps, dx, nullptr, r_dev);
+    ODW_CHECK_LAUNCH("l2norm_rows_kernel");
+    return ODW_OK;
+}
+
+static bool view_groups_ok(int G, int E_cap, const int* n_entries, const int* e0, const uint32_t* keys, const int* src_row,
+                           const float* keep_sum) {
+    return G >= 1 && E_cap >= 1 && n_entries && e0 && keys && keep_sum && src_row;
+}
+
+// The drop view and the noise view of EVERY sampled row of the step (loss.py:292-305) as the operand of the first head
+// Linear, one launch: odw_rows_views_cm with the groups' sizes on the device.  e0 (G + 1 entry prefix), n_entries, src_row
+// come from odw_loss_lists_a; keys (G x 4: kd0 kd1 kn0 kn1) from the host; keep_sum (G floats) is written here.
+// E_cap = the most entries that can exist (the launch covers them; rows [2 *n_entries, 2 E_cap) of the outputs stay unwritten).
+ODW_EXPORT int odw_rows_views_cm_grouped(const void* src_cm, int64_t ld_src, int64_t src_mid, int G, int E_cap,
+                                         const int* n_entries, const int* e0, const uint32_t* keys, const int* src_row, int C,
+                                         int S, float gamma, float* keep_sum, void* out_cm, int64_t ld_cm, int64_t cm_mid,
+                                         void* out_hi, int64_t ld_hi, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(C > 0 && C % kViewCh == 0 && S >= 4 && S <= kMaxS, "rows_views_cm_grouped: bad dims (C=%d a multiple of 64, S=%d)", C, S);
+    ODW_REQUIRE(view_groups_ok(G, E_cap, n_entries, e0, keys, src_row, keep_sum) && src_cm && out_cm && out_hi,
+                "rows_views_cm_grouped: bad arguments (G=%d, E_cap=%d)", G, E_cap);
+    const long long cs = (long long)C * S;
+    ODW_REQUIRE(src_mid >= cs && ld_src >= src_mid + cs && cm_mid >= cs && ld_cm >= cm_mid + cs && ld_hi >= cs && ld_src % 8 == 0 &&
+                src_mid % 8 == 0 && ld_cm % 8 == 0 && cm_mid % 8 == 0 && ld_hi % 4 == 0 && (long long)E_cap * cs < (1ll << 32),
+                "rows_views_cm_grouped: planes [hi | mid] of %lld elements must fit the rows", cs);
+    ODW_REQUIRE((((uintptr_t)src_cm) & 15) == 0 && (((uintptr_t)out_cm) & 15) == 0 && (((uintptr_t)out_hi) & 7) == 0,
+                "rows_views_cm_grouped: alignment");
+    ViewGroups vg;
+    vg.n_entries = n_entries; vg.e0 = e0; vg.keys = keys; vg.src_row = src_row; vg.keep_sum = keep_sum; vg.G = G;
+    rows_keep_sum_grouped_kernel<<<G, 256, 0, stream>>>(vg, S, gamma, keep_sum);
+    const size_t lds = (size_t)3 * kViewCh * S * sizeof(float);
+    ODW_REQUIRE(lds + kMaxS * sizeof(float) <= (size_t)ODW_LDS_BYTES, "rows_views_cm_grouped: S=%d cells per ROI need %zu bytes of LDS", S, lds);
+    ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(rows_views_cm_grouped_kernel), (int)lds), "rows_views_cm_grouped attr");
+    rows_views_cm_grouped_kernel<<<dim3(E_cap, C / kViewCh), 256, lds, stream>>>(
+        (const unsigned short*)src_cm, ld_src, src_mid, vg, C, S, gamma, (unsigned short*)out_cm, ld_cm, cm_mid,
+        (unsigned short*)out_hi, ld_hi);
+    ODW_CHECK_LAUNCH("rows_views_cm_grouped_kernel");
+    return ODW_OK;
+}
+
+// Backward of the grouped views into the pooling node's side buffer (one fp32 row of C*S per entry): entry e's gradient =
+// the fold of its drop-view row and its noise-view row of dX, STORED at row *dst_off + e of `extra` (dst_off null = 0).
+ODW_EXPORT int odw_rows_views_bwd_store_grouped(const void* dX, int dx_is_f32, int ld, int G, int E_cap, const int* n_entries,
+                                                const int* e0, const uint32_t* keys, const float* keep_sum, int C, int S,
+                                                float gamma, const int* dst_off, float* extra, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    ODW_REQUIRE(C > 0 && S >= 4 && S <= kMaxS && G >= 1 && E_cap >= 1 && n_entries && e0 && keys && keep_sum && dX && extra,
+                "rows_views_bwd_store_grouped: bad arguments");
+    const long cs = (long)C * S;
+    ODW_REQUIRE(cs % 4 == 0 && ld >= cs && ld % 4 == 0, "rows_views_bwd_store_grouped: C*S=%ld, ld=%d", cs, ld);
+    ODW_REQUIRE((((uintptr_t)dX) & 15) == 0 && (((uintptr_t)extra) & 15) == 0, "rows_views_bwd_store_grouped: alignment");
+    ViewGroups vg;
+    vg.n_entries = n_entries; vg.e0 = e0; vg.keys = keys; vg.src_row = nullptr; vg.keep_sum = keep_sum; vg.G = G;
+    if (dx_is_f32)
+        rows_views_bwd_store_grouped_kernel<true><<<dim3(E_cap, kRowSlices), 256, 0, stream>>>(dX, ld, vg, (int)cs, S, gamma, dst_off, extra);
+    else
+        rows_views_bwd_store_grouped_kernel<false><<<dim3(E_cap, kRowSlices), 256, 0, stream>>>(dX, ld, vg, (int)cs, S, gamma, dst_off, extra);
+    ODW_CHECK_LAUNCH("rows_views_bwd_store_grouped_kernel");
     return ODW_OK;
 }

@@ -18,8 +18,11 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 
 // max |x| as the bit pattern of a non-negative float (bit patterns of non-negative floats order like the values;
 // NaN sorts above inf).  out must be zeroed before the launch.  BF16: x holds bf16 values (n of them, n % 8 == 0).
+// rows_dev (optional): x holds rows of row_elems values and only the first *rows_dev of them exist (a device-resident count).
 template <bool BF16>
-__global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ xv, size_t n, unsigned* __restrict__ out) {
+__global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ xv, size_t n, unsigned* __restrict__ out,
+                                                     const int* __restrict__ rows_dev = nullptr, size_t row_elems = 0) {
+    if (rows_dev) { const size_t live = (size_t)(*rows_dev > 0 ? *rows_dev : 0) * row_elems; n = live < n ? live : n; }
     unsigned m = 0;
     if (BF16) {
         const uint4* x = reinterpret_cast<const uint4*>(xv);

@@ -486,8 +486,9 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_pool_stack_bwd_plane_fx(
     const void* __restrict__ dXv, int ld, const unsigned short* __restrict__ argmax, const float* __restrict__ rois,
     const float* __restrict__ keep, const float* __restrict__ keep_sum, const float* __restrict__ extra,
     const int* __restrict__ extra_roi, int E, int skip_clean, const unsigned* __restrict__ absmax_bits, int C, int H,
-    int W, int R, int nb, float* __restrict__ grad_in) {
+    int W, int R, int nb, float* __restrict__ grad_in, const int* __restrict__ e_dev) {
     extern __shared__ __attribute__((aligned(16))) long long iacc[];
+    if (e_dev) { const int ed = *e_dev; E = ed < E ? (ed > 0 ? ed : 0) : E; }      // side-buffer entries that exist (device-resident count)
     // workgroup i runs on XCD i % 8: hand each XCD a CONTIGUOUS range of planes -- neighbouring planes read the two
     // halves of the same 128-byte lines of dX / argmax (49 x 2 bytes per ROI and plane), which then meet in one L2
     int plane = blockIdx.x;
@@ -1238,11 +1239,39 @@ ODW_EXPORT int odw_roi_pool_stack_backward(const void* dX, int dx_is_f32, int ld
                                           B, C, H, W, R, PH, PW, grad_in, nullptr, 0, stream_);
 }
 
+static int roi_pool_stack_backward_launch(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
+                                          const float* rois, const float* keep, const float* keep_sum,
+                                          const float* extra, const int* extra_roi, int E, int skip_clean, int B, int C,
+                                          int H, int W, int R, int PH, int PW, float* grad_in, void* workspace,
+                                          int64_t workspace_bytes, void* stream_, const int* e_dev);
+
 ODW_EXPORT int odw_roi_pool_stack_backward_ws(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
                                               const float* rois, const float* keep, const float* keep_sum,
                                               const float* extra, const int* extra_roi, int E, int skip_clean, int B, int C,
                                               int H, int W, int R, int PH, int PW, float* grad_in, void* workspace,
                                               int64_t workspace_bytes, void* stream_) {
+    return roi_pool_stack_backward_launch(dX, dx_is_f32, ld, argmax_u16, rois, keep, keep_sum, extra, extra_roi, E, skip_clean, B, C,
+                                          H, W, R, PH, PW, grad_in, workspace, workspace_bytes, stream_, nullptr);
+}
+
+// The same backward with the number of side-buffer entries on the device (round 6: the sampled rows and the re-attached
+// clean rows of the contrastive loss are counted by loss_lists.hip): E_cap entries of `extra` / `extra_roi` exist as memory,
+// the first *e_dev are scattered.  Needs the fixed-point form (a 4-byte workspace).
+ODW_EXPORT int odw_roi_pool_stack_backward_dyn(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
+                                               const float* rois, const float* keep, const float* keep_sum,
+                                               const float* extra, const int* extra_roi, int E_cap, const int* e_dev,
+                                               int skip_clean, int B, int C, int H, int W, int R, int PH, int PW,
+                                               float* grad_in, void* workspace, int64_t workspace_bytes, void* stream_) {
+    ODW_REQUIRE(e_dev && E_cap >= 1 && extra && extra_roi, "roi_pool_stack_backward_dyn: the side buffer and its device-resident count");
+    return roi_pool_stack_backward_launch(dX, dx_is_f32, ld, argmax_u16, rois, keep, keep_sum, extra, extra_roi, E_cap, skip_clean, B,
+                                          C, H, W, R, PH, PW, grad_in, workspace, workspace_bytes, stream_, e_dev);
+}
+
+static int roi_pool_stack_backward_launch(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
+                                          const float* rois, const float* keep, const float* keep_sum,
+                                          const float* extra, const int* extra_roi, int E, int skip_clean, int B, int C,
+                                          int H, int W, int R, int PH, int PW, float* grad_in, void* workspace,
+                                          int64_t workspace_bytes, void* stream_, const int* e_dev) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(B >= 1 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 1 && E >= 0,
                 "roi_pool_stack_backward: bad dims");
@@ -1263,23 +1292,24 @@ ODW_EXPORT int odw_roi_pool_stack_backward_ws(const void* dX, int dx_is_f32, int
         const size_t n = (size_t)(skip_clean ? R : 2 * R) * ld;
         if (dx_is_f32) odwfx::absmax_kernel<false><<<1024, 256, 0, stream>>>(first, n, mx);
         else odwfx::absmax_kernel<true><<<1024, 256, 0, stream>>>(first, n, mx);
-        if (E > 0) odwfx::absmax_kernel<false><<<256, 256, 0, stream>>>(extra, (size_t)E * C * nb, mx);
+        if (E > 0) odwfx::absmax_kernel<false><<<256, 256, 0, stream>>>(extra, (size_t)E * C * nb, mx, e_dev, (size_t)C * nb);
         ODW_CHECK_LAUNCH("absmax_kernel");
         const size_t lds8 = (size_t)HW * 8;
         if (dx_is_f32) {
             ODW_CHECK_HIP(allow_lds(roi_pool_stack_bwd_plane_fx<true>, lds8), "roi_pool_stack_bwd_plane_fx attr");
             roi_pool_stack_bwd_plane_fx<true><<<B * C, kPlaneThreads, lds8, stream>>>(
                 dX, ld, (const unsigned short*)argmax_u16, rois, keep, keep_sum, extra, extra_roi, E, skip_clean, mx, C, H, W, R,
-                nb, grad_in);
+                nb, grad_in, e_dev);
         } else {
             ODW_CHECK_HIP(allow_lds(roi_pool_stack_bwd_plane_fx<false>, lds8), "roi_pool_stack_bwd_plane_fx attr");
             roi_pool_stack_bwd_plane_fx<false><<<B * C, kPlaneThreads, lds8, stream>>>(
                 dX, ld, (const unsigned short*)argmax_u16, rois, keep, keep_sum, extra, extra_roi, E, skip_clean, mx, C, H, W, R,
-                nb, grad_in);
+                nb, grad_in, e_dev);
         }
         ODW_CHECK_LAUNCH("roi_pool_stack_bwd_plane_fx");
         return ODW_OK;
     }
+    ODW_REQUIRE(!e_dev, "roi_pool_stack_backward_dyn: the fixed-point form does not apply (workspace, alignment or plane size)");
     const int cg = ((int64_t)2 * HW * 4 <= ODW_LDS_BYTES && (int64_t)B * ((C + 1) / 2) >= 2 * ODW_NUM_CU) ? 2 : 1;
     const int grid = B * ((C + cg - 1) / cg);
     const size_t lds = (size_t)cg * HW * 4;

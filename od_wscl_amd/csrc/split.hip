@@ -57,7 +57,8 @@ __device__ __forceinline__ float finite_or_zero(float x, float r) {      // inf 
 // The pattern is wave-uniform, so picking a plane is a scalar branch.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ in, long long ld_in, int R, int Cc,
                                                          Pattern pat, unsigned short* __restrict__ out,
-                                                         long long ld_out, int block) {
+                                                         long long ld_out, int block, const int* __restrict__ r_dev) {
+    if (r_dev) { const int rd = *r_dev; R = rd < R ? rd : R; }      // rows that exist (device-resident count; R = the capacity)
     const unsigned chunks = (unsigned)block / 4u;
     const unsigned total = (unsigned)R * chunks;
     bool need_lo = false;
@@ -225,8 +226,23 @@ __global__ __launch_bounds__(512) void split_rows_cm_kernel(const float* __restr
 
 }  // namespace
 
+static int split_rows_launch(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
+                             int64_t ld_out, int block, void* stream_, const int* r_dev);
+
 ODW_EXPORT int odw_split_rows_bf16(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
                                    int64_t ld_out, int block, void* stream_) {
+    return split_rows_launch(in, ld_in, R, Cc, pattern, T, out, ld_out, block, stream_, nullptr);
+}
+
+// the same with the number of rows on the device (R_cap bounds the launch; rows >= *r_dev are neither read nor written)
+ODW_EXPORT int odw_split_rows_bf16_dyn(const float* in, int64_t ld_in, int R_cap, int Cc, const int* pattern, int T, void* out,
+                                       int64_t ld_out, int block, const int* r_dev, void* stream_) {
+    ODW_REQUIRE(r_dev, "split_rows_dyn: r_dev is null");
+    return split_rows_launch(in, ld_in, R_cap, Cc, pattern, T, out, ld_out, block, stream_, r_dev);
+}
+
+static int split_rows_launch(const float* in, int64_t ld_in, int R, int Cc, const int* pattern, int T, void* out,
+                             int64_t ld_out, int block, void* stream_, const int* r_dev) {
     Pattern pat;
     ODW_REQUIRE(pattern_ok(pattern, T, pat), "split_rows: pattern = up to %d plane codes in 0..3", kMaxTerms);
     ODW_REQUIRE(R >= 0 && Cc >= 0 && ld_in >= Cc && block >= Cc && block % 8 == 0 && ld_out >= (int64_t)T * block && ld_out % 8 == 0,
@@ -237,7 +253,7 @@ ODW_EXPORT int odw_split_rows_bf16(const float* in, int64_t ld_in, int R, int Cc
     ODW_REQUIRE(total < (1ll << 31), "split_rows: R * block / 4 must stay below 2^31");
     const long long blocks = (total + 255) / 256;
     split_rows_kernel<<<(int)(blocks > 65536 ? 65536 : blocks), 256, 0, (hipStream_t)stream_>>>(
-        in, ld_in, R, Cc, pat, (unsigned short*)out, ld_out, block);
+        in, ld_in, R, Cc, pat, (unsigned short*)out, ld_out, block, r_dev);
     ODW_CHECK_LAUNCH("split_rows_kernel");
     return ODW_OK;
 }

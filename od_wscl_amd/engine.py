@@ -28,6 +28,7 @@ from . import synthetic
 from .layers import linear as linear_layer
 from .modeling.detector import build_detection_model
 from .utils.kernel_timer import kernel_timer  # noqa: F401  (re-exported for bench.py)
+from .utils.step_trace import step_trace
 
 
 def load_formula_weights(model, seed, overrides=None):
@@ -657,6 +658,7 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         k = (iteration - 1) % iter_size if iteration is not None else micro[0] % iter_size
         micro[0] += 1
         last = k == iter_size - 1
+        sched_before = (opt.sched_steps, opt.lr_scale)
         if iteration is not None and k == 0:        # WarmupMultiStepLR + update_momentum (lr_scheduler.py, trainer.py:38-51)
             opt.sched_steps += 1
             opt.set_iteration(opt.sched_steps)
@@ -667,9 +669,11 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         hip = getattr(model, "backbone_hip", None)
         if hip is not None:
             hip.accumulate = accumulate
+        step_trace.mark("begin_step")
         try:
             losses, accs = model(images, targets, rois, rand=rand)
             mark("forward")
+            step_trace.mark("loss_tail")
             finish = getattr(losses, "finish_backward", None)
             if finish is not None:          # the dense losses' backward already ran inside the loss (early_backward)
                 finish()
@@ -682,22 +686,36 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
             # A step that dies mid-way (out of memory, the > 2048 pseudo-GT error of the fused loss after its early backward
             # has already written gradients) must not leave a half-built sum behind: a caller that skips the batch or retries
             # (engine/trainer.py:80-82 skips bad batches) would otherwise ADD its next backward to the partial gradients.
-            # An ITER_SIZE == 1 step starts fresh again; inside a group the sum so far is lost with the failed micro-step,
-            # so the group restarts.
+            # An ITER_SIZE == 1 step starts fresh again.  Inside a SOLVER.ITER_SIZE group the sum so far is dropped with the
+            # failed micro-step; the optimiser still steps at the group's last INDEX (the position is a function of the
+            # iteration number, like the reference's trainer.py:86,118), over the micro-steps that follow the failure.
+            # With the early update on (head_grads_ready), the head's SGD pass of a step that fails AFTER the pooling node's
+            # backward has already been applied; a failure before that point (the fused loss, the head's backward) has not.
             opt.grads_clean = True
             opt.hold = False
             for sh in opt.shadows:
                 b = getattr(sh, "batch", None)
                 if b is not None:
                     b.reset()
+            # the feature extractor's parked gradients belong to the failed step too: the next forward must not find them
+            # ("the gradient of the previous step's sampled-row views was never folded")
+            holder = getattr(fe, "_grad_holder", None)
+            if holder is not None:
+                holder.pending, holder.dyn_extra = [], None
+                fe._grad_holder = None
+            # the scheduler step taken for this (failed) iteration (a momentum rescale at a learning-rate jump, trainer.py:38-51,
+            # is not undone: it belongs to the schedule position the retried iteration reaches again)
+            opt.sched_steps, opt.lr_scale = sched_before
             raise
         mark("backward")
+        step_trace.mark("backward_launch")
         if last:
             opt.all_reduce()
             opt.step()
         else:
             opt.flush_wgrad()
         mark("optimizer")
+        step_trace.mark("optimizer_launch")
         if "loss" in debug:
             print("[odw] losses", {k: round(float(v), 5) for k, v in losses.items()}, flush=True)
         return losses, accs

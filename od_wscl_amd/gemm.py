@@ -12,6 +12,7 @@ import torch
 from . import _lib as L
 from . import precision as P
 from .utils.kernel_timer import kernel_timer
+from .utils.step_trace import step_trace
 
 
 MAX_SEGS = 8      # dropout row segments one GEMM launch carries keys for (kMaxSeg in csrc/gemm_bf16.hip)
@@ -53,6 +54,7 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     key = (M, N, K, a.stride(0), b.stride(0), out.stride(0), out_bf16, out.data_ptr() & 15)
     plan = _PLAN_CACHE.get(key)
     if plan is None:
+        step_trace.count("gemm_plan_miss")
         var = ctypes.c_int(0)
         ws_bytes = L.lib().odw_gemm_nt_bf16_workspace(M, N, K, a.stride(0), b.stride(0), out_ptr, out.stride(0),
                                                       1 if out_bf16 else 0, ctypes.byref(var))
@@ -233,6 +235,10 @@ class WgradBatch(object):
     # few hundred).  Beyond the reserve the buffers are re-allocated and the filled blocks copied.
     reserve = 0
     split = False     # this layer's backward runs on split planes although the process-wide mode's does not (Shadow.bwd2)
+    # dyn.Dyn: the LENGTH of the reduction lives on the device (round 6, weak_head/loss_device.py): blocks registered by
+    # CAPACITY whose live widths only the GPU knows are packed behind one another at device-side offsets; the GEMM then
+    # runs over [0, *dyn_k.t) of the sum(rows) columns that exist
+    dyn_k = None
 
     def __init__(self):
         self.rows, self.filled, self.dzt, self.xt, self.kpad, self.done = [], 0, None, None, 0, []
@@ -244,6 +250,7 @@ class WgradBatch(object):
             self.done.append(False)
             need = sum(self.rows)
             if need > self.dzt.shape[1]:
+                step_trace.count("wgrad_batch_regrow")
                 old = need - self.rows[-1]
                 dzt = torch.empty((self.dzt.shape[0], need + self.reserve), dtype=torch.bfloat16, device=self.dzt.device)
                 xt = torch.empty((self.xt.shape[0], need + self.reserve), dtype=torch.bfloat16, device=self.xt.device)
@@ -267,6 +274,7 @@ class WgradBatch(object):
 
     def reset(self):
         self.rows, self.filled, self.dzt, self.xt, self.kpad, self.done = [], 0, None, None, 0, []
+        self.dyn_k = None
 
     def flush(self, weight, tag=None):
         """Run the GEMM over whatever was filled (blocks of evaluations whose backward never ran are zeroed)."""
@@ -291,14 +299,23 @@ class WgradBatch(object):
         ready = getattr(weight, "_odw_grad_ready", None)
         rows = int(getattr(weight, "_odw_slice_rows", 0)) if ready is not None else 0
         tp = len(P.patterns("gemm")[0]) if (P.bwd_split() or self.split) else 1
+        if self.dyn_k is not None:          # the reduction's live length is a device value (blocks packed at device offsets)
+            from . import dyn as _dyn
+
+            def product(a, m_rows, out):
+                _dyn.gemm_nt(a, self.xt, m_rows, k_in, self.kpad, out, accumulate=not fresh, k=self.dyn_k, planes=tp,
+                             tag=tag and tag + "_wgrad")
+        else:
+            def product(a, m_rows, out):
+                gemm_nt(a, self.xt, m_rows, k_in, self.kpad, out, accumulate=not fresh, planes=tp)
         if rows <= 0 or rows >= n_out:
-            gemm_nt(self.dzt, self.xt, n_out, k_in, self.kpad, weight.grad, accumulate=not fresh, planes=tp)
+            product(self.dzt, n_out, weight.grad)
             if ready is not None:
                 ready(weight, 0, n_out)
         else:
             for r0 in range(0, n_out, rows):
                 r1 = min(n_out, r0 + rows)
-                gemm_nt(self.dzt[r0:r1], self.xt, r1 - r0, k_in, self.kpad, weight.grad[r0:r1], accumulate=not fresh, planes=tp)
+                product(self.dzt[r0:r1], r1 - r0, weight.grad[r0:r1])
                 ready(weight, r0, r1)
         kernel_timer.layer = None
         self.reset()

@@ -65,6 +65,9 @@ class _GradHolder(object):
         # kind "extra": there is no pooled tensor (ROI pooling writes the stacked operand itself) -- folds fill an
         #               (E, C*h*w) fp32 side buffer, one row per sampled entry, roi_index[e] = the ROI it belongs to
         self.kind, self.pending, self.done, self.roi_index = kind, [], False, None
+        # (extra buffer (E_cap, C*h*w) fp32, entry -> ROI list, E_cap, dyn.Dyn of the live entry count): the side buffer as the
+        # device-resident contrastive branch leaves it (weak_head/loss_device.py) -- filled, its length on the device
+        self.dyn_extra = None
         self.grad_out = None        # where the pooling node writes d(feature map) (a HIP-graphed body: its static input buffer)
         self.clean_rows = None      # _PoolStack: number of leading rows of dX whose gradient is meaningful (None = all)
 
@@ -248,6 +251,9 @@ class _PoolStack(torch.autograd.Function):
         dx = dx if dx.stride(1) == 1 else dx.contiguous()
         holder = ctx.holder
         extra, roi_index, E = None, None, 0
+        dyn_extra = getattr(holder, "dyn_extra", None) if holder is not None else None
+        if dyn_extra is not None and holder.pending:
+            raise RuntimeError("_PoolStack: both a device-resident side buffer and parked host-shaped folds")
         if holder is not None and holder.pending:
             roi_index = holder.roi_index
             if isinstance(roi_index, (list, tuple)):
@@ -268,6 +274,17 @@ class _PoolStack(torch.autograd.Function):
         ws = torch.empty(64, dtype=torch.uint8, device=dx.device)       # the launch's fixed-point scale (odw_fixed.h)
         K = C * ph * pw
         nbytes = float((R if skip_clean else 2 * R) * K * dx.element_size() + R * K * 2 + E * K * 4 + B * C * H * W * 4)
+        if dyn_extra is not None:
+            extra, roi_index, e_cap, e_dyn = dyn_extra
+            holder.dyn_extra = None
+            nbytes += float(e_dyn.hint * K * 4)
+            with kernel_timer.region("roi_pool_stack_backward", nbytes=nbytes, alg=float(2 * R * K * 4 + B * C * H * W * 4)):
+                L.check(L.lib().odw_roi_pool_stack_backward_dyn(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
+                                                                L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
+                                                                L.ptr(extra), L.ptr(roi_index), e_cap, L.ptr(e_dyn.t), skip_clean,
+                                                                B, C, H, W, R, ph, pw, L.ptr(dfeat), L.ptr(ws), 64, L.stream()),
+                        "roi_pool_stack_backward_dyn")
+            return dfeat, None, None, None, None, None, None, None, None
         with kernel_timer.region("roi_pool_stack_backward", nbytes=nbytes, alg=float(2 * R * K * 4 + B * C * H * W * 4)):
             L.check(L.lib().odw_roi_pool_stack_backward_ws(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
                                                            L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),

@@ -68,6 +68,7 @@ class RoIRegLossComputation(object):
             raise ValueError("only loss='supconv2' is functional in the reference (SURVEY.md item 5)")
         self.sim_loss = SupConLossV2(self.temp)
         self.trace = None       # set to a dict to record the selected index sets (tests)
+        self.max_sampled_rows = int(getattr(getattr(cfg, "ODW", None), "MAX_SAMPLED_ROWS", 4096))
 
     def __call__(self, class_score, det_score, ref_scores, ref_bbox_preds, sim_feature, clean_pooled_feats,
                  feature_extractor, model_sim, proposals, targets, epsilon=1e-8):

@@ -23,6 +23,7 @@ from .... import _lib as L
 from ....layers import smooth_l1_loss
 from ... import registry
 from ..sim_head.sim_loss import SupConLossV2
+from ....utils.step_trace import step_trace
 from .loss import RoIRegLossComputation
 
 
@@ -71,6 +72,10 @@ class _Staging(object):
         self.host_np = self.host.numpy()
         self.dev = torch.zeros((self.slots, width), dtype=torch.int32, device=self.device)
         self.width = width
+        # one event per slot, recorded behind the slot's copy: the host may only rewrite the pinned slot once that copy has
+        # run.  (Rounds 2-5 blocked on the GPU twice per step and could never be a ring ahead; with the device-resident
+        # lists the host runs steps ahead of the GPU, and this wait is the back-pressure that bounds how far.)
+        self.copied = [None] * self.slots
 
     def upload(self, arrays):
         """arrays: list of 1-D integer numpy arrays / lists -> list of int32 device views (one H2D copy)."""
@@ -79,9 +84,12 @@ class _Staging(object):
             # a larger batch (the reference's IMS_PER_BATCH 8 on one GPU stages ~70 k indices): grow once.  Copies still
             # in flight out of the old pinned ring keep it alive through the stream's references; a sync keeps it simple.
             torch.cuda.current_stream().synchronize()
+            step_trace.count("staging_grow")
             self._allocate(1 << (need - 1).bit_length())
         k = self.slot
         self.slot = (self.slot + 1) % self.slots
+        if self.copied[k] is not None:
+            self.copied[k].synchronize()        # (returns at once unless the host is a whole ring of uploads ahead)
         pos, views = 0, []
         for a in arrays:
             n = len(a)
@@ -89,6 +97,10 @@ class _Staging(object):
             views.append((pos, n))
             pos += n
         self.dev[k, :pos].copy_(self.host[k, :pos], non_blocking=True)
+        ev = self.copied[k]
+        if ev is None:
+            ev = self.copied[k] = torch.cuda.Event()
+        ev.record()
         return [self.dev[k, o:o + n] for o, n in views]
 
 
@@ -109,6 +121,7 @@ class _AsyncRead(object):
         st["k"] = (k + 1) % len(st["bufs"])
         buf = st["bufs"][k]
         if buf is None or buf.numel() < n or buf.dtype != src.dtype:
+            step_trace.count("pinned_ring_alloc")
             buf = st["bufs"][k] = torch.empty(max(n, 1 << 14), dtype=src.dtype).pin_memory()
         main = torch.cuda.current_stream(dev)
         ready = torch.cuda.Event()
@@ -224,6 +237,7 @@ class RoIRegLossFused(RoIRegLossComputation):
                                  clean_pooled_feats, feature_extractor, model_sim, proposals, targets, epsilon)
         lib = L.lib()
         sizes = [len(p) for p in proposals]
+        step_trace.mark("forward_launch")
         n_img, sum_p, max_p = len(sizes), sum(sizes), max(sizes)
         device = class_score[0].device
         rand = feature_extractor.rand
@@ -303,10 +317,17 @@ class RoIRegLossFused(RoIRegLossComputation):
                                      L.ptr(img_off), n_img, max_p, L.ptr(pos_cls), L.ptr(n_pos), maxpos,
                                      float(self.p_thres), L.ptr(tops), L.ptr(masks), L.ptr(rows), max_p,
                                      L.ptr(counts), L.stream()), "discover_iou")
+        if self._device_lists_ok(feature_extractor, clean_pooled_feats, ybase, model_sim, sim_feature, sum_p):
+            # ---- round 6: the rest of the loss with its control flow ON THE DEVICE -- no host read, no host-built list
+            return self._call_device(lib, device, feature_extractor, model_sim, sim_feature, clean_pooled_feats, sizes, offs,
+                                     pos_host, C, n_img, sum_p, max_p, maxpos, counts, rows, tops, masks, srcs, boxes_all, img_off,
+                                     pos_cls, n_pos, ybase, final_score, colstat, lab_vecs, dense_ws, ws_bytes, epsilon, tr)
         read_a = _AsyncRead(state_a[:n_cnt + n_rows])                         # host read 1 (side stream)
         if callable(sim_feature):
             sim_feature = sim_feature()          # Sim_Net over the clean pass: queued behind discover_iou, runs under the read
+        step_trace.mark("loss_a_launch")
         host_a = read_a.wait()
+        step_trace.mark("wait_read_a")
         counts_h = host_a[:n_cnt].reshape(n_img, maxpos)
         rows_h = host_a[n_cnt:].reshape(n_img, maxpos, max_p)
 
@@ -337,6 +358,8 @@ class RoIRegLossFused(RoIRegLossComputation):
         bank_off, bank_cnt, bank_index_all, roi_index = self._staging.upload(
             [bank_off_h, bank_cnt_h, np.concatenate([bank_index_h[c] for c in classes]),
              np.concatenate([m[5] + offs[m[0]] for m in meta]) if meta else []])
+        step_trace.mark("numpy_a")
+        step_trace.note("sampled_rows", int(sum(m[3] for m in meta)))
         views = feature_extractor.sampled_row_views(clean_pooled_feats, groups, roi_index)
         if views is not None:       # production path: gather + both views + bf16 cast = two launches per class
             x, segs6, segs7 = views
@@ -393,75 +416,14 @@ class RoIRegLossFused(RoIRegLossComputation):
                                      L.ptr(gt_idx), L.ptr(gt_cls), L.ptr(gt_score), L.ptr(gt_cnt), L.stream()),
                 "discover_sim")
         read_b = _AsyncRead(state_b[:n_back])                                  # host read 2 (side stream)
-        # ---- pseudo labels of the three branches (od_layer tail, fused kernel) and the dense losses: everything they
-        # need is on the device (the pseudo-GT counts included), so they are queued BEFORE the host waits for the
-        # discovery lists and run while it assembles the SupCon gather indices
-        pseudo_all = torch.empty((3, sum_p), dtype=torch.int64, device=device)
-        weight_all = torch.empty((3, sum_p), dtype=torch.float32, device=device)
-        target_all = torch.empty((3, sum_p, 4), dtype=torch.float32, device=device)
-        wts = self.od_layer.weights
-        for idx in range(n_img):
-            sl = slice(offs[idx], offs[idx + 1])
-            bx = boxes_all[sl]
-            for i in range(n_ref):
-                # pseudo-GT boxes are gathered inside the kernel from their int32 proposal indices
-                L.check(lib.odw_od_assign_indexed_dev(L.ptr(bx), bx.shape[0], L.ptr(gt_idx[idx, i]), L.ptr(gt_cls[idx, i]),
-                                                      L.ptr(gt_score[idx, i]), L.ptr(gt_cnt[idx, i]), maxpos * max_p,
-                                                      float(self.od_layer.fg_thresh), float(wts[0]), float(wts[1]),
-                                                      float(wts[2]), float(wts[3]), L.ptr(pseudo_all[i, sl]),
-                                                      L.ptr(weight_all[i, sl]), L.ptr(target_all[i, sl]), L.stream()),
-                        "od_assign_indexed")
-        dense = None
-        early = None
-        if ybase is not None and not self.cls_agnostic_bbox_reg:
-            # ---- MIL + refinement losses and their gradient in ONE launch (csrc/refine_loss.hip)
-            import ctypes
-            out = torch.empty((n_img, 16), dtype=torch.float32, device=device)
-            dy = torch.empty_like(ybase)
-            L.check(lib.odw_refine_losses(L.ptr(ybase), ybase.shape[1], ctypes.cast(self._heads, ctypes.c_void_p), C,
-                                          L.ptr(img_off), n_img, sum_p, max_p, L.ptr(final_score), L.ptr(colstat),
-                                          L.ptr(lab_vecs), L.ptr(pseudo_all), L.ptr(weight_all), L.ptr(target_all),
-                                          L.ptr(n_pos), float(epsilon), L.ptr(out), L.ptr(dy), L.ptr(dense_ws), ws_bytes,
-                                          L.stream()), "refine_losses")
-            tot = out.sum(dim=0)
-            col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
-            dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
-            if (self.early_backward and torch.is_grad_enabled() and clean_pooled_feats.dim() == 2
-                    and clean_pooled_feats.requires_grad and clean_pooled_feats.grad_fn is not None
-                    and getattr(feature_extractor, "sparse_clean", False)):     # (only then does no other loss reach these nodes)
-                # ---- the backward of the seven dense losses NOW: predictor, the DropBlock half of the stacked fc7 /
-                # fc6 pass (input and weight gradients: ~1.5 ms of large GEMMs at P = 2000) down to the gradient of the
-                # stacked operand.  Nothing on that path depends on the discovery lists, so it is queued before the host
-                # waits for them: the GPU works through it while the host reads the lists, assembles the SupCon gather
-                # indices and issues the ~150 small launches of the contrastive loss and of its backward -- the stretch
-                # of the step in which the GPU used to idle for ~1 ms waiting for launches (profiles/r03/hip_v2_gaps.csv).
-                # The rest of the backward (finish_backward) starts from loss_sim AND from this gradient.
-                # (leaf tensors on the way whose gradient autograd itself delivers -- the Linear layers write theirs in
-                # place -- are asked for too and accumulated by hand: e.g. the eight predictor heads behind a torch.cat
-                # when the optimiser does not lay them out as one matrix)
-                dsum = dense.sum()
-                leaves = _leaves_between(dsum.grad_fn, clean_pooled_feats.grad_fn)
-                # the one product of this stretch whose result nobody reads before the pooling node at the very end --
-                # fc6's input gradient, 0.3 ms -- is handed back and launched in finish_backward, right before the late
-                # backward starts: the host then issues the contrastive loss's ~100 small backward launches under it
-                from .... import gemm as _gemm
-                # (OFF by default: 9.08-10.5 / 9.16-9.63 / 9.22-9.39 ms for late / mid / off over four alternating runs each --
-                # no gain outside the run-to-run noise; ODW_DEFER_DGRAD=late|mid switches it on)
-                _gemm.deferred_dgrad = [] if _os2.environ.get("ODW_DEFER_DGRAD") in ("late", "mid") else None
-                _gemm.deferred_weight = feature_extractor.fc6.weight       # the layer that reads the stacked operand
-                try:
-                    grads = torch.autograd.grad(dsum, [clean_pooled_feats] + leaves, allow_unused=True)
-                finally:
-                    deferred, _gemm.deferred_dgrad, _gemm.deferred_weight = _gemm.deferred_dgrad, None, None
-                for leaf, gl in zip(leaves, grads[1:]):
-                    if gl is not None:
-                        if leaf.grad is None:
-                            leaf.grad = gl.detach().clone()
-                        else:
-                            leaf.grad.add_(gl)
-                early = (clean_pooled_feats, grads[0], deferred or [])
-                dense = dense.detach()
+        step_trace.mark("views_launch")
+        dense, early, tot, pseudo_all, weight_all, target_all = self._pseudo_and_dense(
+            lib, device, n_img, sum_p, max_p, maxpos, offs, boxes_all, gt_idx, gt_cls, gt_score, gt_cnt, ybase, C, img_off,
+            final_score, colstat if ybase is not None else None, lab_vecs, n_pos, epsilon,
+            dense_ws if ybase is not None else None, ws_bytes if ybase is not None else 0, clean_pooled_feats, feature_extractor)
+        step_trace.mark("dense_early_bwd_launch")
         host_b = read_b.wait()
+        step_trace.mark("wait_read_b")
         if early is not None and early[2] and _os2.environ.get("ODW_DEFER_DGRAD") == "mid":
             # the GPU has drained the early backward by now and the host is about to spend ~0.3 ms assembling index lists and
             # issuing the contrastive loss's small forward launches: the handed-back input-gradient GEMM goes here
@@ -539,7 +501,10 @@ class RoIRegLossFused(RoIRegLossComputation):
             tr["supcon_weights"] = weights.clone()
             tr["supcon_n"] = int(weights.numel())
         from ..sim_head.sim_loss import _SupConV2Fn
+        step_trace.mark("numpy_b_and_clean_rows_launch")
+        step_trace.note("supcon_n", int(labels.numel()))
         loss_sim = self.sim_lmda * _SupConV2Fn.apply(features, labels, weights, self.temp)
+        step_trace.mark("supcon_launch")
 
         if int(gt_h.max()) > 2048:
             raise RuntimeError("RoIRegLossFused: %d pseudo-GT boxes in one branch (od_assign holds 2048)" % int(gt_h.max()))
@@ -606,6 +571,184 @@ class RoIRegLossFused(RoIRegLossComputation):
         for k in accs:
             accs[k] = accs[k] / n_img
         return losses, accs
+
+    # ODW.MAX_SAMPLED_ROWS: capacity, per image, of the IoU-sampled rows of a step on the device-resident path (the views'
+    # operand is allocated for twice that many rows of 150 KB); a step that needs more raises one or two steps later
+    max_sampled_rows = 4096
+
+    def _device_lists_ok(self, fe, stacked, ybase, model_sim, sim_feature, sum_p):
+        """The device-resident path applies: precision "bf16x2f" with the pooling kernel writing fc6's operand as planes (the
+        views are read from the clean rows' cell-major planes), row-sparse clean backward with the stacked pass's outputs
+        kept, the fused predictor (one score matrix), a counter-based random source.  ODW_HOST_LISTS=1 forces the host-list
+        path of rounds 2-5 (tests compare the two)."""
+        from .... import precision
+        if _os2.environ.get("ODW_HOST_LISTS") == "1" or precision.get_precision() != "bf16x2f":
+            return False
+        if ybase is None or self.cls_agnostic_bbox_reg or not callable(sim_feature) or stacked.dim() != 2:
+            return False
+        if getattr(stacked, "_odw_planes", None) is None or getattr(stacked, "_odw_planes_cm", None) is None:
+            return False
+        if getattr(stacked, "_odw_pooled32", None) is not None:          # (ODW_VIEWS_F32=1: the views read the fp32 pooled copy)
+            return False
+        if not getattr(fe, "sparse_clean", False) or getattr(fe, "_clean_acts", None) is None or fe._grad_holder is None:
+            return False
+        if fe._grad_holder.kind != "extra" or not hasattr(fe.rand, "key") or fe.sim_drop.block_size != 1:
+            return False
+        if _os2.environ.get("ODW_RECOMPUTE_CLEAN") == "1" or sum_p > 262144:
+            return False
+        return True
+
+    def _call_device(self, lib, device, fe, model_sim, sim_feature, stacked, sizes, offs, pos_host, C, n_img, sum_p, max_p, maxpos,
+                     counts, rows, tops, masks, srcs, boxes_all, img_off, pos_cls, n_pos, ybase, final_score, colstat, lab_vecs,
+                     dense_ws, ws_bytes, epsilon, tr):
+        from .loss_device import DeviceContrastive, HintReader
+        step_trace.mark("loss_a_launch")
+        hints = getattr(self, "_hints", None)
+        if hints is None or hints.device != device:
+            hints = self._hints = HintReader(device)
+        branch = DeviceContrastive(self, fe, model_sim, stacked, sizes, offs, pos_host, C, device, self._staging, hints)
+        E = sim_feature()                       # Sim_Net over the clean pass (no autograd; its two Linear outputs are kept)
+        E = E.detach().contiguous()
+        bank, bank_off, bank_cnt = branch.build(counts, rows, E)
+        step_trace.mark("views_launch")
+        # ---- kernel B: object discovery + pseudo-GT lists (as the host-list path)
+        shp = (n_img, 3, maxpos)
+        nf = n_img * 3 * maxpos
+        n_gt = n_img * 3 * maxpos * max_p
+        state_b = torch.zeros(2 * nf + n_img * 3 + 2 * nf * max_p + 2 * n_gt, dtype=torch.int32, device=device)
+        o = 0
+        fresh_cnt = state_b[o:o + nf].view(shp); o += nf
+        gt_cnt = state_b[o:o + n_img * 3].view(n_img, 3); o += n_img * 3
+        inst_cnt = state_b[o:o + nf].view(shp); o += nf
+        fresh_idx = state_b[o:o + nf * max_p].view(shp + (max_p,)); o += nf * max_p
+        inst_idx = state_b[o:o + nf * max_p].view(shp + (max_p,)); o += nf * max_p
+        gt_idx = state_b[o:o + n_gt].view(n_img, 3, maxpos * max_p); o += n_gt
+        gt_cls = state_b[o:o + n_gt].view(n_img, 3, maxpos * max_p); o += n_gt
+        gt_score = torch.zeros((n_img, 3, maxpos * max_p), dtype=torch.float32, device=device)
+        L.check(lib.odw_discover_sim(L.ptr(E), L.ptr(srcs[0]), L.ptr(srcs[1]), L.ptr(srcs[2]), C, L.ptr(boxes_all),
+                                     L.ptr(img_off), n_img, max_p, L.ptr(pos_cls), L.ptr(n_pos), maxpos, L.ptr(tops),
+                                     L.ptr(masks), L.ptr(bank), L.ptr(bank_off), L.ptr(bank_cnt), float(self.nms),
+                                     max_p, L.ptr(inst_idx), L.ptr(inst_cnt), L.ptr(fresh_idx), L.ptr(fresh_cnt),
+                                     L.ptr(gt_idx), L.ptr(gt_cls), L.ptr(gt_score), L.ptr(gt_cnt), L.stream()),
+                "discover_sim")
+        # ---- lists B + SupCon (a handful of small launches), then the dense losses and -- early_backward -- their backward
+        colstat_flat = colstat.view(-1)
+        raw = branch.finish(fresh_idx, fresh_cnt, gt_cnt, final_score, colstat_flat, colstat.shape[1] * colstat.shape[2],
+                            2 * colstat.shape[2], img_off, n_pos, pos_cls, self.temp)
+        loss_sim = self.sim_lmda * raw
+        step_trace.mark("supcon_launch")
+        dense, early, tot, pseudo_all, weight_all, target_all = self._pseudo_and_dense(
+            lib, device, n_img, sum_p, max_p, maxpos, offs, boxes_all, gt_idx, gt_cls, gt_score, gt_cnt, ybase, C, img_off,
+            final_score, colstat, lab_vecs, n_pos, epsilon, dense_ws, ws_bytes, stacked, fe)
+        step_trace.mark("dense_early_bwd_launch")
+        if tr is not None:
+            branch.fill_trace(tr, rows, counts, inst_idx, inst_cnt, fresh_idx, fresh_cnt)
+            for idx in range(n_img):
+                sl = slice(offs[idx], offs[idx + 1])
+                for i in range(3):
+                    tr["pseudo_%d_%d" % (idx, i)] = pseudo_all[i, sl].clone()
+                    tr["weights_%d_%d" % (idx, i)] = weight_all[i, sl].clone()
+            tr["dense_loss_kernel"] = True
+            tr["device_lists"] = True
+        return self._loss_dict(dense, early, tot, loss_sim)
+
+    @staticmethod
+    def _loss_dict(dense, early, tot, loss_sim):
+        names = ["loss_img", "loss_ref_cls0", "loss_ref_reg0", "loss_ref_cls1", "loss_ref_reg1", "loss_ref_cls2",
+                 "loss_ref_reg2"]
+        if early is not None:
+            loss_sim = _InjectGrad.apply(loss_sim, early[0], early[1], early[2])
+        losses = LossDict({"loss_img": dense[0], "loss_sim": loss_sim})
+        for k in range(1, 7):
+            losses[names[k]] = dense[k]
+        losses.total = dense.sum() + loss_sim
+        if early is not None:
+            def finish_backward(loss_sim=loss_sim, pending=early[2]):
+                while pending:
+                    pending.pop(0)()            # the deferred input-gradient GEMM(s): queued first, cover the launches below
+                loss_sim.backward()
+            losses.finish_backward = finish_backward
+        accs = {"acc_img": tot[7], "acc_ref0": tot[8], "acc_ref1": tot[9], "acc_ref2": tot[10]}
+        return losses, accs
+
+    def _pseudo_and_dense(self, lib, device, n_img, sum_p, max_p, maxpos, offs, boxes_all, gt_idx, gt_cls, gt_score, gt_cnt,
+                          ybase, C, img_off, final_score, colstat, lab_vecs, n_pos, epsilon, dense_ws, ws_bytes,
+                          clean_pooled_feats, feature_extractor):
+        """od_layer's tail (three branches) + MIL / refinement losses with their gradient in one launch + -- early_backward --
+        the backward of those seven losses down to the stacked fc6 operand, queued at once.  Everything they read is on the
+        device.  Returns (dense loss vector or None, early = (operand, its gradient, deferred launches) or None, tot, pseudo,
+        weights)."""
+        n_ref = 3
+        # ---- pseudo labels of the three branches (od_layer tail, fused kernel) and the dense losses: everything they
+        # need is on the device (the pseudo-GT counts included), so they are queued BEFORE the host waits for the
+        # discovery lists and run while it assembles the SupCon gather indices
+        pseudo_all = torch.empty((3, sum_p), dtype=torch.int64, device=device)
+        weight_all = torch.empty((3, sum_p), dtype=torch.float32, device=device)
+        target_all = torch.empty((3, sum_p, 4), dtype=torch.float32, device=device)
+        wts = self.od_layer.weights
+        for idx in range(n_img):
+            sl = slice(offs[idx], offs[idx + 1])
+            bx = boxes_all[sl]
+            for i in range(n_ref):
+                # pseudo-GT boxes are gathered inside the kernel from their int32 proposal indices
+                L.check(lib.odw_od_assign_indexed_dev(L.ptr(bx), bx.shape[0], L.ptr(gt_idx[idx, i]), L.ptr(gt_cls[idx, i]),
+                                                      L.ptr(gt_score[idx, i]), L.ptr(gt_cnt[idx, i]), maxpos * max_p,
+                                                      float(self.od_layer.fg_thresh), float(wts[0]), float(wts[1]),
+                                                      float(wts[2]), float(wts[3]), L.ptr(pseudo_all[i, sl]),
+                                                      L.ptr(weight_all[i, sl]), L.ptr(target_all[i, sl]), L.stream()),
+                        "od_assign_indexed")
+        dense = None
+        early = None
+        tot = None
+        if ybase is not None and not self.cls_agnostic_bbox_reg:
+            # ---- MIL + refinement losses and their gradient in ONE launch (csrc/refine_loss.hip)
+            import ctypes
+            out = torch.empty((n_img, 16), dtype=torch.float32, device=device)
+            dy = torch.empty_like(ybase)
+            L.check(lib.odw_refine_losses(L.ptr(ybase), ybase.shape[1], ctypes.cast(self._heads, ctypes.c_void_p), C,
+                                          L.ptr(img_off), n_img, sum_p, max_p, L.ptr(final_score), L.ptr(colstat),
+                                          L.ptr(lab_vecs), L.ptr(pseudo_all), L.ptr(weight_all), L.ptr(target_all),
+                                          L.ptr(n_pos), float(epsilon), L.ptr(out), L.ptr(dy), L.ptr(dense_ws), ws_bytes,
+                                          L.stream()), "refine_losses")
+            tot = out.sum(dim=0)
+            col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
+            dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
+            if (self.early_backward and torch.is_grad_enabled() and clean_pooled_feats.dim() == 2
+                    and clean_pooled_feats.requires_grad and clean_pooled_feats.grad_fn is not None
+                    and getattr(feature_extractor, "sparse_clean", False)):     # (only then does no other loss reach these nodes)
+                # ---- the backward of the seven dense losses NOW: predictor, the DropBlock half of the stacked fc7 /
+                # fc6 pass (input and weight gradients: ~1.5 ms of large GEMMs at P = 2000) down to the gradient of the
+                # stacked operand.  Nothing on that path depends on the discovery lists, so it is queued before the host
+                # waits for them: the GPU works through it while the host reads the lists, assembles the SupCon gather
+                # indices and issues the ~150 small launches of the contrastive loss and of its backward -- the stretch
+                # of the step in which the GPU used to idle for ~1 ms waiting for launches (profiles/r03/hip_v2_gaps.csv).
+                # The rest of the backward (finish_backward) starts from loss_sim AND from this gradient.
+                # (leaf tensors on the way whose gradient autograd itself delivers -- the Linear layers write theirs in
+                # place -- are asked for too and accumulated by hand: e.g. the eight predictor heads behind a torch.cat
+                # when the optimiser does not lay them out as one matrix)
+                dsum = dense.sum()
+                leaves = _leaves_between(dsum.grad_fn, clean_pooled_feats.grad_fn)
+                # the one product of this stretch whose result nobody reads before the pooling node at the very end --
+                # fc6's input gradient, 0.3 ms -- is handed back and launched in finish_backward, right before the late
+                # backward starts: the host then issues the contrastive loss's ~100 small backward launches under it
+                from .... import gemm as _gemm
+                # (OFF by default: 9.08-10.5 / 9.16-9.63 / 9.22-9.39 ms for late / mid / off over four alternating runs each --
+                # no gain outside the run-to-run noise; ODW_DEFER_DGRAD=late|mid switches it on)
+                _gemm.deferred_dgrad = [] if _os2.environ.get("ODW_DEFER_DGRAD") in ("late", "mid") else None
+                _gemm.deferred_weight = feature_extractor.fc6.weight       # the layer that reads the stacked operand
+                try:
+                    grads = torch.autograd.grad(dsum, [clean_pooled_feats] + leaves, allow_unused=True)
+                finally:
+                    deferred, _gemm.deferred_dgrad, _gemm.deferred_weight = _gemm.deferred_dgrad, None, None
+                for leaf, gl in zip(leaves, grads[1:]):
+                    if gl is not None:
+                        if leaf.grad is None:
+                            leaf.grad = gl.detach().clone()
+                        else:
+                            leaf.grad.add_(gl)
+                early = (clean_pooled_feats, grads[0], deferred or [])
+                dense = dense.detach()
+        return dense, early, (tot if dense is not None else None), pseudo_all, weight_all, target_all
 
     _col2loss_cache = {}
 

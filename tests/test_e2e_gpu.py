@@ -639,3 +639,47 @@ def test_iter_size_follows_the_reference_when_batches_are_skipped(monkeypatch):
     assert step.optimizer.grads_clean and step.optimizer.sched_steps == 2
     close(step.optimizer.flat_m, g[1] + g[3] + g[4], "batches 1 + 3 + 4")
     assert torch.equal(step.optimizer.flat_p, p0)     # lr 0
+
+
+@pytest.mark.parametrize("exact_hints", [True, False])
+@pytest.mark.parametrize("name", ["e2e_voc_2img", "e2e_voc_1img", "e2e_coco_2img"])
+def test_device_resident_lists_equal_the_host_assembled_lists(name, exact_hints, monkeypatch):
+    """Round 6: the contrastive branch with its control flow on the device (csrc/loss_lists.hip, weak_head/loss_device.py:
+    no host read inside the step) against the host-list path of rounds 2-5 (ODW_HOST_LISTS=1: two blocking reads, numpy
+    assembly) on the same goldens: the same losses, the same selections, the same SupCon inputs.
+    exact_hints: the device path plans its GEMMs for the live extents (read back: a test hook) -- then EVERY weight gradient
+    is the host-list path's bit for bit (bias gradients are atomic column sums: 1e-6).  Without it the plans are made for
+    bucketed hints: a differently split product re-associates its fp32 sums (1e-7), and the single-plane bf16 backward
+    turns any such perturbation into rounding flips that saturate at bf16's resolution within a few layers (relative L2
+    sqrt(delta * 2^-8) per layer: the backbone's deepest layers end up 1-3e-3 apart, the noise floor of this mode against
+    the fp32 oracle, MIXED_GRAD_TOL); the head's gradients, one rounding from the top, stay within 1e-3."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.modeling.roi_heads.weak_head import loss_device
+    monkeypatch.delenv("ODW_HOST_LISTS", raising=False)
+    monkeypatch.setattr(loss_device, "_EXACT", exact_hints)
+    l_dev, t_dev, m_dev, g = _run_golden(name, "bf16x2f")
+    assert t_dev.get("device_lists"), "the device-resident path was not taken in bf16x2f"
+    grads_dev = {n: p.grad.detach().clone() for n, p in m_dev.named_parameters() if p.grad is not None}
+    del m_dev
+    monkeypatch.setenv("ODW_HOST_LISTS", "1")
+    l_host, t_host, m_host, _ = _run_golden(name, "bf16x2f")
+    assert not t_host.get("device_lists")
+    for k in l_host:
+        a, b = float(l_dev[k].detach()), float(l_host[k].detach())
+        assert abs(a - b) <= (0.0 if exact_hints else 2e-6 * max(abs(b), 1e-6)), (k, a, b)
+    assert t_dev["supcon_n"] == t_host["supcon_n"]
+    for k in t_host:
+        if k.startswith(("pseudo_", "pgt_instance_", "sim_new_", "iou_samples_")):
+            assert torch.equal(t_dev[k].cpu(), t_host[k].cpu()), k
+    assert torch.equal(t_dev["supcon_weights"].cpu(), t_host["supcon_weights"].cpu())
+    for n, p in m_host.named_parameters():
+        if p.grad is None:
+            assert n not in grads_dev, n
+            continue
+        ref = p.grad.double()
+        err = (grads_dev[n].double() - ref).norm().item() / max(ref.norm().item(), 1e-12)
+        if exact_hints:
+            assert torch.equal(grads_dev[n], p.grad) if not n.endswith("bias") else err <= 1e-6, (n, err)
+        else:
+            assert err <= (MIXED_GRAD_TOL if n.startswith("backbone") else 1e-3) or ref.norm().item() < 1e-7, (n, err)
