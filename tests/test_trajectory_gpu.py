@@ -20,7 +20,8 @@ against itself; what CAN be asserted is that the product is no further from the 
   * CONTROL: a second oracle started 2^-22 away runs beside the first (same inputs, same draws);
   * while the product's selections equal the oracle's (the first ~10 steps) the 8 losses agree within LOSS_TOL = 1 %
     (measured <= 3e-3 before the first differing step);
-  * the product's selections agree with the oracle's for the first FIRST_DIV_SLACK steps at least, and the distance between
+  * the product's selections are the oracle's in the first step (identical weights) and, in the next FIRST_DIV_SLACK - 1,
+    differ at most by near-threshold flips the margin-gated replay accepts (round 6; was: identical), and the distance between
     the weight trajectories |w_product - w_oracle| / |w_oracle - w_0| is at most 1.5 x the control's (measured: 6.2e-2 vs
     6.8e-2 at lr 1e-5, 3.3e-2 vs 4.0e-2 at lr 5e-6; 7.3e-2 vs 5.0e-2 at the end of round 5) -- the single-plane bf16
     backward's 0.5 % gradient error adds nothing measurable to what fp32 rounding already does to this run;
@@ -304,7 +305,15 @@ def _run(bench, H, engine, synthetic, BoxList, to_image_list, DeviceRand, dev):
     # (WHEN a near-tie first flips is itself noise -- at lr 5e-6 the product's first differing step was 2 and the control's 3,
     # at lr 1e-5 11 and 13 -- so the first differing step is only required not to be the very first steps: from identical
     # weights the selections must be identical, which is what the e2e and timed-step tests assert one step at a time)
-    assert first >= FIRST_DIV_SLACK, ("selections differed in step %d already" % (first + 1), diverged_steps)
+    # (round 6: the device-resident loss lists plan the contrastive branch's GEMMs for bucketed hints -- a re-association of
+    # 1e-7 -- and the near-tie that had flipped in step 11 flipped in step 2; the selections of steps 3-10 were the oracle's again.
+    # So: the FIRST step, taken from identical weights, must select identically; a differing step among the next few must be one
+    # the margin-gated replay classifies -- decision by decision, from the product's own weights -- as near-threshold flips
+    # with an exact downstream, never a wrong or an undecidable one.)
+    assert first >= 1, ("selections differed in the very first step (identical weights)", diverged_steps)
+    early = [s for s in diverged_steps if s < FIRST_DIV_SLACK]
+    assert all(s in tf_diverged and s not in tf_unusable and all(s + 1 != w[0] for w in tf_wrong) for s in early), \
+        ("an early step's selections differ beyond what the oracle's margins allow", early, tf_diverged, tf_unusable, tf_wrong)
     # (HOW MANY steps differ is decided by when the first near-tie flips -- after it the two runs are different samples of a chaotic
     # system.  The same code parted from the oracle in step 11 and, after a change of 2^-17 in the contrastive views' inputs, in
     # step 5: the count is not a property of the arithmetic.  What IS one: every single step of the product's run, taken from the
