@@ -622,11 +622,11 @@ int odw_loss_lists_b(const int* grp, const int* cls_order, int G, const int* img
                      int cs_off, int n_cap, int a_cap, int e_cap, int p64, int* scal, int* feat_index, int* labels, float* weights,
                      int* act_rows, int* roi_index_all, void* stream);
 /* out[r] = index[r] < split ? t0[index[r]] : t1[index[r] - split], r < *n_dev (fp32 rows of D values); and its transpose
- * d0 / d1 += scale * g (fp32 atomics; scale = a device scalar or NULL). */
+ * d0 / d1 += (*scale) * alpha * g (fp32 atomics; scale = a device scalar or NULL = 1). */
 int odw_gather_rows2_dyn(const float* t0, const float* t1, int split, const int* index, const int* n_dev, int n_cap, int D,
                          float* out, void* stream);
 int odw_scatter_rows2_dyn(const float* g, const int* index, const int* n_dev, int n_cap, int D, int split, const float* scale,
-                          float* d0, float* d1, void* stream);
+                          float alpha, float* d0, float* d1, void* stream);
 /* out[r][0 : row_bytes) = src[index[r]][0 : row_bytes), r < *n_dev; rows [0, *n_dev) of p zeroed (byte counts % 16 == 0). */
 int odw_gather_rows_dyn(const void* src, int64_t ld_src_bytes, const int* index, const int* n_dev, int n_cap, int64_t row_bytes,
                         void* out, int64_t ld_out_bytes, void* stream);

@@ -159,7 +159,7 @@ SIGNATURES = {
     "odw_loss_lists_b": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i,
                                c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "odw_gather_rows2_dyn": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
-    "odw_scatter_rows2_dyn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "odw_scatter_rows2_dyn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p]),
     "odw_gather_rows_dyn": (c_i, [c_p, c_l, c_p, c_p, c_i, c_l, c_p, c_l, c_p]),
     "odw_zero_rows_dyn": (c_i, [c_p, c_l, c_l, c_p, c_i, c_p]),
     "odw_gemm_nt_bf16_dyn_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),

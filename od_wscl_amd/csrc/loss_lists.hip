@@ -249,10 +249,10 @@ __global__ __launch_bounds__(256) void gather_rows2_kernel(const float* __restri
 // referenced by at most a handful of features; `scale` = a device scalar, e.g. the incoming gradient of the loss)
 __global__ __launch_bounds__(256) void scatter_rows2_kernel(const float* __restrict__ g, const int* __restrict__ index,
                                                             const int* __restrict__ n_dev, int n_cap, int D, int split,
-                                                            const float* __restrict__ scale, float* __restrict__ d0,
-                                                            float* __restrict__ d1) {
+                                                            const float* __restrict__ scale, float alpha,
+                                                            float* __restrict__ d0, float* __restrict__ d1) {
     const int n = *n_dev < n_cap ? *n_dev : n_cap;
-    const float sc = scale ? *scale : 1.0f;
+    const float sc = (scale ? *scale : 1.0f) * alpha;
     const long long total = (long long)n * D;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / D), d = (int)(i - (long long)r * D);
@@ -347,9 +347,9 @@ ODW_EXPORT int odw_gather_rows2_dyn(const float* t0, const float* t1, int split,
 }
 
 ODW_EXPORT int odw_scatter_rows2_dyn(const float* g, const int* index, const int* n_dev, int n_cap, int D, int split,
-                                     const float* scale, float* d0, float* d1, void* stream_) {
+                                     const float* scale, float alpha, float* d0, float* d1, void* stream_) {
     ODW_REQUIRE(n_cap >= 1 && D >= 1 && g && index && n_dev && d0 && d1, "scatter_rows2_dyn: bad arguments");
-    scatter_rows2_kernel<<<grid_for((long long)n_cap * D), 256, 0, (hipStream_t)stream_>>>(g, index, n_dev, n_cap, D, split, scale, d0, d1);
+    scatter_rows2_kernel<<<grid_for((long long)n_cap * D), 256, 0, (hipStream_t)stream_>>>(g, index, n_dev, n_cap, D, split, scale, alpha, d0, d1);
     ODW_CHECK_LAUNCH("scatter_rows2_kernel");
     return ODW_OK;
 }

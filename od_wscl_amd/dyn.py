@@ -164,9 +164,9 @@ def gather_rows2(t0, t1, split, index, n, out=None):
     return out
 
 
-def scatter_rows2(g, index, n, split, d0, d1, scale=None):
-    L.check(L.lib().odw_scatter_rows2_dyn(L.ptr(g), L.ptr(index), L.ptr(n.t), n.cap, g.shape[1], int(split), L.ptr(scale), L.ptr(d0),
-                                          L.ptr(d1), L.stream()), "scatter_rows2_dyn")
+def scatter_rows2(g, index, n, split, d0, d1, scale=None, alpha=1.0):
+    L.check(L.lib().odw_scatter_rows2_dyn(L.ptr(g), L.ptr(index), L.ptr(n.t), n.cap, g.shape[1], int(split), L.ptr(scale), float(alpha),
+                                          L.ptr(d0), L.ptr(d1), L.stream()), "scatter_rows2_dyn")
 
 
 def gather_rows(src, index, n, out=None):

@@ -53,7 +53,7 @@ class HintReader(object):
         self.k = 0
         self.hints = {}
 
-    def post(self, scal_a, scal_b, caps):
+    def post(self, scal_a, scal_b, caps, key=None):
         k = self.k
         self.k = (k + 1) % len(self.slots)
         slot = self.slots[k]
@@ -71,11 +71,12 @@ class HintReader(object):
             ev.record(self.stream)
         scal_a.record_stream(self.stream)
         scal_b.record_stream(self.stream)
-        slot["ev"], slot["caps"], slot["seen"] = ev, caps, False
+        slot["ev"], slot["caps"], slot["seen"], slot["key"] = ev, caps, False, key
 
-    def poll(self):
+    def poll(self, key=None):
         """Take over whatever has arrived; raise on an overflow (loud, one or two steps late: the step that overflowed
-        computed on truncated lists)."""
+        computed on truncated lists).  Hints are kept per `key` -- the number of (image, class) groups of the step, which the
+        host knows and which the extents scale with (an image with three labels samples ~3 x the rows of one with one)."""
         for slot in self.slots:
             if slot is None or slot["ev"] is None or slot.get("seen") or not slot["ev"].query():
                 continue
@@ -87,8 +88,13 @@ class HintReader(object):
                                    % (v[0], v[16], v[17], slot["caps"]))
             if v[16 + 9]:
                 raise RuntimeError("RoIRegLossFused: more than %d pseudo-GT boxes in one branch (od_assign's limit)" % GT_MAX)
-            self.hints = {"E1": int(v[0]), "V": int(v[1]), "N": int(v[16]), "A": int(v[17])}
-        return self.hints
+            self.hints[slot.get("key")] = {"E1": int(v[0]), "V": int(v[1]), "N": int(v[16]), "A": int(v[17])}
+        h = self.hints.get(key)
+        if h is None and self.hints:          # no step with this many groups yet: scale the nearest one's
+            k0 = min(self.hints, key=lambda k: abs((k or 1) - (key or 1)))
+            f = float(key or 1) / float(k0 or 1)
+            h = {n: int(v * f) for n, v in self.hints[k0].items()}
+        return h or {}
 
 
 def _bucket(n, step=128):
@@ -116,7 +122,7 @@ class DeviceContrastive(object):
         self.V_cap = 2 * self.E_cap
         self.A_cap = r64up(min(self.sum_p, self.E_cap + 3 * self.G * self.max_p))
         self.N_cap = 3 * self.E_cap + min(3 * self.G * self.max_p, 4 * cfg_cap)
-        h = hints.poll()
+        h = hints.poll(self.G)
         self.h_E1 = min(self.E_cap, _bucket(h.get("E1", 256), 64))
         self.h_V = min(self.V_cap, _bucket(h.get("V", 512)))
         self.h_A = min(self.A_cap, _bucket(h.get("A", 512)))
@@ -226,8 +232,8 @@ class DeviceContrastive(object):
         return self.bank, self.bank_off, self.bank_cnt
 
     # ------------------------------------------------------------------------------------------------- forward, part 2
-    def finish(self, fresh_idx, fresh_cnt, gt_cnt, final_score, colstat_flat, cs_ld, cs_off, img_off, n_pos, pos_cls, temp):
-        """lists B -> the re-attached clean rows' embeddings -> SupCon.  Returns the loss (autograd-connected)."""
+    def finish(self, fresh_idx, fresh_cnt, gt_cnt, final_score, colstat_flat, cs_ld, cs_off, img_off, n_pos, pos_cls, temp, lmda=1.0):
+        """lists B -> the re-attached clean rows' embeddings -> SupCon.  Returns lmda x the loss (autograd-connected)."""
         lib, dev = L.lib(), self.device
         G, E_cap, A_cap, N_cap = self.G, self.E_cap, self.A_cap, self.N_cap
         # column offset of the views' block in the weight-gradient batches of fc6 / fc7 (behind the stacked pass's static block)
@@ -261,7 +267,7 @@ class DeviceContrastive(object):
         self.dA = dyn.Dyn(self.scal_b[1:2], A_cap, self.h_A)
         self.dE = dyn.Dyn(self.scal_b[2:3], A_cap + E_cap, self.h_A + self.h_E1)
         self.dA64 = dyn.Dyn(self.scal_b[8:9], A_cap, r64up(self.h_A))
-        self.hints.post(self.scal_a, self.scal_b, (E_cap, N_cap, A_cap))
+        self.hints.post(self.scal_a, self.scal_b, (E_cap, N_cap, A_cap), key=self.G)
         # ---- embeddings of the clean rows the loss references: their Sim_Net outputs exist (the no-autograd evaluation over
         # all proposals kept them); only the normalisation is redone (Sim_Net.forward's reuse branch)
         kept = self.model_sim.kept
@@ -271,7 +277,22 @@ class DeviceContrastive(object):
         loss, self.dF = dyn.supcon(features, self.labels, self.weights, temp, self.dN)
         _dbg("supcon", loss=loss)
         step_trace.note("device_lists", True)
+        self.lmda = float(lmda)
+        self.loss = loss
         return _ContrastiveFn.apply(self.stacked, self.fe.fc6.weight, loss, self)
+
+    def backward_now(self):
+        """The branch's backward queued at once, with the unit weight of the reference's plain sum of losses
+        (engine/trainer.py:102) -- what loss_fused's early backward does for the dense losses.  Everything the branch's
+        gradients depend on exists as soon as SupCon has run; queued here, ahead of the dense losses' backward, the views'
+        and the re-attached rows' column blocks of the weight-gradient batches are in place when the stacked pass's block
+        arrives, so fc6's 411 MB gradient is final -- and, at N > 1 ranks, on the wire -- ~1 ms earlier than when this ran
+        behind it.  The autograd node then has nothing left to do."""
+        one = _ONE.get(str(self.device))
+        if one is None:
+            one = _ONE[str(self.device)] = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.backward(one)
+        self.done = True
 
     # ------------------------------------------------------------------------------------------------------- backward
     def backward(self, g):
@@ -286,7 +307,7 @@ class DeviceContrastive(object):
         # ---- d(features) scattered to its two sources
         d_act = dyn.zero_rows(torch.empty((A_cap, 128), dtype=torch.float32, device=dev), self.dA)
         d_emb = dyn.zero_rows(torch.empty((V_cap, 128), dtype=torch.float32, device=dev), self.dV)
-        dyn.scatter_rows2(self.dF, self.feat_index, self.dN, A_cap, d_act, d_emb, scale=g.reshape(1).float())
+        dyn.scatter_rows2(self.dF, self.feat_index, self.dN, A_cap, d_act, d_emb, scale=g.reshape(1), alpha=self.lmda)
         holder = fe._grad_holder
         if holder is None or holder.kind != "extra" or holder.done:
             raise RuntimeError("DeviceContrastive.backward: the pooling node's side buffer is gone (its backward already ran)")
@@ -396,6 +417,9 @@ class DeviceContrastive(object):
         tr["supcon_n"] = n
 
 
+_ONE = {}
+
+
 def r64up(n):
     return (int(n) + 63) // 64 * 64
 
@@ -408,10 +432,11 @@ class _ContrastiveFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, stacked, w6, loss, branch):
         ctx.branch = branch
-        return loss.reshape(()).clone()
+        return loss.reshape(()) * branch.lmda           # (sim_lmda x SupCon, loss.py:347; backward scales by the same)
 
     @staticmethod
     def backward(ctx, g):
         b, ctx.branch = ctx.branch, None
-        b.backward(g)
+        if not getattr(b, "done", False):       # (backward_now already ran it with the unit weight)
+            b.backward(g)
         return None, None, None, None

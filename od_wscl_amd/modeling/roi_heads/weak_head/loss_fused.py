@@ -159,8 +159,21 @@ def _fused_base(tensors):
 class LossDict(dict):
     """The loss dictionary of the reference plus `total`: the same sum, taken once over the kernel's loss vector
     (sum(losses.values()) is 7 add kernels forward and 21 fill/copy/add kernels backward in the part of the step
-    where the GPU waits for every launch)."""
-    total = None
+    where the GPU waits for every launch).  `total` is built when asked for (the training step finishes its backward through
+    finish_backward and never asks)."""
+    _total = None
+    _total_parts = None
+
+    @property
+    def total(self):
+        if self._total is None and self._total_parts is not None:
+            dense, loss_sim = self._total_parts
+            self._total = dense.sum() + loss_sim
+        return self._total
+
+    @total.setter
+    def total(self, value):
+        self._total = value
     # set by RoIRegLossFused.early_backward: the dense losses' backward has ALREADY run down to the stacked fc6 operand;
     # finish_backward() runs the rest (contrastive loss, ROI pooling, body).  engine.build_training_step calls it
     # instead of total.backward().
@@ -634,8 +647,11 @@ class RoIRegLossFused(RoIRegLossComputation):
         # ---- lists B + SupCon (a handful of small launches), then the dense losses and -- early_backward -- their backward
         colstat_flat = colstat.view(-1)
         raw = branch.finish(fresh_idx, fresh_cnt, gt_cnt, final_score, colstat_flat, colstat.shape[1] * colstat.shape[2],
-                            2 * colstat.shape[2], img_off, n_pos, pos_cls, self.temp)
-        loss_sim = self.sim_lmda * raw
+                            2 * colstat.shape[2], img_off, n_pos, pos_cls, self.temp, lmda=self.sim_lmda)
+        loss_sim = raw
+        if (self.early_backward and torch.is_grad_enabled() and stacked.requires_grad and stacked.grad_fn is not None
+                and _os2.environ.get("ODW_NO_EAGER_CONTRA") != "1"):
+            branch.backward_now()       # (see DeviceContrastive.backward_now: the whole head backward is queued in forward order)
         step_trace.mark("supcon_launch")
         dense, early, tot, pseudo_all, weight_all, target_all = self._pseudo_and_dense(
             lib, device, n_img, sum_p, max_p, maxpos, offs, boxes_all, gt_idx, gt_cls, gt_score, gt_cnt, ybase, C, img_off,
@@ -661,7 +677,7 @@ class RoIRegLossFused(RoIRegLossComputation):
         losses = LossDict({"loss_img": dense[0], "loss_sim": loss_sim})
         for k in range(1, 7):
             losses[names[k]] = dense[k]
-        losses.total = dense.sum() + loss_sim
+        losses._total_parts = (dense, loss_sim)
         if early is not None:
             def finish_backward(loss_sim=loss_sim, pending=early[2]):
                 while pending:
@@ -710,12 +726,17 @@ class RoIRegLossFused(RoIRegLossComputation):
                                           L.ptr(lab_vecs), L.ptr(pseudo_all), L.ptr(weight_all), L.ptr(target_all),
                                           L.ptr(n_pos), float(epsilon), L.ptr(out), L.ptr(dy), L.ptr(dense_ws), ws_bytes,
                                           L.stream()), "refine_losses")
-            tot = out.sum(dim=0)
-            col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
-            dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
-            if (self.early_backward and torch.is_grad_enabled() and clean_pooled_feats.dim() == 2
-                    and clean_pooled_feats.requires_grad and clean_pooled_feats.grad_fn is not None
-                    and getattr(feature_extractor, "sparse_clean", False)):     # (only then does no other loss reach these nodes)
+            tot = out[0] if n_img == 1 else out.sum(dim=0)
+            early_ok = (self.early_backward and torch.is_grad_enabled() and clean_pooled_feats.dim() == 2
+                        and clean_pooled_feats.requires_grad and clean_pooled_feats.grad_fn is not None
+                        and ybase.grad_fn is not None
+                        and getattr(feature_extractor, "sparse_clean", False))   # (only then does no other loss reach these nodes)
+            if early_ok:
+                dense = tot[:7]            # (their backward runs right below, from dY: no autograd node needed)
+            else:
+                col2loss = self._col2loss(list(self._heads), C, ybase.shape[1], device)
+                dense = _DenseLossFn.apply(ybase, tot[:7], dy, col2loss)
+            if early_ok:
                 # ---- the backward of the seven dense losses NOW: predictor, the DropBlock half of the stacked fc7 /
                 # fc6 pass (input and weight gradients: ~1.5 ms of large GEMMs at P = 2000) down to the gradient of the
                 # stacked operand.  Nothing on that path depends on the discovery lists, so it is queued before the host
@@ -726,8 +747,9 @@ class RoIRegLossFused(RoIRegLossComputation):
                 # (leaf tensors on the way whose gradient autograd itself delivers -- the Linear layers write theirs in
                 # place -- are asked for too and accumulated by hand: e.g. the eight predictor heads behind a torch.cat
                 # when the optimiser does not lay them out as one matrix)
-                dsum = dense.sum()
-                leaves = _leaves_between(dsum.grad_fn, clean_pooled_feats.grad_fn)
+                # (the backward starts AT the predictor's output with the kernel's own d(sum of the seven losses)/dY: the unit
+                # weights of the reference's plain sum, engine/trainer.py:102 -- no sum / expand / gather / multiply launches)
+                leaves = _leaves_between(ybase.grad_fn, clean_pooled_feats.grad_fn)
                 # the one product of this stretch whose result nobody reads before the pooling node at the very end --
                 # fc6's input gradient, 0.3 ms -- is handed back and launched in finish_backward, right before the late
                 # backward starts: the host then issues the contrastive loss's ~100 small backward launches under it
@@ -737,7 +759,7 @@ class RoIRegLossFused(RoIRegLossComputation):
                 _gemm.deferred_dgrad = [] if _os2.environ.get("ODW_DEFER_DGRAD") in ("late", "mid") else None
                 _gemm.deferred_weight = feature_extractor.fc6.weight       # the layer that reads the stacked operand
                 try:
-                    grads = torch.autograd.grad(dsum, [clean_pooled_feats] + leaves, allow_unused=True)
+                    grads = torch.autograd.grad(ybase, [clean_pooled_feats] + leaves, grad_outputs=dy, allow_unused=True)
                 finally:
                     deferred, _gemm.deferred_dgrad, _gemm.deferred_weight = _gemm.deferred_dgrad, None, None
                 for leaf, gl in zip(leaves, grads[1:]):

@@ -197,8 +197,8 @@ def test_split_norm_gather_scatter_with_rows_on_the_device(mods):
     d0, d1 = torch.zeros_like(t0), torch.zeros_like(t1)
     gg = rnd(20, (2048, 128))
     sc = torch.tensor([0.5], device="cuda")
-    dyn.scatter_rows2(gg, idx, nd, 300, d0, d1, scale=sc)
-    refd = torch.zeros(1200, 128, device="cuda").index_add_(0, idx[:n].long(), gg[:n] * 0.5)
+    dyn.scatter_rows2(gg, idx, nd, 300, d0, d1, scale=sc, alpha=0.25)
+    refd = torch.zeros(1200, 128, device="cuda").index_add_(0, idx[:n].long(), gg[:n] * 0.125)
     assert (torch.cat([d0, d1]) - refd).abs().max().item() < 1e-5
     tab = rnd(21, (700, 4096)).bfloat16()
     rows = torch.from_numpy(np.random.RandomState(2).randint(0, 700, size=512).astype(np.int32)).cuda()
