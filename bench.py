@@ -359,6 +359,7 @@ def main():
         trace = engine.step_trace if (args.timeline and dtype == args.dtype) else None
         if trace is not None:
             trace.enabled, trace.gpu_events, trace.steps = True, True, []
+        host_s = 0.0
         for it in range(steps):
             engine.kernel_timer.active = it % args.time_every == 0
             marks[it].record()
@@ -366,7 +367,9 @@ def main():
             if trace is not None:
                 trace.begin(image=args.first_image + rank + (warmup + it) % n_rot, labels=labels_per_image[(warmup + it) % n_rot],
                             event_step=bool(engine.kernel_timer.active))
+            th = time.perf_counter()
             step_fn(bi, bt, br, DeviceRand(seed + rank, first_stream=(1 << 20) + ((warmup + it) << 12), device=device))
+            host_s += time.perf_counter() - th
             if trace is not None:
                 trace.end()
         marks[steps].record()
@@ -378,7 +381,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         gc.unfreeze()
-        info = dict(info, device_allocs=int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0))
+        info = dict(info, device_allocs=int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0),
+                    host_ms_per_step=host_s / steps * 1e3,
+                    step_images=[(warmup + it) % n_rot for it in range(steps)])
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         if trace is not None:
             trace.enabled = False
@@ -402,12 +407,16 @@ def main():
     value = world * ipr * args.proposals * args.steps / dt
     med = float(np.median(per_step))
 
+    by_labels = {}
+    for it, ms_it in zip(info.get("step_images", []), per_step):
+        by_labels.setdefault(str(sum(labels_per_image[it])), []).append(ms_it)
+    by_labels = {k: round(float(np.mean(v)), 3) for k, v in sorted(by_labels.items())}     # GPU ms of a step by its batch's label count
     if rank == 0:
         if roof is not None:
             # memory-side bytes of the dominant symbol's heaviest launch shape from the committed PMC passes (rocprofv3 cannot
             # run inside the timed region): FETCH_SIZE x 2 (gfx950 under-count of 16-B/lane reads) + WRITE_SIZE, per launch.
             # Keyed on (kernel, dtype, launch shape): a run at another size reports null instead of another shape's bytes.
-            for rnd in ("r05", "r04", "r03", "r02", "r01"):
+            for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
                 tpath = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
                 if os.path.exists(tpath):
                     t = json.load(open(tpath))
@@ -452,6 +461,12 @@ def main():
             "value_at_median_step": round(world * ipr * args.proposals / (med * 1e-3), 1),
             "per_step_ms": [round(float(v), 2) for v in per_step],      # rank 0's HIP-event time of each timed step
             "device_allocs_in_timed_region": info.get("device_allocs"),   # hipMalloc calls of the caching allocator (a spike in per_step_ms)
+            # host time spent INSIDE the step call per step (launching; the call returns with GPU work queued): well below
+            # ms_per_step = the launching thread runs ahead of the GPU and a host hiccup does not reach the step time.  The loss
+            # reads nothing back (csrc/loss_lists.hip); the one wait left is the back-pressure of the index-table ring (8 steps).
+            "host_ms_per_step": round(info.get("host_ms_per_step", 0.0), 3),
+            "host_reads_per_step": 0 if (args.dtype == "bf16x2f" and os.environ.get("ODW_HOST_LISTS") != "1") else 2,
+            "ms_per_step_by_labels": by_labels,
             "config": {"workload": "%s + %d MCG-like proposals, batch %d/GPU, %dpx (padded %d), %s 7x7, "
                                    "OD-WSCL loss (CONTRA), SGD step, %d classes; timed steps rotate over %d synthetic image(s) "
                                    "with labels_per_image %s (mean %.2f)"

@@ -146,7 +146,8 @@ def pairwise_sim(E, padded=False):
     ld = -(-P // 32) * 32 if (padded and D == 128) else P
     buf = torch.empty((P, ld), dtype=torch.float32, device=E.device)
     if P and ld == P and D == 128 and P >= L.lib().odw_pairwise_sim_planes_min():
-        # large dense products: the split kernel + LDS-DMA kernel pair (ahead of the one-launch kernel from ~P = 6000)
+        # (only when ODW_PAIRWISE_PLANES_MIN forces it: the split + LDS-DMA pair, measured behind the one-launch panel kernel
+        # at every size -- profiles/r06/pairwise_min_ab.txt)
         nbytes = L.lib().odw_pairwise_sim_workspace(P, D)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=E.device)
         L.check(L.lib().odw_pairwise_sim_ws(L.ptr(E), P, D, L.ptr(buf), L.ptr(ws), nbytes, L.stream()), "pairwise_sim")

@@ -457,9 +457,13 @@ __global__ __launch_bounds__(kPwWaves * 64, 1) void pairwise_sim_panel_kernel(co
 // P <= 6000 and is within box-to-box noise at P = 8000.  It stays as an explicit entry point (odw_pairwise_sim_planes) for a
 // caller that already has the planes; odw_pairwise_sim_ws keeps the one-launch panel kernel (ODW_PAIRWISE_PLANES_MIN=0 forces
 // this form for comparison).
-constexpr int kPwPlanesMinP = 5600;                 // rows from which odw_pairwise_sim_ws takes the planes + DMA form (round 5; see below:
-                                                    // split + DMA kernel 43.4 / 72.6 us against the panel kernel's 48.5 / 80.7 us at P = 6000 /
-                                                    // 8000, the panel kernel ahead at P <= 4000: profiles/r04/pairwise_forms.txt)
+// Round 6 re-measured both forms THROUGH odw_pairwise_sim_ws with the threshold forced either way (tools/exp/pairwise_min_ab.py,
+// profiles/r06/pairwise_min_ab.txt; live HIP events over graph-replayed launches, as bench.py's roofline.kernels): panel / split + DMA
+// = 12.1 / 18.5 us at P = 2000, 22.6 / 31.0 at 4000, 41.0 / 48.8 at 5600, 44.6 / 52.7 at 6000, 79.7 / 86.0 at 8000 -- the one-launch
+// panel kernel is ahead at EVERY size.  Round 5 had switched the default to the pair from P = 5600 on figures taken from a table
+// (profiles/r04/pairwise_forms.txt) whose `ws_us` column never ran this form; the driver's P = 8000 went 80.7 -> 89.5 us.  Back to
+// never (ODW_PAIRWISE_PLANES_MIN=<P> still forces it for comparison).
+constexpr int kPwPlanesMinP = 1 << 30;
 constexpr int kPdSlot = 3 * 32 * 256;                // one 32-row block: 3 planes x 32 rows x 256 B (no padding)
 constexpr int kPdAreas = 3;                          // panel staging areas besides column-block slot 1
 constexpr int kPdLds = 2 * kPdSlot + kPdAreas * kPdSlot;           // 49152 + 73728 (the transpose scratch overlaps area 0/1)

@@ -1971,6 +1971,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_tn_bf16_ring_kernel(
 // grid covers; *r_dev rows exist; the transposed output is zero padded up to r64(*r_dev) columns and starts *col_off_dev
 // columns into `out` (the column block of a weight-gradient batch whose predecessors have device-resident widths too);
 // src_rows: row r of the input is in[src_rows[r]] (a fused gather).  All three null = the static form.
+constexpr unsigned kDynRowTiles = 16;      // 64-row tiles a dynamic launch puts in its grid (the rest: the kernels' tile loop)
 struct DynRows {
     const int* r_dev;
     const int* col_off_dev;
@@ -1984,31 +1985,36 @@ struct DynRows {
         if ((ROW0) >= OUT_COLS) return;                                                    \
         if (dyn.col_off_dev) OUT_PTR += *dyn.col_off_dev;                                  \
     }
+// (the dynamic launches cover the live rows with a BOUNDED grid: blockIdx.y walks the row tiles in steps of gridDim.y --
+// a grid sized for the capacity cost ~0.35 us per thousand workgroups that exit at once, 10-20 us per call at 12 k rows)
 
 template <bool IN_F32>
 __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __restrict__ in, int ld_in, int R,
                                                                 int Cc, unsigned short* __restrict__ out,
                                                                 int ld_out, int out_cols, DynRows dyn) {
     __shared__ unsigned short t[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    ODW_DYNROWS_ENTER(R, out_cols, out, r0);
+    const int c0 = blockIdx.x * 32;
+    ODW_DYNROWS_ENTER(R, out_cols, out, (int)blockIdx.y * 32);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r0 = blockIdx.y * 32; r0 < out_cols; r0 += gridDim.y * 32) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = r0 + ty + 8 * k, c = c0 + tx;
-        unsigned short v = 0;
-        if (r < R && c < Cc) {
-            const size_t sr = dyn.src_rows ? (size_t)dyn.src_rows[r] : (size_t)r;
-            v = IN_F32 ? f2bf(reinterpret_cast<const float*>(in)[sr * ld_in + c])
-                       : reinterpret_cast<const unsigned short*>(in)[sr * ld_in + c];
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            unsigned short v = 0;
+            if (r < R && c < Cc) {
+                const size_t sr = dyn.src_rows ? (size_t)dyn.src_rows[r] : (size_t)r;
+                v = IN_F32 ? f2bf(reinterpret_cast<const float*>(in)[sr * ld_in + c])
+                           : reinterpret_cast<const unsigned short*>(in)[sr * ld_in + c];
+            }
+            t[ty + 8 * k][tx] = v;
         }
-        t[ty + 8 * k][tx] = v;
-    }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = c0 + ty + 8 * k, r = r0 + tx;
-        if (c < Cc && r < out_cols) out[(size_t)c * ld_out + r] = r < R ? t[tx][ty + 8 * k] : (unsigned short)0;
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (c < Cc && r < out_cols) out[(size_t)c * ld_out + r] = r < R ? t[tx][ty + 8 * k] : (unsigned short)0;
+        }
+        __syncthreads();
     }
 }
 
@@ -2018,34 +2024,37 @@ __global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const unsigned 
                                                                  int Cc, unsigned short* __restrict__ out, int ld_out,
                                                                  int out_cols, DynRows dyn) {
     __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];
-    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    ODW_DYNROWS_ENTER(R, out_cols, out, r0);
+    const int c0 = blockIdx.x * 64;
+    ODW_DYNROWS_ENTER(R, out_cols, out, (int)blockIdx.y * 64);
+    for (int r0 = blockIdx.y * 64; r0 < out_cols; r0 += gridDim.y * 64) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int item = threadIdx.x + 256 * k;
-        const int rl = item >> 3, ch = item & 7;
-        const int r = r0 + rl, c = c0 + ch * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < R && c < Cc) v = *reinterpret_cast<const uint4*>(in + (dyn.src_rows ? (size_t)dyn.src_rows[r] : (size_t)r) * ld_in + c);
-        *reinterpret_cast<uint4*>(&tile[rl][ch * 8]) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int item = threadIdx.x + 256 * k;
-        const int cl = item >> 3, rc = item & 7;
-        const int c = c0 + cl, r = r0 + rc * 8;
-        if (c < Cc && r < out_cols) {
-            unsigned short v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = tile[rc * 8 + q][cl];
-            uint4 o;
-            o.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
-            o.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
-            o.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
-            o.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
-            *reinterpret_cast<uint4*>(out + (size_t)c * ld_out + r) = o;
+        for (int k = 0; k < 2; ++k) {
+            const int item = threadIdx.x + 256 * k;
+            const int rl = item >> 3, ch = item & 7;
+            const int r = r0 + rl, c = c0 + ch * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < R && c < Cc) v = *reinterpret_cast<const uint4*>(in + (dyn.src_rows ? (size_t)dyn.src_rows[r] : (size_t)r) * ld_in + c);
+            *reinterpret_cast<uint4*>(&tile[rl][ch * 8]) = v;
         }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = threadIdx.x + 256 * k;
+            const int cl = item >> 3, rc = item & 7;
+            const int c = c0 + cl, r = r0 + rc * 8;
+            if (c < Cc && r < out_cols) {
+                unsigned short v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = tile[rc * 8 + q][cl];
+                uint4 o;
+                o.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+                o.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+                o.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
+                o.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
+                *reinterpret_cast<uint4*>(out + (size_t)c * ld_out + r) = o;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -2075,9 +2084,10 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __rest
     __shared__ float t[32][33];
     const unsigned short* Y = reinterpret_cast<const unsigned short*>(Y_);
     const unsigned int* Y32 = reinterpret_cast<const unsigned int*>(Y_);
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-    ODW_DYNROWS_ENTER(M, t_cols, dZT, m0);
+    const int n0 = blockIdx.x * 32;
+    ODW_DYNROWS_ENTER(M, t_cols, dZT, (int)blockIdx.y * 32);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int m0 = blockIdx.y * 32; m0 < t_cols; m0 += gridDim.y * 32) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int m = m0 + ty + 8 * k, n = n0 + tx;
@@ -2106,6 +2116,8 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_kernel(const void* __rest
         for (int r = 0; r < 32; ++r) sum += t[r][tx];
         if (n0 + tx < N) atomicAdd(db + n0 + tx, sum);
     }
+    __syncthreads();
+    }
 }
 
 // The same prologue with 16-byte accesses: 64 x 64 tiles, fp32 tile in LDS (column sums for the bias gradient in
@@ -2118,8 +2130,9 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_vec_kernel(const void* __
                                                                   unsigned short* __restrict__ dZT, int ld_t, int t_cols,
                                                                   float* __restrict__ db, DynRows dyn) {
     __shared__ float t[64][65];
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
-    ODW_DYNROWS_ENTER(M, t_cols, dZT, m0);
+    const int n0 = blockIdx.x * 64;
+    ODW_DYNROWS_ENTER(M, t_cols, dZT, (int)blockIdx.y * 64);
+    for (int m0 = blockIdx.y * 64; m0 < t_cols; m0 += gridDim.y * 64) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int item = threadIdx.x + 256 * k;
@@ -2185,6 +2198,8 @@ __global__ __launch_bounds__(256) void linear_bwd_prep_vec_kernel(const void* __
 #pragma unroll 8
         for (int r = 0; r < 64; ++r) sum += t[r][threadIdx.x];
         if (n0 + (int)threadIdx.x < N) atomicAdd(db + n0 + threadIdx.x, sum);
+    }
+    __syncthreads();
     }
 }
 
@@ -3382,12 +3397,14 @@ static int transpose_to_bf16_launch(const void* in, int in_is_f32, int ld_in, in
     if (!in_is_f32 && Cc % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && out_cols % 8 == 0 &&
         (((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 15) == 0) {
         dim3 vgrid((Cc + 63) / 64, (out_cols + 63) / 64);
+        if (dyn.r_dev && vgrid.y > kDynRowTiles) vgrid.y = kDynRowTiles;
         transpose_bf16_vec_kernel<<<vgrid, 256, 0, stream>>>((const unsigned short*)in, ld_in, R, Cc, (unsigned short*)out,
                                                              ld_out, out_cols, dyn);
         ODW_CHECK_LAUNCH("transpose_bf16_vec_kernel");
         return ODW_OK;
     }
     dim3 grid((Cc + 31) / 32, (out_cols + 31) / 32);   // covers the zero padding up to out_cols
+    if (dyn.r_dev && grid.y > 2 * kDynRowTiles) grid.y = 2 * kDynRowTiles;
     if (in_is_f32)
         transpose_to_bf16_kernel<true><<<grid, 256, 0, stream>>>(in, ld_in, R, Cc, (unsigned short*)out, ld_out, out_cols, dyn);
     else
@@ -3476,11 +3493,13 @@ static int linear_bwd_prep_launch(const void* dY, int dy_is_f32, int ld_dy, cons
     } while (0)
     if (vec) {
         dim3 vgrid((ld_z + 63) / 64, (t_cols + 63) / 64);
+        if (dyn.r_dev && vgrid.y > kDynRowTiles) vgrid.y = kDynRowTiles;
         ODW_PREP_LAUNCH(linear_bwd_prep_vec_kernel, vgrid);
         ODW_CHECK_LAUNCH("linear_bwd_prep_vec_kernel");
         return ODW_OK;
     }
     dim3 grid((ld_z + 31) / 32, (t_cols + 31) / 32);     // covers the zero padding of both outputs
+    if (dyn.r_dev && grid.y > 2 * kDynRowTiles) grid.y = 2 * kDynRowTiles;
     ODW_PREP_LAUNCH(linear_bwd_prep_kernel, grid);
 #undef ODW_PREP_LAUNCH
     ODW_CHECK_LAUNCH("linear_bwd_prep_kernel");

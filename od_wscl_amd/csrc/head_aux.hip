@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void rows_drop_noise_kernel(const float* __res
 // known to the host when these kernels are launched: the grid covers the CAPACITY (every entry that could exist), an entry
 // e < *n_entries finds its group by walking the prefix, and the per-group constants the host does know -- the
 // counter-based keys of the group's draws -- come from a table uploaded before the step's first read would have happened.
+constexpr int kViewGrid = 512;        // entries a grouped launch puts in its grid (the kernels stride over the rest)
 struct ViewGroups {
     const int* n_entries;       // [1]   number of sampled rows over all groups (E1)
     const int* e0;              // [G+1] entry prefix: group g owns entries [e0[g], e0[g+1]); its views are rows [2 e0[g], 2 e0[g+1])
@@ -315,14 +316,16 @@ __global__ __launch_bounds__(256) void rows_views_bwd_store_grouped_kernel(const
                                                                            const int* __restrict__ dst_off,
                                                                            float* __restrict__ extra) {
     __shared__ float keep[kMaxS];
-    const int e = blockIdx.x;
-    if (e >= *vg.n_entries) return;
-    const int g = view_group_of(vg, e);
-    const int e0 = vg.e0[g], k = vg.e0[g + 1] - e0;
-    const uint32_t* ky = vg.keys + 4 * g;
-    rows_drop_noise_body<true, DX_F32, false, false, true>(nullptr, dXv, e - e0, (size_t)((dst_off ? *dst_off : 0) + e), k, CS, S,
-                                                           gamma, ky[0], ky[1], ky[2], ky[3], vg.keep_sum[g], nullptr, ld, 2 * e0,
-                                                           extra, keep);
+    const int n_e = *vg.n_entries;
+    for (int e = blockIdx.x; e < n_e; e += gridDim.x) {       // (a bounded grid strides over the entries that exist)
+        const int g = view_group_of(vg, e);
+        const int e0 = vg.e0[g], k = vg.e0[g + 1] - e0;
+        const uint32_t* ky = vg.keys + 4 * g;
+        rows_drop_noise_body<true, DX_F32, false, false, true>(nullptr, dXv, e - e0, (size_t)((dst_off ? *dst_off : 0) + e), k, CS, S,
+                                                               gamma, ky[0], ky[1], ky[2], ky[3], vg.keep_sum[g], nullptr, ld, 2 * e0,
+                                                               extra, keep);
+        __syncthreads();
+    }
 }
 
 // ---- row-wise L2 normalisation of the 128-d embeddings (Sim_Net.forward, sim_head/sim_net.py:25-26: F.normalize) ------
@@ -551,13 +554,15 @@ __global__ __launch_bounds__(256) void rows_views_cm_grouped_kernel(const unsign
                                                                     long long ld_hi) {
     extern __shared__ __attribute__((aligned(16))) float vlds[];
     __shared__ float keep[kMaxS];
-    const int e = blockIdx.x;
-    if (e >= *vg.n_entries) return;
-    const int g = view_group_of(vg, e);
-    const int e0 = vg.e0[g], k = vg.e0[g + 1] - e0;
-    const uint32_t* ky = vg.keys + 4 * g;
-    rows_views_cm_body(src, ld_src, src_mid, e - e0, (size_t)vg.src_row[e], blockIdx.y * kViewCh, k, C, S, gamma, ky[0], ky[1], ky[2],
-                       ky[3], vg.keep_sum[g], out_cm, ld_cm, cm_mid, out_hi, ld_hi, 2 * e0, vlds, keep);
+    const int n_e = *vg.n_entries;
+    for (int e = blockIdx.x; e < n_e; e += gridDim.x) {
+        const int g = view_group_of(vg, e);
+        const int e0 = vg.e0[g], k = vg.e0[g + 1] - e0;
+        const uint32_t* ky = vg.keys + 4 * g;
+        rows_views_cm_body(src, ld_src, src_mid, e - e0, (size_t)vg.src_row[e], blockIdx.y * kViewCh, k, C, S, gamma, ky[0], ky[1], ky[2],
+                           ky[3], vg.keep_sum[g], out_cm, ld_cm, cm_mid, out_hi, ld_hi, 2 * e0, vlds, keep);
+        __syncthreads();
+    }
 }
 
 ODW_EXPORT int odw_rows_views_cm(const void* src_cm, int64_t ld_src, int64_t src_mid, const int* rows, int row_base, int k, int C,
@@ -697,7 +702,7 @@ ODW_EXPORT int odw_rows_views_cm_grouped(const void* src_cm, int64_t ld_src, int
     const size_t lds = (size_t)3 * kViewCh * S * sizeof(float);
     ODW_REQUIRE(lds + kMaxS * sizeof(float) <= (size_t)ODW_LDS_BYTES, "rows_views_cm_grouped: S=%d cells per ROI need %zu bytes of LDS", S, lds);
     ODW_CHECK_HIP(odw_set_max_lds(reinterpret_cast<const void*>(rows_views_cm_grouped_kernel), (int)lds), "rows_views_cm_grouped attr");
-    rows_views_cm_grouped_kernel<<<dim3(E_cap, C / kViewCh), 256, lds, stream>>>(
+    rows_views_cm_grouped_kernel<<<dim3(E_cap < kViewGrid ? E_cap : kViewGrid, C / kViewCh), 256, lds, stream>>>(
         (const unsigned short*)src_cm, ld_src, src_mid, vg, C, S, gamma, (unsigned short*)out_cm, ld_cm, cm_mid,
         (unsigned short*)out_hi, ld_hi);
     ODW_CHECK_LAUNCH("rows_views_cm_grouped_kernel");
@@ -718,9 +723,9 @@ ODW_EXPORT int odw_rows_views_bwd_store_grouped(const void* dX, int dx_is_f32, i
     ViewGroups vg;
     vg.n_entries = n_entries; vg.e0 = e0; vg.keys = keys; vg.src_row = nullptr; vg.keep_sum = keep_sum; vg.G = G;
     if (dx_is_f32)
-        rows_views_bwd_store_grouped_kernel<true><<<dim3(E_cap, kRowSlices), 256, 0, stream>>>(dX, ld, vg, (int)cs, S, gamma, dst_off, extra);
+        rows_views_bwd_store_grouped_kernel<true><<<dim3(E_cap < kViewGrid ? E_cap : kViewGrid, kRowSlices), 256, 0, stream>>>(dX, ld, vg, (int)cs, S, gamma, dst_off, extra);
     else
-        rows_views_bwd_store_grouped_kernel<false><<<dim3(E_cap, kRowSlices), 256, 0, stream>>>(dX, ld, vg, (int)cs, S, gamma, dst_off, extra);
+        rows_views_bwd_store_grouped_kernel<false><<<dim3(E_cap < kViewGrid ? E_cap : kViewGrid, kRowSlices), 256, 0, stream>>>(dX, ld, vg, (int)cs, S, gamma, dst_off, extra);
     ODW_CHECK_LAUNCH("rows_views_bwd_store_grouped_kernel");
     return ODW_OK;
 }

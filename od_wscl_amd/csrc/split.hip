@@ -251,7 +251,8 @@ static int split_rows_launch(const float* in, int64_t ld_in, int R, int Cc, cons
     ODW_REQUIRE(in && out && (((uintptr_t)out) & 15) == 0, "split_rows: pointers");
     const long long total = (long long)R * (block / 4);
     ODW_REQUIRE(total < (1ll << 31), "split_rows: R * block / 4 must stay below 2^31");
-    const long long blocks = (total + 255) / 256;
+    long long blocks = (total + 255) / 256;
+    if (r_dev && blocks > 4096) blocks = 4096;      // (rows on the device: a bounded grid; the kernel strides over what exists)
     split_rows_kernel<<<(int)(blocks > 65536 ? 65536 : blocks), 256, 0, (hipStream_t)stream_>>>(
         in, ld_in, R, Cc, pat, (unsigned short*)out, ld_out, block, r_dev);
     ODW_CHECK_LAUNCH("split_rows_kernel");

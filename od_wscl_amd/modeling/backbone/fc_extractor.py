@@ -158,6 +158,7 @@ class _RowViews(torch.autograd.Function):
                 e0 += k
 
         fold.entries = sum(g[2] for g in groups)         # side-buffer entries [0, entries) are this fold's alone
+        fold.interval = (0, fold.entries)
 
         if holder is not None and not holder.done:
             holder.pending.append(fold)          # the stacked node has not produced its gradient yet: it folds this in
@@ -202,6 +203,7 @@ class _RowGather(torch.autograd.Function):
                                              # the mixed-dtype add_ (104 us for 250 rows against ~10)
 
         fold.entries = n
+        fold.interval = (e0, n)
 
         if holder is None or holder.done:
             raise RuntimeError("_RowGather: the pooling node already ran its backward")
@@ -259,8 +261,17 @@ class _PoolStack(torch.autograd.Function):
             if isinstance(roi_index, (list, tuple)):
                 roi_index = roi_index[0] if len(roi_index) == 1 else torch.cat(list(roi_index))
             E = int(roi_index.numel())
-            # every entry written by exactly one parked fold (the usual case): no zero fill of the 45-90 MB buffer
-            fresh = sum(getattr(f, "entries", 0) for f in holder.pending) == E and os.environ.get("ODW_EXTRA_ZEROS") != "1"
+            # every entry written by exactly one parked fold (the usual case): no zero fill of the 45-90 MB buffer.  Checked on
+            # the folds' INTERVALS, not their sizes: two folds over the same entries with another range missing would add up to
+            # E as well, leave uninitialised rows and lose the overlapped contribution (the STORE form does not accumulate)
+            spans = sorted(getattr(f, "interval", (-1, 0)) for f in holder.pending)
+            pos = 0
+            for a, n in spans:
+                if a != pos or n <= 0:
+                    pos = -1
+                    break
+                pos = a + n
+            fresh = pos == E and os.environ.get("ODW_EXTRA_ZEROS") != "1"
             extra = (torch.empty if fresh else torch.zeros)((E, C * ph * pw), dtype=torch.float32, device=dx.device)
             for fold in holder.pending:
                 fold(extra, True, fresh)

@@ -68,6 +68,19 @@ def planes2_layer(l):
     return l.cp == l.cin and l.cp % 32 == 0 and l.cout % 64 == 0 and l.dil in (1, 2)
 
 
+def _wgrad_tn(l):
+    """The layer's weight gradient runs on the K-major (TN / halo) kernels, which read dZ and the layer input as they are."""
+    return l.cp >= 128 and l.cout % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0"
+
+
+def _wgrad_reads_strided(l):
+    """ONE predicate for "the backward reads the hi plane of the forward's operand in place" (a strided view of the plane
+    buffer, which then stays alive through the backward), used by the forward when it saves the operand AND implied by the
+    backward's kernel choice: the K-major kernels (_wgrad_tn) on shapes their halo form takes (64-channel granules, dilation
+    1 / 2).  Everything else gets a dense copy and the plane buffer is released after the forward."""
+    return _wgrad_tn(l) and l.cout % 64 == 0 and l.cp % 64 == 0 and l.dil in (1, 2)
+
+
 def planes2_body(net):
     """The whole body takes the two-plane path: a direct stem that writes planes, every later layer eligible
     (ODW_CONV_PLANES2=0: the three-pass form of rounds 3-4, for comparison runs)."""
@@ -200,7 +213,7 @@ def _backward_single_plane(ctx, dfeat, seg=None):
             conv.bias.grad = torch.zeros_like(conv.bias)
         if conv.weight.grad is None:
             conv.weight.grad = torch.empty_like(conv.weight)
-        if l.cp >= 128 and l.cout % 8 == 0 and os.environ.get("ODW_CONV_WGRAD_TN") != "0":
+        if _wgrad_tn(l):
             # dZ and the layer input as they are (NHWC rows): K-major operands, transposed fragment reads; the bias
             # gradient (column sums of dZ) comes out of the same launch
             ws_bytes = lib.odw_conv_wgrad_tn_bias_workspace(l.cout, l.cp, m)
@@ -384,8 +397,8 @@ class _VGGMixedFn(torch.autograd.Function):
                 xs = P.split_rows(x, pa, l.cp)
                 # the backward's operand (weight gradient, ReLU mask) is the hi plane: the FIRST block of the planes, read
                 # in place with row stride T * cp (was: a second split pass per layer writing a contiguous copy)
-                x16 = xs[:, :l.cp] if (l.trainable and pa[0] == 0 and l.cp >= 128 and l.cout % 64 == 0 and l.cp % 64 == 0
-                                       and l.dil in (1, 2)) else (P.split_rows(x, (0,), l.cp) if l.trainable else None)
+                x16 = xs[:, :l.cp] if (l.trainable and pa[0] == 0 and _wgrad_reads_strided(l)) else (
+                    P.split_rows(x, (0,), l.cp) if l.trainable else None)
             y = torch.empty((m, l.cout), dtype=torch.float32, device=dev)
             _conv3x3(lib, xs, m, h, w, T * l.cp, l.dil, 0, l.wk, l.cout, y, l.conv.bias, l.relu, None, 0, net.zero_page, st,
                      2.0 * m * l.cout * 9 * l.cin * T, alg=2.0 * m * l.cout * 9 * l.cin)
@@ -454,7 +467,7 @@ class _VGGMixedFn(torch.autograd.Function):
             x16 = None
             if l.trainable:
                 # the TN / halo weight-gradient kernels read the hi plane in place (row stride 2 cp); the others want it dense
-                x16 = xs[:, :l.cp] if (l.cp >= 128 and l.cout % 64 == 0 and l.cp % 64 == 0) else xs[:, :l.cp].contiguous()
+                x16 = xs[:, :l.cp] if _wgrad_reads_strided(l) else xs[:, :l.cp].contiguous()
             pre = None
             if l.pool:
                 pre = y if l.trainable else None

@@ -72,8 +72,9 @@ class KernelTimer(object):
         result (one fp32 product where a split mode issues three or six; default: = flops); shape = the launch shape as a
         string (the PMC traffic table of bench.py is keyed on it)."""
         if self.tally is not None:       # counting pass (a HIP-graph capture's warm-up): FLOPs only, no events
-            self.tally += flops
-            self.tally_alg += flops if alg is None else alg
+            if flops > 0:                # (a byte-counted region -- nbytes > 0, flops == 0: its `alg` is BYTES of the reference
+                self.tally += flops      # operator, not FLOPs -- must not leak into a graph region's algorithmic FLOPs)
+                self.tally_alg += flops if alg is None else alg
             return _NO_REGION
         if not self.enabled or not self.active or name is None:
             return _NO_REGION
@@ -103,7 +104,7 @@ class KernelTimer(object):
                 gbps = v["bytes"] / (v["avg_ms"] * 1e-3) / 1e9
                 # bytes = what this kernel reads and writes by construction; survey_8d_bytes = the bytes of the reference
                 # operator it stands for (fp32 output + int32 argmax + the map once)
-                ref = v["alg"] if v["alg"] != v["flops"] else 0.0
+                ref = v["alg"] if (v["flops"] == 0 and v["alg"] > 0) else 0.0        # byte regions pass flops = 0: alg = reference bytes
                 out[name] = {"bound": "hbm", "avg_launch_us": round(v["avg_ms"] * 1e3, 2), "launches": v["launches"],
                              "algorithmic_bytes": int(v["bytes"]), "achieved_GBps": round(gbps, 1),
                              "peak_GBps": hbm_peak_gbps, "frac": round(gbps / hbm_peak_gbps, 4)}
