@@ -633,7 +633,8 @@ int odw_gather_rows_dyn(const void* src, int64_t ld_src_bytes, const int* index,
 int odw_zero_rows_dyn(void* p, int64_t ld_bytes, int64_t row_bytes, const int* n_dev, int n_cap, void* stream);
 /* odw_gemm_nt_bf16_ws with device-resident extents: M_cap / K_cap bound the launch, *m_dev rows and a reduction of *k_dev
  * (a multiple of 8; operand columns [*k_dev, r64(*k_dev)) zero) are computed; either may be NULL (= the capacity is exact).
- * row_tab: per-row dropout draw (odw_loss_lists_a).  The hints pick the kernel variant and the K slices only. */
+ * row_tab: per-row dropout draw (odw_loss_lists_a).  The hints pick the kernel variant and the K slices only; the workspace
+ * query takes M_hint <= 0 for "the rows are not device-resident" (m_dev == NULL: the static form's tail-column split applies). */
 int64_t odw_gemm_nt_bf16_dyn_workspace(int M_cap, int M_hint, int N, int K_cap, int K_hint, int lda, int ldb, const void* C, int ldc,
                                        int c_is_bf16, int* variant_out);
 int odw_gemm_nt_bf16_dyn(const void* A, int lda, const void* B, int ldb, int M_cap, int N, int K_cap, void* C, int ldc,

@@ -2742,6 +2742,16 @@ static int dyn_hint(int hint, int cap) { return hint > 0 ? (hint < cap ? hint : 
 // workspace of the dynamic form: the split-K partials of the plan made for the hints, over the CAPACITY rows
 ODW_EXPORT int64_t odw_gemm_nt_bf16_dyn_workspace(int M_cap, int M_hint, int N, int K_cap, int K_hint, int lda, int ldb,
                                                   const void* C, int ldc, int c_is_bf16, int* variant_out) {
+    // M_hint <= 0: the rows are NOT device-resident (only the reduction is) -- the tail-column split of the static form applies
+    if (M_hint <= 0) {
+        const int kh = dyn_hint(K_hint, K_cap);
+        const int nt = tail_columns(M_cap, N, kh, lda, ldb, C, ldc, c_is_bf16, 0.0f, true);
+        if (nt > 0) {
+            const Plan pt = pick_plan(M_cap, nt, kh, lda, ldb, C, ldc, c_is_bf16, true);
+            if (variant_out) *variant_out = 3;
+            return pt.splits > 1 ? (int64_t)pt.splits * M_cap * ((nt + 3) / 4 * 4) * 4 : 0;
+        }
+    }
     const Plan p = pick_plan(dyn_hint(M_hint, M_cap), N, dyn_hint(K_hint, K_cap), lda, ldb, C, ldc, c_is_bf16, true);
     if (variant_out) *variant_out = p.variant;
     return p.splits > 1 ? (int64_t)p.splits * M_cap * ((N + 3) / 4 * 4) * 4 : 0;
@@ -2780,15 +2790,18 @@ static int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, int M,
                 "gemm_nt_bf16: K=%d rounded up to 8 must fit in lda=%d / ldb=%d (zero padded)", K, lda, ldb);
     ODW_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && nseg >= 0 && nseg <= kMaxSeg, "gemm_nt_bf16: bad dropout args");
     ODW_REQUIRE(!(accumulate && c_is_bf16), "gemm_nt_bf16: accumulate needs an fp32 C");
-    if (const int nt = dyn ? 0 : tail_columns(M, N, K, lda, ldb, C, ldc, c_is_bf16, drop_p, workspace != nullptr)) {
+    // (device-resident extents: with the ROWS on the device the tile count is unknown -- no tail split; with only the reduction
+    // on the device -- the weight-gradient batches -- it applies as in the static form, planned for the hinted K)
+    const bool tail_ok = !dyn || (!dyn->m_dev && !dyn->row_tab);
+    if (const int nt = tail_ok ? tail_columns(M, N, dyn ? dyn->k_hint : K, lda, ldb, C, ldc, c_is_bf16, drop_p, workspace != nullptr) : 0) {
         const int n1 = N - nt;
-        const int rc = odw_gemm_nt_bf16_ws(A, lda, B, ldb, M, n1, K, C, ldc, c_is_bf16, bias, relu, alpha, 0.0f, 0, nullptr,
-                                           nullptr, nullptr, accumulate, nullptr, 0, stream_);
+        const int rc = gemm_nt_launch(A, lda, B, ldb, M, n1, K, C, ldc, c_is_bf16, bias, relu, alpha, 0.0f, 0, nullptr,
+                                      nullptr, nullptr, accumulate, nullptr, 0, stream_, dyn);
         if (rc != ODW_OK) return rc;
-        return odw_gemm_nt_bf16_ws(A, lda, reinterpret_cast<const unsigned short*>(B) + (size_t)n1 * ldb, ldb, M, nt, K,
-                                   reinterpret_cast<char*>(C) + (size_t)n1 * (c_is_bf16 ? 2 : 4), ldc, c_is_bf16,
-                                   bias ? bias + n1 : nullptr, relu, alpha, 0.0f, 0, nullptr, nullptr, nullptr, accumulate,
-                                   workspace, workspace_bytes, stream_);
+        return gemm_nt_launch(A, lda, reinterpret_cast<const unsigned short*>(B) + (size_t)n1 * ldb, ldb, M, nt, K,
+                              reinterpret_cast<char*>(C) + (size_t)n1 * (c_is_bf16 ? 2 : 4), ldc, c_is_bf16,
+                              bias ? bias + n1 : nullptr, relu, alpha, 0.0f, 0, nullptr, nullptr, nullptr, accumulate,
+                              workspace, workspace_bytes, stream_, dyn);
     }
     Epilogue ep;
     ep.bias = bias; ep.relu = relu; ep.drop_p = drop_p; ep.nseg = nseg; ep.accumulate = accumulate; ep.alpha = alpha;

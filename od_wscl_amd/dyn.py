@@ -65,11 +65,11 @@ def gemm_nt(a, b, M_cap, N, K_cap, out, bias=None, relu=False, alpha=1.0, drop_p
     out_bf16 = out.dtype == torch.bfloat16
     mh, kh = (m.hint if m is not None else M_cap), (k.hint if k is not None else K_cap)
     lib = L.lib()
-    key = (M_cap, mh, N, K_cap, kh, a.stride(0), b.stride(0), out.stride(0), out_bf16, out.data_ptr() & 15)
+    key = (M_cap, mh, m is None, N, K_cap, kh, a.stride(0), b.stride(0), out.stride(0), out_bf16, out.data_ptr() & 15)
     plan = _PLAN.get(key)
     if plan is None:
         var = ctypes.c_int(0)
-        ws_bytes = lib.odw_gemm_nt_bf16_dyn_workspace(M_cap, mh, N, K_cap, kh, a.stride(0), b.stride(0), L.ptr(out), out.stride(0),
+        ws_bytes = lib.odw_gemm_nt_bf16_dyn_workspace(M_cap, mh if m is not None else 0, N, K_cap, kh, a.stride(0), b.stride(0), L.ptr(out), out.stride(0),
                                                       1 if out_bf16 else 0, ctypes.byref(var))
         if len(_PLAN) > 4096:
             _PLAN.clear()
