@@ -45,7 +45,7 @@ def workspace(nbytes, device):
     middle of a step, from the arena it is a view.  Launches on one stream use it one after the other."""
     if not nbytes:
         return None
-    key = str(device)
+    key = (str(device), L.stream().value)       # (per STREAM: two streams' launches run at the same time)
     a = _ARENA.get(key)
     if a is None or a.numel() < nbytes:
         grow = max(int(nbytes * 1.5), 256 << 20)

@@ -244,7 +244,9 @@ class FlatSGD(object):
              cfg.SOLVER.WEIGHT_DECAY_BIAS)]
         self.gemm_params = [p for _, p in gemm_w]
         self.n_gemm = n_gemm
-        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # (ODW_PRIO = "step,optimiser,contrastive" stream priorities, an experiment knob: default -1,0,-1)
+        prio = [int(v) for v in os.environ.get("ODW_PRIO", "-1,0,-1").split(",")]
+        self.side = torch.cuda.Stream(device=dev, priority=prio[1]) if dev.type == "cuda" else None
         odw = getattr(cfg, "ODW", None)
         self.exchange = GradExchange(self.flat_g, world, dtype=getattr(odw, "GRAD_EXCHANGE", "fp32"), side=self.side)
         self.wgrad_slices = int(getattr(odw, "WGRAD_SLICES", 4)) if world > 1 else 1
@@ -637,7 +639,7 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         if not use_hp:
             return _step(images, targets, rois, rand, iteration)
         if hp_stream[0] is None:
-            hp_stream[0] = torch.cuda.Stream(device=device, priority=-1)
+            hp_stream[0] = torch.cuda.Stream(device=device, priority=int(os.environ.get("ODW_PRIO", "-1,0,-1").split(",")[0]))
         hp, cur = hp_stream[0], torch.cuda.current_stream()
         hp.wait_stream(cur)
         with torch.cuda.stream(hp):

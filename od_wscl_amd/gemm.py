@@ -239,6 +239,10 @@ class WgradBatch(object):
     # CAPACITY whose live widths only the GPU knows are packed behind one another at device-side offsets; the GEMM then
     # runs over [0, *dyn_k.t) of the sum(rows) columns that exist
     dyn_k = None
+    # True while another stream is still filling column blocks of this batch (loss_fused: the contrastive branch runs beside
+    # the dense losses' early backward): the evaluation that completes the batch does not run the GEMM, the owner flushes
+    # once both streams have met (flush_held)
+    hold = False
 
     def __init__(self):
         self.rows, self.filled, self.dzt, self.xt, self.kpad, self.done = [], 0, None, None, 0, []
@@ -275,6 +279,7 @@ class WgradBatch(object):
     def reset(self):
         self.rows, self.filled, self.dzt, self.xt, self.kpad, self.done = [], 0, None, None, 0, []
         self.dyn_k = None
+        self.hold = False
 
     def flush(self, weight, tag=None):
         """Run the GEMM over whatever was filled (blocks of evaluations whose backward never ran are zeroed)."""
@@ -433,7 +438,7 @@ def _backward_single_plane(xb, y, weight, bias, cfg, dy, need_dx):
                                                    xt_all.stride(0), m8, L.stream()), "transpose_to_bf16")
         batch.done[slot] = True
         batch.filled += 1
-        if batch.filled == len(batch.rows):
+        if batch.filled == len(batch.rows) and not batch.hold:
             batch.flush(weight, tag)
         if wgrad_first:
             dx = input_gradient()

@@ -281,6 +281,15 @@ class DeviceContrastive(object):
         self.loss = loss
         return _ContrastiveFn.apply(self.stacked, self.fe.fc6.weight, loss, self)
 
+    def held_batches(self):
+        """The weight-gradient batches that also hold a block of ANOTHER evaluation (the stacked pass: fc6, fc7)."""
+        out = []
+        for name, sh in (("fc6", self.sh6), ("fc7", self.sh7), ("sim0", self.shs0)):
+            b = getattr(sh, "batch", None)
+            if name in self.slots and b is not None and len(b.rows) > 2:
+                out.append((b, sh.weight, getattr(getattr(self.fe, name, None), "tag", None) if name != "sim0" else None))
+        return out
+
     def backward_now(self):
         """The branch's backward queued at once, with the unit weight of the reference's plain sum of losses
         (engine/trainer.py:102) -- what loss_fused's early backward does for the dense losses.  Everything the branch's
@@ -352,7 +361,7 @@ class DeviceContrastive(object):
                         batch.dyn_k = dyn.Dyn(scal_b[5:6], sum(batch.rows), self.p64 + dyn.r64(self.h_V) + dyn.r64(self.h_A))
                     else:
                         batch.dyn_k = dyn.Dyn(scal_b[7:8], sum(batch.rows), dyn.r64(self.h_V) + dyn.r64(self.h_A))
-                    if batch.filled == len(batch.rows):
+                    if batch.filled == len(batch.rows) and not batch.hold:
                         batch.flush(w, layer_.tag)
                 elif w.requires_grad:
                     dzt = torch.empty((n_out, dyn.r64(cap)), dtype=torch.bfloat16, device=dev)
@@ -398,6 +407,7 @@ class DeviceContrastive(object):
         _dbg("bwd act")
         holder.dyn_extra = (extra, self.roi_index_all, A_cap + E_cap, self.dE)
         holder.pending = []
+        self.extra = extra
 
     # ------------------------------------------------------------------------------------------------ tests' trace
     def fill_trace(self, tr, rows, counts, inst_idx, inst_cnt, fresh_idx, fresh_cnt):

@@ -646,16 +646,49 @@ class RoIRegLossFused(RoIRegLossComputation):
                 "discover_sim")
         # ---- lists B + SupCon (a handful of small launches), then the dense losses and -- early_backward -- their backward
         colstat_flat = colstat.view(-1)
-        raw = branch.finish(fresh_idx, fresh_cnt, gt_cnt, final_score, colstat_flat, colstat.shape[1] * colstat.shape[2],
-                            2 * colstat.shape[2], img_off, n_pos, pos_cls, self.temp, lmda=self.sim_lmda)
+        eager = (self.early_backward and torch.is_grad_enabled() and stacked.requires_grad and stacked.grad_fn is not None
+                 and _os2.environ.get("ODW_NO_EAGER_CONTRA") != "1")
+        beside = eager and _os2.environ.get("ODW_CONTRA_STREAM") != "0"
+        main = torch.cuda.current_stream(device)
+        side, joined, held = main, None, []
+        if beside:
+            # The contrastive branch (lists B, SupCon, its whole backward: ~0.7 ms of small launches on a few hundred rows)
+            # and the dense losses with their early backward (~0.7 ms of large GEMMs) depend on the discovery lists and on
+            # nothing of each other: the branch goes to a second stream and the two run side by side -- the small kernels in the
+            # tails of the large ones.  They meet in the weight-gradient batches of fc7 / fc6 (column blocks from both):
+            # those are held and flushed once both streams have arrived.
+            side = getattr(self, "_contra_stream", None)
+            if side is None or side.device != device:
+                side = self._contra_stream = torch.cuda.Stream(
+                    device=device, priority=int(_os2.environ.get("ODW_PRIO", "-1,0,-1").split(",")[2]))
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side.wait_event(fork)
+        with torch.cuda.stream(side):
+            raw = branch.finish(fresh_idx, fresh_cnt, gt_cnt, final_score, colstat_flat, colstat.shape[1] * colstat.shape[2],
+                                2 * colstat.shape[2], img_off, n_pos, pos_cls, self.temp, lmda=self.sim_lmda)
+            if beside:
+                held = branch.held_batches()
+                for b, _, _ in held:
+                    b.hold = True
+            if eager:
+                branch.backward_now()   # (see DeviceContrastive.backward_now: the whole head backward is queued in forward order)
+            if beside:
+                joined = torch.cuda.Event()
+                joined.record(side)
         loss_sim = raw
-        if (self.early_backward and torch.is_grad_enabled() and stacked.requires_grad and stacked.grad_fn is not None
-                and _os2.environ.get("ODW_NO_EAGER_CONTRA") != "1"):
-            branch.backward_now()       # (see DeviceContrastive.backward_now: the whole head backward is queued in forward order)
         step_trace.mark("supcon_launch")
         dense, early, tot, pseudo_all, weight_all, target_all = self._pseudo_and_dense(
             lib, device, n_img, sum_p, max_p, maxpos, offs, boxes_all, gt_idx, gt_cls, gt_score, gt_cnt, ybase, C, img_off,
             final_score, colstat, lab_vecs, n_pos, epsilon, dense_ws, ws_bytes, stacked, fe)
+        if beside:
+            main.wait_event(joined)
+            for t in (branch.extra, raw):
+                t.record_stream(main)
+            for b, w, tag in held:
+                b.hold = False
+                if b.rows and b.filled == len(b.rows):
+                    b.flush(w, tag)
         step_trace.mark("dense_early_bwd_launch")
         if tr is not None:
             branch.fill_trace(tr, rows, counts, inst_idx, inst_cnt, fresh_idx, fresh_cnt)
