@@ -88,7 +88,7 @@ inline EPO epilogue_narrow(const Epilogue& e) {
 }
 
 // split-K entry of a DMA kernel: narrow the operands / output to this workgroup's K range
-#define ODW_SPLITK_ENTER(ODW_TILE_M)                                                               \
+#define ODW_SPLITK_ENTER(ODW_TILE_M, ODW_TILE_N)                                                               \
     int kchunk_ = ep.kchunk;                                                               \
     if (ep.m_dev) {             /* rows that exist: workgroups of the capacity-sized grid past them exit */ \
         const int md_ = *ep.m_dev;                                                         \
@@ -110,6 +110,13 @@ inline EPO epilogue_narrow(const Epilogue& e) {
         K = K - ks_ < kchunk_ ? K - ks_ : kchunk_;                                         \
         K = K < 0 ? 0 : K;                                                                 \
         Cv = reinterpret_cast<char*>(Cv) + (long long)blockIdx.y * ep.split_stride;        \
+    }                                                                                      \
+    if (K <= 0) {               /* an empty reduction (a K slice past a device-resident length): the tile is zeros.  NOT through */ \
+        /* the pipeline: with no K step nothing waits for the prologue's DMA, which would land in the LDS the epilogue stages through */ \
+        int tm_, tn_;                                                                      \
+        tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm_, tn_, ep.pm);                     \
+        zero_tile<OUT_BF16>(Cv, ldc, M, N, tm_ * ODW_TILE_M, tn_ * ODW_TILE_N, ODW_TILE_M, ODW_TILE_N, ep.accumulate); \
+        return;                                                                            \
     }
 // (kernels without a split-K form)
 #define ODW_DYN_ENTER(ODW_TILE_M)                                                                  \
@@ -119,7 +126,15 @@ inline EPO epilogue_narrow(const Epilogue& e) {
         tiles_m = (M + ODW_TILE_M - 1) / ODW_TILE_M;                                       \
         if ((int)blockIdx.x >= tiles_m * tiles_n) return;                                  \
     }                                                                                      \
-    if (ep.k_dev) { const int kd_ = *ep.k_dev; K = kd_ < K ? kd_ : K; }
+    if (ep.k_dev) {                                                                        \
+        const int kd_ = *ep.k_dev; K = kd_ < K ? kd_ : K;                                  \
+        if (K <= 0) {                                                                      \
+            int tm_, tn_;                                                                  \
+            tile_coords<8>(blockIdx.x, tiles_m, tiles_n, tm_, tn_, ep.pm);                 \
+            zero_tile<OUT_BF16>(Cv, ldc, M, N, tm_ * BM, tn_ * BN, BM, BN, ep.accumulate); \
+            return;                                                                        \
+        }                                                                                  \
+    }
 
 __device__ __forceinline__ int lds_slot(int row, int chunk) { return row * kChunksPerRow + (chunk ^ ((row >> 1) & 7)); }
 
@@ -231,6 +246,19 @@ __device__ __forceinline__ void tile_coords(int b, int tiles_m, int tiles_n, int
     const int gsize = tiles_m - first < PM ? tiles_m - first : PM;
     tm = first + in_group % gsize;
     tn = in_group / gsize;
+}
+
+// the (TM x TN) tile at (m0, n0) of C set to zero (an empty reduction; accumulate: C += 0 = nothing to do)
+template <bool OUT_BF16>
+__device__ __forceinline__ void zero_tile(void* __restrict__ Cv, int ldc, int M, int N, int m0, int n0, int TM, int TN, int accumulate) {
+    if (accumulate) return;
+    for (int i = threadIdx.x; i < TM * TN; i += blockDim.x) {
+        const int m = m0 + i / TN, n = n0 + i % TN;
+        if (m < M && n < N) {
+            if (OUT_BF16) reinterpret_cast<unsigned short*>(Cv)[(size_t)m * ldc + n] = 0;
+            else reinterpret_cast<float*>(Cv)[(size_t)m * ldc + n] = 0.0f;
+        }
+    }
 }
 
 template <bool OUT_BF16>
@@ -583,7 +611,7 @@ __global__ __launch_bounds__(kRingThreads, 2) void gemm_nt_bf16_ring_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [stage][A 256 rows | B 128 rows]
-    ODW_SPLITK_ENTER(RM);
+    ODW_SPLITK_ENTER(RM, RN);
     int tm, tn;
     tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * RM, n0 = tn * RN;
@@ -965,7 +993,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void gemm_nt_bf16_big_kernel(
     const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ B, int ldb, int M, int N,
     int K, void* __restrict__ Cv, int ldc, Epilogue ep, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];       // [slot][A 256 rows | B 256 rows]
-    ODW_SPLITK_ENTER(GM);
+    ODW_SPLITK_ENTER(GM, GN);
     int tm, tn;
     tile_coords<4>(blockIdx.x, tiles_m, tiles_n, tm, tn, ep.pm);
     const int m0 = tm * GM, n0 = tn * GN;

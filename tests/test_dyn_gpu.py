@@ -75,6 +75,28 @@ def test_gemm_with_the_reduction_length_on_the_device(mods, Kd, Kcap, M, N):
     assert (out2 - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) * np.sqrt(Kd)
 
 
+@pytest.mark.parametrize("Kd,hint,M,N", [(448, 4096, 128, 4096), (64, 8192, 128, 4096), (1024, 8192, 4096, 4096), (192, 6144, 4096, 25088)])
+def test_reduction_much_shorter_than_its_hint_leaves_empty_slices_that_are_zero(mods, Kd, hint, M, N):
+    """a plan made for a long reduction (many K slices) meeting a short live length: the slices past it are EMPTY -- their
+    partial tiles must be zeros, written without going through the operand pipeline (with no K step nothing waits for the
+    prologue's DMA, which then lands in the LDS the epilogue stages through: tests/test_timed_step_gpu.py caught that as a
+    garbage Sim_Net weight gradient, one run in three)"""
+    L, dyn, gemm, precision = mods
+    precision.set_precision("bf16")
+    Kcap = 8192
+    a = rnd(40, (M, Kcap), 0.1).bfloat16()
+    b = rnd(41, (N, Kcap), 0.1).bfloat16()
+    a[:, Kd:] = float("nan")
+    b[:, Kd:] = float("nan")
+    ref = torch.empty((M, N), device="cuda")
+    gemm.gemm_nt(a[:, :Kd].contiguous(), b[:, :Kd].contiguous(), M, N, Kd, ref)
+    for rep in range(6):                                     # (the failure was timing-dependent)
+        out = torch.full((M, N), SENT, device="cuda")
+        dyn.gemm_nt(a, b, M, N, Kcap, out, k=dyn.Dyn(dev_int(Kd), Kcap, hint))
+        assert torch.isfinite(out).all()
+        assert (out - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) * np.sqrt(Kd), rep
+
+
 def test_per_row_draw_table_reproduces_the_stacked_segments(mods):
     """dropout of stacked passes: the table written by odw_loss_lists_a (row inside its pass, key0, key1) draws what the
     host-side segment list drew"""
