@@ -290,7 +290,7 @@ class DeviceContrastive(object):
                 out.append((b, sh.weight, getattr(getattr(self.fe, name, None), "tag", None) if name != "sim0" else None))
         return out
 
-    def backward_now(self):
+    def backward_now(self, act_stream=None):
         """The branch's backward queued at once, with the unit weight of the reference's plain sum of losses
         (engine/trainer.py:102) -- what loss_fused's early backward does for the dense losses.  Everything the branch's
         gradients depend on exists as soon as SupCon has run; queued here, ahead of the dense losses' backward, the views'
@@ -300,12 +300,15 @@ class DeviceContrastive(object):
         one = _ONE.get(str(self.device))
         if one is None:
             one = _ONE[str(self.device)] = torch.ones(1, dtype=torch.float32, device=self.device)
-        self.backward(one)
+        self.backward(one, act_stream=act_stream)
         self.done = True
 
     # ------------------------------------------------------------------------------------------------------- backward
-    def backward(self, g):
-        """d(loss)/d(everything) for an incoming gradient g (a device scalar) of the SupCon value."""
+    def backward(self, g, act_stream=None):
+        """d(loss)/d(everything) for an incoming gradient g (a device scalar) of the SupCon value.
+        act_stream: the re-attached clean rows' chain runs there, beside the views' chain on the current stream -- the two
+        share nothing but the weight-gradient batches (disjoint column blocks, flushed after both) and the side buffer
+        (disjoint rows)."""
         dev, fe = self.device, self.fe
         V_cap, A_cap, E_cap = self.V_cap, self.A_cap, self.E_cap
         fc6, fc7 = fe.fc6, fe.fc7
@@ -322,6 +325,23 @@ class DeviceContrastive(object):
             raise RuntimeError("DeviceContrastive.backward: the pooling node's side buffer is gone (its backward already ran)")
         extra = torch.empty((A_cap + E_cap, self.CS), dtype=torch.float32, device=dev)
         scal_b = self.scal_b
+        # Sim_Net's second Linear (128 x 4096: too small for a registered batch) gets ONE weight-gradient product over both row
+        # sets as well: [views | re-attached rows] column blocks, the second at the device offset r64(V)
+        w2 = sim2.weight
+        s2_dzt = s2_xt = None
+        if w2.requires_grad:
+            s2_cols = dyn.r64(V_cap) + dyn.r64(A_cap)
+            s2_dzt = torch.empty((w2.shape[0], s2_cols), dtype=torch.bfloat16, device=dev)
+            s2_xt = torch.empty((w2.shape[1], s2_cols), dtype=torch.bfloat16, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        held0 = None
+        if act_stream is not None:
+            for name, sh in (("fc6", self.sh6), ("fc7", self.sh7), ("sim0", self.shs0)):      # (allocated HERE, on this stream)
+                if name in self.slots:
+                    sh.batch.buffers(sh.weight.shape[0], sh.weight.shape[1], dev)
+            b0 = self.shs0.batch if "sim0" in self.slots else None
+            if b0 is not None and not b0.hold:
+                b0.hold, held0 = True, b0
 
         def chain(d_e, e_norm, norm, m, m64, which):
             """Sim_Net -> fc7 -> fc6 backward of one row set.  which = "views": saved activations are this object's, the column
@@ -363,6 +383,10 @@ class DeviceContrastive(object):
                         batch.dyn_k = dyn.Dyn(scal_b[7:8], sum(batch.rows), dyn.r64(self.h_V) + dyn.r64(self.h_A))
                     if batch.filled == len(batch.rows) and not batch.hold:
                         batch.flush(w, layer_.tag)
+                elif w.requires_grad and name == "sim2":
+                    col = scal_b[6:7] if act else None
+                    dyn.bwd_prep(dy, y, n_out, scale, dz, s2_dzt, db, m, tcol_off=col, y_rows=rows if y is not None else None)
+                    dyn.transpose(x, k_in, s2_xt, m, col_off=col, src_rows=rows)
                 elif w.requires_grad:
                     dzt = torch.empty((n_out, dyn.r64(cap)), dtype=torch.bfloat16, device=dev)
                     xt = torch.empty((k_in, dyn.r64(cap)), dtype=torch.bfloat16, device=dev)
@@ -401,10 +425,32 @@ class DeviceContrastive(object):
                         "rows_views_bwd_store_grouped")
 
         _dbg("scatter")
-        chain(d_emb, self.emb, self.norm_v, self.dV, self.dV64, "views")
-        _dbg("bwd views")
-        chain(d_act, self.e_act, self.norm_a, self.dA, self.dA64, "act")
+        if act_stream is not None:
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            act_stream.wait_event(fork)
+            with torch.cuda.stream(act_stream):
+                chain(d_act, self.e_act, self.norm_a, self.dA, self.dA64, "act")
+                met = torch.cuda.Event()
+                met.record(act_stream)
+            chain(d_emb, self.emb, self.norm_v, self.dV, self.dV64, "views")
+            cur.wait_event(met)
+        else:
+            chain(d_emb, self.emb, self.norm_v, self.dV, self.dV64, "views")
+            _dbg("bwd views")
+            chain(d_act, self.e_act, self.norm_a, self.dA, self.dA64, "act")
         _dbg("bwd act")
+        if s2_dzt is not None:
+            fresh = w2.grad is None or getattr(w2, "_odw_fresh", False)
+            if w2.grad is None:
+                w2.grad = torch.empty_like(w2)
+            w2._odw_fresh = False
+            dyn.gemm_nt(s2_dzt, s2_xt, w2.shape[0], w2.shape[1], s2_dzt.shape[1], w2.grad, accumulate=not fresh,
+                        k=dyn.Dyn(scal_b[7:8], s2_dzt.shape[1], dyn.r64(self.h_V) + dyn.r64(self.h_A)), tag=None)
+        if held0 is not None:
+            held0.hold = False
+            if held0.rows and held0.filled == len(held0.rows):
+                held0.flush(sim0.weight, sim0.tag)
         holder.dyn_extra = (extra, self.roi_index_all, A_cap + E_cap, self.dE)
         holder.pending = []
         self.extra = extra

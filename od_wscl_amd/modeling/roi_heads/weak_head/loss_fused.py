@@ -672,7 +672,18 @@ class RoIRegLossFused(RoIRegLossComputation):
                 for b, _, _ in held:
                     b.hold = True
             if eager:
-                branch.backward_now()   # (see DeviceContrastive.backward_now: the whole head backward is queued in forward order)
+                act_stream = None
+                # (a THIRD stream for the re-attached rows' chain beside the views' chain: measured and NOT taken -- 12.85 ms per
+                # step against 8.9 unprofiled, 9.6 under rocprofv3, with 4 / 8 / 16 hardware queues alike: the two chains'
+                # ~40 small launches with three streams waiting on each other cost more than their overlap buys;
+                # ODW_ACT_STREAM=1 enables it for comparison)
+                if beside and _os2.environ.get("ODW_ACT_STREAM") == "1":
+                    act_stream = getattr(self, "_act_stream", None)
+                    if act_stream is None or act_stream.device != device:
+                        act_stream = self._act_stream = torch.cuda.Stream(
+                            device=device, priority=int(_os2.environ.get("ODW_PRIO", "-1,0,-1").split(",")[2]))
+                # (see DeviceContrastive.backward_now: the whole head backward is queued in forward order)
+                branch.backward_now(act_stream=act_stream)
             if beside:
                 joined = torch.cuda.Event()
                 joined.record(side)

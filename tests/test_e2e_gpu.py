@@ -680,6 +680,9 @@ def test_device_resident_lists_equal_the_host_assembled_lists(name, exact_hints,
         ref = p.grad.double()
         err = (grads_dev[n].double() - ref).norm().item() / max(ref.norm().item(), 1e-12)
         if exact_hints:
-            assert torch.equal(grads_dev[n], p.grad) if not n.endswith("bias") else err <= 1e-6, (n, err)
+            # (Sim_Net's second Linear: the device path takes its weight gradient as ONE product over [views | re-attached rows],
+            # the host-list path as two accumulating ones -- the same terms, another association; nothing else reads it)
+            loose = n.endswith("bias") or n.endswith("model_sim.mlp.2.weight")
+            assert torch.equal(grads_dev[n], p.grad) if not loose else err <= 1e-6, (n, err)
         else:
             assert err <= (MIXED_GRAD_TOL if n.startswith("backbone") else 1e-3) or ref.norm().item() < 1e-7, (n, err)
