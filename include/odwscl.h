@@ -611,7 +611,8 @@ int odw_rows_views_cm(const void* src_cm, int64_t ld_src, int64_t src_mid, const
  * P64 + r64(V) + r64(A), r64(V), r64(V) + r64(A), r64(A), pseudo-GT overflow, r64(N)}, the SupCon inputs in the reference's
  * orders (features class-major: feat_index into [A_cap re-attached clean rows; views], labels; weights in APPEND order = Q1,
  * = final_score[row, c + 1] / colstat[...]: Q12), the ascending unique proposal rows the features reference (act_rows) and
- * the pooling node's side-buffer entry list roi_index_all = [act_rows | roi_index]. */
+ * the pooling node's side-buffer entry list roi_index_all = [act_rows | roi_index].  sticky (optional, 2 ints the kernels only ever
+ * set): [0] a capacity overflowed in some step, [1] more pseudo-GT boxes than gt_max -- read back at the caller's leisure. */
 int odw_loss_lists_a(const int* grp, const int* cls_order, int G, const int* counts, const int* rows, int maxpos, int pstride,
                      int sum_p, int n_cls1, int e_cap, int* scal, int* e0, int* roi_index, int* bank_index, int* bank_off,
                      int* bank_cnt, void* row_tab6, void* row_tab7, void* stream);
@@ -620,7 +621,7 @@ int odw_loss_lists_b(const int* grp, const int* cls_order, int G, const int* img
                      const int* bank_index, const int* bank_off, const int* bank_cnt, const int* fresh_idx, const int* fresh_cnt,
                      const int* gt_cnt, int gt_max, const float* final_score, int fs_cols, const float* colstat, int cs_ld,
                      int cs_off, int n_cap, int a_cap, int e_cap, int p64, int* scal, int* feat_index, int* labels, float* weights,
-                     int* act_rows, int* roi_index_all, void* stream);
+                     int* act_rows, int* roi_index_all, int* sticky, void* stream);
 /* out[r] = index[r] < split ? t0[index[r]] : t1[index[r] - split], r < *n_dev (fp32 rows of D values); and its transpose
  * d0 / d1 += (*scale) * alpha * g (fp32 atomics; scale = a device scalar or NULL = 1). */
 int odw_gather_rows2_dyn(const float* t0, const float* t1, int split, const int* index, const int* n_dev, int n_cap, int D,

@@ -157,7 +157,7 @@ SIGNATURES = {
     # ---- device-resident control flow of the loss (round 6)
     "odw_loss_lists_a": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "odw_loss_lists_b": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i,
-                               c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+                               c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "odw_gather_rows2_dyn": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "odw_scatter_rows2_dyn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p]),
     "odw_gather_rows_dyn": (c_i, [c_p, c_l, c_p, c_p, c_i, c_l, c_p, c_l, c_p]),

@@ -113,6 +113,8 @@ struct ListsB {
     float* weights;            // [n_cap]
     int* act_rows;             // [a_cap]  ascending unique proposal rows the features reference
     int* roi_index_all;        // [a_cap + e_cap]  = [act_rows | roi_index]  (the pooling node's side-buffer entries)
+    int* sticky;               // optional [2], never cleared by the kernels: [0] |= a capacity overflowed, [1] |= pseudo-GT overflow
+                               // (the host reads the step scalars back only now and then; an overflow must not slip between reads)
 };
 
 // one workgroup; the bit set of referenced proposal rows lives in dynamic LDS: W32 words + W32 + 1 prefix counts
@@ -227,6 +229,10 @@ __global__ __launch_bounds__(kThreads) void loss_lists_b_kernel(ListsB b) {
         b.scal[0] = Nc; b.scal[1] = Ac; b.scal[2] = Ac + E1; b.scal[3] = over;
         b.scal[4] = b.p64 + r64i(V); b.scal[5] = b.p64 + r64i(V) + r64i(Ac);
         b.scal[6] = r64i(V); b.scal[7] = r64i(V) + r64i(Ac); b.scal[8] = r64i(Ac); b.scal[9] = gt_over; b.scal[10] = r64i(Nc);
+        if (b.sticky) {
+            if (over) b.sticky[0] = 1;
+            if (gt_over) b.sticky[1] = 1;
+        }
     }
 }
 
@@ -314,7 +320,7 @@ ODW_EXPORT int odw_loss_lists_b(const int* grp, const int* cls_order, int G, con
                                 const int* fresh_idx, const int* fresh_cnt, const int* gt_cnt, int gt_max, const float* final_score,
                                 int fs_cols, const float* colstat, int cs_ld, int cs_off, int n_cap, int a_cap, int e_cap, int p64,
                                 int* scal, int* feat_index, int* labels, float* weights, int* act_rows, int* roi_index_all,
-                                void* stream_) {
+                                int* sticky, void* stream_) {
     ODW_REQUIRE(G >= 1 && G <= 256 && n_img >= 1 && maxpos >= 1 && pstride >= 1 && sum_p >= 1 && n_cap >= 1 && a_cap >= 1 && e_cap >= 1,
                 "loss_lists_b: bad dims");
     ODW_REQUIRE(grp && cls_order && img_off && n_pos && pos_cls && scal_a && e0 && roi_index && bank_index && bank_off && bank_cnt &&
@@ -326,7 +332,7 @@ ODW_EXPORT int odw_loss_lists_b(const int* grp, const int* cls_order, int G, con
     b.fresh_cnt = fresh_cnt; b.gt_cnt = gt_cnt; b.final_score = final_score; b.colstat = colstat; b.G = G; b.n_img = n_img;
     b.maxpos = maxpos; b.pstride = pstride; b.sum_p = sum_p; b.fs_cols = fs_cols; b.cs_ld = cs_ld; b.cs_off = cs_off;
     b.n_cap = n_cap; b.a_cap = a_cap; b.e_cap = e_cap; b.p64 = p64; b.gt_max = gt_max; b.scal = scal; b.feat_index = feat_index;
-    b.labels = labels; b.weights = weights; b.act_rows = act_rows; b.roi_index_all = roi_index_all;
+    b.labels = labels; b.weights = weights; b.act_rows = act_rows; b.roi_index_all = roi_index_all; b.sticky = sticky;
     const int W32 = (sum_p + 31) / 32;
     const size_t lds = (size_t)W32 * 4 + (size_t)(W32 + 1) * 4;
     ODW_REQUIRE(lds <= (size_t)ODW_LDS_BYTES - 4096, "loss_lists_b: %d proposals in the batch (the bit set must fit LDS)", sum_p);

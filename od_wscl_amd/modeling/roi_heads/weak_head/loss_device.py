@@ -52,6 +52,7 @@ class HintReader(object):
         self.slots = [None] * 4
         self.k = 0
         self.hints = {}
+        self.sticky = torch.zeros(2, dtype=torch.int32, device=device)        # set by odw_loss_lists_b, never cleared
 
     def post(self, scal_a, scal_b, caps, key=None):
         if _os.environ.get("ODW_NO_HINT_POST") == "1":          # (measurement: what the read-back stream costs)
@@ -63,7 +64,7 @@ class HintReader(object):
         self.k = (k + 1) % len(self.slots)
         slot = self.slots[k]
         if slot is None:
-            slot = self.slots[k] = {"buf": torch.zeros(32, dtype=torch.int32).pin_memory(), "ev": None, "caps": None}
+            slot = self.slots[k] = {"buf": torch.zeros(34, dtype=torch.int32).pin_memory(), "ev": None, "caps": None}
         elif slot["ev"] is not None and not slot["ev"].query():
             return                      # four steps behind and still in flight: skip this step's copy, never wait
         ready = torch.cuda.Event()
@@ -71,7 +72,8 @@ class HintReader(object):
         self.stream.wait_event(ready)
         with torch.cuda.stream(self.stream):
             slot["buf"][:16].copy_(scal_a, non_blocking=True)
-            slot["buf"][16:].copy_(scal_b, non_blocking=True)
+            slot["buf"][16:32].copy_(scal_b, non_blocking=True)
+            slot["buf"][32:34].copy_(self.sticky, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         scal_a.record_stream(self.stream)
@@ -87,11 +89,11 @@ class HintReader(object):
                 continue
             slot["seen"] = True
             v = slot["buf"].numpy()
-            if v[4] or v[16 + 3]:
+            if v[4] or v[16 + 3] or v[32]:
                 raise RuntimeError("RoIRegLossFused (device lists): a step's selection did not fit its buffers -- %d sampled rows, "
                                    "%d contrastive rows, %d re-attached rows for capacities %s; raise ODW.MAX_SAMPLED_ROWS"
                                    % (v[0], v[16], v[17], slot["caps"]))
-            if v[16 + 9]:
+            if v[16 + 9] or v[33]:
                 raise RuntimeError("RoIRegLossFused: more than %d pseudo-GT boxes in one branch (od_assign's limit)" % GT_MAX)
             self.hints[slot.get("key")] = {"E1": int(v[0]), "V": int(v[1]), "N": int(v[16]), "A": int(v[17])}
         h = self.hints.get(key)
@@ -263,7 +265,8 @@ class DeviceContrastive(object):
                                      L.ptr(fresh_idx), L.ptr(fresh_cnt), L.ptr(gt_cnt), GT_MAX, L.ptr(final_score),
                                      final_score.shape[1], L.ptr(colstat_flat), cs_ld, cs_off, N_cap, A_cap, E_cap, p64,
                                      L.ptr(self.scal_b), L.ptr(self.feat_index), L.ptr(self.labels), L.ptr(self.weights),
-                                     L.ptr(self.act_rows), L.ptr(self.roi_index_all), L.stream()), "loss_lists_b")
+                                     L.ptr(self.act_rows), L.ptr(self.roi_index_all), L.ptr(self.hints.sticky), L.stream()),
+                "loss_lists_b")
         _dbg("lists_b", scal=self.scal_b)
         if _EXACT:
             vb = self.scal_b.cpu().numpy()

@@ -435,12 +435,14 @@ def test_device_lists_equal_the_host_assembly(mods, case):
     n_pos = cu([len(p) for p in pos_host])
     pos_cls = cu([p + [0] * (maxpos - len(p)) for p in pos_host])
     gt_cnt = torch.zeros((n_img, 3), dtype=torch.int32, device="cuda")
+    sticky = torch.zeros(2, dtype=torch.int32, device="cuda")
     fs_d, cs_d = torch.from_numpy(final_score).cuda(), torch.from_numpy(colstat).cuda()
     L.check(lib.odw_loss_lists_b(L.ptr(grp_d), L.ptr(order_d), G, L.ptr(offs_d), L.ptr(n_pos), L.ptr(pos_cls), n_img, maxpos, max_p,
                                  sum_p, L.ptr(scal_a), L.ptr(e0), L.ptr(roi_index), L.ptr(bank_index), L.ptr(bank_off), L.ptr(bank_cnt),
                                  L.ptr(fresh_rows_d), L.ptr(fresh_cnt_d), L.ptr(gt_cnt), 2048, L.ptr(fs_d), C, L.ptr(cs_d),
                                  3 * 128, 2 * 128, N_cap, A_cap, E_cap, p64, L.ptr(scal_b), L.ptr(feat_index), L.ptr(labels),
-                                 L.ptr(weights), L.ptr(act_rows), L.ptr(roi_all), L.stream()), "lists_b")
+                                 L.ptr(weights), L.ptr(act_rows), L.ptr(roi_all), L.ptr(sticky), L.stream()), "lists_b")
+    assert sticky.cpu().tolist() == [0, 0]
     sb = scal_b.cpu().numpy()
     r64 = lambda v: (v + 63) // 64 * 64
     V = 2 * E1

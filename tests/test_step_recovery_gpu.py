@@ -65,3 +65,19 @@ def test_a_step_that_fails_in_backward_does_not_poison_the_next():
     assert r0 == ref0                                    # (deterministic kernels: the first step is the first step)
     for k in want:
         assert abs(got[k] - want[k]) <= 1e-6 * max(abs(want[k]), 1e-6), (k, got[k], want[k])
+
+
+def test_a_step_that_overflows_the_sampled_row_capacity_raises_soon_after():
+    """ODW.MAX_SAMPLED_ROWS bounds the IoU-sampled rows of a step on the device-resident path; a step that samples more sets a
+    sticky device flag (csrc/loss_lists.hip never writes past a buffer) and a later step's non-blocking look at the flags
+    raises -- loudly, not silently on truncated lists."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.utils.device_rand import DeviceRand
+    cfg, dev, step, (images, targets, rois) = _engine()
+    step.model.roi_heads.loss_evaluator.max_sampled_rows = 8          # (every group of this batch samples more)
+    rand = lambda it: DeviceRand(cfg.SEED, first_stream=(1 << 20) + (it << 12), device=dev)
+    with pytest.raises(RuntimeError, match="did not fit its buffers"):
+        for it in range(6):
+            step(images, targets, rois, rand(it), iteration=it + 1)
+            torch.cuda.synchronize()
