@@ -122,13 +122,17 @@ class DeviceContrastive(object):
         groups = [(idx, ci, c) for idx in range(self.n_img) for ci, c in enumerate(pos_host[idx])]
         self.groups = groups
         self.G = len(groups)
-        # capacity of the sampled rows: what can exist (every proposal of every group), bounded by ODW.MAX_SAMPLED_ROWS per
-        # image (a step that needs more sets the overflow flag: HintReader.poll raises)
-        cfg_cap = int(getattr(owner, "max_sampled_rows", 4096)) * self.n_img
-        self.E_cap = r64up(max(64, min(self.G * self.max_p, cfg_cap)))
+        # Capacities: a function of the batch SHAPE only (images, proposals, classes) -- not of how many labels this batch's
+        # images carry -- so that every step asks the caching allocator for the same block sizes (sizes that changed with the
+        # label count fragmented the pool: 800 MB blocks were still being cut and re-allocated 15 steps into a run).  Sampled
+        # rows: ODW.MAX_SAMPLED_ROWS per image (or every proposal of every class, if that is fewer); a step that needs more
+        # sets the sticky overflow flag and HintReader.poll raises.  The launches' grids are bounded, so a generous capacity
+        # costs memory, not time.
+        per_img = min(int(getattr(owner, "max_sampled_rows", 4096)), (C - 1) * self.max_p)
+        self.E_cap = (max(32, per_img * self.n_img) + 31) // 32 * 32         # (V_cap = 2 E_cap: a multiple of 64)
         self.V_cap = 2 * self.E_cap
-        self.A_cap = r64up(min(self.sum_p, self.E_cap + 3 * self.G * self.max_p))
-        self.N_cap = 3 * self.E_cap + min(3 * self.G * self.max_p, 4 * cfg_cap)
+        self.A_cap = r64up(self.sum_p)
+        self.N_cap = 7 * self.E_cap
         h = hints.poll(self.G)
         self.h_E1 = min(self.E_cap, _bucket(h.get("E1", 256), 64))
         self.h_V = min(self.V_cap, _bucket(h.get("V", 512)))

@@ -694,8 +694,11 @@ class RoIRegLossFused(RoIRegLossComputation):
             final_score, colstat, lab_vecs, n_pos, epsilon, dense_ws, ws_bytes, stacked, fe)
         if beside:
             main.wait_event(joined)
-            for t in (branch.extra, raw):
-                t.record_stream(main)
+            # (No record_stream on what crosses over -- the side buffer, the loss value: a block so marked is parked until an
+            # event on `main` has PASSED, and with the host 8 steps ahead of the GPU that is 8 steps of 800 MB blocks the
+            # allocator has to find elsewhere: 7 hipMallocs in a 20-step run, reserved memory growing by 5 GB.  It is not
+            # needed: the blocks return to the side stream's pool, whose next use is the next step's branch -- behind that
+            # step's fork event, i.e. behind everything `main` does with them in this one.)
             for b, w, tag in held:
                 b.hold = False
                 if b.rows and b.filled == len(b.rows):

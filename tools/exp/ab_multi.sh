@@ -7,6 +7,6 @@ for r in $(seq 1 $R); do
     env $e python bench.py $S 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('%-46s' % '$e', $r, d['value'], d['ms_per_step'], 'median', d['median_ms_per_step'], 'host', d['host_ms_per_step'], d['ms_per_step_by_labels'])"
+print('%-46s' % '$e', $r, d['value'], d['ms_per_step'], 'median', d['median_ms_per_step'], 'host', d['host_ms_per_step'], d['ms_per_step_by_labels'], 'allocs', d['device_allocs_in_timed_region'])"
   done
 done
