@@ -64,20 +64,24 @@ class HintReader(object):
         self.k = (k + 1) % len(self.slots)
         slot = self.slots[k]
         if slot is None:
-            slot = self.slots[k] = {"buf": torch.zeros(34, dtype=torch.int32).pin_memory(), "ev": None, "caps": None}
+            slot = self.slots[k] = {"buf": torch.zeros(34, dtype=torch.int32).pin_memory(), "ev": None, "caps": None,
+                                    "dev": torch.zeros(34, dtype=torch.int32, device=self.device)}
         elif slot["ev"] is not None and not slot["ev"].query():
-            return                      # four steps behind and still in flight: skip this step's copy, never wait
+            return                      # four posts behind and still in flight: skip this step's copy, never wait
+        # the step's scalars go to a PERSISTENT device slot on the step's stream first; the side stream copies that to the
+        # host.  (Copying the step's own tensors from the side stream would need record_stream on them, and a block so
+        # marked is parked until the copy's event has passed -- with the host steps ahead of the GPU, for steps.)
+        d = slot["dev"]
+        d[:16].copy_(scal_a)
+        d[16:32].copy_(scal_b)
+        d[32:34].copy_(self.sticky)
         ready = torch.cuda.Event()
         ready.record()
         self.stream.wait_event(ready)
         with torch.cuda.stream(self.stream):
-            slot["buf"][:16].copy_(scal_a, non_blocking=True)
-            slot["buf"][16:32].copy_(scal_b, non_blocking=True)
-            slot["buf"][32:34].copy_(self.sticky, non_blocking=True)
+            slot["buf"].copy_(d, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        scal_a.record_stream(self.stream)
-        scal_b.record_stream(self.stream)
         slot["ev"], slot["caps"], slot["seen"], slot["key"] = ev, caps, False, key
 
     def poll(self, key=None):
