@@ -678,6 +678,19 @@ int odw_roi_pool_stack_backward_dyn(const void* dX, int dx_is_f32, int ld, const
                                     const float* keep, const float* keep_sum, const float* extra, const int* extra_roi, int E_cap,
                                     const int* e_dev, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW,
                                     float* grad_in, void* workspace, int64_t workspace_bytes, void* stream);
+/* The input gradient of the first Linear and the maximum ROI pooling's backward scales by, from one pass.  The reference's
+ * ROIPool backward (csrc/cuda/ROIPool_cuda.cu:80-108) adds floats with atomicAdd; this path adds in fixed point
+ * (deterministic), which needs max |dX| first -- a 200 MB read of its own until round 6.
+ * odw_gemm_nt_bf16_absmax: C (fp32, N % 4 == 0) = alpha A B^T as odw_gemm_nt_bf16_ws computes it (same plan, same workspace
+ * query), and *absmax (a zeroed 4-byte device word) = max(*absmax, bits of max |C|).
+ * odw_roi_pool_stack_backward_scaled: odw_roi_pool_stack_backward_ws / _dyn (e_dev NULL: E_cap is exact) with that word already
+ * in workspace[0..4): only the side buffer's rows are scanned. */
+int odw_gemm_nt_bf16_absmax(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* C, int ldc, float alpha,
+                            void* absmax, void* workspace, int64_t workspace_bytes, void* stream);
+int odw_roi_pool_stack_backward_scaled(const void* dX, int dx_is_f32, int ld, const void* argmax_u16, const float* rois,
+                                       const float* keep, const float* keep_sum, const float* extra, const int* extra_roi, int E_cap,
+                                       const int* e_dev, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW,
+                                       float* grad_in, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,7 @@ struct EpilogueT {
     const int* k_dev = nullptr;
     const uint4* row_tab = nullptr;  // dropout draws of stacked passes whose boundaries live on the device: row m draws element
                            // (row_tab[m].x, column) of the stream keyed (row_tab[m].y, row_tab[m].z); replaces seg_* / row_ids
+    unsigned* absmax = nullptr;      // fp32 output only: atomicMax of the bit patterns of |value stored| lands here (epi_absmax_commit)
 };
 typedef EpilogueT<kMaxSeg> Epilogue;
 // The pair form of gemm_nt_cm_kernel (two accumulator sets, 256 VGPRs, counted vmcnt waits) takes the two segments it
@@ -79,7 +80,7 @@ template <class EPO>
 inline EPO epilogue_narrow(const Epilogue& e) {
     constexpr int NSEG = EPO::kSegs;
     EPO o;
-    o.m_dev = e.m_dev; o.k_dev = e.k_dev; o.row_tab = e.row_tab;
+    o.m_dev = e.m_dev; o.k_dev = e.k_dev; o.row_tab = e.row_tab; o.absmax = e.absmax;
     o.bias = e.bias; o.relu = e.relu; o.drop_p = e.drop_p; o.nseg = e.nseg < NSEG ? e.nseg : NSEG;
     for (int i = 0; i < NSEG; ++i) { o.seg_row[i] = e.seg_row[i]; o.seg_k0[i] = e.seg_k0[i]; o.seg_k1[i] = e.seg_k1[i]; }
     o.accumulate = e.accumulate; o.alpha = e.alpha; o.mask = e.mask; o.ldmask = e.ldmask; o.pm = e.pm; o.row_ids = e.row_ids;
@@ -187,11 +188,25 @@ __device__ __forceinline__ void store_tile(uint4* __restrict__ sa, uint4* __rest
 }
 
 
+// max |x| over the values a launch STORES, for the consumer that scatters them in fixed point (odw_fixed.h: ROI pooling's
+// backward scales by the power of two above the largest gradient).  The stand-alone pre-pass (odwfx::absmax_kernel) re-reads
+// the 200 MB input gradient of fc6 for it -- 87 us per step; the product's epilogue has every value in registers.  A maximum
+// does not depend on the order it is taken in, so the word ends up bit-identical to the pre-pass's.  One atomic per wave at most:
+// the word only grows, so a wave whose maximum is not above what a (possibly stale, hence smaller) read returns has nothing to
+// add (same-address atomics serialise in L2 at ~14 ns each; almost all are skipped after the first few workgroups).
+__device__ __forceinline__ unsigned epi_absbits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+__device__ __forceinline__ void epi_absmax_commit(unsigned m, unsigned* __restrict__ out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, m);
+}
+
 template <bool OUT_BF16, int MI = 2, int NJ = 2>
 __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[MI][NJ], void* __restrict__ Cv, int ldc, int M, int N,
                                                int m0, int n0, int wm, int wn, int half, int l31,
                                                const Epilogue& ep) {
     // ---- epilogue.  C layout of a 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    unsigned amax = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wn * (32 * NJ) + j * 32 + l31;
@@ -221,11 +236,14 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[MI][NJ], void
                     reinterpret_cast<unsigned short*>(Cv)[(size_t)m * ldc + n] = f2bf(v);
                 } else {
                     float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
-                    *c = ep.accumulate ? *c + v : v;
+                    v = ep.accumulate ? *c + v : v;
+                    *c = v;
+                    amax = max(amax, epi_absbits(v));
                 }
             }
         }
     }
+    if (!OUT_BF16 && ep.absmax) epi_absmax_commit(amax, ep.absmax);
 }
 
 // ---- XCD-aware, L2-patch tile mapping (correctness never depends on it) ------------------------
@@ -459,6 +477,7 @@ __device__ __forceinline__ void band_store(const f32x16 (&acc)[NI][2], void* __r
         bias_s[lane] = ep.bias ? ep.bias[n < N ? n : N - 1] : 0.0f;       // columns >= N are never stored
     }
     const bool mask_vec = ep.mask && ep.ldmask % 4 == 0 && N % 4 == 0 && (((uintptr_t)ep.mask) & 7) == 0;
+    unsigned amax = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const long long m = rowmap(i * 32 + l31);
@@ -517,12 +536,19 @@ __device__ __forceinline__ void band_store(const f32x16 (&acc)[NI][2], void* __r
             if (!OUT_BF16 && ep.accumulate) {
                 const float4 o = *reinterpret_cast<const float4*>(dst);
                 const float4 a = __builtin_bit_cast(float4, d);
-                *reinterpret_cast<float4*>(dst) = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+                const float4 w = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+                *reinterpret_cast<float4*>(dst) = w;
+                if (EP::kDyn && ep.absmax) amax = max(max(amax, max(epi_absbits(w.x), epi_absbits(w.y))), max(epi_absbits(w.z), epi_absbits(w.w)));
             } else {
                 *reinterpret_cast<uint4*>(dst) = d;
+                // (a 16-byte chunk that starts below N may reach past it when N % 4 != 0: those lanes hold values of columns
+                // that do not exist -- the launch refuses absmax for such an N)
+                if (!OUT_BF16 && EP::kDyn && ep.absmax)
+                    amax = max(max(amax, max(d.x & 0x7fffffffu, d.y & 0x7fffffffu)), max(d.z & 0x7fffffffu, d.w & 0x7fffffffu));
             }
         }
     }
+    if (!OUT_BF16 && EP::kDyn && ep.absmax) epi_absmax_commit(amax, ep.absmax);
 }
 
 // The same block without the 16-byte-alignment conditions (any N, any ldc): element stores straight from the
@@ -532,6 +558,7 @@ __device__ __forceinline__ void band_store_scalar(const f32x16 (&acc)[NI][2], vo
                                                   int lane, const EP& ep, RowMap rowmap) {
     const int half = lane >> 5, l31 = lane & 31;
     const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+    unsigned amax = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const long long m = rowmap(i * 32 + l31);
@@ -561,10 +588,13 @@ __device__ __forceinline__ void band_store_scalar(const f32x16 (&acc)[NI][2], vo
                     reinterpret_cast<unsigned short*>(Cv)[(size_t)m * ldc + n] = f2bf(x);
                 } else {
                     float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
-                    *c = ep.accumulate ? *c + x : x;
+                    x = ep.accumulate ? *c + x : x;
+                    *c = x;
+                    amax = max(amax, epi_absbits(x));
                 }
             }
     }
+    if (!OUT_BF16 && EP::kDyn && ep.absmax) epi_absmax_commit(amax, ep.absmax);
 }
 
 // rows of C reachable with 16-byte vector stores for every 16-byte column chunk that starts below N
@@ -2324,6 +2354,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (ep.m_dev) { const int md_ = *ep.m_dev; M = md_ < M ? md_ : M; }
     const long long total = (long long)M * n4;
     const float keep_scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+    unsigned amax = 0;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
         const float* p = ws + (size_t)m * ldw + n;
@@ -2378,9 +2409,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         } else {
             float* c = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (n + q < N) c[q] = ep.accumulate ? c[q] + v[q] : v[q];
+            for (int q = 0; q < 4; ++q)
+                if (n + q < N) {
+                    const float x = ep.accumulate ? c[q] + v[q] : v[q];
+                    c[q] = x;
+                    amax = max(amax, epi_absbits(x));
+                }
         }
     }
+    if (!OUT_BF16 && ep.absmax) epi_absmax_commit(amax, ep.absmax);     // (after the loop: every lane of the wave is back)
 }
 
 // The same second pass when the consumer is the next convolution of the "bf16x2f" forward (conv3x3_halo2_kernel): the sum of
@@ -2750,6 +2787,7 @@ struct DynExtent {
     const int* m_dev; int m_hint;
     const int* k_dev; int k_hint;
     const uint4* row_tab;
+    unsigned* absmax;       // odw_gemm_nt_bf16_absmax: max |C| of the launch, for the consumer's fixed-point scale
 };
 
 static int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
@@ -2799,9 +2837,23 @@ ODW_EXPORT int odw_gemm_nt_bf16_dyn(const void* A, int lda, const void* B, int l
     ODW_REQUIRE(drop_p == 0.0f || row_tab, "gemm_nt_bf16_dyn: dropout needs the per-row draw table");
     DynExtent d;
     d.m_dev = m_dev; d.m_hint = dyn_hint(M_hint, M_cap); d.k_dev = k_dev; d.k_hint = dyn_hint(K_hint, K_cap);
-    d.row_tab = (const uint4*)row_tab;
+    d.row_tab = (const uint4*)row_tab; d.absmax = nullptr;
     return gemm_nt_launch(A, lda, B, ldb, M_cap, N, K_cap, C, ldc, c_is_bf16, bias, relu, alpha, drop_p, 0, nullptr, nullptr,
                           nullptr, accumulate, workspace, workspace_bytes, stream_, &d);
+}
+
+// C[M x N] (fp32) = alpha A B^T, and *absmax = max(*absmax, bit pattern of max |C[m][n]|) -- what odwfx::absmax_kernel would
+// find by re-reading C (odw_fixed.h).  The caller zeroes the word and hands it to the scatter that consumes C
+// (odw_roi_pool_stack_backward_scaled): fc6's input gradient, 200 MB, is no longer read twice.  Plans, workspace and variant as
+// odw_gemm_nt_bf16_workspace / _ws say for the same shape.
+ODW_EXPORT int odw_gemm_nt_bf16_absmax(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* C, int ldc,
+                                       float alpha, void* absmax, void* workspace, int64_t workspace_bytes, void* stream_) {
+    ODW_REQUIRE(absmax && (((uintptr_t)absmax) & 3) == 0, "gemm_nt_bf16_absmax: the 4-byte word the maximum lands in");
+    ODW_REQUIRE(N % 4 == 0, "gemm_nt_bf16_absmax: N=%d must be a multiple of 4 (the staged store's 16-byte chunks end at N)", N);
+    DynExtent d;
+    d.m_dev = nullptr; d.m_hint = M; d.k_dev = nullptr; d.k_hint = K; d.row_tab = nullptr; d.absmax = (unsigned*)absmax;
+    return gemm_nt_launch(A, lda, B, ldb, M, N, K, C, ldc, 0, nullptr, 0, alpha, 0.0f, 0, nullptr, nullptr, nullptr, 0, workspace,
+                          workspace_bytes, stream_, &d);
 }
 
 static int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, int M, int N, int K, void* C,
@@ -2840,7 +2892,7 @@ static int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, int M,
         ep.seg_k0[i] = (i < nseg && seg_keys) ? seg_keys[2 * i] : 0;
         ep.seg_k1[i] = (i < nseg && seg_keys) ? seg_keys[2 * i + 1] : 0;
     }
-    if (dyn) { ep.m_dev = dyn->m_dev; ep.k_dev = dyn->k_dev; ep.row_tab = dyn->row_tab; }
+    if (dyn) { ep.m_dev = dyn->m_dev; ep.k_dev = dyn->k_dev; ep.row_tab = dyn->row_tab; ep.absmax = dyn->absmax; }
     if (drop_p > 0.0f && !(dyn && dyn->row_tab))
         ODW_REQUIRE(nseg >= 1 && seg_rows && seg_keys && seg_rows[0] == 0, "gemm_nt_bf16: dropout needs row segments starting at 0");
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -2857,6 +2909,7 @@ static int gemm_nt_launch(const void* A, int lda, const void* B, int ldb, int M,
         ODW_REQUIRE((((uintptr_t)workspace) & 15) == 0, "gemm_nt_bf16: workspace must be 16-byte aligned");
         Epilogue pe = ep;
         pe.bias = nullptr; pe.relu = 0; pe.drop_p = 0.0f; pe.nseg = 0; pe.accumulate = 0; pe.alpha = 1.0f; pe.row_ids = nullptr;
+        pe.absmax = nullptr;          // (the partials are not what is stored: the reduction pass takes the maximum)
         pe.kchunk = plan.kchunk; pe.split_stride = (long long)M * ldw * 4;
         const dim3 grid_r((unsigned)(((M + RM - 1) / RM) * ((N + RN - 1) / RN)), (unsigned)plan.splits);
         const dim3 grid_b((unsigned)(((M + GM - 1) / GM) * ((N + GN - 1) / GN)), (unsigned)plan.splits);

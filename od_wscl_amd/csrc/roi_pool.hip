@@ -1243,7 +1243,7 @@ static int roi_pool_stack_backward_launch(const void* dX, int dx_is_f32, int ld,
                                           const float* rois, const float* keep, const float* keep_sum,
                                           const float* extra, const int* extra_roi, int E, int skip_clean, int B, int C,
                                           int H, int W, int R, int PH, int PW, float* grad_in, void* workspace,
-                                          int64_t workspace_bytes, void* stream_, const int* e_dev);
+                                          int64_t workspace_bytes, void* stream_, const int* e_dev, int absmax_ready = 0);
 
 ODW_EXPORT int odw_roi_pool_stack_backward_ws(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
                                               const float* rois, const float* keep, const float* keep_sum,
@@ -1267,11 +1267,25 @@ ODW_EXPORT int odw_roi_pool_stack_backward_dyn(const void* dX, int dx_is_f32, in
                                           C, H, W, R, PH, PW, grad_in, workspace, workspace_bytes, stream_, e_dev);
 }
 
+// The same backward when the producer of dX already left max |dX| (over the rows this launch reads: [R, 2R) with skip_clean,
+// all 2R otherwise) in workspace[0..4) -- odw_gemm_nt_bf16_absmax's epilogue: the 200 MB pre-pass over dX is skipped, the side
+// buffer's (small) pre-pass still runs onto the same word.  e_dev null: E is exact.  Fixed-point form only.
+ODW_EXPORT int odw_roi_pool_stack_backward_scaled(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
+                                                  const float* rois, const float* keep, const float* keep_sum,
+                                                  const float* extra, const int* extra_roi, int E_cap, const int* e_dev,
+                                                  int skip_clean, int B, int C, int H, int W, int R, int PH, int PW,
+                                                  float* grad_in, void* workspace, int64_t workspace_bytes, void* stream_) {
+    ODW_REQUIRE(workspace && workspace_bytes >= 4, "roi_pool_stack_backward_scaled: the word holding max |dX|");
+    ODW_REQUIRE(!e_dev || (E_cap >= 1 && extra && extra_roi), "roi_pool_stack_backward_scaled: the side buffer of a device-resident count");
+    return roi_pool_stack_backward_launch(dX, dx_is_f32, ld, argmax_u16, rois, keep, keep_sum, extra, extra_roi, E_cap, skip_clean, B,
+                                          C, H, W, R, PH, PW, grad_in, workspace, workspace_bytes, stream_, e_dev, 1);
+}
+
 static int roi_pool_stack_backward_launch(const void* dX, int dx_is_f32, int ld, const void* argmax_u16,
                                           const float* rois, const float* keep, const float* keep_sum,
                                           const float* extra, const int* extra_roi, int E, int skip_clean, int B, int C,
                                           int H, int W, int R, int PH, int PW, float* grad_in, void* workspace,
-                                          int64_t workspace_bytes, void* stream_, const int* e_dev) {
+                                          int64_t workspace_bytes, void* stream_, const int* e_dev, int absmax_ready) {
     hipStream_t stream = (hipStream_t)stream_;
     ODW_REQUIRE(B >= 1 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && R >= 1 && E >= 0,
                 "roi_pool_stack_backward: bad dims");
@@ -1287,11 +1301,13 @@ static int roi_pool_stack_backward_launch(const void* dX, int dx_is_f32, int ld,
         (int64_t)HW * 8 <= ODW_LDS_BYTES - 1024 && (((uintptr_t)dX) & 15) == 0 && ((size_t)R * ld * el) % 16 == 0 &&
         ((size_t)R * ld) % 8 == 0 && (!extra || (((uintptr_t)extra) & 15) == 0)) {
         unsigned* mx = (unsigned*)workspace;
-        ODW_CHECK_HIP(hipMemsetAsync(mx, 0, 4, stream), "roi_pool_stack_backward memset");
         const char* first = reinterpret_cast<const char*>(dX) + (skip_clean ? (size_t)R * ld * el : 0);     // rows [0, R) are unset
         const size_t n = (size_t)(skip_clean ? R : 2 * R) * ld;
-        if (dx_is_f32) odwfx::absmax_kernel<false><<<1024, 256, 0, stream>>>(first, n, mx);
-        else odwfx::absmax_kernel<true><<<1024, 256, 0, stream>>>(first, n, mx);
+        if (!absmax_ready) {        // (ready: the producing GEMM's epilogue took the maximum, odw_gemm_nt_bf16_absmax)
+            ODW_CHECK_HIP(hipMemsetAsync(mx, 0, 4, stream), "roi_pool_stack_backward memset");
+            if (dx_is_f32) odwfx::absmax_kernel<false><<<1024, 256, 0, stream>>>(first, n, mx);
+            else odwfx::absmax_kernel<true><<<1024, 256, 0, stream>>>(first, n, mx);
+        }
         if (E > 0) odwfx::absmax_kernel<false><<<256, 256, 0, stream>>>(extra, (size_t)E * C * nb, mx, e_dev, (size_t)C * nb);
         ODW_CHECK_LAUNCH("absmax_kernel");
         const size_t lds8 = (size_t)HW * 8;
@@ -1309,7 +1325,7 @@ static int roi_pool_stack_backward_launch(const void* dX, int dx_is_f32, int ld,
         ODW_CHECK_LAUNCH("roi_pool_stack_bwd_plane_fx");
         return ODW_OK;
     }
-    ODW_REQUIRE(!e_dev, "roi_pool_stack_backward_dyn: the fixed-point form does not apply (workspace, alignment or plane size)");
+    ODW_REQUIRE(!e_dev && !absmax_ready, "roi_pool_stack_backward_dyn / _scaled: the fixed-point form does not apply (workspace, alignment or plane size)");
     const int cg = ((int64_t)2 * HW * 4 <= ODW_LDS_BYTES && (int64_t)B * ((C + 1) / 2) >= 2 * ODW_NUM_CU) ? 2 : 1;
     const int grid = B * ((C + cg - 1) / cg);
     const size_t lds = (size_t)cg * HW * 4;

@@ -33,10 +33,12 @@ _PLAN_CACHE = {}      # (M, N, K, lda, ldb, ldc, out_bf16, alignment of C) -> (s
 
 
 def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, segs=None, accumulate=False, row_ids=None,
-            planes=1):
+            planes=1, absmax=None):
     """out[M,N] (+)= epilogue(alpha * a[M,K] @ b[N,K]^T); a, b bf16 2-D tensors (row stride % 8 == 0).
     planes: K spans this many bf16 plane products of ONE fp32-grade product (split precision modes) -- only the timer's
-    bookkeeping uses it (algorithmic FLOPs = issued / planes)."""
+    bookkeeping uses it (algorithmic FLOPs = issued / planes).
+    absmax: a zeroed int32 device word -- the plain product (fp32 out, N % 4 == 0) also leaves the bit pattern of max |out|
+    there (odw_gemm_nt_bf16_absmax: the consumer that scatters `out` in fixed point no longer re-reads it for its scale)."""
     L.need_gpu(a, b, out)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
@@ -66,6 +68,13 @@ def gemm_nt(a, b, M, N, K, out, bias=None, relu=False, alpha=1.0, drop_p=0.0, se
     split = ws is not None
     sym = "gemm_nt_bf16_%skernel<%s>%s" % (_VARIANT_SYMBOL[var], ("false" if split or not out_bf16 else "true")
                                            + (", 7" if var == 3 else ""), " split-K+reduce" if split else "")
+    if absmax is not None:
+        assert not out_bf16 and bias is None and not relu and drop_p == 0.0 and not accumulate and row_ids is None and N % 4 == 0
+        with kernel_timer.region(sym, flops=2.0 * M * N * K, alg=2.0 * M * N * K / planes, shape="M=%d,N=%d,K=%d" % (M, N, K)):
+            L.check(L.lib().odw_gemm_nt_bf16_absmax(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out),
+                                                    out.stride(0), float(alpha), L.ptr(absmax), L.ptr(ws), ws_bytes, L.stream()),
+                    "gemm_nt_bf16_absmax")
+        return out
     with kernel_timer.region(sym, flops=2.0 * M * N * K, alg=2.0 * M * N * K / planes, shape="M=%d,N=%d,K=%d" % (M, N, K)):
         L.check(L.lib().odw_gemm_nt_bf16_ws(L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), M, N, K, L.ptr(out),
                                             out.stride(0), 1 if out_bf16 else 0, L.ptr(bias), 1 if relu else 0,
@@ -364,10 +373,12 @@ class _FusedLinear(torch.autograd.Function):
         return dx, dw, None, None, None, None, None, None, None, None, None, None
 
 
-def _backward_single_plane(xb, y, weight, bias, cfg, dy, need_dx):
+def _backward_single_plane(xb, y, weight, bias, cfg, dy, need_dx, absmax_holder=None):
     """Backward of a fused Linear with every product on ONE bf16 plane per operand ("bf16" and "bf16x2f" modes).
     xb / y are the saved input / output (bf16, or fp32 after a split-precision forward: the prologue and transpose
-    kernels round to bf16 as they read); dy may be fp32 or bf16; dx comes back in the input's dtype."""
+    kernels round to bf16 as they read); dy may be fp32 or bf16; dx comes back in the input's dtype.
+    absmax_holder: the input is ROI pooling's stacked operand and its backward scatters dx in fixed point -- the input-gradient
+    GEMM leaves max |dx| with the holder (`.absmax` = (word, dx's address, first row, rows)) instead of a 200 MB pre-pass."""
     sh, relu, drop_p, x_dtype, tag, grad_rows, slot = cfg
     M_all, K = xb.shape
     N = weight.shape[0]
@@ -415,7 +426,13 @@ def _backward_single_plane(xb, y, weight, bias, cfg, dy, need_dx):
 
         def launch(dz=dz, dx=dx):
             kernel_timer.layer = tag and tag + "_dgrad"
-            gemm_nt(dz, sh.wt, M, K, N, dx)
+            if absmax_holder is not None and dx.dtype == torch.float32 and K % 4 == 0 and dx.stride(0) == K:
+                word = torch.zeros(16, dtype=torch.int32, device=dx.device)
+                gemm_nt(dz, sh.wt, M, K, N, dx, absmax=word)
+                zero_outside = grad_rows is None or len(grad_rows) < 3 or bool(grad_rows[2])
+                absmax_holder.absmax = (word, dx_all.data_ptr(), ra if grad_rows is not None else 0, M, zero_outside)
+            else:
+                gemm_nt(dz, sh.wt, M, K, N, dx)
             kernel_timer.layer = None
         # A caller that runs this backward EARLY (weak_head/loss_fused.py) may ask for the large input-gradient GEMMs to be
         # handed back instead of launched: their result is not read before the very end of the step's backward (the ROI
@@ -648,6 +665,7 @@ class _PairLinear(torch.autograd.Function):
         if batch is not None and weight.is_leaf and weight.requires_grad and grad_mode:
             slot = batch.register((grad_rows[1] - grad_rows[0]) if grad_rows is not None else M2)
         ctx.cfg = (sh, relu, drop_p, x.dtype, timer_tag, grad_rows, slot)
+        ctx.absmax_holder = getattr(x, "_odw_absmax_holder", None)      # (set by ROI pooling's stacked forward on its handle)
         return y
 
     @staticmethod
@@ -655,7 +673,8 @@ class _PairLinear(torch.autograd.Function):
         x16, y, weight, bias = ctx.saved_tensors
         sh, relu, drop_p, x_dtype, tag, grad_rows, slot = ctx.cfg
         cfg = (sh, relu, drop_p, torch.float32, tag, grad_rows, slot)
-        dx, dw = _backward_single_plane(x16, y, weight, bias, cfg, dy, ctx.needs_input_grad[0])
+        dx, dw = _backward_single_plane(x16, y, weight, bias, cfg, dy, ctx.needs_input_grad[0],
+                                        absmax_holder=ctx.absmax_holder if x_dtype == torch.float32 else None)
         if dx is not None and x_dtype != torch.float32:
             dx = dx.to(x_dtype)
         return (dx, dw) + (None,) * 12

@@ -135,9 +135,18 @@ def test_train_net_checkpoints_and_resumes_with_its_momenta(tmp_path):
     a = torch.load(os.path.join(straight, "model_final.pth"), weights_only=False)
     b = torch.load(os.path.join(resumed, "model_final.pth"), weights_only=False)
     assert a["iteration"] == b["iteration"] == 4
-    worst = 0.0
+    # Buffers that are rounding noise are left out: the detection stream's class bias sits under a softmax over the PROPOSALS, so
+    # its true gradient is zero and its buffer holds ~1e-8 of summation-order noise (the other buffers: 1e-3 .. 1).  Its bits
+    # follow the kernel plans, and a fresh process starts from the capacity-sized plans again (loss_device.HintReader) -- measured
+    # (tools/exp/resume_diff.py): that one (21,) buffer differs by 0.48 of its 1.2e-8 norm, every other buffer by < 1e-2, and two
+    # uninterrupted runs agree bit for bit.
+    norms = {i: float(sa["momentum_buffer"].double().norm()) for i, sa in a["optimizer"]["state"].items()}
+    floor = 1e-5 * max(norms.values())
+    worst, compared = 0.0, 0
     for i, sa in a["optimizer"]["state"].items():
         ma, mb = sa["momentum_buffer"].double(), b["optimizer"]["state"][i]["momentum_buffer"].double()
-        if ma.abs().max() > 0:
+        if norms[i] > floor:
             worst = max(worst, float((ma - mb).norm() / ma.norm()))
+            compared += 1
+    assert compared >= len(norms) - 4, (compared, len(norms))
     assert worst < 0.05, worst           # (a zero-momentum restart is off by ~0.5; bf16 run-to-run noise is far below this)
