@@ -41,8 +41,14 @@ constexpr int kChunksPerRow = BK / 8;                 // 16-byte chunks per LDS 
 constexpr int kTileChunks = BM * kChunksPerRow;       // 1024 uint4 per operand tile
 constexpr int kLoadsPerThread = kTileChunks / kThreads;  // 4
 
+// (the absmax word lives in a base the pair kernel's narrow epilogue does not carry: EpilogueS keeps the argument block it was
+// tuned with -- see below for what one more spilled register did to its counted waits)
+template <bool DYN> struct EpilogueAbsmax {
+    unsigned* absmax = nullptr;      // fp32 output only: atomicMax of the bit patterns of |value stored| lands here (epi_absmax_commit)
+};
+template <> struct EpilogueAbsmax<false> { static constexpr unsigned* absmax = nullptr; };
 template <int NSEG, bool DYN = true>
-struct EpilogueT {
+struct EpilogueT : EpilogueAbsmax<DYN> {
     static constexpr int kSegs = NSEG;
     static constexpr bool kDyn = DYN;      // the dynamic-row fields below are honoured (false: the pair kernel, whose registers are spoken for)
     const float* bias;     // (N) or null
@@ -67,7 +73,6 @@ struct EpilogueT {
     const int* k_dev = nullptr;
     const uint4* row_tab = nullptr;  // dropout draws of stacked passes whose boundaries live on the device: row m draws element
                            // (row_tab[m].x, column) of the stream keyed (row_tab[m].y, row_tab[m].z); replaces seg_* / row_ids
-    unsigned* absmax = nullptr;      // fp32 output only: atomicMax of the bit patterns of |value stored| lands here (epi_absmax_commit)
 };
 typedef EpilogueT<kMaxSeg> Epilogue;
 // The pair form of gemm_nt_cm_kernel (two accumulator sets, 256 VGPRs, counted vmcnt waits) takes the two segments it
@@ -80,7 +85,8 @@ template <class EPO>
 inline EPO epilogue_narrow(const Epilogue& e) {
     constexpr int NSEG = EPO::kSegs;
     EPO o;
-    o.m_dev = e.m_dev; o.k_dev = e.k_dev; o.row_tab = e.row_tab; o.absmax = e.absmax;
+    o.m_dev = e.m_dev; o.k_dev = e.k_dev; o.row_tab = e.row_tab;
+    if constexpr (EPO::kDyn) o.absmax = e.absmax;
     o.bias = e.bias; o.relu = e.relu; o.drop_p = e.drop_p; o.nseg = e.nseg < NSEG ? e.nseg : NSEG;
     for (int i = 0; i < NSEG; ++i) { o.seg_row[i] = e.seg_row[i]; o.seg_k0[i] = e.seg_k0[i]; o.seg_k1[i] = e.seg_k1[i]; }
     o.accumulate = e.accumulate; o.alpha = e.alpha; o.mask = e.mask; o.ldmask = e.ldmask; o.pm = e.pm; o.row_ids = e.row_ids;

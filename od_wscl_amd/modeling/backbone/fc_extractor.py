@@ -70,6 +70,7 @@ class _GradHolder(object):
         self.dyn_extra = None
         self.grad_out = None        # where the pooling node writes d(feature map) (a HIP-graphed body: its static input buffer)
         self.clean_rows = None      # _PoolStack: number of leading rows of dX whose gradient is meaningful (None = all)
+        self.absmax = None          # (word, address of dX, first row, rows, rest zeroed): max |dX| left by the GEMM that wrote dX
 
 
 _IOTA = {}
@@ -284,23 +285,45 @@ class _PoolStack(torch.autograd.Function):
         skip_clean = 1 if (holder is not None and holder.clean_rows == 0) else 0      # sparse backward: clean half unset
         ws = torch.empty(64, dtype=torch.uint8, device=dx.device)       # the launch's fixed-point scale (odw_fixed.h)
         K = C * ph * pw
+        # max |dx| left by the GEMM that produced dx (gemm._backward_single_plane): valid for THIS tensor and the rows this
+        # launch reads -- anything else (autograd summed two gradients into a new tensor, other rows) takes the pre-pass
+        pre = getattr(holder, "absmax", None) if holder is not None else None
+        if holder is not None:
+            holder.absmax = None
+        scaled = False
+        if pre is not None and dx.dtype == torch.float32 and dx.stride(0) == K:
+            word, ptr, row0, rows, zero_outside = pre
+            covers = (row0 == R and rows == R) if skip_clean else ((row0 == 0 and rows == 2 * R) or zero_outside)
+            scaled = ptr == dx.data_ptr() and covers and tuple(dx.shape) == (2 * R, K)
+            if scaled:
+                ws = word
         nbytes = float((R if skip_clean else 2 * R) * K * dx.element_size() + R * K * 2 + E * K * 4 + B * C * H * W * 4)
         if dyn_extra is not None:
             extra, roi_index, e_cap, e_dyn = dyn_extra
             holder.dyn_extra = None
             nbytes += float(e_dyn.hint * K * 4)
+            if scaled:
+                nbytes -= float(R * K * 4)          # (the pre-pass's read of dx)
+            fn = L.lib().odw_roi_pool_stack_backward_scaled if scaled else L.lib().odw_roi_pool_stack_backward_dyn
             with kernel_timer.region("roi_pool_stack_backward", nbytes=nbytes, alg=float(2 * R * K * 4 + B * C * H * W * 4)):
-                L.check(L.lib().odw_roi_pool_stack_backward_dyn(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
-                                                                L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
-                                                                L.ptr(extra), L.ptr(roi_index), e_cap, L.ptr(e_dyn.t), skip_clean,
-                                                                B, C, H, W, R, ph, pw, L.ptr(dfeat), L.ptr(ws), 64, L.stream()),
+                L.check(fn(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
+                           L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
+                           L.ptr(extra), L.ptr(roi_index), e_cap, L.ptr(e_dyn.t), skip_clean,
+                           B, C, H, W, R, ph, pw, L.ptr(dfeat), L.ptr(ws), 64, L.stream()),
                         "roi_pool_stack_backward_dyn")
             return dfeat, None, None, None, None, None, None, None, None
         with kernel_timer.region("roi_pool_stack_backward", nbytes=nbytes, alg=float(2 * R * K * 4 + B * C * H * W * 4)):
-            L.check(L.lib().odw_roi_pool_stack_backward_ws(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
-                                                           L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
-                                                           L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph, pw,
-                                                           L.ptr(dfeat), L.ptr(ws), 64, L.stream()), "roi_pool_stack_backward")
+            if scaled:
+                L.check(L.lib().odw_roi_pool_stack_backward_scaled(L.ptr(dx), 1, dx.stride(0), L.ptr(argmax), L.ptr(rois5),
+                                                                   L.ptr(keep), L.ptr(keep_sum), L.ptr(extra), L.ptr(roi_index),
+                                                                   E, None, skip_clean, B, C, H, W, R, ph, pw, L.ptr(dfeat),
+                                                                   L.ptr(ws), 64, L.stream()), "roi_pool_stack_backward_scaled")
+            else:
+                L.check(L.lib().odw_roi_pool_stack_backward_ws(L.ptr(dx), 1 if dx.dtype == torch.float32 else 0, dx.stride(0),
+                                                               L.ptr(argmax), L.ptr(rois5), L.ptr(keep), L.ptr(keep_sum),
+                                                               L.ptr(extra), L.ptr(roi_index), E, skip_clean, B, C, H, W, R, ph,
+                                                               pw, L.ptr(dfeat), L.ptr(ws), 64, L.stream()),
+                        "roi_pool_stack_backward")
         return dfeat, None, None, None, None, None, None, None, None
 
 
@@ -544,6 +567,10 @@ class TwoFCROIFeatureExtractor(nn.Module):
             if use_pair:
                 x._odw_planes_cm = out[3]       # (rows [0, P) only: the clean half)
                 pair = (out[3], planes, block_c.view(P, -1), block_sum)
+                if self._grad_holder is not None and os.environ.get("ODW_ABSMAX_PREPASS") != "1":
+                    # fc6's input-gradient GEMM leaves max |dx| with the holder: the pooling backward's scale without its
+                    # 200 MB pre-pass (gemm._backward_single_plane, csrc/gemm_bf16.hip: epi_absmax_commit)
+                    x._odw_absmax_holder = self._grad_holder
         else:
             x = _PoolStack.apply(feat, rois5, block.contiguous(), _keep_sum(block), self._grad_holder,
                                  float(self.pooler.poolers[0].spatial_scale), res[0], res[1], nhwc)

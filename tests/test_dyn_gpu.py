@@ -494,3 +494,77 @@ def test_pooling_backward_with_the_entry_count_on_the_device(mods):
                                                 L.ptr(eroi), Ecap, L.ptr(e_d), 1, B, C, H, W, R, ph, pw, L.ptr(g), L.ptr(ws), 64,
                                                 L.stream()), "bwd dyn")
     assert torch.equal(g, g_ref)
+
+
+def _absbits(t):
+    return int((t.float().contiguous().view(torch.int32) & 0x7fffffff).max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(2000, 25088, 4096),       # fc6's input gradient: 256 x 256 tiles + the tail columns' split-K product
+                                   (300, 1024, 8192),          # split-K: the reduction pass takes the maximum
+                                   (100, 132, 72),             # the register-staged kernel's element stores
+                                   (513, 4096, 256), (64, 64, 64)])
+def test_input_gradient_product_leaves_the_maximum_the_prepass_would_find(mods, M, N, K):
+    """odw_gemm_nt_bf16_absmax: the same C as the plain launch, bit for bit, and the bit pattern of max |C| in the word -- what
+    odwfx::absmax_kernel finds by re-reading C (a maximum does not depend on the order it is taken in)."""
+    L, dyn, gemm, precision = mods
+    precision.set_precision("bf16")
+    a = rnd(61, (M, K), 0.3).bfloat16()
+    b = rnd(62, (N, K), 0.05).bfloat16()
+    ref = torch.full((M, N), SENT, device="cuda")
+    gemm.gemm_nt(a, b, M, N, K, ref, alpha=0.5)
+    out = torch.full((M, N), SENT, device="cuda")
+    word = torch.zeros(16, dtype=torch.int32, device="cuda")
+    gemm.gemm_nt(a, b, M, N, K, out, alpha=0.5, absmax=word)
+    assert torch.equal(out, ref)
+    assert int(word[0].item()) == _absbits(ref), (hex(int(word[0].item())), hex(_absbits(ref)))
+    assert int(word[1:].abs().max().item()) == 0
+    # the word only grows: a second product onto a word that already holds more leaves it alone
+    big = torch.full((16,), 0x7f000000, dtype=torch.int32, device="cuda")
+    gemm.gemm_nt(a, b, M, N, K, out, alpha=0.5, absmax=big)
+    assert int(big[0].item()) == 0x7f000000
+
+
+@pytest.mark.parametrize("skip_clean,with_extra", [(1, True), (0, True), (1, False)])
+def test_pooling_backward_with_the_maximum_already_taken(mods, skip_clean, with_extra):
+    """odw_roi_pool_stack_backward_scaled (max |dX| left in the workspace word by the GEMM that wrote dX; only the side buffer
+    is scanned) = odw_roi_pool_stack_backward_ws / _dyn, bit for bit."""
+    L, dyn, gemm, precision = mods
+    lib = L.lib()
+    B, C, H, W, R, ph, pw = 1, 64, 24, 24, 50, 7, 7
+    K = C * ph * pw
+    from od_wscl_amd import synthetic
+    boxes = synthetic.make_proposals(5, 0, R, 192, 192, min_size=12)
+    rois = torch.from_numpy(np.concatenate([np.zeros((R, 1), np.float32), boxes], 1)).cuda()
+    argmax = torch.from_numpy(np.random.RandomState(4).randint(0, H * W, size=(R, K)).astype(np.int16)).cuda()
+    keep = torch.ones((R, ph * pw), device="cuda")
+    ksum = keep.sum().reshape(1)
+    dx = rnd(41, (2 * R, K))
+    if skip_clean:
+        dx[:R] = float("nan")                   # the clean half is unset in the sparse backward: never read
+    E, Ecap = (23, 64) if with_extra else (0, 0)
+    extra = rnd(42, (Ecap, K), 3.0) if with_extra else None         # (larger than dX: the side buffer's scan must still land)
+    eroi = torch.from_numpy(np.random.RandomState(5).randint(0, R, size=max(Ecap, 1)).astype(np.int32)).cuda() if with_extra else None
+    ws = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    g_ref = torch.empty((B, C, H, W), device="cuda")
+    extra_live = extra[:E].contiguous() if with_extra else None
+    L.check(lib.odw_roi_pool_stack_backward_ws(L.ptr(dx), 1, K, L.ptr(argmax), L.ptr(rois), L.ptr(keep), L.ptr(ksum), L.ptr(extra_live),
+                                               L.ptr(eroi), E, skip_clean, B, C, H, W, R, ph, pw, L.ptr(g_ref), L.ptr(ws), 64,
+                                               L.stream()), "bwd")
+    live = dx[R:] if skip_clean else dx
+    word = torch.zeros(16, dtype=torch.int32, device="cuda")
+    word[0] = _absbits(live)
+    g = torch.empty((B, C, H, W), device="cuda")
+    L.check(lib.odw_roi_pool_stack_backward_scaled(L.ptr(dx), 1, K, L.ptr(argmax), L.ptr(rois), L.ptr(keep), L.ptr(ksum),
+                                                   L.ptr(extra_live), L.ptr(eroi), E, None, skip_clean, B, C, H, W, R, ph, pw,
+                                                   L.ptr(g), L.ptr(word), 64, L.stream()), "bwd scaled")
+    assert torch.equal(g, g_ref)
+    if with_extra:                              # the device-resident entry count
+        extra[E:] = float("nan")
+        word.zero_()
+        word[0] = _absbits(live)
+        g2 = torch.empty((B, C, H, W), device="cuda")
+        L.check(lib.odw_roi_pool_stack_backward_scaled(L.ptr(dx), 1, K, L.ptr(argmax), L.ptr(rois), L.ptr(keep), L.ptr(ksum),
+                                                       L.ptr(extra), L.ptr(eroi), Ecap, L.ptr(dev_int(E)), skip_clean, B, C, H, W, R,
+                                                       ph, pw, L.ptr(g2), L.ptr(word), 64, L.stream()), "bwd scaled dyn")
+        assert torch.equal(g2, g_ref)

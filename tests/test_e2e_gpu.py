@@ -686,3 +686,39 @@ def test_device_resident_lists_equal_the_host_assembled_lists(name, exact_hints,
             assert torch.equal(grads_dev[n], p.grad) if not loose else err <= 1e-6, (n, err)
         else:
             assert err <= (MIXED_GRAD_TOL if n.startswith("backbone") else 1e-3) or ref.norm().item() < 1e-7, (n, err)
+
+
+def test_maximum_taken_in_the_input_gradient_product_changes_no_bit(monkeypatch):
+    """Round 6: fc6's input-gradient GEMM leaves max |dX| for ROI pooling's fixed-point backward (csrc/gemm_bf16.hip:
+    epi_absmax_commit) instead of the 200 MB pre-pass (ODW_ABSMAX_PREPASS=1): the same scale, so every gradient is the
+    pre-pass path's bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from od_wscl_amd.modeling.backbone import fc_extractor
+    from od_wscl_amd.modeling.roi_heads.weak_head import loss_device
+    monkeypatch.delenv("ODW_HOST_LISTS", raising=False)
+    monkeypatch.setattr(loss_device, "_EXACT", True)
+    taken = []
+    orig = fc_extractor._PoolStack.backward
+
+    def spy(ctx, dx):
+        taken.append(getattr(ctx.holder, "absmax", None) is not None)
+        return orig(ctx, dx)
+    monkeypatch.setattr(fc_extractor._PoolStack, "backward", staticmethod(spy))
+    monkeypatch.delenv("ODW_ABSMAX_PREPASS", raising=False)
+    l_new, _, m_new, _ = _run_golden("e2e_voc_2img", "bf16x2f")
+    assert taken and all(taken), "the input-gradient product did not leave its maximum with the pooling node"
+    grads_new = {n: p.grad.detach().clone() for n, p in m_new.named_parameters() if p.grad is not None}
+    del m_new
+    taken.clear()
+    monkeypatch.setenv("ODW_ABSMAX_PREPASS", "1")
+    l_old, _, m_old, _ = _run_golden("e2e_voc_2img", "bf16x2f")
+    assert taken and not any(taken)
+    for k in l_old:
+        assert float(l_new[k].detach()) == float(l_old[k].detach()), k
+    for n, p in m_old.named_parameters():
+        if p.grad is not None:
+            if n.endswith("bias"):          # (atomic column sums)
+                assert (grads_new[n] - p.grad).abs().max().item() <= 1e-6 * max(p.grad.abs().max().item(), 1e-12), n
+            else:
+                assert torch.equal(grads_new[n], p.grad), n

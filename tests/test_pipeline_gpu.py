@@ -148,5 +148,6 @@ def test_train_net_checkpoints_and_resumes_with_its_momenta(tmp_path):
         if norms[i] > floor:
             worst = max(worst, float((ma - mb).norm() / ma.norm()))
             compared += 1
-    assert compared >= len(norms) - 4, (compared, len(norms))
+    nonzero = sum(1 for v in norms.values() if v > 0)
+    assert compared >= nonzero - 4 and compared > 20, (compared, nonzero, len(norms))
     assert worst < 0.05, worst           # (a zero-momentum restart is off by ~0.5; bf16 run-to-run noise is far below this)
