@@ -28,6 +28,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import od_wscl_amd  # noqa: E402,F401  (before the first device call: the package sets the HIP runtime's queue count, see its __init__)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 DTYPE_NOTE = {
@@ -479,7 +480,7 @@ def main():
                        "conv_backend": info["conv_backend"], "optimizer": info["optimizer"]},
             "per_gpu": round(value / world, 1),
             "collective": info["collective"],
-            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ODW_")},
+            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ODW_") or k == "GPU_MAX_HW_QUEUES"},
             "roofline": roof,
         }
     if world == 1 and not args.no_secondary and args.dtype != "bf16":

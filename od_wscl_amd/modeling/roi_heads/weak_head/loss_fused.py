@@ -661,7 +661,8 @@ class RoIRegLossFused(RoIRegLossComputation):
             if side is None or side.device != device:
                 side = self._contra_stream = torch.cuda.Stream(
                     device=device, priority=int(_os2.environ.get("ODW_PRIO", "-1,0,-1").split(",")[2]))
-            fork = torch.cuda.Event()
+            otrace = _os2.environ.get("ODW_OVERLAP_TRACE") == "1"      # (measurement: how much of the two branches overlaps)
+            fork = torch.cuda.Event(enable_timing=otrace)
             fork.record(main)
             side.wait_event(fork)
         with torch.cuda.stream(side):
@@ -685,7 +686,7 @@ class RoIRegLossFused(RoIRegLossComputation):
                 # (see DeviceContrastive.backward_now: the whole head backward is queued in forward order)
                 branch.backward_now(act_stream=act_stream)
             if beside:
-                joined = torch.cuda.Event()
+                joined = torch.cuda.Event(enable_timing=otrace)
                 joined.record(side)
         loss_sim = raw
         step_trace.mark("supcon_launch")
@@ -693,6 +694,9 @@ class RoIRegLossFused(RoIRegLossComputation):
             lib, device, n_img, sum_p, max_p, maxpos, offs, boxes_all, gt_idx, gt_cls, gt_score, gt_cnt, ybase, C, img_off,
             final_score, colstat, lab_vecs, n_pos, epsilon, dense_ws, ws_bytes, stacked, fe)
         if beside:
+            if otrace:
+                a_end = torch.cuda.Event(enable_timing=True)
+                a_end.record(main)
             main.wait_event(joined)
             # (No record_stream on what crosses over -- the side buffer, the loss value: a block so marked is parked until an
             # event on `main` has PASSED, and with the host 8 steps ahead of the GPU that is 8 steps of 800 MB blocks the
@@ -703,6 +707,18 @@ class RoIRegLossFused(RoIRegLossComputation):
                 b.hold = False
                 if b.rows and b.filled == len(b.rows):
                     b.flush(w, tag)
+            if otrace:
+                f_end = torch.cuda.Event(enable_timing=True)
+                f_end.record(main)
+                prev = getattr(self, "_otrace_prev", None)
+                if prev is not None:            # the PREVIOUS step's events (long passed: no stall beyond this print)
+                    pf, pj, pa, pe, lab = prev
+                    pe.synchronize()
+                    import sys as _sys
+                    _sys.stderr.write("[overlap] labels %s: fork->contrastive end %.3f ms, fork->dense early backward end %.3f ms, "
+                                      "fork->held batches flushed %.3f ms\n"
+                                      % (lab, pf.elapsed_time(pj), pf.elapsed_time(pa), pf.elapsed_time(pe)))
+                self._otrace_prev = (fork, joined, a_end, f_end, [len(p) for p in pos_host])
         step_trace.mark("dense_early_bwd_launch")
         if tr is not None:
             branch.fill_trace(tr, rows, counts, inst_idx, inst_cnt, fresh_idx, fresh_cnt)
