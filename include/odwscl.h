@@ -692,6 +692,11 @@ int odw_roi_pool_stack_backward_scaled(const void* dX, int dx_is_f32, int ld, co
                                        const int* e_dev, int skip_clean, int B, int C, int H, int W, int R, int PH, int PW,
                                        float* grad_in, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* A stream confined to a subset of the compute units (bit i of mask[i / 32] = CU i usable); the caller destroys it.  No
+ * reference counterpart: the reference runs its loss on one stream (weak_head/loss.py:233-411). */
+int odw_stream_create_cu_mask(int n_words, const uint32_t* mask, void** stream_out);
+int odw_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,6 +180,8 @@ SIGNATURES = {
     "odw_supcon_v2_dyn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_l, c_p]),
     "odw_roi_pool_stack_backward_dyn": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
                                               c_i, c_i, c_p, c_p, c_l, c_p]),
+    "odw_stream_create_cu_mask": (c_i, [c_i, c_p, c_p]),
+    "odw_stream_destroy": (c_i, [c_p]),
     "odw_gemm_nt_bf16_absmax": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_f, c_p, c_p, c_l, c_p]),
     "odw_roi_pool_stack_backward_scaled": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
                                                  c_i, c_i, c_p, c_p, c_l, c_p]),
