@@ -28,7 +28,6 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import od_wscl_amd  # noqa: E402,F401  (before the first device call: the package sets the HIP runtime's queue count, see its __init__)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 DTYPE_NOTE = {
@@ -104,8 +103,8 @@ def parse():
                     help="element type of the gradients on the wire (ODW.GRAD_EXCHANGE): fp32 = the reference's DDP; bf16 = "
                          "half the xGMI bytes, rounded once before the sum, fp32 again in the optimiser")
     ap.add_argument("--hp-stream", default="auto", choices=["auto", "0", "1"],
-                    help="run the step on a high-priority HIP stream: auto = only at N = 1 (at N > 1 RCCL's kernels sit on "
-                         "default-priority streams and must not be starved of CUs)")
+                    help="run the step on a high-priority HIP stream of its own: auto = off (round 6: the two stream hops per step "
+                         "cost more than the priority buys, engine.py); 1 = on")
     return ap.parse_args()
 
 

@@ -629,11 +629,14 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
     # with the step's launches dispatched first: 9.39-9.41 against 9.64-9.68 ms per step (tools/exp/ab_env.sh 3 X=1
     # ODW_HP_STREAM=0).  The caller's stream waits for the step's at the end, so nothing changes for code around it.
     hp_stream = [None]
-    # (One rank only: at N > 1 RCCL's kernels sit on default-priority streams too, and a step that always dispatches first
-    # could keep them off the CUs until its own gaps -- the exchange would slide behind the backward it is meant to hide
-    # under.  Unmeasured here, so data-parallel runs keep equal priorities unless ODW_HP_STREAM=1 asks otherwise.)
+    # Round 6: OFF unless ODW_HP_STREAM=1.  That measurement predates the paced optimiser pass (ODW_SGD_PACE) and the device-resident
+    # loss; with both, the two stream hops per step (caller -> step stream -> caller) cost more than the priority buys: alternating
+    # runs on two boxes (profiles/r06/ab_hp.txt, ab_hp_pace.txt) 8.29-8.31 against 8.36 ms per step with two hardware queues,
+    # 8.59 against 8.77 with the runtime's four -- and without the extra stream the queue count no longer matters (2 / 3 / 4 queues:
+    # 8.30 / 8.29 / 8.31), so the runtime's default stays.  (At N > 1 it was never on: RCCL's kernels sit on default-priority
+    # streams, and a step that always dispatches first could keep them off the CUs.)
     hp_env = os.environ.get("ODW_HP_STREAM")
-    use_hp = torch.device(device).type == "cuda" and (hp_env == "1" or (hp_env != "0" and world == 1))
+    use_hp = torch.device(device).type == "cuda" and hp_env == "1"
 
     def step(images, targets, rois, rand, iteration=None):
         if not use_hp:

@@ -7,7 +7,6 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-import od_wscl_amd  # noqa: E402,F401  (before any device call: the package picks the HIP runtime's queue count, as in bench.py)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

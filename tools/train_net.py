@@ -20,7 +20,6 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import od_wscl_amd  # noqa: E402,F401  (before the first device call: see the package's __init__)
 
 
 def synthetic_loader(cfg, rank, device, size, proposals, max_iter, start_iter=0):
