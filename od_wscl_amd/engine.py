@@ -244,8 +244,11 @@ class FlatSGD(object):
              cfg.SOLVER.WEIGHT_DECAY_BIAS)]
         self.gemm_params = [p for _, p in gemm_w]
         self.n_gemm = n_gemm
-        # (ODW_PRIO = "step,optimiser,contrastive" stream priorities, an experiment knob: default -1,0,-1)
-        prio = [int(v) for v in os.environ.get("ODW_PRIO", "-1,0,-1").split(",")]
+        # (ODW_PRIO = "step,optimiser,contrastive" stream priorities, an experiment knob.  Default 0,0,0 since the end of round 6:
+        # EVERY stream of the process at normal priority, so that all of them share the runtime's pool of GPU_MAX_HW_QUEUES = 4
+        # hardware queues.  A stream of another priority gets a queue of its own, and with five queues busy at once the whole
+        # step runs at two thirds of its speed -- 12.3 against 8.3 ms, body forward included (profiles/r06/ab_actstream*.txt).)
+        prio = [int(v) for v in os.environ.get("ODW_PRIO", "0,0,0").split(",")]
         self.side = torch.cuda.Stream(device=dev, priority=prio[1]) if dev.type == "cuda" else None
         odw = getattr(cfg, "ODW", None)
         self.exchange = GradExchange(self.flat_g, world, dtype=getattr(odw, "GRAD_EXCHANGE", "fp32"), side=self.side)
@@ -642,7 +645,7 @@ def build_training_step(cfg, device, dtype="bf16", world=1, seed=1234, backend="
         if not use_hp:
             return _step(images, targets, rois, rand, iteration)
         if hp_stream[0] is None:
-            hp_stream[0] = torch.cuda.Stream(device=device, priority=int(os.environ.get("ODW_PRIO", "-1,0,-1").split(",")[0]))
+            hp_stream[0] = torch.cuda.Stream(device=device, priority=int(os.environ.get("ODW_PRIO", "0,0,0").split(",")[0]))
         hp, cur = hp_stream[0], torch.cuda.current_stream()
         hp.wait_stream(cur)
         with torch.cuda.stream(hp):

@@ -660,7 +660,7 @@ class RoIRegLossFused(RoIRegLossComputation):
             side = getattr(self, "_contra_stream", None)
             if side is None or side.device != device:
                 side = self._contra_stream = torch.cuda.Stream(
-                    device=device, priority=int(_os2.environ.get("ODW_PRIO", "-1,0,-1").split(",")[2]))
+                    device=device, priority=int(_os2.environ.get("ODW_PRIO", "0,0,0").split(",")[2]))
             otrace = _os2.environ.get("ODW_OVERLAP_TRACE") == "1"      # (measurement: how much of the two branches overlaps)
             fork = torch.cuda.Event(enable_timing=otrace)
             fork.record(main)
@@ -674,15 +674,18 @@ class RoIRegLossFused(RoIRegLossComputation):
                     b.hold = True
             if eager:
                 act_stream = None
-                # (a THIRD stream for the re-attached rows' chain beside the views' chain: measured and NOT taken -- 12.85 ms per
-                # step against 8.9 unprofiled, 9.6 under rocprofv3, with 4 / 8 / 16 hardware queues alike: the two chains'
-                # ~40 small launches with three streams waiting on each other cost more than their overlap buys;
-                # ODW_ACT_STREAM=1 enables it for comparison)
-                if beside and _os2.environ.get("ODW_ACT_STREAM") == "1":
+                # A THIRD stream for the re-attached rows' chain beside the views' chain (the two share nothing but the held
+                # weight-gradient batches and disjoint rows of the side buffer): -0.13 ms per step (8.30 against 8.44, alternating,
+                # profiles/r06/ab_actstream4.txt) -- PROVIDED every stream of the process has normal priority.  Rounds 5-6 had
+                # measured it at 12.5 ms per step and left it off: with the contrastive streams at high priority they took
+                # hardware queues of their own, a fifth and sixth beside the runtime's pool of four, and five queues busy at once
+                # slow the WHOLE step by half (the body's forward graph included); GPU_MAX_HW_QUEUES >= 5 does the same with
+                # normal priorities.  ODW_ACT_STREAM=0 puts the chain back on the branch's stream.
+                if beside and _os2.environ.get("ODW_ACT_STREAM", "1") != "0":
                     act_stream = getattr(self, "_act_stream", None)
                     if act_stream is None or act_stream.device != device:
                         act_stream = self._act_stream = torch.cuda.Stream(
-                            device=device, priority=int(_os2.environ.get("ODW_PRIO", "-1,0,-1").split(",")[2]))
+                            device=device, priority=int(_os2.environ.get("ODW_ACT_PRIO", _os2.environ.get("ODW_PRIO", "0,0,0").split(",")[2])))
                 # (see DeviceContrastive.backward_now: the whole head backward is queued in forward order)
                 branch.backward_now(act_stream=act_stream)
             if beside:
