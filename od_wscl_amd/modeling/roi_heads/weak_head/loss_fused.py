@@ -648,7 +648,11 @@ class RoIRegLossFused(RoIRegLossComputation):
         colstat_flat = colstat.view(-1)
         eager = (self.early_backward and torch.is_grad_enabled() and stacked.requires_grad and stacked.grad_fn is not None
                  and _os2.environ.get("ODW_NO_EAGER_CONTRA") != "1")
-        beside = eager and _os2.environ.get("ODW_CONTRA_STREAM") != "0"
+        # (one rank per job only, unless ODW_CONTRA_STREAM=1: at N > 1 RCCL's stream is the third heavily used one, and a fourth
+        # is what put the whole step into its slow mode in every configuration measured -- see the note on the third stream below)
+        cs = _os2.environ.get("ODW_CONTRA_STREAM")
+        many = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        beside = eager and cs != "0" and (cs == "1" or not many)
         main = torch.cuda.current_stream(device)
         side, joined, held = main, None, []
         if beside:
@@ -675,13 +679,14 @@ class RoIRegLossFused(RoIRegLossComputation):
             if eager:
                 act_stream = None
                 # A THIRD stream for the re-attached rows' chain beside the views' chain (the two share nothing but the held
-                # weight-gradient batches and disjoint rows of the side buffer): -0.13 ms per step (8.30 against 8.44, alternating,
-                # profiles/r06/ab_actstream4.txt) -- PROVIDED every stream of the process has normal priority.  Rounds 5-6 had
-                # measured it at 12.5 ms per step and left it off: with the contrastive streams at high priority they took
-                # hardware queues of their own, a fifth and sixth beside the runtime's pool of four, and five queues busy at once
-                # slow the WHOLE step by half (the body's forward graph included); GPU_MAX_HW_QUEUES >= 5 does the same with
-                # normal priorities.  ODW_ACT_STREAM=0 puts the chain back on the branch's stream.
-                if beside and _os2.environ.get("ODW_ACT_STREAM", "1") != "0":
+                # weight-gradient batches and disjoint rows of the side buffer).  OFF: it is worth -0.13 ms per step at the bench's
+                # shape when every stream of the process has normal priority (8.30 against 8.44, profiles/r06/ab_actstream4.txt) --
+                # and it throws the C4 shape (4000 proposals, 81 classes) into a mode in which the WHOLE step, the body's forward
+                # graph included, runs at two thirds of its speed (median 15.3 against 11.2 ms, ab_c4_streams.txt), as it does the
+                # bench's shape as soon as a contrastive stream has another priority or GPU_MAX_HW_QUEUES exceeds 4 (12.3 ms;
+                # rounds 5-6 had only seen that).  A fourth heavily used stream is one too many for this runtime; what triggers
+                # the mode is not understood beyond that.  ODW_ACT_STREAM=1 enables it for comparison.
+                if beside and _os2.environ.get("ODW_ACT_STREAM") == "1":
                     act_stream = getattr(self, "_act_stream", None)
                     if act_stream is None or act_stream.device != device:
                         act_stream = self._act_stream = torch.cuda.Stream(
